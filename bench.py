@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py -- GNNML3 training-step throughput on ZINC-12k-shaped synthetic graphs (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W [--batch GRAPHS_PER_GPU]
+
+A step = forward + L1-sum loss + backward + (N>1: one flat SUM all-reduce of the gradients) + Adam,
+of the reference's ZINC GNNML3 (Zinc12k.py:310-371: 4 x ML3Layer 30+2, S = 8 supports, 25 input
+features, add-pool, fc 32 -> 1, lr 1e-3) over one batch of synthetic ZINC-like graphs per GPU (weak
+scaling: graphs per GPU fixed).  Inputs are resident in HBM before the timed region.  fp32.
+Rank 0 prints ONE JSON line; ``roofline`` is for the dominant kernel (the fused SpectConv forward),
+timed live with HIP events inside the timed region; ``cpu_baseline`` is the CPU oracle (a port of the
+reference algorithm, op for op) timed on this box's host cores on a bounded sample (N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 measured achievable
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32-in MFMA (= fp32 vector) peak
+
+
+def build_batch(graphs_per_gpu, pool, seed, device):
+    """pool distinct ZINC-like graphs -> supports -> tiled on the device to graphs_per_gpu graphs."""
+    from gnn_matlang_amd import SpectralDesign, collate, synthetic
+    from gnn_matlang_amd.graph import Batch
+    pool = min(pool, graphs_per_gpu)
+    raw = synthetic.make_graphs('zinc', pool, seed=seed)
+    ds = SpectralDesign(recfield=2, dv=2, nfreq=7).design_many(raw)      # Zinc12k.py:12
+    base = collate(ds).to(device)
+    reps = (graphs_per_gpu + pool - 1) // pool
+    n, B = base.x.size(0), base.num_graphs
+    offs = (torch.arange(reps, device=device) * n)
+    x = base.x.repeat(reps, 1)
+    ei2 = (base.edge_index2.unsqueeze(1) + offs.view(1, -1, 1)).reshape(2, -1)
+    ei = (base.edge_index.unsqueeze(1) + offs.view(1, -1, 1)).reshape(2, -1)
+    ea = base.edge_attr2.repeat(reps, 1)
+    batch = (base.batch.unsqueeze(0) + (torch.arange(reps, device=device) * B).view(-1, 1)).reshape(-1)
+    ptr = (base.ptr[:-1].long().view(1, -1) + offs.view(-1, 1)).reshape(-1)
+    ptr = torch.cat([ptr, torch.tensor([n * reps], device=device)])
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    y = torch.randn(B * reps, generator=g).to(device)
+    full = Batch(x=x, edge_index=ei, edge_index2=ei2, edge_attr2=ea, batch=batch, ptr=ptr.int(), y=y)
+    return full, base
+
+
+def cpu_baseline(host_batch, nsteps, warm):
+    """the oracle (port of the reference CPU algorithm) on the host cores: graphs / s"""
+    from oracle import models_oracle as MO
+    torch.set_num_threads(os.cpu_count() or 1)
+    b = host_batch
+    torch.manual_seed(0)
+    m = MO.zinc_gnnml3(25, 8)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    B = b.num_graphs
+
+    def step():
+        opt.zero_grad()
+        l = MO.zinc_loss(m(b.x, b.edge_index2, b.edge_attr2, b.batch, B), b.y)
+        l.backward()
+        opt.step()
+    for _ in range(warm):
+        step()
+    t = []
+    for _ in range(nsteps):
+        t0 = time.perf_counter()
+        step()
+        t.append(time.perf_counter() - t0)
+    med = float(np.median(t))
+    return dict(value=B / med, unit='graphs/s', cores=torch.get_num_threads(), kind='port',
+                sample='%d ZINC-like graphs/step (N=%d, E=%d), %d timed steps after %d warm-up, median; fwd+bwd+Adam, '
+                       'torch CPU fp32' % (B, b.x.size(0), b.edge_index2.size(1), nsteps, warm),
+                ms_per_step=med * 1e3)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=32768, help='graphs per GPU per step')
+    ap.add_argument('--pool', type=int, default=2048, help='distinct synthetic graphs (tiled to --batch)')
+    ap.add_argument('--cpu-graphs', type=int, default=2048)
+    ap.add_argument('--cpu-steps', type=int, default=6)
+    ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--no-profile', action='store_true', help='skip the live per-kernel HIP-event timing')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d'
+                         % (args.gpus, world, args.gpus))
+    assert torch.cuda.is_available(), 'bench.py needs the MI355X (no CPU fallback)'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from gnn_matlang_amd import functional as Fn, models
+    from gnn_matlang_amd.dist import FlatGradSync, broadcast_parameters
+
+    data, base = build_batch(args.batch, args.pool, seed=1000 + rank, device=dev)
+    data.csr('edge_index2')                            # built once per batch (data loading, not the step)
+    torch.manual_seed(0)
+    model = models.zinc_gnnml3().to(dev)
+    broadcast_parameters(model)
+    sync = FlatGradSync(model.parameters())
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+
+    def step():
+        sync.zero()
+        loss = models.zinc_loss(model(data), data.y)
+        loss.backward()
+        sync.sync()
+        opt.step()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    if not args.no_profile:
+        Fn.PROFILE = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof, Fn.PROFILE = Fn.PROFILE, None
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    graphs = data.num_graphs * world
+    lossv = float(loss.item())
+    assert np.isfinite(lossv), 'loss diverged'
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        res = dict(metric='GNNML3 training graphs/sec on ZINC-12k', value=graphs * args.steps / dt, unit='graphs/s',
+                   n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms, higher_is_better=True,
+                   scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+                   config=dict(workload='Zinc12k.py GNNML3 regression train step (4x ML3Layer 30+2, S=8 supports, '
+                                        'learnedge, add-pool, L1-sum, Adam 1e-3), ZINC-like synthetic graphs',
+                               graphs_per_gpu=data.num_graphs, global_batch=graphs, nodes_per_gpu=int(data.x.size(0)),
+                               support_edges_per_gpu=int(data.edge_index2.size(1)), supports=8,
+                               parallelism='dp%d' % world, params=sum(p.numel() for p in model.parameters())),
+                   final_loss=lossv)
+        if prof:
+            summ = Fn.profile_summary(prof)
+            k = summ['spectconv_fwd']
+            t = k['ms'] * 1e-3
+            gbs, tfs = k['bytes'] / t / 1e9, k['flops'] / t / 1e12
+            t_hbm, t_mfma = k['bytes'] / (HBM_PEAK_GBS * 1e9), k['flops'] / (MFMA_F32_PEAK_TFLOPS * 1e12)
+            if t_mfma >= t_hbm:
+                roof = dict(bound='mfma', achieved=tfs, peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
+                            frac=tfs / MFMA_F32_PEAK_TFLOPS)
+            else:
+                roof = dict(bound='hbm', achieved=gbs, peak=HBM_PEAK_GBS, unit='GB/s', frac=gbs / HBM_PEAK_GBS)
+            roof.update(traffic=None, kernel='gml_k_spectconv_fwd (fused SpectConv forward, 4 launches/step)',
+                        launches=k['launches'], avg_launch_ms=k['ms'], algorithmic_bytes_per_launch=k['bytes'],
+                        algorithmic_flops_per_launch=k['flops'], hbm_GBps=gbs, hbm_frac=gbs / HBM_PEAK_GBS,
+                        mfma_f32_TFLOPs=tfs, mfma_frac=tfs / MFMA_F32_PEAK_TFLOPS)
+            res['roofline'] = roof
+            res['kernels_ms_per_step'] = {tag: round(v['ms'] * v['launches'] / args.steps, 4) for tag, v in summ.items()}
+        if world == 1 and not args.no_cpu:
+            from gnn_matlang_amd import SpectralDesign, collate, synthetic
+            raw = synthetic.make_graphs('zinc', args.cpu_graphs, seed=1000)
+            host = collate(SpectralDesign(recfield=2, dv=2, nfreq=7).design_many(raw))
+            res['cpu_baseline'] = cpu_baseline(host, args.cpu_steps, 2)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,68 @@
+"""ctypes binding of libgml_hip.so (the C ABI declared in include/gml.h).
+
+There is deliberately NO fallback: if the shared library is missing or a kernel returns an error
+the call raises -- the MI355X path either runs or fails loudly."""
+import ctypes
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, 'libgml_hip.so')
+
+_i32, _i64, _u32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32
+_p, _sz = ctypes.c_void_p, ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/gml.h one to one
+SIGNATURES = {
+    'gml_version': (ctypes.c_int, []),
+    'gml_error_string': (ctypes.c_char_p, [ctypes.c_int]),
+    'gml_csr_workspace_bytes': (_sz, [_i64, _i64]),
+    'gml_csr_from_coo': (ctypes.c_int, [_p, _p, _i64, _i64, _p, _p, _p, _p, _sz, _p]),
+    'gml_csr_link_transpose': (ctypes.c_int, [_p, _p, _i64, _p, _p, _p]),
+    'gml_gather_rows': (ctypes.c_int, [_p, _p, _p, _i64, _i32, _p]),
+    'gml_scatter_rows': (ctypes.c_int, [_p, _p, _p, _i64, _i32, _p]),
+    'gml_spectconv_fwd': (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _p, _p, _i64,
+                                         _i64, _i32, _i32, _i32, _u32, _p]),
+    'gml_spmm_fwd': (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _p, _i64, _i32, _i32, _p]),
+    'gml_sddmm': (ctypes.c_int, [_p, _p, _p, _p, _i64, _p, _p, _i64, _i32, _i32, _p]),
+    'gml_edge_mlp_fwd': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
+    'gml_edge_mlp_bwd_workspace_bytes': (_sz, [_i64, _i32, _i32]),
+    'gml_edge_mlp_bwd': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p, _sz, _p]),
+    'gml_node_mix_fwd': (ctypes.c_int, [_p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _i32, _i32, _p]),
+    'gml_node_mix_bwd': (ctypes.c_int, [_p, _i64, _p, _p, _p, _p, _p, _i64, _p, _i64, _i32, _i32, _p]),
+    'gml_relu_bwd': (ctypes.c_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i32, _p]),
+    'gml_segment_sum': (ctypes.c_int, [_p, _i64, _p, _p, _i64, _i64, _i32, _i32, _p]),
+}
+
+GML_RELU, GML_ACCUM = 1, 2
+
+_lib = None
+
+
+class GmlError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library (loads on first use)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                '%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                '(or python gnn_matlang_amd/_build.py). There is no CPU fallback.' % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the .so does not export it
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().gml_error_string(int(rc))
+        raise GmlError('libgml_hip: %s (code %d)' % (msg.decode() if msg else '?', rc))
+
+
+def call(name, *args):
+    check(getattr(lib(), name)(*args))

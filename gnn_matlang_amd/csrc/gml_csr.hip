@@ -1,0 +1,170 @@
+// COO -> CSR on the device, integer-exact and deterministic.
+//
+// The reference never builds a CSR: edge_index [2,E] goes to PyG propagate whose CPU scatter-add
+// sums the messages of one target in ascending edge order (/root/reference/libs/spect_conv.py:77).
+// To walk rows instead of scattering, edges are bucketed by key (histogram + scan + atomic slots)
+// and every bucket is then sorted by input edge id, which makes the result equal to a STABLE sort
+// by key whatever order the atomics retired in (oracle: oracle/csr_oracle.py).
+#include "gml_common.h"
+
+#define SCAN_BLOCK 256
+#define SCAN_ITEMS 4
+#define SCAN_TILE (SCAN_BLOCK * SCAN_ITEMS)
+
+__global__ void gml_k_hist(const int64_t* __restrict__ key, int64_t E, int32_t* __restrict__ counts1) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < E) atomicAdd(&counts1[key[e] + 1], 1);
+}
+
+// in-place inclusive scan of tiles; tile totals -> sums[b]
+__global__ __launch_bounds__(SCAN_BLOCK) void gml_k_scan_tiles(int32_t* __restrict__ a, int64_t n,
+                                                              int32_t* __restrict__ sums) {
+    __shared__ int32_t wsum[SCAN_BLOCK / 64];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int32_t v[SCAN_ITEMS];
+    int32_t run = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        v[i] = (base + i < n) ? a[base + i] : 0;
+        run += v[i];
+        v[i] = run;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int32_t incl = run;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int32_t t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int32_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    const int32_t excl = woff + incl - run;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i)
+        if (base + i < n) a[base + i] = v[i] + excl;
+    if (threadIdx.x == SCAN_BLOCK - 1) sums[blockIdx.x] = woff + incl;
+}
+
+// exclusive scan of the tile totals by one workgroup (serial over chunks, carry kept in a register)
+__global__ __launch_bounds__(SCAN_BLOCK) void gml_k_scan_sums(int32_t* __restrict__ sums, int64_t nb) {
+    __shared__ int32_t wsum[SCAN_BLOCK / 64];
+    __shared__ int32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t c0 = 0; c0 < nb; c0 += SCAN_BLOCK) {
+        const int64_t i = c0 + threadIdx.x;
+        const int32_t x = (i < nb) ? sums[i] : 0;
+        int32_t incl = x;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int32_t t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int32_t woff = carry_s;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        if (i < nb) sums[i] = woff + incl - x;
+        __syncthreads();
+        if (threadIdx.x == SCAN_BLOCK - 1) carry_s = woff + incl;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void gml_k_scan_add(int32_t* __restrict__ a, int64_t n,
+                                                            const int32_t* __restrict__ sums) {
+    const int32_t off = sums[blockIdx.x];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i)
+        if (base + i < n) a[base + i] += off;
+}
+
+__global__ void gml_k_slot(const int64_t* __restrict__ key, int64_t E, int32_t* __restrict__ cursor,
+                           int32_t* __restrict__ perm) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < E) perm[atomicAdd(&cursor[key[e]], 1)] = (int32_t)e;
+}
+
+// one lane per row: insertion sort of the row's edge ids (rows are short and nearly sorted)
+__global__ void gml_k_sort_rows(const int32_t* __restrict__ rowptr, int64_t N, int32_t* __restrict__ perm) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= N) return;
+    const int b = rowptr[r], e = rowptr[r + 1];
+    for (int i = b + 1; i < e; ++i) {
+        const int32_t v = perm[i];
+        int j = i - 1;
+        while (j >= b && perm[j] > v) { perm[j + 1] = perm[j]; --j; }
+        perm[j + 1] = v;
+    }
+}
+
+__global__ void gml_k_take_i64(const int64_t* __restrict__ in, const int32_t* __restrict__ perm, int64_t E,
+                               int32_t* __restrict__ out) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < E) out[k] = (int32_t)in[perm[k]];
+}
+
+extern "C" size_t gml_csr_workspace_bytes(int64_t num_nodes, int64_t num_edges) {
+    (void)num_edges;
+    if (num_nodes < 0) return 0;
+    const int64_t nb = gml_cdiv(num_nodes + 1, SCAN_TILE);
+    return (size_t)(nb + 1 + num_nodes + 1) * sizeof(int32_t);
+}
+
+extern "C" int gml_csr_from_coo(const int64_t* key, const int64_t* other_in, int64_t num_nodes, int64_t num_edges,
+                                int32_t* rowptr, int32_t* other, int32_t* perm, void* ws, size_t ws_bytes,
+                                gml_stream_t stream) {
+    if (num_nodes < 0 || num_edges < 0) return GML_E_BADARG;
+    if (num_nodes >= INT32_MAX || num_edges >= INT32_MAX) return GML_E_UNSUPPORTED;
+    if (!rowptr) return GML_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n1 = num_nodes + 1;
+    hipError_t he = hipMemsetAsync(rowptr, 0, sizeof(int32_t) * n1, st);
+    if (he != hipSuccess) return (int)he;
+    if (num_edges == 0 || num_nodes == 0) return GML_OK;
+    if (!key || !other_in || !other || !perm || !ws) return GML_E_BADARG;
+    if (ws_bytes < gml_csr_workspace_bytes(num_nodes, num_edges)) return GML_E_WORKSPACE;
+    const int64_t nb = gml_cdiv(n1, SCAN_TILE);
+    int32_t* sums = (int32_t*)ws;
+    int32_t* cursor = sums + nb + 1;
+    const unsigned eg = (unsigned)gml_cdiv(num_edges, 256);
+
+    hipLaunchKernelGGL(gml_k_hist, dim3(eg), dim3(256), 0, st, key, num_edges, rowptr);
+    hipLaunchKernelGGL(gml_k_scan_tiles, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, rowptr, n1, sums);
+    hipLaunchKernelGGL(gml_k_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, st, sums, nb);
+    hipLaunchKernelGGL(gml_k_scan_add, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, rowptr, n1, sums);
+    he = hipMemcpyAsync(cursor, rowptr, sizeof(int32_t) * n1, hipMemcpyDeviceToDevice, st);
+    if (he != hipSuccess) return (int)he;
+    hipLaunchKernelGGL(gml_k_slot, dim3(eg), dim3(256), 0, st, key, num_edges, cursor, perm);
+    hipLaunchKernelGGL(gml_k_sort_rows, dim3((unsigned)gml_cdiv(num_nodes, 256)), dim3(256), 0, st, rowptr,
+                       num_nodes, perm);
+    hipLaunchKernelGGL(gml_k_take_i64, dim3(eg), dim3(256), 0, st, other_in, perm, num_edges, other);
+    return gml_launch_status();
+}
+
+__global__ void gml_k_invert(const int32_t* __restrict__ perm, int64_t E, int32_t* __restrict__ inv) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < E) inv[perm[k]] = (int32_t)k;
+}
+
+__global__ void gml_k_take_i32(const int32_t* __restrict__ in, const int32_t* __restrict__ perm, int64_t E,
+                               int32_t* __restrict__ out) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < E) out[k] = in[perm[k]];
+}
+
+extern "C" int gml_csr_link_transpose(const int32_t* perm_fwd, const int32_t* perm_t, int64_t num_edges,
+                                      int32_t* inv_scratch, int32_t* pos_t, gml_stream_t stream) {
+    if (num_edges < 0) return GML_E_BADARG;
+    if (num_edges == 0) return GML_OK;
+    if (!perm_fwd || !perm_t || !inv_scratch || !pos_t) return GML_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned eg = (unsigned)gml_cdiv(num_edges, 256);
+    hipLaunchKernelGGL(gml_k_invert, dim3(eg), dim3(256), 0, st, perm_fwd, num_edges, inv_scratch);
+    hipLaunchKernelGGL(gml_k_take_i32, dim3(eg), dim3(256), 0, st, inv_scratch, perm_t, num_edges, pos_t);
+    return gml_launch_status();
+}

@@ -1,0 +1,83 @@
+// C-ABI dispatch of the ML3Layer edge-branch kernels + the partial-sum fold.
+#include "gml_edge_mlp_impl.h"
+
+__global__ void gml_k_reduce_partials(const float* __restrict__ partial, int64_t nwaves, int nw,
+                                      float* __restrict__ d0, int n0, float* __restrict__ d1, int n1,
+                                      float* __restrict__ d2, int n2, float* __restrict__ d3, int n3) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nw) return;
+    float a = 0.f;
+    for (int64_t w = 0; w < nwaves; ++w) a += partial[w * nw + j];
+    if (j < n0) d0[j] = a;
+    else if (j < n0 + n1) d1[j - n0] = a;
+    else if (j < n0 + n1 + n2) d2[j - n0 - n1] = a;
+    else if (j < n0 + n1 + n2 + n3) d3[j - n0 - n1 - n2] = a;
+}
+
+#define GML_DECL_EMLP(SV)                                                                                    \
+    template <> int gml_launch_edge_mlp_fwd<SV, SV>(const float*, const float*, const float*, const float*,  \
+                                                    const float*, float*, int64_t, hipStream_t);             \
+    template <> int gml_launch_edge_mlp_bwd<SV, SV>(const float*, const float*, const float*, const float*,  \
+                                                    const float*, const float*, float*, float*, float*,      \
+                                                    float*, float*, int64_t, void*, size_t, hipStream_t);
+GML_DECL_EMLP(1) GML_DECL_EMLP(2) GML_DECL_EMLP(3) GML_DECL_EMLP(4) GML_DECL_EMLP(5) GML_DECL_EMLP(6)
+GML_DECL_EMLP(7) GML_DECL_EMLP(8) GML_DECL_EMLP(9) GML_DECL_EMLP(10) GML_DECL_EMLP(11) GML_DECL_EMLP(12)
+GML_DECL_EMLP(13) GML_DECL_EMLP(14) GML_DECL_EMLP(15) GML_DECL_EMLP(16)
+
+#define GML_EMLP_SWITCH(CALL)                                                                   \
+    switch (S) {                                                                                \
+        case 1: return CALL(1); case 2: return CALL(2); case 3: return CALL(3);                 \
+        case 4: return CALL(4); case 5: return CALL(5); case 6: return CALL(6);                 \
+        case 7: return CALL(7); case 8: return CALL(8); case 9: return CALL(9);                 \
+        case 10: return CALL(10); case 11: return CALL(11); case 12: return CALL(12);           \
+        case 13: return CALL(13); case 14: return CALL(14); case 15: return CALL(15);           \
+        case 16: return CALL(16);                                                               \
+    }                                                                                           \
+    return GML_E_UNSUPPORTED;
+
+extern "C" int gml_edge_mlp_fwd(const float* ea, const float* w1, const float* w2, const float* w3,
+                                const float* w4, float* out, int64_t num_edges, int32_t S, int32_t Sout,
+                                gml_stream_t stream) {
+    if (num_edges < 0 || S <= 0 || Sout <= 0) return GML_E_BADARG;
+    if (num_edges == 0) return GML_OK;
+    if (!ea || !w1 || !w2 || !w3 || !w4 || !out) return GML_E_BADARG;
+    if (S != Sout) return GML_E_UNSUPPORTED;   // every reference script uses nedgeoutput == nedgeinput
+    if ((((uintptr_t)ea | (uintptr_t)out) & 15) != 0) return GML_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+#define GML_CALL_F(SV) gml_launch_edge_mlp_fwd<SV, SV>(ea, w1, w2, w3, w4, out, num_edges, st)
+    GML_EMLP_SWITCH(GML_CALL_F)
+}
+
+static int64_t emlp_bwd_waves(int64_t E, int S) {
+    const int chb = 7 * S, cha = 5 * S;
+    const int str = (chb > cha ? chb : cha) | 1;
+    const int waves = (str * 64 * 4 * 4 <= 64 * 1024) ? 4 : 2;
+    return gml_edge_mlp_bwd_waves(E, waves);
+}
+
+extern "C" size_t gml_edge_mlp_bwd_workspace_bytes(int64_t num_edges, int32_t S, int32_t Sout) {
+    if (num_edges <= 0 || S <= 0 || Sout != S) return 0;
+    return (size_t)emlp_bwd_waves(num_edges, S) * (size_t)(6 * S * S + Sout * 4 * S) * sizeof(float);
+}
+
+extern "C" int gml_edge_mlp_bwd(const float* ea, const float* w1, const float* w2, const float* w3,
+                                const float* w4, const float* gout, float* gin, float* dw1, float* dw2,
+                                float* dw3, float* dw4, int64_t num_edges, int32_t S, int32_t Sout,
+                                void* ws, size_t ws_bytes, gml_stream_t stream) {
+    if (num_edges < 0 || S <= 0 || Sout <= 0) return GML_E_BADARG;
+    if (!w1 || !w2 || !w3 || !w4 || !dw1 || !dw2 || !dw3 || !dw4) return GML_E_BADARG;
+    if (S != Sout) return GML_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (num_edges == 0) {
+        hipMemsetAsync(dw1, 0, sizeof(float) * 2 * S * S, st);
+        hipMemsetAsync(dw2, 0, sizeof(float) * 2 * S * S, st);
+        hipMemsetAsync(dw3, 0, sizeof(float) * 2 * S * S, st);
+        hipMemsetAsync(dw4, 0, sizeof(float) * 4 * S * Sout, st);
+        return gml_launch_status();
+    }
+    if (!ea || !gout || !ws) return GML_E_BADARG;
+    if ((((uintptr_t)ea | (uintptr_t)gout | (uintptr_t)gin) & 15) != 0) return GML_E_BADARG;
+#define GML_CALL_B(SV) \
+    gml_launch_edge_mlp_bwd<SV, SV>(ea, w1, w2, w3, w4, gout, gin, dw1, dw2, dw3, dw4, num_edges, ws, ws_bytes, st)
+    GML_EMLP_SWITCH(GML_CALL_B)
+}

@@ -1,0 +1,5 @@
+// explicit instantiations of the fused forward kernel families (SC supports x FPL features/lane)
+#include "gml_spectconv_impl.h"
+GML_DEFINE_FWD_FAMILY(2, 4)
+GML_DEFINE_FWD_FAMILY(3, 4)
+GML_DEFINE_FWD_FAMILY(4, 4)

@@ -1,0 +1,254 @@
+// Dispatch of the fused forward kernel families + the unfused SpMM / SDDMM kernels.
+#include "gml_spectconv_impl.h"
+
+// ---- families defined in gml_fwd_fam_*.hip ---------------------------------------------------
+#define GML_DECL_FAM(SC, FPL) \
+    template <> int gml_launch_fwd_family<SC, FPL>(const GmlFwdParams&, int, bool, dim3, size_t, hipStream_t);
+GML_DECL_FAM(1, 8) GML_DECL_FAM(2, 8) GML_DECL_FAM(3, 8) GML_DECL_FAM(4, 8) GML_DECL_FAM(6, 8) GML_DECL_FAM(8, 8)
+GML_DECL_FAM(1, 4) GML_DECL_FAM(2, 4) GML_DECL_FAM(3, 4) GML_DECL_FAM(4, 4) GML_DECL_FAM(6, 4) GML_DECL_FAM(8, 4)
+GML_DECL_FAM(12, 4) GML_DECL_FAM(16, 4)
+
+static int launch_family(int SC, int FPL, const GmlFwdParams& p, int NB, bool xvec, dim3 grid, size_t lds,
+                         hipStream_t st) {
+#define GML_FAM(SCV, FPLV) \
+    if (SC == SCV && FPL == FPLV) return gml_launch_fwd_family<SCV, FPLV>(p, NB, xvec, grid, lds, st);
+    GML_FAM(1, 8) GML_FAM(2, 8) GML_FAM(3, 8) GML_FAM(4, 8) GML_FAM(6, 8) GML_FAM(8, 8)
+    GML_FAM(1, 4) GML_FAM(2, 4) GML_FAM(3, 4) GML_FAM(4, 4) GML_FAM(6, 4) GML_FAM(8, 4)
+    GML_FAM(12, 4) GML_FAM(16, 4)
+    return GML_E_UNSUPPORTED;
+}
+
+static const int kSC8[] = {8, 6, 4, 3, 2, 1};
+static const int kSC4[] = {16, 12, 8, 6, 4, 3, 2, 1};
+
+extern "C" int gml_spectconv_fwd(const int32_t* rowptr, const int32_t* col, const int32_t* epos,
+                                 const float* val, const float* x, int64_t ldx,
+                                 const float* w, int64_t w_ss, int64_t w_si, int64_t w_so,
+                                 const float* bias, float* out, int64_t ldo,
+                                 int64_t num_rows, int32_t S, int32_t Fin, int32_t Fout,
+                                 uint32_t flags, gml_stream_t stream) {
+    if (num_rows < 0 || S <= 0 || Fin <= 0 || Fout <= 0 || ldx < Fin || ldo < Fout) return GML_E_BADARG;
+    if (num_rows == 0) return GML_OK;
+    if (!rowptr || !col || !val || !x || !w || !out) return GML_E_BADARG;
+    if (num_rows > (int64_t)INT32_MAX - 16) return GML_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+
+    // features per lane per chunk: 8 unless 4 pads the contraction less
+    const int pad8 = (Fin + 31) / 32 * 32, pad4 = (Fin + 15) / 16 * 16;
+    const int FPL = (pad4 < pad8) ? 4 : 8;
+    const int CH = 4 * FPL;
+    const int nchunks = (Fin + CH - 1) / CH;
+    const bool xvec = (Fin % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)x & 15) == 0);
+    const bool val_ok = (((uintptr_t)val & 15) == 0);
+    if (!val_ok) return GML_E_BADARG;
+
+    // support passes: one launch if S = npass * SC for a compiled SC, else a greedy split with accumulation
+    const int* scs = (FPL == 8) ? kSC8 : kSC4;
+    const int nscs = (FPL == 8) ? 6 : 8;
+    struct Part { int s0, count, sc; } parts[32];
+    int nparts = 0;
+    for (int i = 0; i < nscs && nparts == 0; ++i)
+        if (S % scs[i] == 0 && (scs[i] >= 4 || scs[i] == S)) { parts[0] = {0, S, scs[i]}; nparts = 1; }
+    if (nparts == 0) {
+        int s0 = 0;
+        while (s0 < S) {
+            int sc = 1;
+            for (int i = 0; i < nscs; ++i) if (scs[i] <= S - s0) { sc = scs[i]; break; }
+            if (nparts == 32) return GML_E_UNSUPPORTED;
+            parts[nparts++] = {s0, sc, sc};
+            s0 += sc;
+        }
+    }
+
+    const int ntiles = (int)gml_cdiv(num_rows, 16);
+    int grid = (int)gml_cdiv(ntiles, 4);
+    const int maxwg = GML_NUM_CU * 8;
+    if (grid > maxwg) grid = maxwg;
+    int tiles_per_wg = (int)gml_cdiv(ntiles, grid);
+    tiles_per_wg = (tiles_per_wg + 3) / 4 * 4;
+    grid = (int)gml_cdiv(ntiles, tiles_per_wg);
+
+    for (int ip = 0; ip < nparts; ++ip) {
+        const int SC = parts[ip].sc;
+        const int colgrp = (SC * FPL > 32) ? 64 : 128;   // keep one W block <= 64 KiB of LDS
+        for (int o0 = 0; o0 < Fout; o0 += colgrp) {
+            const int fo = (Fout - o0 < colgrp) ? Fout - o0 : colgrp;
+            const int nb16 = (fo + 15) / 16;
+            const int NB = nb16 <= 1 ? 1 : (nb16 <= 2 ? 2 : (nb16 <= 4 ? 4 : 8));
+            GmlFwdParams p;
+            p.rowptr = rowptr; p.col = col; p.epos = epos; p.val = val; p.x = x; p.ldx = ldx;
+            p.w = w + (int64_t)o0 * w_so; p.w_ss = w_ss; p.w_si = w_si; p.w_so = w_so;
+            p.out = out + o0; p.ldo = ldo; p.nrows = num_rows; p.S = S; p.Fin = Fin; p.Fout = fo;
+            p.s0 = parts[ip].s0; p.npass = parts[ip].count / SC; p.nchunks = nchunks;
+            p.ntiles = ntiles; p.tiles_per_wg = tiles_per_wg;
+            const bool last = (ip == nparts - 1), first = (ip == 0);
+            p.bias = (last && bias) ? bias + o0 : nullptr;
+            p.flags = (first ? (flags & GML_ACCUM) : GML_ACCUM) | (last ? (flags & GML_RELU) : 0u);
+            const size_t wblk = (size_t)SC * FPL * NB * 64 * sizeof(float);
+            const size_t all = wblk * p.npass * nchunks;
+            p.allw = all <= 64 * 1024;
+            const int va = (SC % 4 == 0) ? 4 : ((SC % 2 == 0) ? 2 : 1);
+            p.val_vec = (S % va == 0) && (p.s0 % va == 0);
+            const size_t lds = p.allw ? all : wblk;
+            int rc = launch_family(SC, FPL, p, NB, xvec && FPL >= 4, dim3(grid), lds, st);
+            if (rc != GML_OK) return rc;
+        }
+    }
+    return GML_OK;
+}
+
+// =============================================================================================
+// Unfused SpMM: H[r, s, :] = sum_k val[pos(k), s] * x[col[k], :]   (materialises H; used for dW)
+// GW lanes share one row (lane <-> feature, coalesced X rows), 64/GW rows per wave.
+// =============================================================================================
+template <int SC, int GW>
+__global__ __launch_bounds__(256) void gml_k_spmm(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                 const int32_t* __restrict__ epos, const float* __restrict__ val,
+                                                 const float* __restrict__ x, int64_t ldx, float* __restrict__ h,
+                                                 int64_t nrows, int S, int s0, int Fin) {
+    constexpr int RPW = 64 / GW;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t row = wave * RPW + lane / GW;
+    const int lr = lane % GW;
+    if (row >= nrows) return;
+    const int kbeg = rowptr[row], kend = rowptr[row + 1];
+    for (int f = lr; f < Fin; f += GW) {
+        float acc[SC];
+#pragma unroll
+        for (int s = 0; s < SC; ++s) acc[s] = 0.f;
+        for (int k = kbeg; k < kend; ++k) {
+            const int64_t pk = epos ? (int64_t)epos[k] : (int64_t)k;
+            const float xv = x[(int64_t)col[k] * ldx + f];
+            const float* vr = val + pk * S + s0;
+#pragma unroll
+            for (int s = 0; s < SC; ++s) acc[s] = fmaf(vr[s], xv, acc[s]);
+        }
+#pragma unroll
+        for (int s = 0; s < SC; ++s) h[(row * S + s0 + s) * Fin + f] = acc[s];
+    }
+}
+
+template <int SC>
+static int launch_spmm(const int32_t* rowptr, const int32_t* col, const int32_t* epos, const float* val,
+                       const float* x, int64_t ldx, float* h, int64_t nrows, int S, int s0, int Fin, hipStream_t st) {
+    const int GW = Fin <= 16 ? 16 : (Fin <= 32 ? 32 : 64);
+    const int64_t waves = gml_cdiv(nrows, 64 / GW);
+    const dim3 grid((unsigned)gml_cdiv(waves, 4));
+    if (GW == 16) hipLaunchKernelGGL((gml_k_spmm<SC, 16>), grid, dim3(256), 0, st, rowptr, col, epos, val, x, ldx, h, nrows, S, s0, Fin);
+    else if (GW == 32) hipLaunchKernelGGL((gml_k_spmm<SC, 32>), grid, dim3(256), 0, st, rowptr, col, epos, val, x, ldx, h, nrows, S, s0, Fin);
+    else hipLaunchKernelGGL((gml_k_spmm<SC, 64>), grid, dim3(256), 0, st, rowptr, col, epos, val, x, ldx, h, nrows, S, s0, Fin);
+    return gml_launch_status();
+}
+
+extern "C" int gml_spmm_fwd(const int32_t* rowptr, const int32_t* col, const int32_t* epos, const float* val,
+                            const float* x, int64_t ldx, float* h, int64_t num_rows, int32_t S, int32_t Fin,
+                            gml_stream_t stream) {
+    if (num_rows < 0 || S <= 0 || Fin <= 0 || ldx < Fin) return GML_E_BADARG;
+    if (num_rows == 0) return GML_OK;
+    if (!rowptr || !col || !val || !x || !h) return GML_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    int s0 = 0;
+    while (s0 < S) {
+        const int rem = S - s0;
+        int rc;
+        if (rem >= 8) { rc = launch_spmm<8>(rowptr, col, epos, val, x, ldx, h, num_rows, S, s0, Fin, st); s0 += 8; }
+        else if (rem >= 4) { rc = launch_spmm<4>(rowptr, col, epos, val, x, ldx, h, num_rows, S, s0, Fin, st); s0 += 4; }
+        else if (rem >= 2) { rc = launch_spmm<2>(rowptr, col, epos, val, x, ldx, h, num_rows, S, s0, Fin, st); s0 += 2; }
+        else { rc = launch_spmm<1>(rowptr, col, epos, val, x, ldx, h, num_rows, S, s0, Fin, st); s0 += 1; }
+        if (rc != GML_OK) return rc;
+    }
+    return GML_OK;
+}
+
+// =============================================================================================
+// SDDMM: dval[pos(k), s] = < x[col[k], :], gw[r, s, :] >   (gradient of message() w.r.t. norm)
+// GW lanes share one row; each lane keeps its slice of gw[r] in registers; width-GW shuffle tree.
+// =============================================================================================
+template <int SC, int GW, int NFC>
+__global__ __launch_bounds__(256) void gml_k_sddmm(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                  const int32_t* __restrict__ epos, const float* __restrict__ x,
+                                                  int64_t ldx, const float* __restrict__ gw, float* __restrict__ dval,
+                                                  int64_t nrows, int S, int s0, int Fin) {
+    constexpr int RPW = 64 / GW;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t row = wave * RPW + lane / GW;
+    const int lr = lane % GW;
+    const bool valid = row < nrows;
+    const int kbeg = valid ? rowptr[row] : 0, kend = valid ? rowptr[row + 1] : 0;
+    float g[SC][NFC];
+#pragma unroll
+    for (int s = 0; s < SC; ++s)
+#pragma unroll
+        for (int c = 0; c < NFC; ++c) {
+            const int f = lr + c * GW;
+            g[s][c] = (valid && f < Fin) ? gw[(row * S + s0 + s) * Fin + f] : 0.f;
+        }
+    // all lanes of a wave must run the same trip count for the shuffles
+    int n = kend - kbeg;
+#pragma unroll
+    for (int off = 32; off >= GW; off >>= 1) n = max(n, __shfl_xor(n, off));
+    for (int i = 0; i < n; ++i) {
+        const int k = kbeg + i;
+        const bool kv = k < kend;
+        float part[SC];
+#pragma unroll
+        for (int s = 0; s < SC; ++s) part[s] = 0.f;
+        if (kv) {
+            const float* xr = x + (int64_t)col[k] * ldx;
+#pragma unroll
+            for (int c = 0; c < NFC; ++c) {
+                const int f = lr + c * GW;
+                const float xv = (f < Fin) ? xr[f] : 0.f;
+#pragma unroll
+                for (int s = 0; s < SC; ++s) part[s] = fmaf(xv, g[s][c], part[s]);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < SC; ++s)
+#pragma unroll
+            for (int off = GW / 2; off >= 1; off >>= 1) part[s] += __shfl_xor(part[s], off);
+        if (kv && lr == 0) {
+            const int64_t pk = epos ? (int64_t)epos[k] : (int64_t)k;
+#pragma unroll
+            for (int s = 0; s < SC; ++s) dval[pk * S + s0 + s] = part[s];
+        }
+    }
+}
+
+template <int SC>
+static int launch_sddmm(const int32_t* rowptr, const int32_t* col, const int32_t* epos, const float* x, int64_t ldx,
+                        const float* gw, float* dval, int64_t nrows, int S, int s0, int Fin, hipStream_t st) {
+    const int GW = Fin <= 16 ? 16 : (Fin <= 32 ? 32 : 64);
+    const int64_t waves = gml_cdiv(nrows, 64 / GW);
+    const dim3 grid((unsigned)gml_cdiv(waves, 4));
+#define GML_SDDMM(GWV, NFCV) \
+    hipLaunchKernelGGL((gml_k_sddmm<SC, GWV, NFCV>), grid, dim3(256), 0, st, rowptr, col, epos, x, ldx, gw, dval, nrows, S, s0, Fin)
+    if (GW == 16) GML_SDDMM(16, 1);
+    else if (GW == 32) GML_SDDMM(32, 1);
+    else if (Fin <= 64) GML_SDDMM(64, 1);
+    else if (Fin <= 128) GML_SDDMM(64, 2);
+    else if (Fin <= 256) GML_SDDMM(64, 4);
+    else return GML_E_UNSUPPORTED;
+    return gml_launch_status();
+}
+
+extern "C" int gml_sddmm(const int32_t* rowptr, const int32_t* col, const int32_t* epos, const float* x, int64_t ldx,
+                         const float* gw, float* dval, int64_t num_rows, int32_t S, int32_t Fin, gml_stream_t stream) {
+    if (num_rows < 0 || S <= 0 || Fin <= 0 || ldx < Fin) return GML_E_BADARG;
+    if (num_rows == 0) return GML_OK;
+    if (!rowptr || !col || !x || !gw || !dval) return GML_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    int s0 = 0;
+    while (s0 < S) {
+        const int rem = S - s0;
+        int rc;
+        if (rem >= 8) { rc = launch_sddmm<8>(rowptr, col, epos, x, ldx, gw, dval, num_rows, S, s0, Fin, st); s0 += 8; }
+        else if (rem >= 4) { rc = launch_sddmm<4>(rowptr, col, epos, x, ldx, gw, dval, num_rows, S, s0, Fin, st); s0 += 4; }
+        else if (rem >= 2) { rc = launch_sddmm<2>(rowptr, col, epos, x, ldx, gw, dval, num_rows, S, s0, Fin, st); s0 += 2; }
+        else { rc = launch_sddmm<1>(rowptr, col, epos, x, ldx, gw, dval, num_rows, S, s0, Fin, st); s0 += 1; }
+        if (rc != GML_OK) return rc;
+    }
+    return GML_OK;
+}

@@ -1,0 +1,273 @@
+"""Autograd functions over the C ABI of libgml_hip.so.
+
+Forward of one SpectConv (libs/spect_conv.py:64-96) is ONE fused launch; backward is
+  dX   = the same fused kernel on the source-keyed CSR with W transposed (a strided view),
+  dW   = H^T G   with H = gml_spmm_fwd(X) (plain GEMM through torch.mm),
+  dval = gml_sddmm(X, G W^T),   dbias = colsum(G).
+Every tensor handed to the library is fp32, contiguous and on the current CUDA(HIP) device; the
+launches go to torch's current stream, so they order with the surrounding torch ops and are
+captured by torch.cuda.graphs like any other kernel.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from .graph import _ptr, _stream, _require_cuda
+
+
+# ---------------------------------------------------------------------------- live kernel timing
+# bench.py sets PROFILE = {} for the timed region: every tagged launch is then bracketed by two HIP
+# events recorded on the stream the kernel runs on, with its algorithmic bytes / flops.
+PROFILE = None
+
+
+class _Timed(object):
+    __slots__ = ('tag', 'q', 'f', 'e0')
+
+    def __init__(self, tag, q=0, f=0):
+        self.tag, self.q, self.f = tag, q, f
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *a):
+        if PROFILE is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            PROFILE.setdefault(self.tag, []).append((self.e0, e1, self.q, self.f))
+
+
+def profile_summary(prof):
+    """tag -> dict(launches, ms (mean per launch), bytes, flops (mean per launch))."""
+    out = {}
+    for tag, recs in prof.items():
+        ms = [a.elapsed_time(b) for a, b, _, _ in recs]
+        out[tag] = dict(launches=len(recs), ms=sum(ms) / len(ms), bytes=sum(r[2] for r in recs) / len(recs),
+                        flops=sum(r[3] for r in recs) / len(recs))
+    return out
+
+
+def conv_cost(N, E, S, Fin, Fout):
+    """fusion-agnostic compulsory traffic / flops of one SpectConv forward, fp32:
+       Q = 4 (E S + N Fin + N Fout + S Fin Fout + Fout) + 4 (E + N + 1);  F = 2 E S Fin + 2 N S Fin Fout."""
+    q = 4 * (E * S + N * Fin + N * Fout + S * Fin * Fout + Fout) + 4 * (E + N + 1)
+    f = 2 * E * S * Fin + 2 * N * S * Fin * Fout
+    return q, f
+
+
+def _off(t, elems):
+    return ctypes.c_void_p(t.data_ptr() + 4 * int(elems))
+
+
+def _f32c(t, name):
+    _require_cuda(t, name)
+    if t.dtype != torch.float32:
+        raise TypeError('%s must be float32, got %s' % (name, t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ---------------------------------------------------------------------------- raw launches
+def fused_conv(rowptr, col, epos, val, x, ldx, w, w_strides, bias, out, ldo, nrows, S, Fin, Fout, flags=0,
+               out_off=0, tag='spectconv_fwd'):
+    q, f = conv_cost(int(nrows), int(val.size(0)), int(S), int(Fin), int(Fout)) if PROFILE is not None else (0, 0)
+    with _Timed(tag, q + (4 * int(val.size(0)) if epos is not None else 0), f):
+        _fused_conv(rowptr, col, epos, val, x, ldx, w, w_strides, bias, out, ldo, nrows, S, Fin, Fout, flags, out_off)
+
+
+def _fused_conv(rowptr, col, epos, val, x, ldx, w, w_strides, bias, out, ldo, nrows, S, Fin, Fout, flags, out_off):
+    _lib.call('gml_spectconv_fwd', _ptr(rowptr), _ptr(col), _ptr(epos), _ptr(val), _ptr(x), int(ldx),
+              _ptr(w), int(w_strides[0]), int(w_strides[1]), int(w_strides[2]), _ptr(bias),
+              _off(out, out_off), int(ldo), int(nrows), int(S), int(Fin), int(Fout), int(flags), _stream(x.device))
+
+
+def spmm(csr, val, x, S, Fin):
+    h = torch.empty(csr.N, S * Fin, dtype=torch.float32, device=x.device)
+    _lib.call('gml_spmm_fwd', _ptr(csr.rowptr), _ptr(csr.col), _ptr(None), _ptr(val), _ptr(x), int(x.stride(0)),
+              _ptr(h), csr.N, int(S), int(Fin), _stream(x.device))
+    return h
+
+
+def sddmm(csr, x, gw, S, Fin):
+    dval = torch.empty(csr.E, S, dtype=torch.float32, device=x.device)
+    _lib.call('gml_sddmm', _ptr(csr.rowptr), _ptr(csr.col), _ptr(None), _ptr(x), int(x.stride(0)), _ptr(gw),
+              _ptr(dval), csr.N, int(S), int(Fin), _stream(x.device))
+    return dval
+
+
+def relu_bwd(gy, gy_off, ldgy, y, ldy, nrows, F):
+    g = torch.empty(nrows, F, dtype=torch.float32, device=gy.device)
+    _lib.call('gml_relu_bwd', _off(gy, gy_off), int(ldgy), _ptr(y), int(ldy), _ptr(g), int(F), int(nrows), int(F),
+              _stream(gy.device))
+    return g
+
+
+def edge_mlp_fwd(ea, w1, w2, w3, w4):
+    E, S = ea.shape
+    So = w4.size(0)
+    out = torch.empty(E, So, dtype=torch.float32, device=ea.device)
+    _lib.call('gml_edge_mlp_fwd', _ptr(ea), _ptr(w1), _ptr(w2), _ptr(w3), _ptr(w4), _ptr(out), int(E), int(S),
+              int(So), _stream(ea.device))
+    return out
+
+
+def edge_mlp_bwd(ea, w1, w2, w3, w4, gout, need_gin):
+    E, S = ea.shape
+    So = w4.size(0)
+    dev = ea.device
+    nbytes = int(_lib.lib().gml_edge_mlp_bwd_workspace_bytes(int(E), int(S), int(So)))
+    ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=dev)
+    gin = torch.empty_like(ea) if need_gin else None
+    dw1, dw2, dw3, dw4 = torch.empty_like(w1), torch.empty_like(w2), torch.empty_like(w3), torch.empty_like(w4)
+    _lib.call('gml_edge_mlp_bwd', _ptr(ea), _ptr(w1), _ptr(w2), _ptr(w3), _ptr(w4), _ptr(gout), _ptr(gin),
+              _ptr(dw1), _ptr(dw2), _ptr(dw3), _ptr(dw4), int(E), int(S), int(So), _ptr(ws), ws.numel(), _stream(dev))
+    return gin, dw1, dw2, dw3, dw4
+
+
+def segment_sum(x, ptr, mean=False):
+    """global_add_pool / global_mean_pool over a batch whose nodes are grouped per graph (ptr [B+1] int32)."""
+    B, F = int(ptr.numel() - 1), int(x.size(1))
+    out = torch.empty(B, F, dtype=torch.float32, device=x.device)
+    _lib.call('gml_segment_sum', _ptr(x), int(x.stride(0)), _ptr(ptr), _ptr(out), F, B, F, 1 if mean else 0,
+              _stream(x.device))
+    return out
+
+
+# ---------------------------------------------------------------------------- shared backward pieces
+def _conv_backward(csr, x, val, weight, G, need_x, need_val, need_w):
+    """G [N,Fout] contiguous = gradient at the (pre-activation) conv output."""
+    S, Fin, Fout = weight.shape
+    N = csr.N
+    dx = dval = dw = None
+    if need_x:
+        dx = torch.empty(N, Fin, dtype=torch.float32, device=x.device)
+        # dX = sum_s A_s (G W_s^T): rows keyed by SOURCE, features = G, weight element (s, o, f) = W[s, f, o]
+        fused_conv(csr.rowptr_t, csr.col_t, csr.pos_t, val, G, Fout, weight, (Fin * Fout, 1, Fout), None,
+                   dx, Fin, N, S, Fout, Fin, tag='spectconv_dx')
+    if need_w:
+        with _Timed('dw_spmm'):
+            h = spmm(csr, val, x, S, Fin)                                # [N, S*Fin]
+        with _Timed('dw_gemm'):
+            dw = torch.mm(h.t(), G).view(S, Fin, Fout)
+    if need_val:
+        with _Timed('dval_gemm'):
+            gw = torch.mm(G, weight.view(S * Fin, Fout).t())             # [N, S*Fin]
+        with _Timed('dval_sddmm'):
+            dval = sddmm(csr, x, gw, S, Fin)
+    return dx, dval, dw
+
+
+class SpectConvFunction(torch.autograd.Function):
+    """out = act( sum_s (A_s^T x) W_s + bias ),  val = supports in target-sorted order."""
+
+    @staticmethod
+    def forward(ctx, x, val, weight, bias, csr, relu):
+        x, val, weight = _f32c(x, 'x'), _f32c(val, 'edge_attr'), _f32c(weight, 'weight')
+        S, Fin, Fout = weight.shape
+        if x.size(1) != Fin or val.size(1) < S or val.size(0) != csr.E or x.size(0) != csr.N:
+            raise ValueError('shape mismatch: x %s, edge_attr %s, weight %s, graph N=%d E=%d'
+                             % (tuple(x.shape), tuple(val.shape), tuple(weight.shape), csr.N, csr.E))
+        if val.size(1) != S:
+            val = val[:, :S].contiguous()
+        if bias is not None:
+            bias = _f32c(bias, 'bias')
+        with torch.cuda.device(x.device):
+            out = torch.empty(csr.N, Fout, dtype=torch.float32, device=x.device)
+            fused_conv(csr.rowptr, csr.col, None, val, x, Fin, weight, (Fin * Fout, Fout, 1), bias, out, Fout,
+                       csr.N, S, Fin, Fout, _lib.GML_RELU if relu else 0)
+        ctx.csr, ctx.relu, ctx.has_bias = csr, relu, bias is not None
+        ctx.save_for_backward(x, val, weight, out if relu else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, val, weight, out = ctx.saved_tensors
+        csr = ctx.csr
+        gout = _f32c(gout, 'grad_out')
+        with torch.cuda.device(x.device):
+            Fout = weight.size(2)
+            G = relu_bwd(gout, 0, Fout, out, Fout, csr.N, Fout) if ctx.relu else gout
+            need = ctx.needs_input_grad
+            dx, dval, dw = _conv_backward(csr, x, val, weight, G, need[0], need[1], need[2])
+            db = G.sum(0) if (ctx.has_bias and need[3]) else None
+        return dx, dval, dw, db, None, None
+
+
+class ML3LayerFunction(torch.autograd.Function):
+    """Whole ML3Layer.forward (libs/spect_conv.py:204-212) with the concat written in place:
+         ea' = edge-MLP(val)                      (learnedge)
+         out[:, :nout1] = relu(SpectConv(x, ea')) (fused kernel, leading dimension nout1+nout2)
+         out[:, nout1:] = tanh(fc11 x) * tanh(fc12 x)
+    """
+
+    @staticmethod
+    def forward(ctx, x, val, w1, w2, w3, w4, cw, cb, w11, b11, w12, b12, csr, learnedge, nout2):
+        x, val, cw = _f32c(x, 'x'), _f32c(val, 'edge_attr'), _f32c(cw, 'conv1.weight')
+        S, Fin, nout1 = cw.shape
+        N = csr.N
+        if x.size(0) != N or x.size(1) != Fin or val.size(0) != csr.E:
+            raise ValueError('shape mismatch: x %s, edge_attr %s, conv1.weight %s, graph N=%d E=%d'
+                             % (tuple(x.shape), tuple(val.shape), tuple(cw.shape), N, csr.E))
+        C = nout1 + nout2
+        with torch.cuda.device(x.device):
+            if learnedge:
+                w1, w2, w3, w4 = (_f32c(w1, 'fc1_1.weight'), _f32c(w2, 'fc1_2.weight'), _f32c(w3, 'fc1_3.weight'),
+                                  _f32c(w4, 'fc1_4.weight'))
+                with _Timed('edge_mlp_fwd', 4 * val.numel() * 2, 20 * val.size(0) * val.size(1) ** 2):
+                    ea = edge_mlp_fwd(val, w1, w2, w3, w4)
+            else:
+                ea = val
+            if ea.size(1) != S:
+                raise ValueError('conv1 expects %d supports, edge branch produced %d' % (S, ea.size(1)))
+            out = torch.empty(N, C, dtype=torch.float32, device=x.device)
+            cb_ = _f32c(cb, 'conv1.bias') if cb is not None else None
+            fused_conv(csr.rowptr, csr.col, None, ea, x, Fin, cw, (Fin * nout1, nout1, 1), cb_, out, C, N, S, Fin,
+                       nout1, _lib.GML_RELU)
+            if nout2 > 0:
+                w11, b11, w12, b12 = (_f32c(w11, 'fc11.weight'), _f32c(b11, 'fc11.bias'), _f32c(w12, 'fc12.weight'),
+                                      _f32c(b12, 'fc12.bias'))
+                _lib.call('gml_node_mix_fwd', _ptr(x), Fin, _ptr(w11), _ptr(b11), _ptr(w12), _ptr(b12),
+                          _off(out, nout1), C, N, Fin, nout2, _stream(x.device))
+        ctx.csr, ctx.learnedge, ctx.nout2, ctx.has_cb = csr, learnedge, nout2, cb is not None
+        ctx.save_for_backward(x, val, ea if learnedge else None, w1, w2, w3, w4, cw, w11, b11, w12, b12, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, val, ea, w1, w2, w3, w4, cw, w11, b11, w12, b12, out = ctx.saved_tensors
+        csr, learnedge, nout2 = ctx.csr, ctx.learnedge, ctx.nout2
+        S, Fin, nout1 = cw.shape
+        N, C = csr.N, nout1 + nout2
+        need = ctx.needs_input_grad
+        gy = _f32c(gy, 'grad_out')
+        if not learnedge:
+            ea = val
+        g = [None] * 15
+        with torch.cuda.device(x.device):
+            G = relu_bwd(gy, 0, C, out, C, N, nout1)
+            need_val = need[1] or (learnedge and any(need[2:6]))
+            dx, dea, dcw = _conv_backward(csr, x, ea, cw, G, need[0], need_val, need[6])
+            g[6] = dcw
+            if ctx.has_cb and need[7]:
+                g[7] = G.sum(0)
+            if nout2 > 0:
+                gz = torch.empty(N, 2 * nout2, dtype=torch.float32, device=x.device)
+                _lib.call('gml_node_mix_bwd', _ptr(x), Fin, _ptr(w11), _ptr(b11), _ptr(w12), _ptr(b12),
+                          _off(gy, nout1), C, _ptr(gz), N, Fin, nout2, _stream(x.device))
+                g1, g2 = gz[:, :nout2], gz[:, nout2:]
+                if need[0]:
+                    dx.addmm_(g1, w11)
+                    dx.addmm_(g2, w12)
+                g[8], g[9] = torch.mm(g1.t(), x), g1.sum(0)
+                g[10], g[11] = torch.mm(g2.t(), x), g2.sum(0)
+            g[0] = dx
+            if learnedge:
+                if need_val:
+                    with _Timed('edge_mlp_bwd', 4 * val.numel() * 2, 60 * val.size(0) * val.size(1) ** 2):
+                        gin, g[2], g[3], g[4], g[5] = edge_mlp_bwd(val, w1, w2, w3, w4, dea, need[1])
+                    g[1] = gin
+            else:
+                g[1] = dea if need[1] else None
+        return tuple(g)

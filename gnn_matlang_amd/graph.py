@@ -1,0 +1,178 @@
+"""Batch plumbing around the spectral layer: block-diagonal collate (the role PyG's DataLoader/Batch
+plays in the reference scripts, e.g. /root/reference/Zinc12k.py:20-22) and the per-batch index
+structure the HIP kernels walk.
+
+``GraphCSR`` holds, on the device, for one ``edge_index`` [2,E] (row 0 = source, row 1 = target):
+  rowptr/col/perm        edges stably sorted by TARGET  (forward: out[t] = sum over in-edges of t)
+  rowptr_t/col_t/pos_t   edges stably sorted by SOURCE  (backward d/dX), pos_t = where that edge's
+                         values live in target-sorted order (values are stored once)
+It is built once per batch by the integer kernels of csrc/gml_csr.hip and cached on the
+``edge_index`` tensor's identity, so the 4-5 layers of a model and every epoch re-use it.
+"""
+import ctypes
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream(device=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _require_cuda(t, name):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError('%s must be a torch.Tensor, got %s' % (name, type(t).__name__))
+    if not t.is_cuda:
+        raise RuntimeError('%s is on %s: the spectral layer runs only on an MI355X device through '
+                           'libgml_hip.so; there is no CPU fallback' % (name, t.device))
+
+
+class GraphCSR(object):
+    __slots__ = ('N', 'E', 'device', 'rowptr', 'col', 'perm', 'rowptr_t', 'col_t', 'pos_t', 'perm_t',
+                 '_val_cache', '_keep')
+
+    def __init__(self):
+        self._val_cache = OrderedDict()
+        self._keep = None
+
+    @staticmethod
+    def from_edge_index(edge_index, num_nodes):
+        _require_cuda(edge_index, 'edge_index')
+        if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.size(0) != 2:
+            raise ValueError('edge_index must be int64 [2, E], got %s %s' % (edge_index.dtype, tuple(edge_index.shape)))
+        ei = edge_index.contiguous()
+        dev = ei.device
+        E, N = int(ei.size(1)), int(num_nodes)
+        g = GraphCSR()
+        g.N, g.E, g.device = N, E, dev
+        i32 = dict(dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            st = _stream(dev)
+            L = _lib.lib()
+            ws = torch.empty(max(int(L.gml_csr_workspace_bytes(N, E)), 4), dtype=torch.uint8, device=dev)
+            src, dst = ei[0], ei[1]
+            g.rowptr, g.col, g.perm = torch.empty(N + 1, **i32), torch.empty(E, **i32), torch.empty(E, **i32)
+            _lib.call('gml_csr_from_coo', _ptr(dst), _ptr(src), N, E, _ptr(g.rowptr), _ptr(g.col), _ptr(g.perm),
+                      _ptr(ws), ws.numel(), st)
+            g.rowptr_t, g.col_t, g.perm_t = torch.empty(N + 1, **i32), torch.empty(E, **i32), torch.empty(E, **i32)
+            _lib.call('gml_csr_from_coo', _ptr(src), _ptr(dst), N, E, _ptr(g.rowptr_t), _ptr(g.col_t), _ptr(g.perm_t),
+                      _ptr(ws), ws.numel(), st)
+            inv = torch.empty(E, **i32)
+            g.pos_t = torch.empty(E, **i32)
+            _lib.call('gml_csr_link_transpose', _ptr(g.perm), _ptr(g.perm_t), E, _ptr(inv), _ptr(g.pos_t), st)
+        return g
+
+    # values [E, S] in input-edge order -> target-sorted order (cached: raw supports are per-batch data)
+    def sort_values(self, edge_attr, cache=True):
+        key = (edge_attr.data_ptr(), edge_attr._version, tuple(edge_attr.shape))
+        if cache and key in self._val_cache:
+            return self._val_cache[key][1]
+        ea = edge_attr.contiguous()
+        out = torch.empty_like(ea)
+        _lib.call('gml_gather_rows', _ptr(ea), _ptr(self.perm), _ptr(out), self.E, int(ea.size(1)), _stream(ea.device))
+        if cache:
+            self._val_cache[key] = (edge_attr, out)        # keep the source alive: its address is the key
+            while len(self._val_cache) > 4:
+                self._val_cache.popitem(last=False)
+        return out
+
+    def unsort_values(self, val_sorted):
+        """target-sorted [E,S] -> input-edge order (gradient of sort_values)."""
+        out = torch.empty_like(val_sorted)
+        _lib.call('gml_scatter_rows', _ptr(val_sorted), _ptr(self.perm), _ptr(out), self.E, int(val_sorted.size(1)),
+                  _stream(val_sorted.device))
+        return out
+
+
+_CSR_CACHE = OrderedDict()
+_CSR_CACHE_MAX = 8
+
+
+def csr_for(edge_index, num_nodes):
+    """GraphCSR for this edge_index (or pass-through if one is given)."""
+    if isinstance(edge_index, GraphCSR):
+        if edge_index.N != num_nodes:
+            raise ValueError('GraphCSR was built for %d nodes, x has %d rows' % (edge_index.N, num_nodes))
+        return edge_index
+    _require_cuda(edge_index, 'edge_index')
+    key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), int(num_nodes), str(edge_index.device))
+    hit = _CSR_CACHE.get(key)
+    if hit is not None:
+        _CSR_CACHE.move_to_end(key)
+        return hit
+    g = GraphCSR.from_edge_index(edge_index, num_nodes)
+    g._keep = edge_index
+    _CSR_CACHE[key] = g
+    while len(_CSR_CACHE) > _CSR_CACHE_MAX:
+        _CSR_CACHE.popitem(last=False)
+    return g
+
+
+def clear_caches():
+    _CSR_CACHE.clear()
+
+
+# --------------------------------------------------------------------------------------------
+# collate: list of graphs -> one block-diagonal batch (PyG-compatible field names)
+# --------------------------------------------------------------------------------------------
+class Batch(object):
+    """x [N,F], edge_index [2,e], edge_index2 [2,E], edge_attr2 [E,S], batch [N], ptr [B+1], y [B]."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+        self._csr = {}
+
+    @property
+    def num_graphs(self):
+        return int(self.ptr.numel() - 1)
+
+    def to(self, device):
+        out = Batch(**{k: (v.to(device, non_blocking=True) if isinstance(v, torch.Tensor) else v)
+                       for k, v in self.__dict__.items() if not k.startswith('_')})
+        return out
+
+    def csr(self, which='edge_index2'):
+        """GraphCSR of ``edge_index2`` (spectral supports) or ``edge_index`` (raw adjacency), built once."""
+        if which not in self._csr:
+            self._csr[which] = GraphCSR.from_edge_index(getattr(self, which), int(self.x.size(0)))
+        return self._csr[which]
+
+
+def collate(graphs):
+    """graphs: iterable of dicts with x [n,f], edge_index [2,e] and optionally edge_index2/edge_attr2/y
+    (numpy or torch).  Node ids are offset per graph; everything stays on the host."""
+    graphs = list(graphs)
+    xs, e1, e2, ea, bt, ys, ptr, off = [], [], [], [], [], [], [0], 0
+    for g, d in enumerate(graphs):
+        x = np.asarray(d['x'], dtype=np.float32)
+        n = x.shape[0]
+        xs.append(x)
+        e1.append(np.asarray(d['edge_index'], dtype=np.int64) + off)
+        if 'edge_index2' in d:
+            e2.append(np.asarray(d['edge_index2'], dtype=np.int64) + off)
+            ea.append(np.asarray(d['edge_attr2'], dtype=np.float32))
+        bt.append(np.full(n, g, dtype=np.int64))
+        ys.append(d.get('y', 0))
+        off += n
+        ptr.append(off)
+    out = dict(x=torch.from_numpy(np.concatenate(xs)), edge_index=torch.from_numpy(np.concatenate(e1, 1)),
+               batch=torch.from_numpy(np.concatenate(bt)), ptr=torch.tensor(ptr, dtype=torch.int32),
+               y=torch.tensor(np.asarray(ys)))
+    if e2:
+        out['edge_index2'] = torch.from_numpy(np.concatenate(e2, 1))
+        out['edge_attr2'] = torch.from_numpy(np.concatenate(ea))
+    return Batch(**out)
+
+
+def shard_graphs(num_graphs, rank, world_size):
+    """Contiguous, balanced split of graph ids over ranks (data parallel over graphs)."""
+    base, rem = divmod(num_graphs, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)

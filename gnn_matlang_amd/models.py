@@ -1,0 +1,129 @@
+"""GNNML1 / GNNML3 model assemblies of the BASELINE configs on top of the MI355X layers.
+
+The reference defines these classes inside its experiment scripts with hard-coded sizes
+(Zinc12k.py:310-345, counting.py:335-372, sr25.py:248-278, mutag.py:214-309); here they are one
+configurable class each with the same attribute names, so ``state_dict`` keys match the reference's.
+``forward`` takes a ``gnn_matlang_amd.Batch`` (PyG-compatible field names: x, edge_index,
+edge_index2, edge_attr2, batch, ptr, y).
+"""
+import torch
+import torch.nn.functional as F
+
+from .functional import segment_sum
+from .spect_conv import ML3Layer, SpectConv
+
+
+class _SegmentPool(torch.autograd.Function):
+    """global_add_pool / global_mean_pool (torch_geometric.nn, used at Zinc12k.py:343, mutag.py:307)."""
+
+    @staticmethod
+    def forward(ctx, x, ptr, batch, mean):
+        ctx.save_for_backward(ptr, batch)
+        ctx.mean = mean
+        return segment_sum(x.contiguous(), ptr, mean)
+
+    @staticmethod
+    def backward(ctx, g):
+        ptr, batch = ctx.saved_tensors
+        if ctx.mean:
+            cnt = (ptr[1:] - ptr[:-1]).clamp(min=1).to(g.dtype).unsqueeze(-1)
+            g = g / cnt
+        return g.index_select(0, batch), None, None, None
+
+
+def global_add_pool(x, data):
+    return _SegmentPool.apply(x, data.ptr, data.batch, False)
+
+
+def global_mean_pool(x, data):
+    return _SegmentPool.apply(x, data.ptr, data.batch, True)
+
+
+class GNNML3(torch.nn.Module):
+    """head 'mlp32': fc2(relu(fc1 x)), fc1: nin->32, fc2: 32->nclass;  'tanh10': tanh(fc1 x), fc1: nin->10."""
+
+    def __init__(self, ninp, ne, nout1, nout2, nlayers, learnedge=True, bn=False, pool='add', head='mlp32',
+                 nclass=1):
+        super().__init__()
+        nin = nout1 + nout2
+        self.nlayers, self.bn, self.pool, self.head = nlayers, bn, pool, head
+        for i in range(nlayers):
+            setattr(self, 'conv%d' % (i + 1),
+                    ML3Layer(learnedge=learnedge, nedgeinput=ne, nedgeoutput=ne,
+                             ninp=ninp if i == 0 else nin, nout1=nout1, nout2=nout2))
+        if bn:
+            for i in range(nlayers):
+                setattr(self, 'bn%d' % (i + 1), torch.nn.BatchNorm1d(nin))
+        if head == 'mlp32':
+            self.fc1 = torch.nn.Linear(nin, 32)
+            self.fc2 = torch.nn.Linear(32, nclass)
+        else:
+            self.fc1 = torch.nn.Linear(nin, 10)
+
+    def forward(self, data):
+        x = data.x
+        csr = data.csr('edge_index2')
+        for i in range(self.nlayers):
+            x = getattr(self, 'conv%d' % (i + 1))(x, csr, data.edge_attr2)
+            if self.bn:
+                x = getattr(self, 'bn%d' % (i + 1))(x)
+        x = global_add_pool(x, data) if self.pool == 'add' else global_mean_pool(x, data)
+        if self.head == 'mlp32':
+            return self.fc2(F.relu(self.fc1(x)))
+        return torch.tanh(self.fc1(x))
+
+
+class GNNML1Mutag(torch.nn.Module):
+    """mutag.py:214-266: three blocks of [relu(fc x) | relu(SpectConv_{S=1}(x)) | relu(fc x)*relu(fc x)] + BN."""
+
+    def __init__(self, ninp, nout1=16, nout2=32, nout3=16):
+        super().__init__()
+        nin = nout1 + nout2 + nout3
+        for i, fin in enumerate([ninp, nin, nin], start=1):
+            setattr(self, 'bn%d' % i, torch.nn.BatchNorm1d(nin))
+            setattr(self, 'conv%d1' % i, SpectConv(fin, nout2, 1, selfconn=False))
+            setattr(self, 'fc%d1' % i, torch.nn.Linear(fin, nout1))
+            setattr(self, 'fc%d2' % i, torch.nn.Linear(fin, nout3))
+            setattr(self, 'fc%d3' % i, torch.nn.Linear(fin, nout3))
+        self.fc1 = torch.nn.Linear(nin, 32)
+        self.fc2 = torch.nn.Linear(32, 1)
+
+    def forward(self, data):
+        x = data.x
+        csr = data.csr('edge_index')
+        ones = torch.ones(csr.E, 1, dtype=x.dtype, device=x.device)      # mutag.py:253
+        for i in (1, 2, 3):
+            g = lambda n: getattr(self, n % i)
+            x = torch.cat([F.relu(g('fc%d1')(x)), F.relu(g('conv%d1')(x, csr, ones)),
+                           F.relu(g('fc%d2')(x)) * F.relu(g('fc%d3')(x))], 1)
+            x = g('bn%d')(x)
+        x = global_mean_pool(x, data)
+        return self.fc2(F.relu(self.fc1(x)))
+
+
+def zinc_gnnml3(ninp=25, ne=8):            # Zinc12k.py:316-329
+    return GNNML3(ninp, ne, 30, 2, 4)
+
+
+def counting_gnnml3(ninp=2, ne=12):        # counting.py:343-358
+    return GNNML3(ninp, ne, 16, 16, 5)
+
+
+def sr25_gnnml3(ninp=2, ne=6):             # sr25.py:252-262
+    return GNNML3(ninp, ne, 32, 16, 3, head='tanh10')
+
+
+def mutag_gnnml3(ninp=8, ne=4):            # mutag.py:272-288
+    return GNNML3(ninp, ne, 24, 24, 3, learnedge=False, bn=True, pool='mean')
+
+
+def zinc_loss(pre, y):                     # Zinc12k.py:365
+    return F.l1_loss(pre, y.unsqueeze(-1), reduction='sum')
+
+
+def counting_loss(pre, y):                 # counting.py:411
+    return torch.square(pre - y.view(-1, 1)).sum()
+
+
+def mutag_loss(pre, y):                    # mutag.py:345-348
+    return F.binary_cross_entropy(torch.sigmoid(pre)[:, 0], y, reduction='sum')

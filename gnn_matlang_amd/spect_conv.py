@@ -1,0 +1,215 @@
+"""Drop-in modules for /root/reference/libs/spect_conv.py on MI355X.
+
+Same class names, constructor signatures, forward signatures, attributes, ``state_dict`` keys and
+parameter initialisation as the reference (SpectConv :23-103, SpectConCatConv :105-165,
+ML3Layer :182-212), so the GNNML1/GNNML3 model classes of the experiment scripts build on them
+unchanged and a reference checkpoint loads.  The arithmetic runs in the hand-written gfx950 kernels
+of libgml_hip.so; inputs must live on the GPU -- there is no CPU fallback.
+
+Differences a caller can observe: none in values beyond fp32 round-off (summation inside a target
+row keeps the reference's edge order; the projection is accumulated in a different order);
+``edge_index`` may also be a prebuilt ``GraphCSR``; the PyG ``MessagePassing`` base class is not
+required (only ``aggr='add'``, ``flow='source_to_target'``, ``node_dim=0`` exist in the reference).
+"""
+import math
+
+import torch
+from torch.nn import Parameter
+
+from .functional import ML3LayerFunction, SpectConvFunction
+from .graph import csr_for, GraphCSR, _require_cuda
+
+
+def glorot(tensor):
+    """U(-a, a), a = sqrt(6 / (size(-2) + size(-1)))   (libs/spect_conv.py:13-16)."""
+    if tensor is not None:
+        stdv = math.sqrt(6.0 / (tensor.size(-2) + tensor.size(-1)))
+        tensor.data.uniform_(-stdv, stdv)
+
+
+def zeros(tensor):
+    if tensor is not None:
+        tensor.data.fill_(0)
+
+
+def _check_mp_kwargs(kwargs):
+    aggr = kwargs.pop('aggr', 'add')
+    flow = kwargs.pop('flow', 'source_to_target')
+    node_dim = kwargs.pop('node_dim', 0)
+    if aggr != 'add' or flow != 'source_to_target' or node_dim != 0:
+        raise NotImplementedError("only aggr='add', flow='source_to_target', node_dim=0 are supported "
+                                  "(the reference uses no other setting)")
+    if kwargs:
+        raise TypeError('unexpected keyword arguments: %s' % sorted(kwargs))
+    return aggr, flow, node_dim
+
+
+def _sorted_values(csr, edge_index, edge_attr):
+    """supports in target-sorted order, differentiable w.r.t. edge_attr."""
+    _require_cuda(edge_attr, 'edge_attr')
+    if edge_attr.dim() == 1:
+        edge_attr = edge_attr.view(-1, 1)
+    if edge_attr.size(0) != csr.E:
+        raise ValueError('edge_attr has %d rows, edge_index has %d edges' % (edge_attr.size(0), csr.E))
+    if edge_attr.dtype != torch.float32:
+        raise TypeError('edge_attr must be float32, got %s' % edge_attr.dtype)
+    if edge_attr.requires_grad:
+        return _SortValues.apply(edge_attr, csr)
+    return csr.sort_values(edge_attr.detach())
+
+
+class _SortValues(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, edge_attr, csr):
+        ctx.csr = csr
+        return csr.sort_values(edge_attr.detach(), cache=False)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.csr.unsort_values(g.contiguous()), None
+
+
+class SpectConv(torch.nn.Module):
+    r"""out = sum_i (A_i^T x) W_i (+ x W_last if selfconn) + bias, A_i[src, dst] = edge_attr[e, i].
+
+    depthwise: out = ( DS_last*x [selfconn] + (1+DS_0)*H_0 + sum_{i>=1} DS_i*H_i ) W_0 + bias.
+    """
+
+    def __init__(self, in_channels, out_channels, K=1, selfconn=True, depthwise=False, bias=True, **kwargs):
+        super(SpectConv, self).__init__()
+        self.aggr, self.flow, self.node_dim = _check_mp_kwargs(kwargs)
+        assert K > 0
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.depthwise = depthwise
+        self.selfconn = selfconn
+        if self.selfconn:
+            K = K + 1
+        if self.depthwise:
+            self.DSweight = Parameter(torch.Tensor(K, in_channels))
+            self.nsup = K
+            K = 1
+        self.weight = Parameter(torch.Tensor(K, in_channels, out_channels))
+        if bias:
+            self.bias = Parameter(torch.Tensor(out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        glorot(self.weight)
+        zeros(self.bias)
+        if self.depthwise:
+            zeros(self.DSweight)
+
+    def _effective(self):
+        """(support weights [S, Fin, Fout], self weight [Fin, Fout] or None) of the equivalent plain form."""
+        if not self.depthwise:
+            if self.selfconn:
+                return self.weight[:-1], self.weight[-1]
+            return self.weight, None
+        ds = self.DSweight
+        nsup = self.nsup - 1 if self.selfconn else self.nsup
+        scale = torch.cat([1 + ds[0:1], ds[1:nsup]], 0)                 # [S, Fin]
+        w = scale.unsqueeze(-1) * self.weight[0].unsqueeze(0)           # diag(scale_s) W_0
+        wself = ds[-1].unsqueeze(-1) * self.weight[0] if self.selfconn else None
+        return w, wself
+
+    def forward(self, x, edge_index, edge_attr, edge_weight=None, batch=None, lambda_max=None):
+        _require_cuda(x, 'x')
+        csr = csr_for(edge_index, x.size(0))
+        w, wself = self._effective()
+        val = _sorted_values(csr, edge_index, edge_attr)
+        out = SpectConvFunction.apply(x, val, w.contiguous(), None if wself is not None else self.bias, csr, False)
+        if wself is not None:
+            out = torch.addmm(self.bias, x, wself) + out if self.bias is not None else torch.mm(x, wself) + out
+        return out
+
+    def __repr__(self):
+        return '{}({}, {}, K={})'.format(self.__class__.__name__, self.in_channels, self.out_channels,
+                                         self.weight.size(0))
+
+
+class SpectConCatConv(torch.nn.Module):
+    r"""out = cat_i( (A_i^T x) W_i ) (x W_last first if selfconn) + bias[K*Fout]."""
+
+    def __init__(self, in_channels, out_channels, K, selfconn=True, bias=True, **kwargs):
+        super(SpectConCatConv, self).__init__()
+        self.aggr, self.flow, self.node_dim = _check_mp_kwargs(kwargs)
+        assert K > 0
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.selfconn = selfconn
+        if self.selfconn:
+            K = K + 1
+        self.weight = Parameter(torch.Tensor(K, in_channels, out_channels))
+        if bias:
+            self.bias = Parameter(torch.Tensor(K * out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        glorot(self.weight)
+        zeros(self.bias)
+
+    def forward(self, x, edge_index, edge_attr, edge_weight=None, batch=None, lambda_max=None):
+        _require_cuda(x, 'x')
+        csr = csr_for(edge_index, x.size(0))
+        Kp, Fin, Fout = self.weight.shape
+        S = Kp - 1 if self.selfconn else Kp
+        val = _sorted_values(csr, edge_index, edge_attr)
+        # block-structured weights: support i only feeds output columns [i*Fout, (i+1)*Fout)
+        off = 1 if self.selfconn else 0
+        wbig = x.new_zeros(S, Fin, Kp * Fout)
+        for i in range(S):
+            wbig[i, :, (i + off) * Fout:(i + off + 1) * Fout] = self.weight[i]
+        out = SpectConvFunction.apply(x, val, wbig, None, csr, False)
+        if self.selfconn:
+            pad = x.new_zeros(Fin, Kp * Fout)
+            pad[:, :Fout] = self.weight[-1]
+            out = out + torch.mm(x, pad)
+        if self.bias is not None:
+            out = out + self.bias
+        return out
+
+    def __repr__(self):
+        return '{}({}, {}, K={})'.format(self.__class__.__name__, self.in_channels, self.out_channels,
+                                         self.weight.size(0))
+
+
+class ML3Layer(torch.nn.Module):
+    """One GNNML3 layer: optional per-edge MLP on the supports, relu(SpectConv) || tanh(fc11 x)*tanh(fc12 x)."""
+
+    def __init__(self, learnedge, nedgeinput, nedgeoutput, ninp, nout1, nout2):
+        super(ML3Layer, self).__init__()
+        self.learnedge = learnedge
+        self.nout2 = nout2
+        if self.learnedge:
+            self.fc1_1 = torch.nn.Linear(nedgeinput, 2 * nedgeinput, bias=False)
+            self.fc1_2 = torch.nn.Linear(nedgeinput, 2 * nedgeinput, bias=False)
+            self.fc1_3 = torch.nn.Linear(nedgeinput, 2 * nedgeinput, bias=False)
+            self.fc1_4 = torch.nn.Linear(4 * nedgeinput, nedgeoutput, bias=False)
+        else:
+            nedgeoutput = nedgeinput
+        self.conv1 = SpectConv(ninp, nout1, nedgeoutput, selfconn=False)
+        if nout2 > 0:
+            self.fc11 = torch.nn.Linear(ninp, nout2)
+            self.fc12 = torch.nn.Linear(ninp, nout2)
+
+    def forward(self, x, edge_index, edge_attr):
+        _require_cuda(x, 'x')
+        csr = csr_for(edge_index, x.size(0))
+        val = _sorted_values(csr, edge_index, edge_attr)
+        le, n2 = self.learnedge, self.nout2
+        return ML3LayerFunction.apply(
+            x, val,
+            self.fc1_1.weight if le else None, self.fc1_2.weight if le else None,
+            self.fc1_3.weight if le else None, self.fc1_4.weight if le else None,
+            self.conv1.weight, self.conv1.bias,
+            self.fc11.weight if n2 > 0 else None, self.fc11.bias if n2 > 0 else None,
+            self.fc12.weight if n2 > 0 else None, self.fc12.bias if n2 > 0 else None,
+            csr, le, n2)
+
+
+__all__ = ['SpectConv', 'SpectConCatConv', 'ML3Layer', 'GraphCSR', 'glorot', 'zeros']

@@ -1,0 +1,135 @@
+/*
+ * gml.h -- C ABI of libgml_hip.so: the MI355X (gfx950) kernels behind the GNNML1/GNNML3
+ * spectral layer (SpectConv / ML3Layer of balcilar/gnn-matlang).
+ *
+ * Conventions
+ *   - every entry point returns int: 0 = ok, >0 = hipError_t, <0 = GML_E_* argument error;
+ *   - no allocation, no global state, no synchronisation inside: the caller owns every buffer
+ *     (device pointers), passes the hipStream_t the work is ordered on, and sizes scratch with
+ *     the *_workspace_bytes helpers;
+ *   - all matrices are row-major fp32 with an explicit leading dimension in ELEMENTS;
+ *     node ids / edge positions are int32 on the device (int64 only at the COO boundary, which
+ *     is what the reference hands over);
+ *   - inputs are never written.
+ *
+ * What each entry replaces in the reference (pure Python, so the "FFI" a maintainer binds is
+ * ctypes -- see INTEGRATION.md):
+ *   gml_csr_*            nothing (the reference hands edge_index [2,E] int64 straight to PyG
+ *                        MessagePassing.propagate, libs/spect_conv.py:77); the CSR keeps PyG's
+ *                        per-target summation order (stable in input-edge order)
+ *   gml_spectconv_fwd    SpectConv.forward default branch, libs/spect_conv.py:68-80,93-96 +
+ *                        message :98-99 + PyG propagate (gather, scale, scatter-add) + matmul
+ *   gml_spmm_fwd         the S propagate() calls alone (libs/spect_conv.py:77): H_s = A_s^T X
+ *   gml_sddmm            autograd of message() w.r.t. norm (libs/spect_conv.py:98-99)
+ *   gml_edge_mlp_*       ML3Layer.forward edge branch, libs/spect_conv.py:205-207
+ *   gml_node_mix_*       ML3Layer.forward Hadamard branch, libs/spect_conv.py:209 (tanh*tanh)
+ *   gml_relu_bwd / gml_segment_sum   glue the fused layer needs around the above
+ */
+#ifndef GML_H_
+#define GML_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* gml_stream_t; /* hipStream_t */
+
+enum {
+    GML_OK = 0,
+    GML_E_BADARG = -1,       /* null pointer / negative size / bad stride */
+    GML_E_UNSUPPORTED = -2,  /* shape outside the compiled kernel set */
+    GML_E_WORKSPACE = -3     /* workspace too small */
+};
+
+/* flags of gml_spectconv_fwd */
+enum {
+    GML_RELU = 1,   /* out = max(out, 0) in the epilogue          (ML3Layer: relu(conv1(..))) */
+    GML_ACCUM = 2   /* out += result instead of out = result      (gradient accumulation)     */
+};
+
+int gml_version(void);
+/* static string for any return code of this library (hipGetErrorString for >0) */
+const char* gml_error_string(int code);
+
+/* ---------------------------------------------------------------- CSR build (integer-exact)
+ * Stable sort of the COO edge list by `key` (key = dst for the forward view, key = src for the
+ * transposed view): rowptr[N+1], other[E] = the non-key endpoint of each sorted edge, perm[E] =
+ * input edge id of each sorted edge (ascending inside a row).  ws: gml_csr_workspace_bytes(). */
+size_t gml_csr_workspace_bytes(int64_t num_nodes, int64_t num_edges);
+int gml_csr_from_coo(const int64_t* key, const int64_t* other_in, int64_t num_nodes, int64_t num_edges,
+                     int32_t* rowptr, int32_t* other, int32_t* perm,
+                     void* ws, size_t ws_bytes, gml_stream_t stream);
+/* pos_t[j] = inverse(perm_fwd)[perm_t[j]]: where, in forward (target-sorted) order, the j-th
+ * source-sorted edge keeps its values.  inv_scratch: E int32. */
+int gml_csr_link_transpose(const int32_t* perm_fwd, const int32_t* perm_t, int64_t num_edges,
+                           int32_t* inv_scratch, int32_t* pos_t, gml_stream_t stream);
+/* out[k, :] = in[perm[k], :]   (rows of `width` floats) */
+int gml_gather_rows(const float* in, const int32_t* perm, float* out, int64_t rows, int32_t width,
+                    gml_stream_t stream);
+/* out[perm[k], :] = in[k, :] */
+int gml_scatter_rows(const float* in, const int32_t* perm, float* out, int64_t rows, int32_t width,
+                     gml_stream_t stream);
+
+/* ---------------------------------------------------------------- fused multi-support layer
+ *   out[r, 0:Fout] (op)= act( sum_s ( sum_{k in row r} val[pos(k), s] * x[col[k], :] ) @ W[s] + bias )
+ * rowptr/col: CSR keyed by the OUTPUT row; pos(k) = epos ? epos[k] : k; val is [E, S] (S contiguous).
+ * W element (s, i, o) lives at w[s*w_ss + i*w_si + o*w_so] so the transposed weights of the
+ * backward pass need no copy.  bias may be NULL.  Used for: forward (CSR by target, x = X),
+ * d/dX (CSR by source, x = dOut, W transposed view, epos = pos_t). */
+int gml_spectconv_fwd(const int32_t* rowptr, const int32_t* col, const int32_t* epos,
+                      const float* val, const float* x, int64_t ldx,
+                      const float* w, int64_t w_ss, int64_t w_si, int64_t w_so,
+                      const float* bias, float* out, int64_t ldo,
+                      int64_t num_rows, int32_t S, int32_t Fin, int32_t Fout,
+                      uint32_t flags, gml_stream_t stream);
+
+/* H[r, s, :] = sum_{k in row r} val[pos(k), s] * x[col[k], :]     H is [N, S, Fin] contiguous */
+int gml_spmm_fwd(const int32_t* rowptr, const int32_t* col, const int32_t* epos,
+                 const float* val, const float* x, int64_t ldx, float* h,
+                 int64_t num_rows, int32_t S, int32_t Fin, gml_stream_t stream);
+
+/* dval[pos(k), s] = < x[col[k], :], gw[r, s, :] >  for k in row r;   gw is [N, S, Fin] contiguous */
+int gml_sddmm(const int32_t* rowptr, const int32_t* col, const int32_t* epos,
+              const float* x, int64_t ldx, const float* gw, float* dval,
+              int64_t num_rows, int32_t S, int32_t Fin, gml_stream_t stream);
+
+/* ---------------------------------------------------------------- ML3Layer edge branch
+ *   out = relu( W4 . [ relu(W1 . e) ; tanh(W2 . e) * tanh(W3 . e) ] )      per edge e in R^S
+ * w1,w2,w3: [2S, S]; w4: [Sout, 4S]  (torch.nn.Linear layout, bias-free).  S, Sout <= 16. */
+int gml_edge_mlp_fwd(const float* ea, const float* w1, const float* w2, const float* w3, const float* w4,
+                     float* out, int64_t num_edges, int32_t S, int32_t Sout, gml_stream_t stream);
+size_t gml_edge_mlp_bwd_workspace_bytes(int64_t num_edges, int32_t S, int32_t Sout);
+/* gout: dL/dout [E, Sout].  Writes dw1..dw4 (same shapes as the weights) and, if gin != NULL,
+ * dL/dea [E, S].  Intermediates are recomputed from ea. */
+int gml_edge_mlp_bwd(const float* ea, const float* w1, const float* w2, const float* w3, const float* w4,
+                     const float* gout, float* gin, float* dw1, float* dw2, float* dw3, float* dw4,
+                     int64_t num_edges, int32_t S, int32_t Sout,
+                     void* ws, size_t ws_bytes, gml_stream_t stream);
+
+/* ---------------------------------------------------------------- ML3Layer Hadamard branch
+ *   out[r, 0:F2] = tanh(x[r] . w11^T + b11) * tanh(x[r] . w12^T + b12)      w1x: [F2, Fin] */
+int gml_node_mix_fwd(const float* x, int64_t ldx, const float* w11, const float* b11,
+                     const float* w12, const float* b12, float* out, int64_t ldo,
+                     int64_t num_rows, int32_t Fin, int32_t F2, gml_stream_t stream);
+/* gz[r, 0:F2] = dL/dz11, gz[r, F2:2F2] = dL/dz12 (pre-activation grads), recomputed from x.
+ * gout: dL/dout with leading dimension ldg.  gz is [N, 2*F2] contiguous. */
+int gml_node_mix_bwd(const float* x, int64_t ldx, const float* w11, const float* b11,
+                     const float* w12, const float* b12, const float* gout, int64_t ldg,
+                     float* gz, int64_t num_rows, int32_t Fin, int32_t F2, gml_stream_t stream);
+
+/* ---------------------------------------------------------------- glue
+ * g[r, c] = (y[r, c] > 0) ? gy[r, c] : 0   for c < F        (relu backward on a strided slice) */
+int gml_relu_bwd(const float* gy, int64_t ldgy, const float* y, int64_t ldy, float* g, int64_t ldg,
+                 int64_t num_rows, int32_t F, gml_stream_t stream);
+/* out[g, :] = sum_{r in [ptr[g], ptr[g+1])} x[r, :]  (global_add_pool over a sorted batch vector;
+ * mean != 0 divides by the segment length: global_mean_pool) */
+int gml_segment_sum(const float* x, int64_t ldx, const int32_t* ptr, float* out, int64_t ldo,
+                    int64_t num_segments, int32_t F, int32_t mean, gml_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GML_H_ */

@@ -1,0 +1,361 @@
+"""GPU parity: the HIP path (through the C ABI of libgml_hip.so) against the oracle and the golden
+vectors captured from the reference.  Tolerance: north_star's 1e-4 relative fp32
+(max|got-ref| / max|ref| <= 1e-4, conftest.rel_err); integer/index work bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+T = lambda a: torch.tensor(np.asarray(a))
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    from gnn_matlang_amd import _lib
+    assert _lib.lib().gml_version() >= 1          # the .so is loaded: no silent fallback exists
+    return torch.device('cuda:0')
+
+
+def cu(a, dev):
+    return T(a).to(dev)
+
+
+def close(got, ref, tol=TOL, what=''):
+    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    ref = ref.detach().cpu().numpy() if isinstance(ref, torch.Tensor) else np.asarray(ref)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert np.isfinite(got).all(), what
+    e = rel_err(got, ref)
+    assert e <= tol, '%s: rel err %.3e > %.1e' % (what, e, tol)
+
+
+# ------------------------------------------------------------------------------------------ CSR
+def _csr_check(ei, N, dev):
+    from gnn_matlang_amd.graph import GraphCSR
+    from oracle.csr_oracle import csr_from_coo, transpose_view
+    g = GraphCSR.from_edge_index(cu(ei, dev), N)
+    rowptr, col, perm = csr_from_coo(ei[0], ei[1], N)
+    rp_t, col_t, pos_t = transpose_view(ei[0], ei[1], N, perm)
+    for got, ref, name in ((g.rowptr, rowptr, 'rowptr'), (g.col, col, 'col'), (g.perm, perm, 'perm'),
+                           (g.rowptr_t, rp_t, 'rowptr_t'), (g.col_t, col_t, 'col_t'), (g.pos_t, pos_t, 'pos_t')):
+        assert np.array_equal(got.cpu().numpy(), ref), name          # integer work: bit-exact
+
+
+def test_csr_bit_exact(dev, golden):
+    for f in ('model_zinc_gnnml3.npz', 'model_counting_gnnml3.npz', 'model_mutag_gnnml3.npz',
+              'model_sr25_gnnml3.npz'):
+        g = golden(f)
+        _csr_check(g['batch/edge_index2'], g['batch/x'].shape[0], dev)
+        _csr_check(g['batch/edge_index'], g['batch/x'].shape[0], dev)
+    rng = np.random.default_rng(0)
+    # unsorted input with duplicates, empty rows and a long row (stability matters)
+    N, E = 5000, 60000
+    ei = rng.integers(0, N, size=(2, E))
+    ei[1, :3000] = 17
+    ei[:, 100:110] = ei[:, 90:100]
+    _csr_check(ei, N, dev)
+    _csr_check(np.zeros((2, 0), dtype=np.int64), 7, dev)            # no edges
+    _csr_check(np.array([[0], [0]], dtype=np.int64), 1, dev)
+
+
+def test_csr_large_is_stable_sort(dev):
+    from gnn_matlang_amd.graph import GraphCSR
+    torch.manual_seed(0)
+    N, E = 1_500_000, 9_000_000
+    src = torch.randint(0, N, (E,), device=dev)
+    dst = (src + torch.randint(-20, 21, (E,), device=dev)).clamp_(0, N - 1)
+    g = GraphCSR.from_edge_index(torch.stack([src, dst]), N)
+    perm = g.perm.long()
+    d = dst[perm]
+    assert bool((d[1:] >= d[:-1]).all())                                   # sorted by target
+    same = d[1:] == d[:-1]
+    assert bool((perm[1:][same] > perm[:-1][same]).all())                  # stable inside a row
+    assert bool((g.col.long() == src[perm]).all())
+    assert int(g.rowptr[-1]) == E
+    assert bool((torch.bincount(dst, minlength=N) == (g.rowptr[1:] - g.rowptr[:-1])).all())
+    assert bool((perm[g.pos_t.long()] == g.perm_t.long()).all())
+
+
+# ------------------------------------------------------------------------------------------ SpectConv
+def test_spectconv_golden(dev, golden):
+    from gnn_matlang_amd import SpectConv
+    g = golden('spectconv.npz')
+    for k in range(int(g['ncases'])):
+        c = g.sub('case%03d/' % k)
+        S, fin, fout, selfconn, depthwise, bias = [int(v) for v in c['meta']]
+        m = SpectConv(fin, fout, S, selfconn=bool(selfconn), depthwise=bool(depthwise), bias=bool(bias)).to(dev)
+        sd = {'weight': T(c['weight'])}
+        if bias:
+            sd['bias'] = T(c['bias'])
+        if depthwise:
+            sd['DSweight'] = T(c['DSweight'])
+        m.load_state_dict(sd)
+        x = cu(c['x'], dev).requires_grad_(True)
+        ea = cu(c['edge_attr'], dev).requires_grad_(True)
+        y = m(x, cu(c['edge_index'], dev), ea)
+        what = 'case %d meta %s' % (k, c['meta'])
+        close(y, c['out'], what=what + ' out')
+        (y * cu(c['gout'], dev)).sum().backward()
+        close(x.grad, c['g_x'], what=what + ' g_x')
+        close(ea.grad, c['g_edge_attr'], what=what + ' g_edge_attr')
+        close(m.weight.grad, c['g_weight'], what=what + ' g_weight')
+        if bias:
+            close(m.bias.grad, c['g_bias'], what=what + ' g_bias')
+        if depthwise:
+            close(m.DSweight.grad, c['g_DSweight'], what=what + ' g_DSweight')
+
+
+def test_spectconcat_golden(dev, golden):
+    from gnn_matlang_amd import SpectConCatConv
+    g = golden('spectconv.npz')
+    for k in range(int(g['nconcat'])):
+        c = g.sub('concat%d/' % k)
+        S, fin, fout, selfconn = [int(v) for v in c['meta']]
+        m = SpectConCatConv(fin, fout, S, selfconn=bool(selfconn)).to(dev)
+        m.load_state_dict({'weight': T(c['weight']), 'bias': T(c['bias'])})
+        x = cu(c['x'], dev).requires_grad_(True)
+        ea = cu(c['edge_attr'], dev).requires_grad_(True)
+        y = m(x, cu(c['edge_index'], dev), ea)
+        close(y, c['out'], what='concat out')
+        (y * cu(c['gout'], dev)).sum().backward()
+        close(x.grad, c['g_x'], what='concat g_x')
+        close(ea.grad, c['g_edge_attr'], what='concat g_ea')
+        close(m.weight.grad, c['g_weight'], what='concat g_w')
+        close(m.bias.grad, c['g_bias'], what='concat g_b')
+
+
+def _random_graph(rng, N, deg, sort=True):
+    src = np.repeat(np.arange(N), deg)
+    dst = np.clip(src + rng.integers(-6, 7, size=src.shape), 0, N - 1)
+    ei = np.unique(np.vstack((src, dst)), axis=1)      # row-major order like np.where
+    return ei.astype(np.int64)
+
+
+@pytest.mark.parametrize('S,fin,fout', [(1, 1, 1), (2, 3, 17), (5, 25, 30), (7, 32, 33), (9, 20, 16), (10, 48, 8),
+                                        (11, 64, 64), (12, 2, 16), (12, 32, 16), (13, 36, 40), (16, 16, 130),
+                                        (24, 32, 32), (48, 48, 32), (6, 128, 128), (6, 2, 64), (3, 200, 24)])
+def test_fused_forward_and_grads_vs_oracle(dev, S, fin, fout):
+    """shape sweep (support splits, odd widths, Fout > 128, wide Fin) against the CPU oracle."""
+    from gnn_matlang_amd import SpectConv
+    from oracle import spect_conv_oracle as O
+    rng = np.random.default_rng(S * 1000 + fin)
+    torch.manual_seed(S * 7 + fout)
+    N = 203                                            # not a multiple of 16; includes empty rows
+    ei = _random_graph(rng, N, 5)
+    ei = ei[:, ei[1] != 77]                            # node 77 has no in-edges
+    E = ei.shape[1]
+    ea = torch.randn(E, S)
+    x = torch.randn(N, fin)
+    m = SpectConv(fin, fout, S, selfconn=False).to(dev)
+    with torch.no_grad():
+        m.bias.uniform_(-0.5, 0.5)
+    w, b = m.weight.detach().cpu(), m.bias.detach().cpu()
+    xo, eo, wo, bo = (t.clone().requires_grad_(True) for t in (x, ea, w, b))
+    yo = O.spectconv_forward(xo, T(ei), eo, wo, bo, False)
+    gout = torch.randn_like(yo)
+    (yo * gout).sum().backward()
+    xg, eg = x.to(dev).requires_grad_(True), ea.to(dev).requires_grad_(True)
+    y = m(xg, T(ei).to(dev), eg)
+    close(y, yo, what='out')
+    (y * gout.to(dev)).sum().backward()
+    close(xg.grad, xo.grad, what='g_x')
+    close(eg.grad, eo.grad, what='g_edge_attr')
+    close(m.weight.grad, wo.grad, what='g_weight')
+    close(m.bias.grad, bo.grad, what='g_bias')
+
+
+def test_empty_and_tiny_inputs(dev):
+    from gnn_matlang_amd import SpectConv, ML3Layer
+    m = SpectConv(4, 3, 2, selfconn=False).to(dev)
+    x = torch.randn(5, 4, device=dev)
+    ei = torch.zeros(2, 0, dtype=torch.int64, device=dev)
+    y = m(x, ei, torch.zeros(0, 2, device=dev))                     # no edges: out = bias
+    assert torch.equal(y, m.bias.detach().expand(5, 3))
+    l = ML3Layer(True, 2, 2, 4, 3, 2).to(dev)
+    xg = x.clone().requires_grad_(True)
+    out = l(xg, ei, torch.zeros(0, 2, device=dev))
+    out.sum().backward()
+    assert out.shape == (5, 5) and torch.isfinite(xg.grad).all()
+    assert float(l.fc1_1.weight.grad.abs().sum()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------ C ABI pieces
+def test_spmm_sddmm_edge_mlp_node_mix_vs_oracle(dev):
+    from gnn_matlang_amd import functional as Fn
+    from gnn_matlang_amd.graph import GraphCSR
+    from oracle import spect_conv_oracle as O
+    rng = np.random.default_rng(5)
+    torch.manual_seed(5)
+    N = 333
+    ei = _random_graph(rng, N, 6)
+    E = ei.shape[1]
+    csr = GraphCSR.from_edge_index(T(ei).to(dev), N)
+    for S, fin in ((8, 32), (3, 7), (12, 70), (1, 130)):
+        ea, x = torch.randn(E, S), torch.randn(N, fin)
+        val = csr.sort_values(ea.to(dev), cache=False)
+        h = Fn.spmm(csr, val, x.to(dev), S, fin).view(N, S, fin)
+        href = torch.stack([O.propagate_add(x, T(ei), ea[:, s]) for s in range(S)], 1)
+        close(h, href, what='spmm S=%d' % S)
+        gw = torch.randn(N, S, fin)
+        dval = csr.unsort_values(Fn.sddmm(csr, x.to(dev), gw.to(dev).view(N, S * fin), S, fin))
+        ref = torch.einsum('ef,esf->es', x[ei[0]], gw[ei[1]])
+        close(dval, ref, what='sddmm S=%d' % S)
+    for S in range(1, 17):
+        E2 = 1000 + S
+        ea = torch.randn(E2, S)
+        ws = [torch.randn(2 * S, S) * 0.7 for _ in range(3)] + [torch.randn(S, 4 * S) * 0.5]
+        eo = ea.clone().requires_grad_(True)
+        wo = [w.clone().requires_grad_(True) for w in ws]
+        yo = O.edge_mlp_forward(eo, *wo)
+        gout = torch.randn_like(yo)
+        (yo * gout).sum().backward()
+        wd = [w.to(dev) for w in ws]
+        y = Fn.edge_mlp_fwd(ea.to(dev), *wd)
+        close(y, yo, what='edge mlp fwd S=%d' % S)
+        gin, d1, d2, d3, d4 = Fn.edge_mlp_bwd(ea.to(dev), *wd, gout.to(dev), True)
+        close(gin, eo.grad, what='edge mlp gin S=%d' % S)
+        for got, w, n in ((d1, wo[0], 'dw1'), (d2, wo[1], 'dw2'), (d3, wo[2], 'dw3'), (d4, wo[3], 'dw4')):
+            close(got, w.grad, what='edge mlp %s S=%d' % (n, S))
+
+
+# ------------------------------------------------------------------------------------------ ML3Layer
+def test_ml3layer_golden(dev, golden):
+    from gnn_matlang_amd import ML3Layer
+    g = golden('ml3layer.npz')
+    for k in range(int(g['ncases'])):
+        c = g.sub('case%03d/' % k)
+        learnedge, ne, neo, ninp, nout1, nout2 = [int(v) for v in c['meta']]
+        m = ML3Layer(bool(learnedge), ne, neo, ninp, nout1, nout2).to(dev)
+        m.load_state_dict({n[len('param/'):]: T(v) for n, v in c.items() if n.startswith('param/')})
+        x = cu(c['x'], dev).requires_grad_(True)
+        ea = cu(c['edge_attr'], dev).requires_grad_(True)
+        y = m(x, cu(c['edge_index'], dev), ea)
+        what = 'ml3 case %d %s' % (k, c['meta'])
+        close(y, c['out'], what=what + ' out')
+        (y * cu(c['gout'], dev)).sum().backward()
+        close(x.grad, c['g_x'], what=what + ' g_x')
+        close(ea.grad, c['g_edge_attr'], what=what + ' g_edge_attr')
+        for n, p in m.named_parameters():
+            close(p.grad, c['grad/' + n], what=what + ' ' + n)
+
+
+# ------------------------------------------------------------------------------------------ models (H1-H5)
+def _batch_from(g, dev):
+    from gnn_matlang_amd.graph import Batch
+    b = g.sub('batch/')
+    ptr = np.concatenate([[0], np.cumsum(np.bincount(b['batch']))]).astype(np.int32)
+    return Batch(x=T(b['x']), edge_index=T(b['edge_index']), edge_index2=T(b['edge_index2']),
+                 edge_attr2=T(b['edge_attr2']), batch=T(b['batch']), ptr=T(ptr), y=T(b['y'])).to(dev)
+
+
+@pytest.mark.parametrize('fname,ctor,loss', [
+    ('model_zinc_gnnml3.npz', 'zinc_gnnml3', 'zinc_loss'),
+    ('model_counting_gnnml3.npz', 'counting_gnnml3', 'counting_loss'),
+    ('model_mutag_gnnml3.npz', 'mutag_gnnml3', 'mutag_loss'),
+    ('model_mutag_gnnml1.npz', 'GNNML1Mutag', 'mutag_loss'),
+])
+def test_model_step_golden(dev, golden, fname, ctor, loss):
+    from gnn_matlang_amd import models
+    g = golden(fname)
+    data = _batch_from(g, dev)
+    m = getattr(models, ctor)(8) if ctor == 'GNNML1Mutag' else getattr(models, ctor)()
+    m.load_state_dict({k: T(v) for k, v in g.sub('param/').items()})      # reference state_dict keys
+    m = m.to(dev).train()
+    loss_fn = getattr(models, loss)
+    pre = m(data)
+    l = loss_fn(pre, data.y)
+    l.backward()
+    close(pre, g['logits'], what='logits')
+    assert abs(l.item() - float(g['loss'])) <= TOL * abs(float(g['loss']))
+    for n, p in m.named_parameters():
+        close(p.grad, g['grad/' + n], tol=2e-4, what='grad ' + n)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    traj = []
+    for _ in range(5):
+        opt.zero_grad()
+        l = loss_fn(m(data), data.y)
+        l.backward()
+        opt.step()
+        traj.append(l.item())
+    np.testing.assert_allclose(traj, g['loss_traj'], rtol=2e-4)
+
+
+def test_sr25_isomorphism_golden(dev, golden):
+    """sr25.py:282-300 -- forward only, untrained nets, pairs never separated across seeds."""
+    from gnn_matlang_amd import models
+    g = golden('model_sr25_gnnml3.npz')
+    data = _batch_from(g, dev)
+    Mcnt = 0
+    for seed in range(3):
+        m = models.sr25_gnnml3()
+        m.load_state_dict({k: T(v) for k, v in g.sub('seed%d/param/' % seed).items()})
+        m = m.to(dev).eval()
+        with torch.no_grad():
+            E = m(data).cpu().numpy()
+        close(E, g['seed%d/emb' % seed], what='sr25 embeddings seed %d' % seed)
+        Mcnt = Mcnt + 1 * (np.abs(E[:, None] - E[None]).sum(2) > 0.001)
+        assert int(((Mcnt == 0).sum() - 15) / 2) == int(g['seed%d/similar' % seed])
+
+
+# ------------------------------------------------------------------------------------------ full size
+def _big_zinc_batch(dev, ngraph_pool=512, reps=64):
+    from gnn_matlang_amd import synthetic, SpectralDesign
+    from gnn_matlang_amd.graph import collate
+    raw = synthetic.make_graphs('zinc', ngraph_pool, seed=3)
+    ds = SpectralDesign(recfield=2, dv=2, nfreq=7).design_many(raw)
+    return collate(ds * reps).to(dev)
+
+
+def test_full_size_properties(dev):
+    """BASELINE-size ZINC-like batch (32768 graphs, ~0.75M nodes, ~4.9M support edges): properties that
+    need no oracle -- bitwise run-to-run determinism (no atomics on the value path), linearity in x,
+    fused forward == unfused SpMM + GEMM, d/dx matches a directional finite difference in fp64 of the
+    same fp32 function within tolerance, and agreement with the oracle on a slice of whole graphs."""
+    from gnn_matlang_amd import ML3Layer, SpectConv, functional as Fn
+    from oracle import spect_conv_oracle as O
+    torch.manual_seed(0)
+    data = _big_zinc_batch(dev)
+    N = data.x.size(0)
+    csr = data.csr()
+    conv = SpectConv(25, 30, 8, selfconn=False).to(dev)
+    y1 = conv(data.x, csr, data.edge_attr2)
+    y2 = conv(data.x, csr, data.edge_attr2)
+    assert torch.equal(y1, y2)                                             # deterministic
+    x2 = torch.randn_like(data.x)
+    ya = conv(data.x + 2 * x2, csr, data.edge_attr2) - conv.bias
+    yb = (y1 - conv.bias) + 2 * (conv(x2, csr, data.edge_attr2) - conv.bias)
+    close(ya, yb, what='linearity')
+    val = csr.sort_values(data.edge_attr2)
+    h = Fn.spmm(csr, val, data.x, 8, 25)
+    yu = torch.addmm(conv.bias, h, conv.weight.view(8 * 25, 30))
+    close(y1, yu, what='fused vs unfused')
+    # oracle on the first 40 graphs (whole graphs: block-diagonal => independent of the rest)
+    ng = 40
+    n0 = int(data.ptr[ng])
+    e_mask = (data.edge_index2[1] < n0)
+    ei = data.edge_index2[:, e_mask].cpu()
+    ea = data.edge_attr2[e_mask].cpu()
+    layer = ML3Layer(True, 8, 8, 25, 30, 2).to(dev)
+    out = layer(data.x, csr, data.edge_attr2)
+    p = {n: v.detach().cpu() for n, v in layer.named_parameters()}
+    ref = O.ml3layer_forward(data.x[:n0].cpu(), ei, ea, p, True, 2)
+    close(out[:n0], ref, what='ML3Layer vs oracle on a slice')
+    # gradients at full size: sharded evaluation must give the same parameter gradients
+    out.square().sum().backward()
+    gfull = {n: v.grad.clone() for n, v in layer.named_parameters()}
+    layer.zero_grad()
+    from gnn_matlang_amd.graph import GraphCSR
+    half = int(data.ptr[data.num_graphs // 2])
+    acc = None
+    for lo, hi in ((0, half), (half, N)):
+        m = (data.edge_index2[1] >= lo) & (data.edge_index2[1] < hi)
+        ei_s = (data.edge_index2[:, m] - lo).contiguous()
+        o = layer(data.x[lo:hi].contiguous(), GraphCSR.from_edge_index(ei_s, hi - lo), data.edge_attr2[m].contiguous())
+        o.square().sum().backward()
+    for n, v in layer.named_parameters():
+        close(v.grad, gfull[n], tol=5e-4, what='sharded grad ' + n)

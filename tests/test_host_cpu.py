@@ -1,0 +1,156 @@
+"""CPU: host-side logic of the product package (no kernel launches): module surface == reference
+surface, SpectralDesign against the golden vectors, collate/sharding, the C-ABI library loads and
+exports what include/gml.h declares, and the GPU-only path refuses CPU tensors loudly."""
+import ast
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import gnn_matlang_amd as G
+from gnn_matlang_amd import _lib, models, synthetic
+from gnn_matlang_amd.graph import collate, shard_graphs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+T = lambda a: torch.tensor(np.asarray(a))
+
+
+def test_library_exports_match_header():
+    hdr = open(os.path.join(ROOT, 'include', 'gml.h')).read()
+    names = set(re.findall(r'\b(gml_[a-z0-9_]+)\s*\(', hdr))
+    assert len(names) >= 15
+    assert names == set(_lib.SIGNATURES), names ^ set(_lib.SIGNATURES)
+    L = ctypes.CDLL(_lib.LIB_PATH)                   # loads without a GPU
+    for n in names:
+        assert hasattr(L, n), n
+    assert _lib.lib().gml_version() >= 1
+    assert b'workspace' in _lib.lib().gml_error_string(-3)
+
+
+def test_cpu_tensors_fail_loudly():
+    m = G.SpectConv(4, 3, 2, selfconn=False)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        m(torch.randn(5, 4), torch.zeros(2, 0, dtype=torch.int64), torch.zeros(0, 2))
+    l = G.ML3Layer(True, 2, 2, 4, 3, 2)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        l(torch.randn(5, 4), torch.zeros(2, 0, dtype=torch.int64), torch.zeros(0, 2))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'gnn_matlang_amd')
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, re.M), f
+                assert '/root/reference' not in src.replace('/root/reference/', 'REF/'), f
+
+
+def test_module_surface_matches_reference(golden):
+    # ctor signature, attributes, repr, K handling (libs/spect_conv.py:26-56,101-103)
+    m = G.SpectConv(7, 5, 3)
+    assert m.selfconn and not m.depthwise and m.weight.shape == (4, 7, 5) and m.bias.shape == (5,)
+    assert repr(m) == 'SpectConv(7, 5, K=4)'
+    m = G.SpectConv(7, 5, 3, selfconn=False, depthwise=True, bias=False)
+    assert m.weight.shape == (1, 7, 5) and m.DSweight.shape == (3, 7) and m.nsup == 3 and m.bias is None
+    assert list(m.state_dict()) == ['DSweight', 'weight']
+    assert float(m.DSweight.abs().sum()) == 0.0
+    bound = (6.0 / (7 + 5)) ** 0.5
+    assert float(m.weight.abs().max()) <= bound
+    with pytest.raises(AssertionError):
+        G.SpectConv(3, 3, 0)
+    with pytest.raises(NotImplementedError):
+        G.SpectConv(3, 3, 1, aggr='mean')
+    c = G.SpectConCatConv(4, 6, 2)
+    assert c.weight.shape == (3, 4, 6) and c.bias.shape == (18,)
+    # ML3Layer state_dict keys/shapes == the reference's (captured in the golden fixture)
+    g = golden('ml3layer.npz')
+    for k in range(int(g['ncases'])):
+        c = g.sub('case%03d/' % k)
+        learnedge, ne, neo, ninp, nout1, nout2 = [int(v) for v in c['meta']]
+        l = G.ML3Layer(bool(learnedge), ne, neo, ninp, nout1, nout2)
+        ref = {n[len('param/'):]: v.shape for n, v in c.items() if n.startswith('param/')}
+        assert {n: tuple(v.shape) for n, v in l.state_dict().items()} == ref
+        assert l.learnedge == bool(learnedge) and l.nout2 == nout2
+    # model assemblies load the reference state_dicts
+    for f, ctor in (('model_zinc_gnnml3.npz', models.zinc_gnnml3), ('model_counting_gnnml3.npz', models.counting_gnnml3),
+                    ('model_mutag_gnnml3.npz', models.mutag_gnnml3), ('model_mutag_gnnml1.npz', lambda: models.GNNML1Mutag(8))):
+        ctor().load_state_dict({k: T(v) for k, v in golden(f).sub('param/').items()})
+    assert sum(p.numel() for p in models.zinc_gnnml3().parameters()) == 33309
+    assert sum(p.numel() for p in models.counting_gnnml3().parameters()) == 37649
+    assert sum(p.numel() for p in models.sr25_gnnml3().parameters()) == 23714
+
+
+def test_compat_import_path():
+    from gnn_matlang_amd.libs.spect_conv import SpectConv, ML3Layer
+    from gnn_matlang_amd.libs.utils import SpectralDesign, get_n_params
+    assert SpectConv is G.SpectConv and ML3Layer is G.ML3Layer and SpectralDesign is G.SpectralDesign
+    assert get_n_params(torch.nn.Linear(3, 2)) == 8
+
+
+def test_spectral_design_matches_reference_vectors(golden):
+    g = golden('spectral_design.npz')
+    for k in range(int(g['ncases'])):
+        c = g.sub('case%02d/' % k)
+        kw = ast.literal_eval(str(c['kw']))
+        d = G.SpectralDesign(**kw).design_many([(c['in_x'], c['in_edge_index'], 0)])[0]
+        assert np.array_equal(d['edge_index2'], c['edge_index2']) and np.array_equal(d['x'], c['x'])
+        np.testing.assert_allclose(d['edge_attr2'], c['edge_attr2'], rtol=0, atol=5e-6, err_msg=str(c['name']))
+        np.testing.assert_allclose(d['lmax'], c['lmax'], rtol=1e-6)
+
+
+def test_spectral_design_batched_equals_single_and_call_convention():
+    raw = synthetic.make_graphs('zinc', 40, seed=5) + synthetic.make_graphs('counting', 10, seed=6)
+    sd = G.SpectralDesign(recfield=2, dv=2, nfreq=7, adddegree=True)
+    many = sd.design_many(raw)
+    for (x, ei, y), d in zip(raw, many):
+        one = sd.design_many([(x, ei, y)])[0]
+        assert np.array_equal(one['edge_index2'], d['edge_index2'])
+        np.testing.assert_allclose(one['edge_attr2'], d['edge_attr2'], rtol=0, atol=2e-6)
+
+    class Data:
+        pass
+    dd = Data()
+    dd.x, dd.edge_index = T(raw[0][0]), T(raw[0][1])
+    out = sd(dd)
+    assert out.edge_index2.dtype == torch.int64 and out.edge_attr2.dtype == torch.float32
+    assert out.x.shape[1] == raw[0][0].shape[1] + 1 and out.edge_attr2.shape[1] == 8
+    assert np.array_equal(out.edge_index2.numpy(), many[0]['edge_index2'])
+
+
+def test_collate_and_shards():
+    raw = synthetic.make_graphs('zinc', 9, seed=1)
+    ds = G.SpectralDesign(recfield=2, dv=2, nfreq=7).design_many(raw)
+    b = collate(ds)
+    n = [d['x'].shape[0] for d in ds]
+    assert b.num_graphs == 9 and b.x.shape == (sum(n), 25) and b.ptr.tolist() == np.concatenate([[0], np.cumsum(n)]).tolist()
+    assert b.edge_index2.shape[1] == b.edge_attr2.shape[0] and b.edge_attr2.shape[1] == 8
+    # block diagonal: every edge stays inside its graph
+    gid = b.batch
+    assert bool((gid[b.edge_index2[0]] == gid[b.edge_index2[1]]).all())
+    assert bool((gid[b.edge_index[0]] == gid[b.edge_index[1]]).all())
+    cover = []
+    for r in range(4):
+        lo, hi = shard_graphs(9, r, 4)
+        cover += list(range(lo, hi))
+    assert cover == list(range(9))
+    assert [shard_graphs(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+
+
+def test_synthetic_generators_are_seeded_and_shaped():
+    a = synthetic.make_graphs('zinc', 20, seed=0)
+    b = synthetic.make_graphs('zinc', 20, seed=0)
+    for (x1, e1, y1), (x2, e2, y2) in zip(a, b):
+        assert np.array_equal(x1, x2) and np.array_equal(e1, e2) and y1 == y2
+        n = x1.shape[0]
+        assert 9 <= n <= 37 and x1.shape[1] == 25
+        A = np.zeros((n, n)); A[e1[0], e1[1]] = 1
+        assert np.array_equal(A, A.T) and A.sum(0).max() <= 4 and np.trace(A) == 0
+    x, ei, y = synthetic.make_graphs('counting', 1, seed=2)[0]
+    A = np.zeros((x.shape[0],) * 2); A[ei[0], ei[1]] = 1
+    assert y == pytest.approx(np.trace(A @ A @ A) / 6)            # libs/utils.py:395-397
+    x, ei, y = synthetic.make_graphs('mnist75', 1, seed=2)[0]
+    assert x.shape == (75, 2)
