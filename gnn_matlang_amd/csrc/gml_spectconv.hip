@@ -29,7 +29,7 @@ extern "C" int gml_spectconv_fwd(const int32_t* rowptr, const int32_t* col, cons
                                  uint32_t flags, gml_stream_t stream) {
     if (num_rows < 0 || S <= 0 || Fin <= 0 || Fout <= 0 || ldx < Fin || ldo < Fout) return GML_E_BADARG;
     if (num_rows == 0) return GML_OK;
-    if (!rowptr || !col || !val || !x || !w || !out) return GML_E_BADARG;
+    if (!rowptr || !x || !w || !out) return GML_E_BADARG;   /* col/val may be null when there are no edges */
     if (num_rows > (int64_t)INT32_MAX - 16) return GML_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
 
@@ -146,7 +146,7 @@ extern "C" int gml_spmm_fwd(const int32_t* rowptr, const int32_t* col, const int
                             gml_stream_t stream) {
     if (num_rows < 0 || S <= 0 || Fin <= 0 || ldx < Fin) return GML_E_BADARG;
     if (num_rows == 0) return GML_OK;
-    if (!rowptr || !col || !val || !x || !h) return GML_E_BADARG;
+    if (!rowptr || !x || !h) return GML_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     int s0 = 0;
     while (s0 < S) {
@@ -238,7 +238,7 @@ extern "C" int gml_sddmm(const int32_t* rowptr, const int32_t* col, const int32_
                          const float* gw, float* dval, int64_t num_rows, int32_t S, int32_t Fin, gml_stream_t stream) {
     if (num_rows < 0 || S <= 0 || Fin <= 0 || ldx < Fin) return GML_E_BADARG;
     if (num_rows == 0) return GML_OK;
-    if (!rowptr || !col || !x || !gw || !dval) return GML_E_BADARG;
+    if (!rowptr || !x || !gw) return GML_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     int s0 = 0;
     while (s0 < S) {
