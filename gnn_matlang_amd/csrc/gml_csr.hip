@@ -168,3 +168,42 @@ extern "C" int gml_csr_link_transpose(const int32_t* perm_fwd, const int32_t* pe
     hipLaunchKernelGGL(gml_k_take_i32, dim3(eg), dim3(256), 0, st, inv_scratch, perm_t, num_edges, pos_t);
     return gml_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------
+// Per 64-row group: {first edge, #edges, smallest column id, width of the column window}.  The fused
+// layer kernels read one 16-byte record per group and know at once which CSR slice / value rows / X
+// rows to prefetch (no dependent rowptr -> col -> min/max chain inside the hot kernel).
+__global__ __launch_bounds__(64) void gml_k_group_info(const int32_t* __restrict__ rowptr,
+                                                      const int32_t* __restrict__ col, int64_t nrows,
+                                                      int32_t* __restrict__ ginfo) {
+    const int64_t g = blockIdx.x;
+    const int64_t r0 = g * 64;
+    const int64_t r1 = min(r0 + 64, nrows);
+    const int kb = rowptr[r0], ke = rowptr[r1];
+    int mn = INT32_MAX, mx = -1;
+    for (int k = kb + (int)threadIdx.x; k < ke; k += 64) {
+        const int c = col[k];
+        mn = min(mn, c);
+        mx = max(mx, c);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        mn = min(mn, __shfl_xor(mn, off));
+        mx = max(mx, __shfl_xor(mx, off));
+    }
+    if (threadIdx.x == 0) {
+        int4 o;
+        o.x = kb; o.y = ke - kb; o.z = (ke > kb) ? mn : 0; o.w = (ke > kb) ? mx - mn + 1 : 0;
+        reinterpret_cast<int4*>(ginfo)[g] = o;
+    }
+}
+
+extern "C" int gml_csr_group_info(const int32_t* rowptr, const int32_t* col, int64_t num_rows, int32_t* ginfo,
+                                  gml_stream_t stream) {
+    if (num_rows < 0) return GML_E_BADARG;
+    if (num_rows == 0) return GML_OK;
+    if (!rowptr || !ginfo) return GML_E_BADARG;
+    hipLaunchKernelGGL(gml_k_group_info, dim3((unsigned)gml_cdiv(num_rows, 64)), dim3(64), 0, (hipStream_t)stream,
+                       rowptr, col, num_rows, ginfo);
+    return gml_launch_status();
+}

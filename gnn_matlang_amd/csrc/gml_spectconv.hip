@@ -21,7 +21,7 @@ static int launch_family(int SC, int FPL, const GmlFwdParams& p, int NB, bool xv
 static const int kSC8[] = {8, 6, 4, 3, 2, 1};
 static const int kSC4[] = {16, 12, 8, 6, 4, 3, 2, 1};
 
-extern "C" int gml_spectconv_fwd(const int32_t* rowptr, const int32_t* col, const int32_t* epos,
+extern "C" int gml_spectconv_fwd(const int32_t* rowptr, const int32_t* col, const int32_t* ginfo, const int32_t* epos,
                                  const float* val, const float* x, int64_t ldx,
                                  const float* w, int64_t w_ss, int64_t w_si, int64_t w_so,
                                  const float* bias, float* out, int64_t ldo,
@@ -29,7 +29,7 @@ extern "C" int gml_spectconv_fwd(const int32_t* rowptr, const int32_t* col, cons
                                  uint32_t flags, gml_stream_t stream) {
     if (num_rows < 0 || S <= 0 || Fin <= 0 || Fout <= 0 || ldx < Fin || ldo < Fout) return GML_E_BADARG;
     if (num_rows == 0) return GML_OK;
-    if (!rowptr || !x || !w || !out) return GML_E_BADARG;   /* col/val may be null when there are no edges */
+    if (!rowptr || !ginfo || !x || !w || !out) return GML_E_BADARG;   /* col/val may be null when there are no edges */
     if (num_rows > (int64_t)INT32_MAX - 16) return GML_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
 
@@ -60,13 +60,11 @@ extern "C" int gml_spectconv_fwd(const int32_t* rowptr, const int32_t* col, cons
         }
     }
 
-    const int ntiles = (int)gml_cdiv(num_rows, 16);
-    int grid = (int)gml_cdiv(ntiles, 4);
-    const int maxwg = GML_NUM_CU * 8;
-    if (grid > maxwg) grid = maxwg;
-    int tiles_per_wg = (int)gml_cdiv(ntiles, grid);
-    tiles_per_wg = (tiles_per_wg + 3) / 4 * 4;
-    grid = (int)gml_cdiv(ntiles, tiles_per_wg);
+    // persistent workgroups, each a contiguous range of 64-row groups; 2 resident per CU (LDS bound)
+    const int ngroups = (int)gml_cdiv(num_rows, GML_GROUP);
+    int grid = ngroups < GML_NUM_CU * 2 ? ngroups : GML_NUM_CU * 2;
+    const int groups_per_wg = (int)gml_cdiv(ngroups, grid);
+    grid = (int)gml_cdiv(ngroups, groups_per_wg);
 
     for (int ip = 0; ip < nparts; ++ip) {
         const int SC = parts[ip].sc;
@@ -76,20 +74,22 @@ extern "C" int gml_spectconv_fwd(const int32_t* rowptr, const int32_t* col, cons
             const int nb16 = (fo + 15) / 16;
             const int NB = nb16 <= 1 ? 1 : (nb16 <= 2 ? 2 : (nb16 <= 4 ? 4 : 8));
             GmlFwdParams p;
-            p.rowptr = rowptr; p.col = col; p.epos = epos; p.val = val; p.x = x; p.ldx = ldx;
+            p.rowptr = rowptr; p.col = col; p.ginfo = ginfo; p.epos = epos; p.val = val; p.x = x; p.ldx = ldx;
             p.w = w + (int64_t)o0 * w_so; p.w_ss = w_ss; p.w_si = w_si; p.w_so = w_so;
             p.out = out + o0; p.ldo = ldo; p.nrows = num_rows; p.S = S; p.Fin = Fin; p.Fout = fo;
             p.s0 = parts[ip].s0; p.npass = parts[ip].count / SC; p.nchunks = nchunks;
-            p.ntiles = ntiles; p.tiles_per_wg = tiles_per_wg;
+            p.ngroups = ngroups; p.groups_per_wg = groups_per_wg;
             const bool last = (ip == nparts - 1), first = (ip == 0);
             p.bias = (last && bias) ? bias + o0 : nullptr;
-            p.flags = (first ? (flags & GML_ACCUM) : GML_ACCUM) | (last ? (flags & GML_RELU) : 0u);
+            p.flags = (first ? (flags & GML_ACCUM) : GML_ACCUM) | (last ? (flags & GML_RELU) : 0u) | (flags & 0xff00u);
             const size_t wblk = (size_t)SC * FPL * NB * 64 * sizeof(float);
             const size_t all = wblk * p.npass * nchunks;
-            p.allw = all <= 64 * 1024;
+            const size_t stage = (size_t)(76 + GML_ECAP + GML_ECAP * SC + GML_XCAP * (4 * FPL + 4)) * sizeof(float);
+            p.allw = all + stage <= 80 * 1024;           // two workgroups per CU
             const int va = (SC % 4 == 0) ? 4 : ((SC % 2 == 0) ? 2 : 1);
             p.val_vec = (S % va == 0) && (p.s0 % va == 0);
-            const size_t lds = p.allw ? all : wblk;
+            p.wfloats = (int)((p.allw ? all : wblk) / sizeof(float));
+            const size_t lds = (size_t)p.wfloats * sizeof(float) + stage;
             int rc = launch_family(SC, FPL, p, NB, xvec && FPL >= 4, dim3(grid), lds, st);
             if (rc != GML_OK) return rc;
         }

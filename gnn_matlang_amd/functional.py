@@ -70,15 +70,17 @@ def _f32c(t, name):
 
 
 # ---------------------------------------------------------------------------- raw launches
-def fused_conv(rowptr, col, epos, val, x, ldx, w, w_strides, bias, out, ldo, nrows, S, Fin, Fout, flags=0,
+def fused_conv(rowptr, col, ginfo, epos, val, x, ldx, w, w_strides, bias, out, ldo, nrows, S, Fin, Fout, flags=0,
                out_off=0, tag='spectconv_fwd'):
     q, f = conv_cost(int(nrows), int(val.size(0)), int(S), int(Fin), int(Fout)) if PROFILE is not None else (0, 0)
     with _Timed(tag, q + (4 * int(val.size(0)) if epos is not None else 0), f):
-        _fused_conv(rowptr, col, epos, val, x, ldx, w, w_strides, bias, out, ldo, nrows, S, Fin, Fout, flags, out_off)
+        _fused_conv(rowptr, col, ginfo, epos, val, x, ldx, w, w_strides, bias, out, ldo, nrows, S, Fin, Fout, flags,
+                    out_off)
 
 
-def _fused_conv(rowptr, col, epos, val, x, ldx, w, w_strides, bias, out, ldo, nrows, S, Fin, Fout, flags, out_off):
-    _lib.call('gml_spectconv_fwd', _ptr(rowptr), _ptr(col), _ptr(epos), _ptr(val), _ptr(x), int(ldx),
+def _fused_conv(rowptr, col, ginfo, epos, val, x, ldx, w, w_strides, bias, out, ldo, nrows, S, Fin, Fout, flags,
+                out_off):
+    _lib.call('gml_spectconv_fwd', _ptr(rowptr), _ptr(col), _ptr(ginfo), _ptr(epos), _ptr(val), _ptr(x), int(ldx),
               _ptr(w), int(w_strides[0]), int(w_strides[1]), int(w_strides[2]), _ptr(bias),
               _off(out, out_off), int(ldo), int(nrows), int(S), int(Fin), int(Fout), int(flags), _stream(x.device))
 
@@ -136,7 +138,7 @@ def segment_sum(x, ptr, mean=False):
 
 
 # ---------------------------------------------------------------------------- shared backward pieces
-def _conv_backward(csr, x, val, weight, G, need_x, need_val, need_w):
+def _conv_backward(csr, x, val, weight, G, need_x, need_val, need_w, val_t=None):
     """G [N,Fout] contiguous = gradient at the (pre-activation) conv output."""
     S, Fin, Fout = weight.shape
     N = csr.N
@@ -144,7 +146,10 @@ def _conv_backward(csr, x, val, weight, G, need_x, need_val, need_w):
     if need_x:
         dx = torch.empty(N, Fin, dtype=torch.float32, device=x.device)
         # dX = sum_s A_s (G W_s^T): rows keyed by SOURCE, features = G, weight element (s, o, f) = W[s, f, o]
-        fused_conv(csr.rowptr_t, csr.col_t, csr.pos_t, val, G, Fout, weight, (Fin * Fout, 1, Fout), None,
+        if val_t is None:
+            with _Timed('val_to_source_order'):
+                val_t = csr.to_source_order(val)
+        fused_conv(csr.rowptr_t, csr.col_t, csr.ginfo_t, None, val_t, G, Fout, weight, (Fin * Fout, 1, Fout), None,
                    dx, Fin, N, S, Fout, Fin, tag='spectconv_dx')
     if need_w:
         with _Timed('dw_spmm'):
@@ -175,8 +180,8 @@ class SpectConvFunction(torch.autograd.Function):
             bias = _f32c(bias, 'bias')
         with torch.cuda.device(x.device):
             out = torch.empty(csr.N, Fout, dtype=torch.float32, device=x.device)
-            fused_conv(csr.rowptr, csr.col, None, val, x, Fin, weight, (Fin * Fout, Fout, 1), bias, out, Fout,
-                       csr.N, S, Fin, Fout, _lib.GML_RELU if relu else 0)
+            fused_conv(csr.rowptr, csr.col, csr.ginfo, None, val, x, Fin, weight, (Fin * Fout, Fout, 1), bias, out,
+                       Fout, csr.N, S, Fin, Fout, _lib.GML_RELU if relu else 0)
         ctx.csr, ctx.relu, ctx.has_bias = csr, relu, bias is not None
         ctx.save_for_backward(x, val, weight, out if relu else None)
         return out
@@ -223,8 +228,8 @@ class ML3LayerFunction(torch.autograd.Function):
                 raise ValueError('conv1 expects %d supports, edge branch produced %d' % (S, ea.size(1)))
             out = torch.empty(N, C, dtype=torch.float32, device=x.device)
             cb_ = _f32c(cb, 'conv1.bias') if cb is not None else None
-            fused_conv(csr.rowptr, csr.col, None, ea, x, Fin, cw, (Fin * nout1, nout1, 1), cb_, out, C, N, S, Fin,
-                       nout1, _lib.GML_RELU)
+            fused_conv(csr.rowptr, csr.col, csr.ginfo, None, ea, x, Fin, cw, (Fin * nout1, nout1, 1), cb_, out, C, N,
+                       S, Fin, nout1, _lib.GML_RELU)
             if nout2 > 0:
                 w11, b11, w12, b12 = (_f32c(w11, 'fc11.weight'), _f32c(b11, 'fc11.bias'), _f32c(w12, 'fc12.weight'),
                                       _f32c(b12, 'fc12.bias'))

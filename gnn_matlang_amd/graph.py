@@ -36,7 +36,7 @@ def _require_cuda(t, name):
 
 class GraphCSR(object):
     __slots__ = ('N', 'E', 'device', 'rowptr', 'col', 'perm', 'rowptr_t', 'col_t', 'pos_t', 'perm_t',
-                 '_val_cache', '_keep')
+                 'ginfo', 'ginfo_t', '_val_cache', '_keep')
 
     def __init__(self):
         self._val_cache = OrderedDict()
@@ -67,6 +67,10 @@ class GraphCSR(object):
             inv = torch.empty(E, **i32)
             g.pos_t = torch.empty(E, **i32)
             _lib.call('gml_csr_link_transpose', _ptr(g.perm), _ptr(g.perm_t), E, _ptr(inv), _ptr(g.pos_t), st)
+            ng = max((N + 63) // 64, 1)
+            g.ginfo, g.ginfo_t = torch.zeros(ng, 4, **i32), torch.zeros(ng, 4, **i32)
+            _lib.call('gml_csr_group_info', _ptr(g.rowptr), _ptr(g.col), N, _ptr(g.ginfo), st)
+            _lib.call('gml_csr_group_info', _ptr(g.rowptr_t), _ptr(g.col_t), N, _ptr(g.ginfo_t), st)
         return g
 
     # values [E, S] in input-edge order -> target-sorted order (cached: raw supports are per-batch data)
@@ -81,6 +85,20 @@ class GraphCSR(object):
             self._val_cache[key] = (edge_attr, out)        # keep the source alive: its address is the key
             while len(self._val_cache) > 4:
                 self._val_cache.popitem(last=False)
+        return out
+
+    def to_source_order(self, val_sorted):
+        """target-sorted [E,S] -> source-sorted (the order the d/dX kernel walks)."""
+        out = torch.empty_like(val_sorted)
+        _lib.call('gml_gather_rows', _ptr(val_sorted), _ptr(self.pos_t), _ptr(out), self.E, int(val_sorted.size(1)),
+                  _stream(val_sorted.device))
+        return out
+
+    def from_source_order(self, val_t):
+        """source-sorted [E,S] -> target-sorted."""
+        out = torch.empty_like(val_t)
+        _lib.call('gml_scatter_rows', _ptr(val_t), _ptr(self.pos_t), _ptr(out), self.E, int(val_t.size(1)),
+                  _stream(val_t.device))
         return out
 
     def unsort_values(self, val_sorted):

@@ -66,6 +66,10 @@ int gml_csr_from_coo(const int64_t* key, const int64_t* other_in, int64_t num_no
  * source-sorted edge keeps its values.  inv_scratch: E int32. */
 int gml_csr_link_transpose(const int32_t* perm_fwd, const int32_t* perm_t, int64_t num_edges,
                            int32_t* inv_scratch, int32_t* pos_t, gml_stream_t stream);
+/* ginfo[g] = {first edge, #edges, smallest column id, column-window width} of the 64-row group g
+ * (int32 x 4 x ceil(num_rows/64)): the prefetch schedule of gml_spectconv_fwd. */
+int gml_csr_group_info(const int32_t* rowptr, const int32_t* col, int64_t num_rows, int32_t* ginfo,
+                       gml_stream_t stream);
 /* out[k, :] = in[perm[k], :]   (rows of `width` floats) */
 int gml_gather_rows(const float* in, const int32_t* perm, float* out, int64_t rows, int32_t width,
                     gml_stream_t stream);
@@ -75,11 +79,12 @@ int gml_scatter_rows(const float* in, const int32_t* perm, float* out, int64_t r
 
 /* ---------------------------------------------------------------- fused multi-support layer
  *   out[r, 0:Fout] (op)= act( sum_s ( sum_{k in row r} val[pos(k), s] * x[col[k], :] ) @ W[s] + bias )
- * rowptr/col: CSR keyed by the OUTPUT row; pos(k) = epos ? epos[k] : k; val is [E, S] (S contiguous).
+ * rowptr/col: CSR keyed by the OUTPUT row (ginfo: gml_csr_group_info of it); pos(k) = epos ? epos[k] : k
+ * (epos = NULL, i.e. values stored in the order of this CSR, is the fast path); val is [E, S] (S contiguous).
  * W element (s, i, o) lives at w[s*w_ss + i*w_si + o*w_so] so the transposed weights of the
  * backward pass need no copy.  bias may be NULL.  Used for: forward (CSR by target, x = X),
  * d/dX (CSR by source, x = dOut, W transposed view, epos = pos_t). */
-int gml_spectconv_fwd(const int32_t* rowptr, const int32_t* col, const int32_t* epos,
+int gml_spectconv_fwd(const int32_t* rowptr, const int32_t* col, const int32_t* ginfo, const int32_t* epos,
                       const float* val, const float* x, int64_t ldx,
                       const float* w, int64_t w_ss, int64_t w_si, int64_t w_so,
                       const float* bias, float* out, int64_t ldo,
