@@ -1,17 +1,27 @@
 // C-ABI dispatch of the ML3Layer edge-branch kernels + the partial-sum fold.
 #include "gml_edge_mlp_impl.h"
 
-__global__ void gml_k_reduce_partials(const float* __restrict__ partial, int64_t nwaves, int nw,
-                                      float* __restrict__ d0, int n0, float* __restrict__ d1, int n1,
-                                      float* __restrict__ d2, int n2, float* __restrict__ d3, int n3) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= nw) return;
+// dst[j] = sum_w partial[w][j] in a fixed order: 16 lanes split the partial index, LDS tree in fixed order
+__global__ __launch_bounds__(256) void gml_k_reduce_partials(const float* __restrict__ partial, int64_t nwaves, int nw,
+                                                            float* __restrict__ d0, int n0, float* __restrict__ d1, int n1,
+                                                            float* __restrict__ d2, int n2, float* __restrict__ d3, int n3) {
+    __shared__ float red[16][17];
+    const int jl = threadIdx.x & 15, wl = threadIdx.x >> 4;
+    const int j = blockIdx.x * 16 + jl;
     float a = 0.f;
-    for (int64_t w = 0; w < nwaves; ++w) a += partial[w * nw + j];
-    if (j < n0) d0[j] = a;
-    else if (j < n0 + n1) d1[j - n0] = a;
-    else if (j < n0 + n1 + n2) d2[j - n0 - n1] = a;
-    else if (j < n0 + n1 + n2 + n3) d3[j - n0 - n1 - n2] = a;
+    if (j < nw)
+        for (int64_t w = wl; w < nwaves; w += 16) a += partial[w * nw + j];
+    red[wl][jl] = a;
+    __syncthreads();
+    if (wl == 0 && j < nw) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][jl];
+        if (j < n0) d0[j] = t;
+        else if (j < n0 + n1) d1[j - n0] = t;
+        else if (j < n0 + n1 + n2) d2[j - n0 - n1] = t;
+        else if (j < n0 + n1 + n2 + n3) d3[j - n0 - n1 - n2] = t;
+    }
 }
 
 #define GML_DECL_EMLP(SV)                                                                                    \

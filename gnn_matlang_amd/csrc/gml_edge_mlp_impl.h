@@ -291,7 +291,7 @@ static inline int64_t gml_edge_mlp_bwd_waves(int64_t E, int waves_per_wg) {
         int rc = gml_launch_status();                                                                        \
         if (rc != GML_OK) return rc;                                                                         \
         const int n123 = 2 * SV * SV, n4 = SV * 4 * SV;                                                      \
-        hipLaunchKernelGGL(gml_k_reduce_partials, dim3((unsigned)gml_cdiv(C::NW, 64)), dim3(64), 0, st,      \
+        hipLaunchKernelGGL(gml_k_reduce_partials, dim3((unsigned)gml_cdiv(C::NW, 16)), dim3(256), 0, st,      \
                            (const float*)ws, nwaves, C::NW, dw1, n123, dw2, n123, dw3, n123, dw4, n4);       \
         return gml_launch_status();                                                                          \
     }

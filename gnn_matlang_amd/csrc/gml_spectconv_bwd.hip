@@ -1,0 +1,109 @@
+// C-ABI dispatch of the fused backward kernel + the deterministic partial fold.
+#include "gml_spectconv_bwd_impl.h"
+
+__global__ __launch_bounds__(256) void gml_k_reduce_rows(const float* __restrict__ partial, int64_t nparts, int64_t n,
+                                                        float* __restrict__ out) {
+    __shared__ float red[16][17];
+    const int jl = threadIdx.x & 15, wl = threadIdx.x >> 4;
+    const int64_t j = (int64_t)blockIdx.x * 16 + jl;
+    float a = 0.f;
+    if (j < n)
+        for (int64_t w = wl; w < nparts; w += 16) a += partial[w * n + j];
+    red[wl][jl] = a;
+    __syncthreads();
+    if (wl == 0 && j < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][jl];
+        out[j] = t;
+    }
+}
+
+#define GML_DECL_BWD(S, A, B) \
+    template <> int gml_launch_bwd<S, A, B>(const GmlBwdParams&, dim3, size_t, hipStream_t);
+GML_DECL_BWD(8, 2, 2) GML_DECL_BWD(8, 1, 2) GML_DECL_BWD(4, 2, 2) GML_DECL_BWD(4, 1, 2)
+GML_DECL_BWD(12, 2, 1) GML_DECL_BWD(12, 1, 1) GML_DECL_BWD(6, 3, 2) GML_DECL_BWD(6, 1, 2)
+GML_DECL_BWD(4, 3, 2) GML_DECL_BWD(6, 2, 2) GML_DECL_BWD(8, 2, 1) GML_DECL_BWD(4, 4, 2)
+
+struct BwdPlan {
+    int ok, S, nfb, nob, grid, groups_per_wg, ecap, xcap;
+    size_t lds;
+};
+
+#define GML_BWD_TRY(SV, A, B)                                                              \
+    if (S == SV && nfb == A && nob == B) {                                                 \
+        pl.lds = GmlBwdCfg<SV, A, B>::lds_bytes(pl.ecap, pl.xcap);                         \
+        pl.ok = pl.lds <= 160 * 1024;                                                      \
+        return pl;                                                                         \
+    }
+
+static BwdPlan plan_bwd(int64_t num_rows, int S, int Fin, int Fout, int max_edges, int max_window) {
+    BwdPlan pl;
+    pl.ok = 0; pl.S = S;
+    const int nfb = (Fin + 15) / 16, nob = (Fout + 15) / 16;
+    pl.nfb = nfb; pl.nob = nob;
+    pl.ecap = (max_edges + 15) / 16 * 16;
+    if (pl.ecap < 64) pl.ecap = 64;
+    pl.xcap = (max_window + 15) / 16 * 16;
+    if (pl.xcap < 64) pl.xcap = 64;
+    const int ngroups = (int)gml_cdiv(num_rows, 64);
+    int grid = ngroups < GML_NUM_CU * 2 ? ngroups : GML_NUM_CU * 2;
+    if (grid < 1) grid = 1;
+    pl.groups_per_wg = (int)gml_cdiv(ngroups, grid);
+    pl.grid = pl.groups_per_wg > 0 ? (int)gml_cdiv(ngroups, pl.groups_per_wg) : 1;
+    pl.lds = 0;
+    GML_BWD_TRY(8, 2, 2) GML_BWD_TRY(8, 1, 2) GML_BWD_TRY(4, 2, 2) GML_BWD_TRY(4, 1, 2)
+    GML_BWD_TRY(12, 2, 1) GML_BWD_TRY(12, 1, 1) GML_BWD_TRY(6, 3, 2) GML_BWD_TRY(6, 1, 2)
+    GML_BWD_TRY(4, 3, 2) GML_BWD_TRY(6, 2, 2) GML_BWD_TRY(8, 2, 1) GML_BWD_TRY(4, 4, 2)
+    return pl;
+}
+
+extern "C" size_t gml_spectconv_bwd_workspace_bytes(int64_t num_rows, int32_t S, int32_t Fin, int32_t Fout,
+                                                    int32_t max_group_edges, int32_t max_group_window) {
+    if (num_rows <= 0 || S <= 0 || Fin <= 0 || Fout <= 0) return 0;
+    const BwdPlan pl = plan_bwd(num_rows, S, Fin, Fout, max_group_edges, max_group_window);
+    if (!pl.ok) return 0;                                     /* 0 = this shape has no fused backward */
+    return (size_t)pl.grid * S * Fin * Fout * sizeof(float);
+}
+
+extern "C" int gml_spectconv_bwd(const int32_t* rowptr, const int32_t* col, const int32_t* ginfo, const float* val,
+                                 const float* x, int64_t ldx, const float* g, int64_t ldg, const float* w,
+                                 float* dx, int64_t lddx, float* dval, float* dw,
+                                 int64_t num_rows, int32_t S, int32_t Fin, int32_t Fout,
+                                 int32_t max_group_edges, int32_t max_group_window, uint32_t flags,
+                                 void* ws, size_t ws_bytes, gml_stream_t stream) {
+    if (num_rows < 0 || S <= 0 || Fin <= 0 || Fout <= 0 || ldx < Fin || ldg < Fout) return GML_E_BADARG;
+    if (dx && lddx < Fin) return GML_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (num_rows == 0) {
+        if (dw) hipMemsetAsync(dw, 0, sizeof(float) * S * Fin * Fout, st);
+        return gml_launch_status();
+    }
+    if (!rowptr || !ginfo || !x || !g || !w) return GML_E_BADARG;
+    if ((((uintptr_t)val | (uintptr_t)dval) & 15) != 0) return GML_E_BADARG;
+    const BwdPlan pl = plan_bwd(num_rows, S, Fin, Fout, max_group_edges, max_group_window);
+    if (!pl.ok) return GML_E_UNSUPPORTED;
+    const size_t need = (size_t)pl.grid * S * Fin * Fout * sizeof(float);
+    if (dw && (!ws || ws_bytes < need)) return GML_E_WORKSPACE;
+
+    GmlBwdParams p;
+    p.rowptr = rowptr; p.col = col; p.ginfo = ginfo; p.val = val; p.x = x; p.ldx = ldx; p.g = g; p.ldg = ldg;
+    p.w = w; p.dx = dx; p.lddx = lddx; p.dval = dval; p.dw_partial = dw ? (float*)ws : nullptr;
+    p.nrows = num_rows; p.S = S; p.Fin = Fin; p.Fout = Fout; p.flags = flags;
+    p.ngroups = (int)gml_cdiv(num_rows, 64); p.groups_per_wg = pl.groups_per_wg; p.ecap = pl.ecap; p.xcap = pl.xcap;
+    const int nfb = pl.nfb, nob = pl.nob;
+    int rc = GML_E_UNSUPPORTED;
+#define GML_BWD_GO(SV, A, B) \
+    if (S == SV && nfb == A && nob == B) rc = gml_launch_bwd<SV, A, B>(p, dim3(pl.grid), pl.lds, st);
+    GML_BWD_GO(8, 2, 2) GML_BWD_GO(8, 1, 2) GML_BWD_GO(4, 2, 2) GML_BWD_GO(4, 1, 2)
+    GML_BWD_GO(12, 2, 1) GML_BWD_GO(12, 1, 1) GML_BWD_GO(6, 3, 2) GML_BWD_GO(6, 1, 2)
+    GML_BWD_GO(4, 3, 2) GML_BWD_GO(6, 2, 2) GML_BWD_GO(8, 2, 1) GML_BWD_GO(4, 4, 2)
+    if (rc != GML_OK) return rc;
+    if (dw) {
+        const int64_t n = (int64_t)S * Fin * Fout;
+        hipLaunchKernelGGL(gml_k_reduce_rows, dim3((unsigned)gml_cdiv(n, 16)), dim3(256), 0, st,
+                           (const float*)ws, (int64_t)pl.grid, n, dw);
+        return gml_launch_status();
+    }
+    return GML_OK;
+}

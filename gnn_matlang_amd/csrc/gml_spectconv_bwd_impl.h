@@ -1,0 +1,307 @@
+// Fused backward of the multi-support spectral convolution for gfx950 -- ONE launch produces
+//
+//   dX[r, :]      = sum_s ( sum_{e out of r} val[e, s] * G[dst(e), :] ) @ W[s]^T
+//   dval[e, s]    = < X[src(e), :] @ W[s] , G[dst(e), :] >
+//   dW[s]         = sum_r X[r, :]^T ( sum_{e out of r} val[e, s] * G[dst(e), :] )
+//
+// i.e. the autograd of /root/reference/libs/spect_conv.py:76-80 (gather backward, message() backward
+// w.r.t. x_j and norm, scatter backward, matmul backward) without materialising any [N, S*F] tensor.
+// G = gradient at the conv output (after the relu mask).  Everything is organised by SOURCE rows
+// (the CSR passed in is keyed by source, values in that order), so nothing is scattered: no atomics,
+// bitwise deterministic.
+//
+// Workgroup = 4 waves = one group of 64 source rows at a time (16 per wave).  Per group:
+//   stage   CSR slice, value rows, the window of G rows the group's targets fall into, the group's own
+//           X rows -> LDS (coalesced);
+//   Z       Z[r][s][o] = X[r] W[s]        v_mfma_f32_16x16x4_f32, computed transposed so lane
+//                                         (r = l&15, kq = l>>4) holds o = ob*16 + 4*kq + reg;
+//   edges   P[r][s][o] += val[e,s] G[dst][o];   d[s] = <Z[r][s][:], G[dst][:]>  -> quad reduce -> dval
+//   dX      P is already the A fragment of the (s,o)-contraction: 16x16x4 MFMAs against W^T from LDS
+//   dW      contraction over ROWS: P goes through a small LDS exchange buffer (one SE-support slab at a
+//           time); wave w owns the (s, fb, ob) output blocks with index = w (mod 4) and keeps their
+//           accumulators in registers across all its groups; one partial per workgroup at the end.
+#pragma once
+#include "gml_common.h"
+
+struct GmlBwdParams {
+    const int32_t* rowptr;
+    const int32_t* col;
+    const int32_t* ginfo;
+    const float* val;
+    const float* x;
+    int64_t ldx;
+    const float* g;
+    int64_t ldg;
+    const float* w;
+    float* dx;
+    int64_t lddx;
+    float* dval;
+    float* dw_partial;
+    int64_t nrows;
+    int32_t S, Fin, Fout;
+    uint32_t flags;
+    int32_t ngroups, groups_per_wg;
+    int32_t ecap, xcap;      // LDS capacities (edges per group, G-window rows), multiples of 4
+};
+
+template <int S, int NFB, int NOB>
+struct GmlBwdCfg {
+    static constexpr int FINP = NFB * 16, FOUTP = NOB * 16;
+    static constexpr int LDW = FOUTP + 1;       // W_l[s][f][LDW]: both MFMA read patterns <= 2-way conflicts
+    static constexpr int LDG = FOUTP + 4;       // G window rows (b128 aligned)
+    static constexpr int LDP = FOUTP + 4;       // P exchange rows (b128 aligned)
+    static constexpr int LDXO = FINP + 1;       // own X rows
+    static constexpr int NBLK = S * NFB * NOB;  // dW output blocks of 16x16
+    // supports exchanged per slab: smallest SE | S with SE*NFB*NOB a multiple of 4 (one block per wave per step)
+    static constexpr int se_() {
+        for (int se = 1; se <= 4; ++se)
+            if (S % se == 0 && (se * NFB * NOB) % 4 == 0) return se;
+        return 0;
+    }
+    static constexpr int SE = se_();
+    static constexpr bool OK = SE > 0;
+    static constexpr int IPS = OK ? SE * NFB * NOB / 4 : 1;   // blocks per wave per slab
+    static constexpr int NSLAB = OK ? S / SE : 1;
+    static constexpr int NACC = IPS * NSLAB;                  // persistent dW accumulators (f32x4) per wave
+    static constexpr int W_FLOATS = (S * FINP * LDW + 3) / 4 * 4;
+    static constexpr int XO_FLOATS = (64 * LDXO + 3) / 4 * 4;
+    static constexpr int RP_FLOATS = 68;
+    __host__ __device__ static constexpr int pex_floats() { return 2 * SE * 64 * LDP; }
+    __host__ __device__ static int gs_floats(int xcap) {
+        const int a = xcap * LDG, b = pex_floats();
+        return a > b ? a : b;
+    }
+    __host__ __device__ static size_t lds_bytes(int ecap, int xcap) {
+        return sizeof(float) * (size_t)(W_FLOATS + XO_FLOATS + RP_FLOATS + ecap + ecap * S + gs_floats(xcap));
+    }
+};
+
+template <int S, int NFB, int NOB>
+__global__ __launch_bounds__(256) void gml_k_spectconv_bwd(const GmlBwdParams p) {
+    using C = GmlBwdCfg<S, NFB, NOB>;
+    constexpr int FINP = C::FINP, LDW = C::LDW, LDG = C::LDG, LDP = C::LDP, LDXO = C::LDXO;
+    constexpr int KF = FINP / 4;
+    constexpr int VAL_ALIGN = (S % 4 == 0) ? 4 : ((S % 2 == 0) ? 2 : 1);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* W_l = lds;
+    float* xs_own = W_l + C::W_FLOATS;
+    int* rp_l = reinterpret_cast<int*>(xs_own + C::XO_FLOATS);
+    int* col_l = rp_l + C::RP_FLOATS;
+    float* ea_l = reinterpret_cast<float*>(col_l + p.ecap);
+    float* gs = ea_l + (size_t)p.ecap * S;
+    float* pex = gs;                                        // aliases the G window once the edge phase is over
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int wg = gml_xcd_remap(blockIdx.x, gridDim.x);
+    const int g0 = wg * p.groups_per_wg;
+    const int g1 = min(g0 + p.groups_per_wg, p.ngroups);
+
+    // W[s][f][o] -> W_l[(s*FINP + f)*LDW + o], zero padded
+    for (int e = tid; e < S * FINP * C::FOUTP; e += 256) {
+        const int o = e % C::FOUTP, f = (e / C::FOUTP) % FINP, s = e / (C::FOUTP * FINP);
+        float v = 0.f;
+        if (f < p.Fin && o < p.Fout) v = p.w[((int64_t)s * p.Fin + f) * p.Fout + o];
+        W_l[(s * FINP + f) * LDW + o] = v;
+    }
+
+    f32x4 dwacc[C::NACC];
+#pragma unroll
+    for (int i = 0; i < C::NACC; ++i) dwacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int g = g0; g < g1; ++g) {
+        const int64_t r0 = (int64_t)g * 64;
+        const int nr = (int)min((int64_t)64, p.nrows - r0);
+        const int4 gi = reinterpret_cast<const int4*>(p.ginfo)[g];
+        const int kb = gi.x, ne = gi.y, lo = gi.z, nwin = gi.w;
+        __syncthreads();                                     // previous group is done with every LDS region
+
+        // ---- stage (coalesced): rowptr slice, local column ids, value rows, G window, own X rows
+        if (tid <= nr) rp_l[tid] = p.rowptr[r0 + tid];
+        for (int i = tid; i < ne; i += 256) col_l[i] = p.col[kb + i] - lo;
+        if constexpr (S % 4 == 0) {
+            const f32x4* src = reinterpret_cast<const f32x4*>(p.val + (int64_t)kb * S);
+            for (int i = tid; i < ne * (S / 4); i += 256) reinterpret_cast<f32x4*>(ea_l)[i] = src[i];
+        } else {
+            for (int i = tid; i < ne * S; i += 256) ea_l[i] = p.val[(int64_t)kb * S + i];
+        }
+        for (int i = tid; i < nwin * C::FOUTP; i += 256) {
+            const int rr = i / C::FOUTP, o = i % C::FOUTP;
+            gs[rr * LDG + o] = (o < p.Fout) ? p.g[(int64_t)(lo + rr) * p.ldg + o] : 0.f;
+        }
+        for (int i = tid; i < 64 * FINP; i += 256) {
+            const int rr = i / FINP, f = i % FINP;
+            xs_own[rr * LDXO + f] = (rr < nr && f < p.Fin) ? p.x[(r0 + rr) * p.ldx + f] : 0.f;
+        }
+        __syncthreads();
+
+        const int row = wave * 16 + r16;                     // row of the group owned by this lane
+        const bool rvalid = row < nr;
+        const int kbeg = rvalid ? rp_l[row] - kb : 0;
+        const int kend = rvalid ? rp_l[row + 1] - kb : 0;
+
+        // ---- Z^T = W^T X^T : lane (r16, kq) gets Z[row][s][ob*16 + 4*kq + reg]
+        float Z[S][NOB][4], P[S][NOB][4];
+        {
+            float xb[KF];
+#pragma unroll
+            for (int t = 0; t < KF; ++t) xb[t] = xs_own[row * LDXO + 4 * t + kq];
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int ob = 0; ob < NOB; ++ob) {
+                    f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int t = 0; t < KF; ++t) {
+                        const float a = W_l[(s * FINP + 4 * t + kq) * LDW + ob * 16 + r16];
+                        d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xb[t], d, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { Z[s][ob][i] = d[i]; P[s][ob][i] = 0.f; }
+                }
+        }
+
+        // ---- edge phase
+        for (int k = kbeg; k < kend; ++k) {
+            const int dstl = col_l[k];
+            float ev[S];
+            gml_load_row<S, VAL_ALIGN>(ea_l + k * S, ev);
+            float gv[NOB][4];
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(gs + dstl * LDG + ob * 16 + 4 * kq);
+                gv[ob][0] = t.x; gv[ob][1] = t.y; gv[ob][2] = t.z; gv[ob][3] = t.w;
+            }
+            float d[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                float a = 0.f;
+#pragma unroll
+                for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        P[s][ob][i] = fmaf(ev[s], gv[ob][i], P[s][ob][i]);
+                        a = fmaf(Z[s][ob][i], gv[ob][i], a);
+                    }
+                d[s] = a;
+            }
+            // the 4 lanes of a row (kq = 0..3) each hold a quarter of the o-sum
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                d[s] += __shfl_xor(d[s], 16);
+                d[s] += __shfl_xor(d[s], 32);
+            }
+            if (kq == 0) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) ea_l[k * S + s] = d[s];     // value row k is consumed: reuse it for dval
+            }
+        }
+        __syncthreads();                                     // dval rows complete; G window no longer needed
+
+        if (p.dval) {
+            if constexpr (S % 4 == 0) {
+                f32x4* dst = reinterpret_cast<f32x4*>(p.dval + (int64_t)kb * S);
+                for (int i = tid; i < ne * (S / 4); i += 256) dst[i] = reinterpret_cast<const f32x4*>(ea_l)[i];
+            } else {
+                for (int i = tid; i < ne * S; i += 256) p.dval[(int64_t)kb * S + i] = ea_l[i];
+            }
+        }
+
+        // ---- dX = P W^T : contraction over (s, o), P registers are the A fragments
+        if (p.dx) {
+#pragma unroll
+            for (int fb = 0; fb < NFB; ++fb) {
+                f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < S; ++s)
+#pragma unroll
+                    for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float b = W_l[(s * FINP + fb * 16 + r16) * LDW + ob * 16 + 4 * kq + i];
+                            d = __builtin_amdgcn_mfma_f32_16x16x4f32(P[s][ob][i], b, d, 0, 0, 0);
+                        }
+                const int f = fb * 16 + r16;
+                if (f < p.Fin) {
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int lr = wave * 16 + 4 * kq + reg;
+                        if (lr < nr) {
+                            float* dst = p.dx + (r0 + lr) * p.lddx + f;
+                            float v = d[reg];
+                            if (p.flags & GML_ACCUM) v += *dst;
+                            *dst = v;
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- dW += X^T P : contraction over the 64 rows of the group, slab of SE supports at a time
+        if (p.dw_partial) {
+#pragma unroll
+            for (int sl = 0; sl < C::NSLAB; ++sl) {
+                float* pb = pex + (sl & 1) * (C::SE * 64 * LDP);
+#pragma unroll
+                for (int se = 0; se < C::SE; ++se)
+#pragma unroll
+                    for (int ob = 0; ob < NOB; ++ob)
+                        *reinterpret_cast<f32x4*>(pb + (se * 64 + row) * LDP + ob * 16 + 4 * kq) =
+                            f32x4{P[sl * C::SE + se][ob][0], P[sl * C::SE + se][ob][1], P[sl * C::SE + se][ob][2],
+                                  P[sl * C::SE + se][ob][3]};
+                __syncthreads();
+#pragma unroll
+                for (int it = 0; it < C::IPS; ++it) {
+                    const int blk = it * 4 + wave;           // (se, fb, ob) block inside the slab
+                    const int ob = blk % NOB, fb = (blk / NOB) % NFB, se = blk / (NOB * NFB);
+                    f32x4 d = dwacc[sl * C::IPS + it];
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) {
+                        const float a = xs_own[(4 * t + kq) * LDXO + fb * 16 + r16];       // A[i = f][k = row]
+                        const float b = pb[(se * 64 + 4 * t + kq) * LDP + ob * 16 + r16];  // B[k = row][j = o]
+                        d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, d, 0, 0, 0);
+                    }
+                    dwacc[sl * C::IPS + it] = d;
+                }
+                // the other half of the exchange buffer is free again after the NEXT barrier pair
+            }
+        }
+    }
+
+    // ---- one dW partial per workgroup: block (s, fb, ob): D[i = f][j = o], lane rows 4*kq + reg, col r16
+    if (p.dw_partial && g0 < g1) {
+        float* out = p.dw_partial + (int64_t)wg * S * p.Fin * p.Fout;
+#pragma unroll
+        for (int sl = 0; sl < C::NSLAB; ++sl)
+#pragma unroll
+            for (int it = 0; it < C::IPS; ++it) {
+                const int blk = it * 4 + wave;
+                const int ob = blk % NOB, fb = (blk / NOB) % NFB, s = sl * C::SE + blk / (NOB * NFB);
+                const int o = ob * 16 + r16;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int f = fb * 16 + 4 * kq + reg;
+                    if (f < p.Fin && o < p.Fout) out[((int64_t)s * p.Fin + f) * p.Fout + o] = dwacc[sl * C::IPS + it][reg];
+                }
+            }
+    }
+}
+
+// out[j] = sum_w partial[w][j]   (fixed order -> deterministic)
+__global__ void gml_k_reduce_rows(const float* __restrict__ partial, int64_t nparts, int64_t n, float* __restrict__ out);
+
+template <int S, int NFB, int NOB>
+int gml_launch_bwd(const GmlBwdParams& p, dim3 grid, size_t lds, hipStream_t st);
+
+#define GML_DEFINE_BWD(SV, NFBV, NOBV)                                                                       \
+    template <>                                                                                              \
+    int gml_launch_bwd<SV, NFBV, NOBV>(const GmlBwdParams& p, dim3 grid, size_t lds, hipStream_t st) {       \
+        static_assert(GmlBwdCfg<SV, NFBV, NOBV>::OK, "no slab size for this shape");                         \
+        static const hipError_t attr_rc = hipFuncSetAttribute(                                               \
+            reinterpret_cast<const void*>(&gml_k_spectconv_bwd<SV, NFBV, NOBV>),                             \
+            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                         \
+        if (attr_rc != hipSuccess) return (int)attr_rc;                                                      \
+        hipLaunchKernelGGL((gml_k_spectconv_bwd<SV, NFBV, NOBV>), grid, dim3(256), lds, st, p);              \
+        return gml_launch_status();                                                                          \
+    }

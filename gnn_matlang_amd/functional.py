@@ -137,12 +137,46 @@ def segment_sum(x, ptr, mean=False):
     return out
 
 
+def fused_bwd_available(csr, S, Fin, Fout):
+    return int(_lib.lib().gml_spectconv_bwd_workspace_bytes(csr.N, int(S), int(Fin), int(Fout), csr.gmax_t[0],
+                                                            csr.gmax_t[1])) > 0
+
+
+def fused_conv_bwd(csr, val_t, x, G, weight, need_x, need_val, need_w, dx_accum_into=None):
+    """one launch: dX, dval (source order), dW.  val_t: supports in source order."""
+    S, Fin, Fout = weight.shape
+    dev = x.device
+    nbytes = int(_lib.lib().gml_spectconv_bwd_workspace_bytes(csr.N, S, Fin, Fout, csr.gmax_t[0], csr.gmax_t[1]))
+    ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=dev) if need_w else None
+    dx = torch.empty(csr.N, Fin, dtype=torch.float32, device=dev) if need_x else None
+    dval_t = torch.empty(csr.E, S, dtype=torch.float32, device=dev) if need_val else None
+    dw = torch.empty(S, Fin, Fout, dtype=torch.float32, device=dev) if need_w else None
+    q, f = conv_cost(csr.N, csr.E, S, Fin, Fout) if PROFILE is not None else (0, 0)
+    # compulsory traffic of the backward (SURVEY s8d): Q_bwd ~ 2 Q_fwd - N Fout; flops 3 projections + 2 edge passes
+    with _Timed('spectconv_bwd', 2 * q, 6 * csr.N * S * Fin * Fout + 4 * csr.E * S * Fout):
+        _lib.call('gml_spectconv_bwd', _ptr(csr.rowptr_t), _ptr(csr.col_t), _ptr(csr.ginfo_t), _ptr(val_t),
+                  _ptr(x), int(x.stride(0)), _ptr(G), int(G.stride(0)), _ptr(weight), _ptr(dx), Fin, _ptr(dval_t),
+                  _ptr(dw), csr.N, S, Fin, Fout, csr.gmax_t[0], csr.gmax_t[1], 0, _ptr(ws),
+                  ws.numel() if ws is not None else 0, _stream(dev))
+    return dx, dval_t, dw
+
+
 # ---------------------------------------------------------------------------- shared backward pieces
-def _conv_backward(csr, x, val, weight, G, need_x, need_val, need_w, val_t=None):
-    """G [N,Fout] contiguous = gradient at the (pre-activation) conv output."""
+def _conv_backward(csr, x, val, weight, G, need_x, need_val, need_w, val_t=None, want_source_order=False):
+    """G [N,Fout] contiguous = gradient at the (pre-activation) conv output.
+    Returns dx, dval, dw; dval is in source order when want_source_order (and the fused kernel ran)."""
     S, Fin, Fout = weight.shape
     N = csr.N
     dx = dval = dw = None
+    if fused_bwd_available(csr, S, Fin, Fout):
+        if val_t is None:
+            with _Timed('val_to_source_order'):
+                val_t = csr.to_source_order(val)
+        dx, dval_t, dw = fused_conv_bwd(csr, val_t, x, G, weight, need_x, need_val, need_w)
+        if need_val and not want_source_order:
+            with _Timed('dval_from_source_order'):
+                dval_t = csr.from_source_order(dval_t)
+        return dx, dval_t, dw, (want_source_order and need_val)
     if need_x:
         dx = torch.empty(N, Fin, dtype=torch.float32, device=x.device)
         # dX = sum_s A_s (G W_s^T): rows keyed by SOURCE, features = G, weight element (s, o, f) = W[s, f, o]
@@ -161,7 +195,7 @@ def _conv_backward(csr, x, val, weight, G, need_x, need_val, need_w, val_t=None)
             gw = torch.mm(G, weight.view(S * Fin, Fout).t())             # [N, S*Fin]
         with _Timed('dval_sddmm'):
             dval = sddmm(csr, x, gw, S, Fin)
-    return dx, dval, dw
+    return dx, dval, dw, False
 
 
 class SpectConvFunction(torch.autograd.Function):
@@ -195,7 +229,7 @@ class SpectConvFunction(torch.autograd.Function):
             Fout = weight.size(2)
             G = relu_bwd(gout, 0, Fout, out, Fout, csr.N, Fout) if ctx.relu else gout
             need = ctx.needs_input_grad
-            dx, dval, dw = _conv_backward(csr, x, val, weight, G, need[0], need[1], need[2])
+            dx, dval, dw, _ = _conv_backward(csr, x, val, weight, G, need[0], need[1], need[2])
             db = G.sum(0) if (ctx.has_bias and need[3]) else None
         return dx, dval, dw, db, None, None
 
@@ -253,25 +287,32 @@ class ML3LayerFunction(torch.autograd.Function):
         with torch.cuda.device(x.device):
             G = relu_bwd(gy, 0, C, out, C, N, nout1)
             need_val = need[1] or (learnedge and any(need[2:6]))
-            dx, dea, dcw = _conv_backward(csr, x, ea, cw, G, need[0], need_val, need[6])
+            dx, dea, dcw, dea_src = _conv_backward(csr, x, ea, cw, G, need[0], need_val, need[6],
+                                                   want_source_order=learnedge)
             g[6] = dcw
             if ctx.has_cb and need[7]:
                 g[7] = G.sum(0)
             if nout2 > 0:
-                gz = torch.empty(N, 2 * nout2, dtype=torch.float32, device=x.device)
-                _lib.call('gml_node_mix_bwd', _ptr(x), Fin, _ptr(w11), _ptr(b11), _ptr(w12), _ptr(b12),
-                          _off(gy, nout1), C, _ptr(gz), N, Fin, nout2, _stream(x.device))
-                g1, g2 = gz[:, :nout2], gz[:, nout2:]
-                if need[0]:
-                    dx.addmm_(g1, w11)
-                    dx.addmm_(g2, w12)
-                g[8], g[9] = torch.mm(g1.t(), x), g1.sum(0)
-                g[10], g[11] = torch.mm(g2.t(), x), g2.sum(0)
+                nbytes = int(_lib.lib().gml_node_mix_bwd_workspace_bytes(N, Fin, nout2))
+                if nbytes == 0:
+                    raise NotImplementedError('Hadamard branch backward: ninp=%d, nout2=%d outside the compiled '
+                                              'kernel range' % (Fin, nout2))
+                ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+                g[8], g[9], g[10], g[11] = (torch.empty_like(w11), torch.empty_like(b11), torch.empty_like(w12),
+                                            torch.empty_like(b12))
+                with _Timed('node_mix_bwd'):
+                    _lib.call('gml_node_mix_bwd', _ptr(x), Fin, _ptr(w11), _ptr(b11), _ptr(w12), _ptr(b12),
+                              _off(gy, nout1), C, _ptr(dx) if need[0] else _ptr(None), Fin, _ptr(g[8]), _ptr(g[9]),
+                              _ptr(g[10]), _ptr(g[11]), N, Fin, nout2, _ptr(ws), ws.numel(), _stream(x.device))
             g[0] = dx
             if learnedge:
                 if need_val:
+                    # the edge MLP is per-edge, so it can run in whichever order dea arrived in
+                    val_in = csr.to_source_order(val, cache=True) if dea_src else val
                     with _Timed('edge_mlp_bwd', 4 * val.numel() * 2, 60 * val.size(0) * val.size(1) ** 2):
-                        gin, g[2], g[3], g[4], g[5] = edge_mlp_bwd(val, w1, w2, w3, w4, dea, need[1])
+                        gin, g[2], g[3], g[4], g[5] = edge_mlp_bwd(val_in, w1, w2, w3, w4, dea, need[1])
+                    if gin is not None and dea_src:
+                        gin = csr.from_source_order(gin)
                     g[1] = gin
             else:
                 g[1] = dea if need[1] else None

@@ -36,7 +36,7 @@ def _require_cuda(t, name):
 
 class GraphCSR(object):
     __slots__ = ('N', 'E', 'device', 'rowptr', 'col', 'perm', 'rowptr_t', 'col_t', 'pos_t', 'perm_t',
-                 'ginfo', 'ginfo_t', '_val_cache', '_keep')
+                 'ginfo', 'ginfo_t', 'gmax', 'gmax_t', '_val_cache', '_keep')
 
     def __init__(self):
         self._val_cache = OrderedDict()
@@ -71,6 +71,11 @@ class GraphCSR(object):
             g.ginfo, g.ginfo_t = torch.zeros(ng, 4, **i32), torch.zeros(ng, 4, **i32)
             _lib.call('gml_csr_group_info', _ptr(g.rowptr), _ptr(g.col), N, _ptr(g.ginfo), st)
             _lib.call('gml_csr_group_info', _ptr(g.rowptr_t), _ptr(g.col_t), N, _ptr(g.ginfo_t), st)
+            # per-batch maxima (edges per 64-row group, column window): they size the LDS staging of the fused
+            # backward kernel.  One device->host read per batch, at index-build time (not in the step).
+            mx = torch.stack([g.ginfo[:, 1].max(), g.ginfo[:, 3].max(), g.ginfo_t[:, 1].max(),
+                              g.ginfo_t[:, 3].max()]).tolist()
+            g.gmax, g.gmax_t = (int(mx[0]), int(mx[1])), (int(mx[2]), int(mx[3]))
         return g
 
     # values [E, S] in input-edge order -> target-sorted order (cached: raw supports are per-batch data)
@@ -87,11 +92,19 @@ class GraphCSR(object):
                 self._val_cache.popitem(last=False)
         return out
 
-    def to_source_order(self, val_sorted):
-        """target-sorted [E,S] -> source-sorted (the order the d/dX kernel walks)."""
+    def to_source_order(self, val_sorted, cache=False):
+        """target-sorted [E,S] -> source-sorted (the order the backward kernel walks).  cache=True for
+        per-batch data (the raw supports), keyed on the tensor's identity."""
+        key = ('t', val_sorted.data_ptr(), val_sorted._version, tuple(val_sorted.shape))
+        if cache and key in self._val_cache:
+            return self._val_cache[key][1]
         out = torch.empty_like(val_sorted)
         _lib.call('gml_gather_rows', _ptr(val_sorted), _ptr(self.pos_t), _ptr(out), self.E, int(val_sorted.size(1)),
                   _stream(val_sorted.device))
+        if cache:
+            self._val_cache[key] = (val_sorted, out)
+            while len(self._val_cache) > 4:
+                self._val_cache.popitem(last=False)
         return out
 
     def from_source_order(self, val_t):

@@ -91,6 +91,25 @@ int gml_spectconv_fwd(const int32_t* rowptr, const int32_t* col, const int32_t* 
                       int64_t num_rows, int32_t S, int32_t Fin, int32_t Fout,
                       uint32_t flags, gml_stream_t stream);
 
+/* ---------------------------------------------------------------- fused backward of the layer above
+ * CSR keyed by SOURCE row (rowptr/col = targets, ginfo of it), val [E, S] in that order.
+ *   dx[r, :]   (op)= sum_s ( sum_{e out of r} val[e, s] g[col[e], :] ) @ W[s]^T          (NULL: skip)
+ *   dval[e, s]  =  < x[r, :] @ W[s], g[col[e], :] >   for e out of r, same order as val    (NULL: skip)
+ *   dw[s]       =  sum_r x[r, :]^T ( sum_{e out of r} val[e, s] g[col[e], :] )           (NULL: skip)
+ * g = gradient at the layer output (after the relu mask), [N, Fout].  max_group_edges / max_group_window
+ * = maxima of ginfo[:, 1] / ginfo[:, 3] (the caller reads them once per batch): they size the LDS
+ * staging.  gml_spectconv_bwd_workspace_bytes returns 0 when the shape has no fused backward
+ * (gml_spectconv_bwd then returns GML_E_UNSUPPORTED): the caller composes gml_spectconv_fwd on the
+ * transposed view + gml_spmm_fwd + gml_sddmm instead.  flags: GML_ACCUM applies to dx. */
+size_t gml_spectconv_bwd_workspace_bytes(int64_t num_rows, int32_t S, int32_t Fin, int32_t Fout,
+                                         int32_t max_group_edges, int32_t max_group_window);
+int gml_spectconv_bwd(const int32_t* rowptr, const int32_t* col, const int32_t* ginfo, const float* val,
+                      const float* x, int64_t ldx, const float* g, int64_t ldg, const float* w,
+                      float* dx, int64_t lddx, float* dval, float* dw,
+                      int64_t num_rows, int32_t S, int32_t Fin, int32_t Fout,
+                      int32_t max_group_edges, int32_t max_group_window, uint32_t flags,
+                      void* ws, size_t ws_bytes, gml_stream_t stream);
+
 /* H[r, s, :] = sum_{k in row r} val[pos(k), s] * x[col[k], :]     H is [N, S, Fin] contiguous */
 int gml_spmm_fwd(const int32_t* rowptr, const int32_t* col, const int32_t* epos,
                  const float* val, const float* x, int64_t ldx, float* h,
@@ -119,11 +138,15 @@ int gml_edge_mlp_bwd(const float* ea, const float* w1, const float* w2, const fl
 int gml_node_mix_fwd(const float* x, int64_t ldx, const float* w11, const float* b11,
                      const float* w12, const float* b12, float* out, int64_t ldo,
                      int64_t num_rows, int32_t Fin, int32_t F2, gml_stream_t stream);
-/* gz[r, 0:F2] = dL/dz11, gz[r, F2:2F2] = dL/dz12 (pre-activation grads), recomputed from x.
- * gout: dL/dout with leading dimension ldg.  gz is [N, 2*F2] contiguous. */
+/* Backward, one launch + fold: with z11 = x w11^T + b11, z12 likewise (recomputed from x),
+ *   dx[r, :] += dL/dz11[r] . w11 + dL/dz12[r] . w12        (accumulates; dx may be NULL)
+ *   dw11 = dL/dz11^T x, db11 = colsum(dL/dz11), dw12, db12 likewise.
+ * gout: dL/dout with leading dimension ldg.  workspace_bytes == 0: shape not supported (caller uses GEMMs). */
+size_t gml_node_mix_bwd_workspace_bytes(int64_t num_rows, int32_t Fin, int32_t F2);
 int gml_node_mix_bwd(const float* x, int64_t ldx, const float* w11, const float* b11,
                      const float* w12, const float* b12, const float* gout, int64_t ldg,
-                     float* gz, int64_t num_rows, int32_t Fin, int32_t F2, gml_stream_t stream);
+                     float* dx, int64_t lddx, float* dw11, float* db11, float* dw12, float* db12,
+                     int64_t num_rows, int32_t Fin, int32_t F2, void* ws, size_t ws_bytes, gml_stream_t stream);
 
 /* ---------------------------------------------------------------- glue
  * g[r, c] = (y[r, c] > 0) ? gy[r, c] : 0   for c < F        (relu backward on a strided slice) */
