@@ -194,13 +194,14 @@ extern "C" int gml_node_mix_bwd(const float* x, int64_t ldx, const float* w11, c
 }
 
 // ---------------------------------------------------------------------------------------------
+// columns [F, ldg) of g are zero-filled so that consumers may read whole aligned float4 groups
 __global__ void gml_k_relu_bwd(const float* __restrict__ gy, int64_t ldgy, const float* __restrict__ y, int64_t ldy,
                                float* __restrict__ g, int64_t ldg, int64_t nrows, int F) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nrows * F) return;
-    const int64_t r = i / F;
-    const int c = (int)(i % F);
-    g[r * ldg + c] = (y[r * ldy + c] > 0.f) ? gy[r * ldgy + c] : 0.f;
+    if (i >= nrows * ldg) return;
+    const int64_t r = i / ldg;
+    const int c = (int)(i % ldg);
+    g[i] = (c < F && y[r * ldy + c] > 0.f) ? gy[r * ldgy + c] : 0.f;
 }
 
 extern "C" int gml_relu_bwd(const float* gy, int64_t ldgy, const float* y, int64_t ldy, float* g, int64_t ldg,
@@ -208,7 +209,7 @@ extern "C" int gml_relu_bwd(const float* gy, int64_t ldgy, const float* y, int64
     if (num_rows < 0 || F <= 0 || ldgy < F || ldy < F || ldg < F) return GML_E_BADARG;
     if (num_rows == 0) return GML_OK;
     if (!gy || !y || !g) return GML_E_BADARG;
-    hipLaunchKernelGGL(gml_k_relu_bwd, dim3((unsigned)gml_cdiv(num_rows * F, 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(gml_k_relu_bwd, dim3((unsigned)gml_cdiv(num_rows * ldg, 256)), dim3(256), 0, (hipStream_t)stream,
                        gy, ldgy, y, ldy, g, ldg, num_rows, F);
     return gml_launch_status();
 }

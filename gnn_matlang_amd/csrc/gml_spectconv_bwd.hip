@@ -90,6 +90,9 @@ extern "C" int gml_spectconv_bwd(const int32_t* rowptr, const int32_t* col, cons
     p.rowptr = rowptr; p.col = col; p.ginfo = ginfo; p.val = val; p.x = x; p.ldx = ldx; p.g = g; p.ldg = ldg;
     p.w = w; p.dx = dx; p.lddx = lddx; p.dval = dval; p.dw_partial = dw ? (float*)ws : nullptr;
     p.nrows = num_rows; p.S = S; p.Fin = Fin; p.Fout = Fout; p.flags = flags;
+    p.xvec = (Fin % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)x & 15) == 0);
+    /* float4 groups up to roundup4(Fout) must exist in every row: true when ldg covers them (zero padded) */
+    p.gvec = (ldg % 4 == 0) && ((Fout + 3) / 4 * 4 <= ldg) && (((uintptr_t)g & 15) == 0);
     p.ngroups = (int)gml_cdiv(num_rows, 64); p.groups_per_wg = pl.groups_per_wg; p.ecap = pl.ecap; p.xcap = pl.xcap;
     const int nfb = pl.nfb, nob = pl.nob;
     int rc = GML_E_UNSUPPORTED;

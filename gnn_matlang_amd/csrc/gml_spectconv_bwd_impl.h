@@ -42,6 +42,7 @@ struct GmlBwdParams {
     uint32_t flags;
     int32_t ngroups, groups_per_wg;
     int32_t ecap, xcap;      // LDS capacities (edges per group, G-window rows), multiples of 4
+    int32_t xvec, gvec;      // x / g rows may be read as aligned float4
 };
 
 template <int S, int NFB, int NOB>
@@ -50,7 +51,6 @@ struct GmlBwdCfg {
     static constexpr int LDW = FOUTP + 1;       // W_l[s][f][LDW]: both MFMA read patterns <= 2-way conflicts
     static constexpr int LDG = FOUTP + 4;       // G window rows (b128 aligned)
     static constexpr int LDP = FOUTP + 4;       // P exchange rows (b128 aligned)
-    static constexpr int LDXO = FINP + 1;       // own X rows
     static constexpr int NBLK = S * NFB * NOB;  // dW output blocks of 16x16
     // supports exchanged per slab: smallest SE | S with SE*NFB*NOB a multiple of 4 (one block per wave per step)
     static constexpr int se_() {
@@ -64,7 +64,6 @@ struct GmlBwdCfg {
     static constexpr int NSLAB = OK ? S / SE : 1;
     static constexpr int NACC = IPS * NSLAB;                  // persistent dW accumulators (f32x4) per wave
     static constexpr int W_FLOATS = (S * FINP * LDW + 3) / 4 * 4;
-    static constexpr int XO_FLOATS = (64 * LDXO + 3) / 4 * 4;
     static constexpr int RP_FLOATS = 68;
     __host__ __device__ static constexpr int pex_floats() { return 2 * SE * 64 * LDP; }
     __host__ __device__ static int gs_floats(int xcap) {
@@ -72,20 +71,19 @@ struct GmlBwdCfg {
         return a > b ? a : b;
     }
     __host__ __device__ static size_t lds_bytes(int ecap, int xcap) {
-        return sizeof(float) * (size_t)(W_FLOATS + XO_FLOATS + RP_FLOATS + ecap + ecap * S + gs_floats(xcap));
+        return sizeof(float) * (size_t)(W_FLOATS + RP_FLOATS + ecap + ecap * S + gs_floats(xcap));
     }
 };
 
 template <int S, int NFB, int NOB>
-__global__ __launch_bounds__(256) void gml_k_spectconv_bwd(const GmlBwdParams p) {
+__global__ __launch_bounds__(256, 2) void gml_k_spectconv_bwd(const GmlBwdParams p) {
     using C = GmlBwdCfg<S, NFB, NOB>;
-    constexpr int FINP = C::FINP, LDW = C::LDW, LDG = C::LDG, LDP = C::LDP, LDXO = C::LDXO;
+    constexpr int FINP = C::FINP, LDW = C::LDW, LDG = C::LDG, LDP = C::LDP;
     constexpr int KF = FINP / 4;
     constexpr int VAL_ALIGN = (S % 4 == 0) ? 4 : ((S % 2 == 0) ? 2 : 1);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* W_l = lds;
-    float* xs_own = W_l + C::W_FLOATS;
-    int* rp_l = reinterpret_cast<int*>(xs_own + C::XO_FLOATS);
+    int* rp_l = reinterpret_cast<int*>(W_l + C::W_FLOATS);
     int* col_l = rp_l + C::RP_FLOATS;
     float* ea_l = reinterpret_cast<float*>(col_l + p.ecap);
     float* gs = ea_l + (size_t)p.ecap * S;
@@ -126,13 +124,18 @@ __global__ __launch_bounds__(256) void gml_k_spectconv_bwd(const GmlBwdParams p)
         } else {
             for (int i = tid; i < ne * S; i += 256) ea_l[i] = p.val[(int64_t)kb * S + i];
         }
-        for (int i = tid; i < nwin * C::FOUTP; i += 256) {
-            const int rr = i / C::FOUTP, o = i % C::FOUTP;
-            gs[rr * LDG + o] = (o < p.Fout) ? p.g[(int64_t)(lo + rr) * p.ldg + o] : 0.f;
-        }
-        for (int i = tid; i < 64 * FINP; i += 256) {
-            const int rr = i / FINP, f = i % FINP;
-            xs_own[rr * LDXO + f] = (rr < nr && f < p.Fin) ? p.x[(r0 + rr) * p.ldx + f] : 0.f;
+        if (p.gvec) {                                        // rows padded to a float4 multiple, 16-B aligned
+            for (int i = tid; i < nwin * (C::FOUTP / 4); i += 256) {
+                const int rr = i / (C::FOUTP / 4), o4 = (i % (C::FOUTP / 4)) * 4;
+                f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (o4 < p.Fout) t = *reinterpret_cast<const f32x4*>(p.g + (int64_t)(lo + rr) * p.ldg + o4);   // pad cols are 0
+                *reinterpret_cast<f32x4*>(gs + rr * LDG + o4) = t;
+            }
+        } else {
+            for (int i = tid; i < nwin * C::FOUTP; i += 256) {
+                const int rr = i / C::FOUTP, o = i % C::FOUTP;
+                gs[rr * LDG + o] = (o < p.Fout) ? p.g[(int64_t)(lo + rr) * p.ldg + o] : 0.f;
+            }
         }
         __syncthreads();
 
@@ -144,9 +147,22 @@ __global__ __launch_bounds__(256) void gml_k_spectconv_bwd(const GmlBwdParams p)
         // ---- Z^T = W^T X^T : lane (r16, kq) gets Z[row][s][ob*16 + 4*kq + reg]
         float Z[S][NOB][4], P[S][NOB][4];
         {
+            // own X row, KF consecutive features per lane: the contraction index of step t is f = KF*kq + t
             float xb[KF];
+            {
+                const float* xr = p.x + (r0 + row) * p.ldx + KF * kq;
+                if (p.xvec && KF % 4 == 0) {
 #pragma unroll
-            for (int t = 0; t < KF; ++t) xb[t] = xs_own[row * LDXO + 4 * t + kq];
+                    for (int q4 = 0; q4 < KF / 4; ++q4) {
+                        f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (rvalid && KF * kq + 4 * q4 < p.Fin) t = *reinterpret_cast<const f32x4*>(xr + 4 * q4);
+                        xb[4 * q4] = t.x; xb[4 * q4 + 1] = t.y; xb[4 * q4 + 2] = t.z; xb[4 * q4 + 3] = t.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < KF; ++t) xb[t] = (rvalid && KF * kq + t < p.Fin) ? xr[t] : 0.f;
+                }
+            }
 #pragma unroll
             for (int s = 0; s < S; ++s)
 #pragma unroll
@@ -154,7 +170,7 @@ __global__ __launch_bounds__(256) void gml_k_spectconv_bwd(const GmlBwdParams p)
                     f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int t = 0; t < KF; ++t) {
-                        const float a = W_l[(s * FINP + 4 * t + kq) * LDW + ob * 16 + r16];
+                        const float a = W_l[(s * FINP + KF * kq + t) * LDW + ob * 16 + r16];
                         d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xb[t], d, 0, 0, 0);
                     }
 #pragma unroll
@@ -186,15 +202,21 @@ __global__ __launch_bounds__(256) void gml_k_spectconv_bwd(const GmlBwdParams p)
                     }
                 d[s] = a;
             }
-            // the 4 lanes of a row (kq = 0..3) each hold a quarter of the o-sum
+            // the 4 lanes of a row (kq = 0..3) each hold a quarter of the o-sum: v_permlane16_swap /
+            // v_permlane32_swap fold four values at a time so that lane kq ends up with the total of
+            // value 4c + kq (6 VALU ops per 4 values, no LDS round trip); value row k is consumed, so
+            // dval overwrites it in place.
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
-                d[s] += __shfl_xor(d[s], 16);
-                d[s] += __shfl_xor(d[s], 32);
-            }
-            if (kq == 0) {
-#pragma unroll
-                for (int s = 0; s < S; ++s) ea_l[k * S + s] = d[s];     // value row k is consumed: reuse it for dval
+            for (int c = 0; c < (S + 3) / 4; ++c) {
+                const float v0 = d[4 * c], v1 = (4 * c + 1 < S) ? d[4 * c + 1] : 0.f;
+                const float v2 = (4 * c + 2 < S) ? d[4 * c + 2] : 0.f, v3 = (4 * c + 3 < S) ? d[4 * c + 3] : 0.f;
+                const auto a01 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v0), __float_as_uint(v1), false, false);
+                const auto a23 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v2), __float_as_uint(v3), false, false);
+                const float c01 = __uint_as_float(a01[0]) + __uint_as_float(a01[1]);
+                const float c23 = __uint_as_float(a23[0]) + __uint_as_float(a23[1]);
+                const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(c01), __float_as_uint(c23), false, false);
+                const float tot = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+                if (4 * c + kq < S) ea_l[k * S + 4 * c + kq] = tot;
             }
         }
         __syncthreads();                                     // dval rows complete; G window no longer needed
@@ -258,7 +280,8 @@ __global__ __launch_bounds__(256) void gml_k_spectconv_bwd(const GmlBwdParams p)
                     f32x4 d = dwacc[sl * C::IPS + it];
 #pragma unroll
                     for (int t = 0; t < 16; ++t) {
-                        const float a = xs_own[(4 * t + kq) * LDXO + fb * 16 + r16];       // A[i = f][k = row]
+                        const int ar = 4 * t + kq, af = fb * 16 + r16;                     // A[i = f][k = row]
+                        const float a = (ar < nr && af < p.Fin) ? p.x[(r0 + ar) * p.ldx + af] : 0.f;
                         const float b = pb[(se * 64 + 4 * t + kq) * LDP + ob * 16 + r16];  // B[k = row][j = o]
                         d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, d, 0, 0, 0);
                     }

@@ -100,10 +100,12 @@ def sddmm(csr, x, gw, S, Fin):
 
 
 def relu_bwd(gy, gy_off, ldgy, y, ldy, nrows, F):
-    g = torch.empty(nrows, F, dtype=torch.float32, device=gy.device)
-    _lib.call('gml_relu_bwd', _off(gy, gy_off), int(ldgy), _ptr(y), int(ldy), _ptr(g), int(F), int(nrows), int(F),
+    """[nrows, F] view of a buffer whose rows are zero-padded to a multiple of 4 floats (float4-readable)."""
+    ld = (F + 3) // 4 * 4
+    g = torch.empty(nrows, ld, dtype=torch.float32, device=gy.device)
+    _lib.call('gml_relu_bwd', _off(gy, gy_off), int(ldgy), _ptr(y), int(ldy), _ptr(g), ld, int(nrows), int(F),
               _stream(gy.device))
-    return g
+    return g[:, :F]
 
 
 def edge_mlp_fwd(ea, w1, w2, w3, w4):
@@ -168,6 +170,8 @@ def _conv_backward(csr, x, val, weight, G, need_x, need_val, need_w, val_t=None,
     S, Fin, Fout = weight.shape
     N = csr.N
     dx = dval = dw = None
+    if G.stride(1) != 1:
+        G = G.contiguous()
     if fused_bwd_available(csr, S, Fin, Fout):
         if val_t is None:
             with _Timed('val_to_source_order'):
@@ -177,6 +181,8 @@ def _conv_backward(csr, x, val, weight, G, need_x, need_val, need_w, val_t=None,
             with _Timed('dval_from_source_order'):
                 dval_t = csr.from_source_order(dval_t)
         return dx, dval_t, dw, (want_source_order and need_val)
+    if not G.is_contiguous():
+        G = G.contiguous()
     if need_x:
         dx = torch.empty(N, Fin, dtype=torch.float32, device=x.device)
         # dX = sum_s A_s (G W_s^T): rows keyed by SOURCE, features = G, weight element (s, o, f) = W[s, f, o]

@@ -149,7 +149,8 @@ int gml_node_mix_bwd(const float* x, int64_t ldx, const float* w11, const float*
                      int64_t num_rows, int32_t Fin, int32_t F2, void* ws, size_t ws_bytes, gml_stream_t stream);
 
 /* ---------------------------------------------------------------- glue
- * g[r, c] = (y[r, c] > 0) ? gy[r, c] : 0   for c < F        (relu backward on a strided slice) */
+ * g[r, c] = (y[r, c] > 0) ? gy[r, c] : 0   for c < F, and 0 for F <= c < ldg (relu backward on a strided
+ * slice; the zero padding lets consumers read aligned float4 groups) */
 int gml_relu_bwd(const float* gy, int64_t ldgy, const float* y, int64_t ldy, float* g, int64_t ldg,
                  int64_t num_rows, int32_t F, gml_stream_t stream);
 /* out[g, :] = sum_{r in [ptr[g], ptr[g+1])} x[r, :]  (global_add_pool over a sorted batch vector;
