@@ -7,8 +7,8 @@ A step = forward + L1-sum loss + backward + (N>1: one flat SUM all-reduce of the
 of the reference's ZINC GNNML3 (Zinc12k.py:310-371: 4 x ML3Layer 30+2, S = 8 supports, 25 input
 features, add-pool, fc 32 -> 1, lr 1e-3) over one batch of synthetic ZINC-like graphs per GPU (weak
 scaling: graphs per GPU fixed).  Inputs are resident in HBM before the timed region.  fp32.
-Rank 0 prints ONE JSON line; ``roofline`` is for the dominant kernel (the fused SpectConv forward),
-timed live with HIP events inside the timed region; ``cpu_baseline`` is the CPU oracle (a port of the
+Rank 0 prints ONE JSON line; ``roofline`` is for the dominant kernel (the fused SpectConv backward; the
+fused forward is under ``roofline_other``), timed live with HIP events inside the timed region; ``cpu_baseline`` is the CPU oracle (a port of the
 reference algorithm, op for op) timed on this box's host cores on a bounded sample (N = 1 only).
 """
 import argparse
@@ -176,20 +176,31 @@ def main():
                    final_loss=lossv)
         if prof:
             summ = Fn.profile_summary(prof)
-            k = summ['spectconv_fwd']
-            t = k['ms'] * 1e-3
-            gbs, tfs = k['bytes'] / t / 1e9, k['flops'] / t / 1e12
-            t_hbm, t_mfma = k['bytes'] / (HBM_PEAK_GBS * 1e9), k['flops'] / (MFMA_F32_PEAK_TFLOPS * 1e12)
-            if t_mfma >= t_hbm:
-                roof = dict(bound='mfma', achieved=tfs, peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
-                            frac=tfs / MFMA_F32_PEAK_TFLOPS)
-            else:
-                roof = dict(bound='hbm', achieved=gbs, peak=HBM_PEAK_GBS, unit='GB/s', frac=gbs / HBM_PEAK_GBS)
-            roof.update(traffic=None, kernel='gml_k_spectconv_fwd (fused SpectConv forward, 4 launches/step)',
-                        launches=k['launches'], avg_launch_ms=k['ms'], algorithmic_bytes_per_launch=k['bytes'],
-                        algorithmic_flops_per_launch=k['flops'], hbm_GBps=gbs, hbm_frac=gbs / HBM_PEAK_GBS,
-                        mfma_f32_TFLOPs=tfs, mfma_frac=tfs / MFMA_F32_PEAK_TFLOPS)
-            res['roofline'] = roof
+
+            def roof(tag, kernel):
+                k = summ[tag]
+                t = k['ms'] * 1e-3
+                gbs, tfs = k['bytes'] / t / 1e9, k['flops'] / t / 1e12
+                t_hbm, t_mfma = k['bytes'] / (HBM_PEAK_GBS * 1e9), k['flops'] / (MFMA_F32_PEAK_TFLOPS * 1e12)
+                if t_mfma >= t_hbm:
+                    r = dict(bound='mfma', achieved=tfs, peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
+                             frac=tfs / MFMA_F32_PEAK_TFLOPS)
+                else:
+                    r = dict(bound='hbm', achieved=gbs, peak=HBM_PEAK_GBS, unit='GB/s', frac=gbs / HBM_PEAK_GBS)
+                r.update(traffic=None, kernel=kernel, launches=k['launches'], avg_launch_ms=k['ms'],
+                         ms_per_step=k['ms'] * k['launches'] / args.steps,
+                         algorithmic_bytes_per_launch=k['bytes'], algorithmic_flops_per_launch=k['flops'],
+                         hbm_GBps=gbs, hbm_frac=gbs / HBM_PEAK_GBS, mfma_f32_TFLOPs=tfs,
+                         mfma_frac=tfs / MFMA_F32_PEAK_TFLOPS)
+                return r
+            cands = []
+            if 'spectconv_bwd' in summ:
+                cands.append(roof('spectconv_bwd', 'gml_k_spectconv_bwd (fused SpectConv backward: dX, dval, dW)'))
+            if 'spectconv_fwd' in summ:
+                cands.append(roof('spectconv_fwd', 'gml_k_spectconv_fwd (fused SpectConv forward)'))
+            cands.sort(key=lambda r: -r['ms_per_step'])
+            res['roofline'] = cands[0]                   # the kernel with the largest share of the step
+            res['roofline_other'] = cands[1:]
             res['kernels_ms_per_step'] = {tag: round(v['ms'] * v['launches'] / args.steps, 4) for tag, v in summ.items()}
         if world == 1 and not args.no_cpu:
             from gnn_matlang_amd import SpectralDesign, collate, synthetic

@@ -58,6 +58,14 @@ def conv_cost(N, E, S, Fin, Fout):
     return q, f
 
 
+def conv_cost_bwd(N, E, S, Fin, Fout):
+    """compulsory traffic / flops of one SpectConv backward incl. d/dval:
+       Q = 4 (2 E S + 2 N Fin + N Fout + 2 S Fin Fout + Fout) + 4 (E + N + 1);  F = 6 E S Fin + 4 N S Fin Fout."""
+    q = 4 * (2 * E * S + 2 * N * Fin + N * Fout + 2 * S * Fin * Fout + Fout) + 4 * (E + N + 1)
+    f = 6 * E * S * Fin + 4 * N * S * Fin * Fout
+    return q, f
+
+
 def _off(t, elems):
     return ctypes.c_void_p(t.data_ptr() + 4 * int(elems))
 
@@ -153,9 +161,8 @@ def fused_conv_bwd(csr, val_t, x, G, weight, need_x, need_val, need_w, dx_accum_
     dx = torch.empty(csr.N, Fin, dtype=torch.float32, device=dev) if need_x else None
     dval_t = torch.empty(csr.E, S, dtype=torch.float32, device=dev) if need_val else None
     dw = torch.empty(S, Fin, Fout, dtype=torch.float32, device=dev) if need_w else None
-    q, f = conv_cost(csr.N, csr.E, S, Fin, Fout) if PROFILE is not None else (0, 0)
-    # compulsory traffic of the backward: Q_bwd ~ 2 Q_fwd - N Fout; flops 3 projections + 2 edge passes
-    with _Timed('spectconv_bwd', 2 * q, 6 * csr.N * S * Fin * Fout + 4 * csr.E * S * Fout):
+    q, f = conv_cost_bwd(csr.N, csr.E, S, Fin, Fout) if PROFILE is not None else (0, 0)
+    with _Timed('spectconv_bwd', q, f):
         _lib.call('gml_spectconv_bwd', _ptr(csr.rowptr_t), _ptr(csr.col_t), _ptr(csr.ginfo_t), _ptr(val_t),
                   _ptr(x), int(x.stride(0)), _ptr(G), int(G.stride(0)), _ptr(weight), _ptr(dx), Fin, _ptr(dval_t),
                   _ptr(dw), csr.N, S, Fin, Fout, csr.gmax_t[0], csr.gmax_t[1], 0, _ptr(ws),
