@@ -26,7 +26,8 @@ __global__ __launch_bounds__(256) void gml_k_reduce_partials(const float* __rest
 
 #define GML_DECL_EMLP(SV)                                                                                    \
     template <> int gml_launch_edge_mlp_fwd<SV, SV>(const float*, const float*, const float*, const float*,  \
-                                                    const float*, float*, int64_t, hipStream_t);             \
+                                                    const float*, float*, const int32_t*, float*, int64_t,   \
+                                                    hipStream_t);                                            \
     template <> int gml_launch_edge_mlp_bwd<SV, SV>(const float*, const float*, const float*, const float*,  \
                                                     const float*, const float*, float*, float*, float*,      \
                                                     float*, float*, int64_t, void*, size_t, hipStream_t);
@@ -46,15 +47,16 @@ GML_DECL_EMLP(13) GML_DECL_EMLP(14) GML_DECL_EMLP(15) GML_DECL_EMLP(16)
     return GML_E_UNSUPPORTED;
 
 extern "C" int gml_edge_mlp_fwd(const float* ea, const float* w1, const float* w2, const float* w3,
-                                const float* w4, float* out, int64_t num_edges, int32_t S, int32_t Sout,
-                                gml_stream_t stream) {
+                                const float* w4, float* out, const int32_t* tpos, float* out_t,
+                                int64_t num_edges, int32_t S, int32_t Sout, gml_stream_t stream) {
     if (num_edges < 0 || S <= 0 || Sout <= 0) return GML_E_BADARG;
     if (num_edges == 0) return GML_OK;
     if (!ea || !w1 || !w2 || !w3 || !w4 || !out) return GML_E_BADARG;
     if (S != Sout) return GML_E_UNSUPPORTED;   // every reference script uses nedgeoutput == nedgeinput
-    if ((((uintptr_t)ea | (uintptr_t)out) & 15) != 0) return GML_E_BADARG;
+    if ((((uintptr_t)ea | (uintptr_t)out | (uintptr_t)out_t) & 15) != 0) return GML_E_BADARG;
+    if (out_t && !tpos) return GML_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
-#define GML_CALL_F(SV) gml_launch_edge_mlp_fwd<SV, SV>(ea, w1, w2, w3, w4, out, num_edges, st)
+#define GML_CALL_F(SV) gml_launch_edge_mlp_fwd<SV, SV>(ea, w1, w2, w3, w4, out, tpos, out_t, num_edges, st)
     GML_EMLP_SWITCH(GML_CALL_F)
 }
 

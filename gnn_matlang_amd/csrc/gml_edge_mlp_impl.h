@@ -51,6 +51,7 @@ template <int S, int SO>
 __global__ __launch_bounds__(256) void gml_k_edge_mlp_fwd(const float* __restrict__ ea, const float* __restrict__ w1_,
                                                          const float* __restrict__ w2_, const float* __restrict__ w3_,
                                                          const float* __restrict__ w4_, float* __restrict__ out,
+                                                         const int32_t* __restrict__ tpos, float* __restrict__ out_t,
                                                          int64_t E) {
     using M = GmlEdgeMlp<S, SO>;
     for (int64_t e0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e0 < E; e0 += (int64_t)gridDim.x * blockDim.x) {
@@ -70,14 +71,20 @@ __global__ __launch_bounds__(256) void gml_k_edge_mlp_fwd(const float* __restric
             }
             o[q] = fmaxf(a, 0.f);
         }
-        float* dst = out + e0 * SO;
-        if constexpr (M::OUT_ALIGN == 4) {
+        // the same row goes out twice when the caller wants it: in this (target-sorted) order for the forward
+        // kernel and at tpos[e] (source-sorted order) for the backward kernel, which then needs no gather pass
 #pragma unroll
-            for (int q = 0; q < SO / 4; ++q)
-                *reinterpret_cast<f32x4*>(dst + 4 * q) = f32x4{o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
-        } else {
+        for (int copy = 0; copy < 2; ++copy) {
+            if (copy == 1 && out_t == nullptr) break;
+            float* dst = (copy == 0) ? out + e0 * SO : out_t + (int64_t)tpos[e0] * SO;
+            if constexpr (M::OUT_ALIGN == 4) {
 #pragma unroll
-            for (int q = 0; q < SO; ++q) dst[q] = o[q];
+                for (int q = 0; q < SO / 4; ++q)
+                    *reinterpret_cast<f32x4*>(dst + 4 * q) = f32x4{o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
+            } else {
+#pragma unroll
+                for (int q = 0; q < SO; ++q) dst[q] = o[q];
+            }
         }
     }
 }
@@ -250,7 +257,7 @@ __global__ void gml_k_reduce_partials(const float* __restrict__ partial, int64_t
 
 template <int S, int SO>
 int gml_launch_edge_mlp_fwd(const float* ea, const float* w1, const float* w2, const float* w3, const float* w4,
-                            float* out, int64_t E, hipStream_t st);
+                            float* out, const int32_t* tpos, float* out_t, int64_t E, hipStream_t st);
 template <int S, int SO>
 int gml_launch_edge_mlp_bwd(const float* ea, const float* w1, const float* w2, const float* w3, const float* w4,
                             const float* gout, float* gin, float* dw1, float* dw2, float* dw3, float* dw4,
@@ -267,11 +274,12 @@ static inline int64_t gml_edge_mlp_bwd_waves(int64_t E, int waves_per_wg) {
 #define GML_DEFINE_EDGE_MLP(SV)                                                                              \
     template <>                                                                                              \
     int gml_launch_edge_mlp_fwd<SV, SV>(const float* ea, const float* w1, const float* w2, const float* w3,  \
-                                        const float* w4, float* out, int64_t E, hipStream_t st) {            \
+                                        const float* w4, float* out, const int32_t* tpos, float* out_t,      \
+                                        int64_t E, hipStream_t st) {                                         \
         int64_t grid = gml_cdiv(E, 256);                                                                     \
         if (grid > GML_NUM_CU * 16) grid = GML_NUM_CU * 16;                                                  \
         hipLaunchKernelGGL((gml_k_edge_mlp_fwd<SV, SV>), dim3((unsigned)grid), dim3(256), 0, st, ea, w1, w2, \
-                           w3, w4, out, E);                                                                  \
+                           w3, w4, out, tpos, out_t, E);                                                     \
         return gml_launch_status();                                                                          \
     }                                                                                                        \
     template <>                                                                                              \

@@ -116,13 +116,15 @@ def relu_bwd(gy, gy_off, ldgy, y, ldy, nrows, F):
     return g[:, :F]
 
 
-def edge_mlp_fwd(ea, w1, w2, w3, w4):
+def edge_mlp_fwd(ea, w1, w2, w3, w4, tpos=None):
+    """returns out (same edge order as ea) and, when tpos is given, the same rows at out_t[tpos[e]]."""
     E, S = ea.shape
     So = w4.size(0)
     out = torch.empty(E, So, dtype=torch.float32, device=ea.device)
-    _lib.call('gml_edge_mlp_fwd', _ptr(ea), _ptr(w1), _ptr(w2), _ptr(w3), _ptr(w4), _ptr(out), int(E), int(S),
-              int(So), _stream(ea.device))
-    return out
+    out_t = torch.empty(E, So, dtype=torch.float32, device=ea.device) if tpos is not None else None
+    _lib.call('gml_edge_mlp_fwd', _ptr(ea), _ptr(w1), _ptr(w2), _ptr(w3), _ptr(w4), _ptr(out), _ptr(tpos),
+              _ptr(out_t), int(E), int(S), int(So), _stream(ea.device))
+    return out, out_t
 
 
 def edge_mlp_bwd(ea, w1, w2, w3, w4, gout, need_gin):
@@ -267,10 +269,12 @@ class ML3LayerFunction(torch.autograd.Function):
             if learnedge:
                 w1, w2, w3, w4 = (_f32c(w1, 'fc1_1.weight'), _f32c(w2, 'fc1_2.weight'), _f32c(w3, 'fc1_3.weight'),
                                   _f32c(w4, 'fc1_4.weight'))
-                with _Timed('edge_mlp_fwd', 4 * val.numel() * 2, 20 * val.size(0) * val.size(1) ** 2):
-                    ea = edge_mlp_fwd(val, w1, w2, w3, w4)
+                # when the fused backward will run, the edge branch also emits its output in source order
+                dual = any(ctx.needs_input_grad) and fused_bwd_available(csr, S, Fin, nout1)
+                with _Timed('edge_mlp_fwd', 4 * val.numel() * (3 if dual else 2), 20 * val.size(0) * val.size(1) ** 2):
+                    ea, ea_t = edge_mlp_fwd(val, w1, w2, w3, w4, csr.tpos if dual else None)
             else:
-                ea = val
+                ea, ea_t = val, None
             if ea.size(1) != S:
                 raise ValueError('conv1 expects %d supports, edge branch produced %d' % (S, ea.size(1)))
             out = torch.empty(N, C, dtype=torch.float32, device=x.device)
@@ -283,12 +287,12 @@ class ML3LayerFunction(torch.autograd.Function):
                 _lib.call('gml_node_mix_fwd', _ptr(x), Fin, _ptr(w11), _ptr(b11), _ptr(w12), _ptr(b12),
                           _off(out, nout1), C, N, Fin, nout2, _stream(x.device))
         ctx.csr, ctx.learnedge, ctx.nout2, ctx.has_cb = csr, learnedge, nout2, cb is not None
-        ctx.save_for_backward(x, val, ea if learnedge else None, w1, w2, w3, w4, cw, w11, b11, w12, b12, out)
+        ctx.save_for_backward(x, val, ea if learnedge else None, w1, w2, w3, w4, cw, w11, b11, w12, b12, out, ea_t)
         return out
 
     @staticmethod
     def backward(ctx, gy):
-        x, val, ea, w1, w2, w3, w4, cw, w11, b11, w12, b12, out = ctx.saved_tensors
+        x, val, ea, w1, w2, w3, w4, cw, w11, b11, w12, b12, out, ea_t = ctx.saved_tensors
         csr, learnedge, nout2 = ctx.csr, ctx.learnedge, ctx.nout2
         S, Fin, nout1 = cw.shape
         N, C = csr.N, nout1 + nout2
@@ -300,7 +304,9 @@ class ML3LayerFunction(torch.autograd.Function):
         with torch.cuda.device(x.device):
             G = relu_bwd(gy, 0, C, out, C, N, nout1)
             need_val = need[1] or (learnedge and any(need[2:6]))
-            dx, dea, dcw, dea_src = _conv_backward(csr, x, ea, cw, G, need[0], need_val, need[6],
+            if not learnedge and fused_bwd_available(csr, S, Fin, nout1):
+                ea_t = csr.to_source_order(val, cache=True)              # raw supports: per-batch data
+            dx, dea, dcw, dea_src = _conv_backward(csr, x, ea, cw, G, need[0], need_val, need[6], val_t=ea_t,
                                                    want_source_order=learnedge)
             g[6] = dcw
             if ctx.has_cb and need[7]:

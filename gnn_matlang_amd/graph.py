@@ -36,7 +36,7 @@ def _require_cuda(t, name):
 
 class GraphCSR(object):
     __slots__ = ('N', 'E', 'device', 'rowptr', 'col', 'perm', 'rowptr_t', 'col_t', 'pos_t', 'perm_t',
-                 'ginfo', 'ginfo_t', 'gmax', 'gmax_t', '_val_cache', '_keep')
+                 'ginfo', 'ginfo_t', 'gmax', 'gmax_t', 'tpos', '_val_cache', '_keep')
 
     def __init__(self):
         self._val_cache = OrderedDict()
@@ -67,6 +67,9 @@ class GraphCSR(object):
             inv = torch.empty(E, **i32)
             g.pos_t = torch.empty(E, **i32)
             _lib.call('gml_csr_link_transpose', _ptr(g.perm), _ptr(g.perm_t), E, _ptr(inv), _ptr(g.pos_t), st)
+            # tpos = inverse of pos_t: source-sorted position of every target-sorted edge
+            g.tpos = torch.empty(E, **i32)
+            _lib.call('gml_csr_link_transpose', _ptr(g.pos_t), _ptr(g.pos_t), E, _ptr(g.tpos), _ptr(inv), st)
             ng = max((N + 63) // 64, 1)
             g.ginfo, g.ginfo_t = torch.zeros(ng, 4, **i32), torch.zeros(ng, 4, **i32)
             _lib.call('gml_csr_group_info', _ptr(g.rowptr), _ptr(g.col), N, _ptr(g.ginfo), st)

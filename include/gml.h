@@ -122,9 +122,12 @@ int gml_sddmm(const int32_t* rowptr, const int32_t* col, const int32_t* epos,
 
 /* ---------------------------------------------------------------- ML3Layer edge branch
  *   out = relu( W4 . [ relu(W1 . e) ; tanh(W2 . e) * tanh(W3 . e) ] )      per edge e in R^S
- * w1,w2,w3: [2S, S]; w4: [Sout, 4S]  (torch.nn.Linear layout, bias-free).  S, Sout <= 16. */
+ * w1,w2,w3: [2S, S]; w4: [Sout, 4S]  (torch.nn.Linear layout, bias-free).  S = Sout <= 16.
+ * If out_t != NULL the row of edge e is also written to out_t[tpos[e], :] (the same values in a second
+ * edge order: the backward kernel walks the source-sorted order). */
 int gml_edge_mlp_fwd(const float* ea, const float* w1, const float* w2, const float* w3, const float* w4,
-                     float* out, int64_t num_edges, int32_t S, int32_t Sout, gml_stream_t stream);
+                     float* out, const int32_t* tpos, float* out_t,
+                     int64_t num_edges, int32_t S, int32_t Sout, gml_stream_t stream);
 size_t gml_edge_mlp_bwd_workspace_bytes(int64_t num_edges, int32_t S, int32_t Sout);
 /* gout: dL/dout [E, Sout].  Writes dw1..dw4 (same shapes as the weights) and, if gin != NULL,
  * dL/dea [E, S].  Intermediates are recomputed from ea. */

@@ -215,7 +215,10 @@ def test_spmm_sddmm_edge_mlp_node_mix_vs_oracle(dev):
         gout = torch.randn_like(yo)
         (yo * gout).sum().backward()
         wd = [w.to(dev) for w in ws]
-        y = Fn.edge_mlp_fwd(ea.to(dev), *wd)
+        y, _ = Fn.edge_mlp_fwd(ea.to(dev), *wd)
+        tp = torch.randperm(E2, device=dev).int()
+        y2, yt = Fn.edge_mlp_fwd(ea.to(dev), *wd, tpos=tp)
+        assert torch.equal(y2, y) and torch.equal(yt[tp.long()], y)          # second order: same rows, permuted
         close(y, yo, what='edge mlp fwd S=%d' % S)
         gin, d1, d2, d3, d4 = Fn.edge_mlp_bwd(ea.to(dev), *wd, gout.to(dev), True)
         close(gin, eo.grad, what='edge mlp gin S=%d' % S)
