@@ -17,16 +17,18 @@ extern "C" const char* gml_error_string(int code) {
 
 // ---------------------------------------------------------------------------------------------
 // ML3Layer Hadamard branch:  out[r, o] = tanh(x[r] . w11[o] + b11[o]) * tanh(x[r] . w12[o] + b12[o])
-// Tiles of 64 rows: the x tile and both weight matrices sit in LDS (coalesced loads), one lane per
-// (row, o) pair.  Backward recomputes the tanh's, keeps gz = [dL/dz11 | dL/dz12] of the tile in LDS and
-// from it forms, in the same launch, dx += gz [w11; w12], and the weight / bias gradients as
-// per-lane register accumulators over all tiles of the (persistent) workgroup -> one partial per
-// workgroup, folded in fixed order by gml_k_reduce_rows_misc (deterministic, no atomics).
+// (/root/reference/libs/spect_conv.py:198-202,209).
+// One ROW per lane, 256 rows per workgroup step: the x tile is staged through LDS with coalesced loads,
+// each lane keeps its row in registers, the weights are LDS broadcast reads.  Backward recomputes the
+// tanh's and, in the same launch, adds dx += dz [w11; w12] (row in registers) and contracts the
+// weight / bias gradients dz^T [x | 1] over the rows on the matrix cores (v_mfma_f32_16x16x4_f32,
+// A = dz tile, B = x tile, both already in LDS), accumulating per wave across all its tiles; one
+// partial per wave, folded in fixed order (deterministic, no atomics).
 // ---------------------------------------------------------------------------------------------
-#define NM_TILE 64
-#define NM_NA 16
+#define NM_ROWS 256
+#define NM_MAXCB 3      /* 2*F2 <= 48 */
 
-template <bool BWD>
+template <int FINP, bool BWD>
 __global__ __launch_bounds__(256) void gml_k_node_mix(const float* __restrict__ x, int64_t ldx,
                                                      const float* __restrict__ w11, const float* __restrict__ b11,
                                                      const float* __restrict__ w12, const float* __restrict__ b12,
@@ -35,111 +37,179 @@ __global__ __launch_bounds__(256) void gml_k_node_mix(const float* __restrict__ 
                                                      float* __restrict__ dx, int64_t lddx, float* __restrict__ partial,
                                                      int64_t nrows, int Fin, int F2, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int LDX = Fin | 1;                                  // odd: conflict-free row-strided reads
-    const int C2 = 2 * F2, LDZ = C2 | 1;
-    float* xs = lds;                                          // [64][LDX]
-    float* wc = xs + NM_TILE * LDX;                           // [2*F2][LDX]  rows: w11 then w12
-    float* bc = wc + C2 * LDX;                                // [2*F2]
-    float* gz = bc + C2;                                      // [64][LDZ]   (backward only)
-    const int tid = threadIdx.x;
-    for (int i = tid; i < C2 * Fin; i += 256) {
-        const int c = i / Fin, f = i % Fin;
-        wc[c * LDX + f] = (c < F2) ? w11[c * Fin + f] : w12[(c - F2) * Fin + f];
+    constexpr int LDX = FINP + 1;                              // odd: row-per-lane reads are conflict free
+    constexpr int NFB = FINP / 16;
+    const int C2 = 2 * F2, C2P = (C2 + 15) / 16 * 16, LDZ = C2P + 1, ncb = C2P / 16;
+    float* xs = lds;                                           // [256][LDX]
+    float* wc = xs + NM_ROWS * LDX;                            // [C2][FINP]  rows: w11 then w12, zero padded
+    float* bc = wc + C2 * FINP;                                // [C2]
+    float* gz = bc + ((C2 + 3) / 4 * 4);                       // [256][LDZ]  (backward only)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    for (int i = tid; i < C2 * FINP; i += 256) {
+        const int c = i / FINP, f = i % FINP;
+        wc[i] = (f < Fin) ? ((c < F2) ? w11[c * Fin + f] : w12[(c - F2) * Fin + f]) : 0.f;
     }
     for (int i = tid; i < C2; i += 256) bc[i] = (i < F2) ? (b11 ? b11[i] : 0.f) : (b12 ? b12[i - F2] : 0.f);
 
-    const int npair = C2 * Fin + C2;                          // weight entries + bias entries
-    float acc[NM_NA];
+    f32x4 acc[NM_MAXCB][NFB + 1];
 #pragma unroll
-    for (int a = 0; a < NM_NA; ++a) acc[a] = 0.f;
+    for (int a = 0; a < NM_MAXCB; ++a)
+#pragma unroll
+        for (int b = 0; b <= NFB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int64_t r0 = (int64_t)t * NM_TILE;
-        const int nr = (int)min((int64_t)NM_TILE, nrows - r0);
+        const int64_t r0 = (int64_t)t * NM_ROWS;
+        const int nr = (int)min((int64_t)NM_ROWS, nrows - r0);
         __syncthreads();
-        for (int i = tid; i < NM_TILE * Fin; i += 256) {
-            const int rr = i / Fin, f = i % Fin;
-            xs[rr * LDX + f] = (rr < nr) ? x[(r0 + rr) * ldx + f] : 0.f;
+        {                                                      // coalesced tile load, no runtime division:
+            const int f = tid % FINP;                          // lane <-> feature, 256/FINP rows per sweep
+#pragma unroll 4
+            for (int rr = tid / FINP; rr < NM_ROWS; rr += 256 / FINP)
+                xs[rr * LDX + f] = (rr < nr && f < Fin) ? x[(r0 + rr) * ldx + f] : 0.f;
         }
         __syncthreads();
-        for (int pidx = tid; pidx < NM_TILE * F2; pidx += 256) {
-            const int rr = pidx / F2, o = pidx % F2;
+        const bool rv = tid < nr;
+        float xr[FINP];
+#pragma unroll
+        for (int f = 0; f < FINP; ++f) xr[f] = xs[tid * LDX + f];
+        float dxr[BWD ? FINP : 1];
+        if constexpr (BWD) {
+#pragma unroll
+            for (int f = 0; f < FINP; ++f) dxr[f] = 0.f;
+            for (int c = C2; c < C2P; ++c) gz[tid * LDZ + c] = 0.f;               // zero the padding columns
+        }
+        for (int o = 0; o < F2; ++o) {
             float a = bc[o], b = bc[F2 + o];
-            const float* xr = xs + rr * LDX;
-            const float* wa = wc + o * LDX;
-            const float* wb = wc + (F2 + o) * LDX;
-            for (int f = 0; f < Fin; ++f) {
-                a = fmaf(xr[f], wa[f], a);
-                b = fmaf(xr[f], wb[f], b);
+            const float* wa = wc + o * FINP;
+            const float* wb = wc + (F2 + o) * FINP;
+#pragma unroll
+            for (int f4 = 0; f4 < FINP / 4; ++f4) {
+                const f32x4 va = *reinterpret_cast<const f32x4*>(wa + 4 * f4);
+                const f32x4 vb = *reinterpret_cast<const f32x4*>(wb + 4 * f4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    a = fmaf(xr[4 * f4 + i], va[i], a);
+                    b = fmaf(xr[4 * f4 + i], vb[i], b);
+                }
             }
             const float ta = tanhf(a), tb = tanhf(b);
             if constexpr (!BWD) {
-                if (rr < nr) out[(r0 + rr) * ldo + o] = ta * tb;
+                if (rv) out[(r0 + tid) * ldo + o] = ta * tb;
             } else {
-                const float g = (rr < nr) ? gout[(r0 + rr) * ldg + o] : 0.f;
-                gz[rr * LDZ + o] = g * tb * (1.f - ta * ta);
-                gz[rr * LDZ + F2 + o] = g * ta * (1.f - tb * tb);
+                const float g = rv ? gout[(r0 + tid) * ldg + o] : 0.f;
+                const float g1 = g * tb * (1.f - ta * ta), g2 = g * ta * (1.f - tb * tb);
+                gz[tid * LDZ + o] = g1;
+                gz[tid * LDZ + F2 + o] = g2;
+#pragma unroll
+                for (int f4 = 0; f4 < FINP / 4; ++f4) {
+                    const f32x4 va = *reinterpret_cast<const f32x4*>(wa + 4 * f4);
+                    const f32x4 vb = *reinterpret_cast<const f32x4*>(wb + 4 * f4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dxr[4 * f4 + i] = fmaf(g1, va[i], fmaf(g2, vb[i], dxr[4 * f4 + i]));
+                }
             }
         }
         if constexpr (BWD) {
-            __syncthreads();
-            if (dx) {
-                for (int q = tid; q < nr * Fin; q += 256) {
-                    const int rr = q / Fin, f = q % Fin;
-                    float a = 0.f;
-                    for (int c = 0; c < C2; ++c) a = fmaf(gz[rr * LDZ + c], wc[c * LDX + f], a);
-                    dx[(r0 + rr) * lddx + f] += a;
-                }
+            if (dx && rv) {
+                float* dr = dx + (r0 + tid) * lddx;
+                for (int f = 0; f < Fin; ++f) dr[f] += dxr[f];
             }
+            // weight / bias gradients of this wave's 64 rows: D[c][f] += sum_rows dz[row][c] * [x | 1][row][f]
+            const int rb = wave * 64;
 #pragma unroll
-            for (int a = 0; a < NM_NA; ++a) {
-                const int pidx = tid + 256 * a;
-                if (pidx < npair) {
-                    float s = acc[a];
-                    if (pidx < C2 * Fin) {
-                        const int c = pidx / Fin, f = pidx % Fin;
-                        for (int rr = 0; rr < NM_TILE; ++rr) s = fmaf(gz[rr * LDZ + c], xs[rr * LDX + f], s);
-                    } else {
-                        const int c = pidx - C2 * Fin;
-                        for (int rr = 0; rr < NM_TILE; ++rr) s += gz[rr * LDZ + c];
+            for (int t16 = 0; t16 < 16; ++t16) {
+                const int rr = rb + 4 * t16 + kq;
+#pragma unroll
+                for (int cb = 0; cb < NM_MAXCB; ++cb) {
+                    if (cb < ncb) {
+                        const float a = gz[rr * LDZ + cb * 16 + r16];
+#pragma unroll
+                        for (int fb = 0; fb < NFB; ++fb)
+                            acc[cb][fb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xs[rr * LDX + fb * 16 + r16], acc[cb][fb], 0, 0, 0);
+                        acc[cb][NFB] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, (r16 == 0) ? 1.f : 0.f, acc[cb][NFB], 0, 0, 0);
                     }
-                    acc[a] = s;
                 }
             }
         }
     }
     if constexpr (BWD) {
+        // D layout: lane (col j = r16, rows i = 4*kq + reg): i = c index, j = f index
+        const int npair = C2 * Fin + C2;
+        float* P = partial + ((int64_t)blockIdx.x * 4 + wave) * npair;
 #pragma unroll
-        for (int a = 0; a < NM_NA; ++a) {
-            const int pidx = tid + 256 * a;
-            if (pidx < npair) partial[(int64_t)blockIdx.x * npair + pidx] = acc[a];
+        for (int cb = 0; cb < NM_MAXCB; ++cb) {
+            if (cb < ncb) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int c = cb * 16 + 4 * kq + reg;
+                    if (c < C2) {
+#pragma unroll
+                        for (int fb = 0; fb < NFB; ++fb) {
+                            const int f = fb * 16 + r16;
+                            if (f < Fin) P[c * Fin + f] = acc[cb][fb][reg];
+                        }
+                        if (r16 == 0) P[C2 * Fin + c] = acc[cb][NFB][reg];
+                    }
+                }
+            }
         }
     }
 }
 
 // fold [nparts][n] partials in fixed order and split into dw11 | dw12 | db11 | db12
-__global__ void gml_k_node_mix_fold(const float* __restrict__ partial, int64_t nparts, int Fin, int F2,
-                                    float* __restrict__ dw11, float* __restrict__ db11, float* __restrict__ dw12,
-                                    float* __restrict__ db12) {
+__global__ __launch_bounds__(256) void gml_k_node_mix_fold(const float* __restrict__ partial, int64_t nparts, int Fin,
+                                                          int F2, float* __restrict__ dw11, float* __restrict__ db11,
+                                                          float* __restrict__ dw12, float* __restrict__ db12) {
+    __shared__ float red[16][17];
     const int n = 2 * F2 * Fin + 2 * F2;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
+    const int jl = threadIdx.x & 15, wl = threadIdx.x >> 4;
+    const int j = blockIdx.x * 16 + jl;
     float a = 0.f;
-    for (int64_t w = 0; w < nparts; ++w) a += partial[w * n + j];
-    if (j < F2 * Fin) dw11[j] = a;
-    else if (j < 2 * F2 * Fin) dw12[j - F2 * Fin] = a;
-    else if (j < 2 * F2 * Fin + F2) { if (db11) db11[j - 2 * F2 * Fin] = a; }
-    else { if (db12) db12[j - 2 * F2 * Fin - F2] = a; }
+    if (j < n)
+        for (int64_t w = wl; w < nparts; w += 16) a += partial[w * n + j];
+    red[wl][jl] = a;
+    __syncthreads();
+    if (wl != 0 || j >= n) return;
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][jl];
+    if (j < F2 * Fin) dw11[j] = t;
+    else if (j < 2 * F2 * Fin) dw12[j - F2 * Fin] = t;
+    else if (j < 2 * F2 * Fin + F2) { if (db11) db11[j - 2 * F2 * Fin] = t; }
+    else { if (db12) db12[j - 2 * F2 * Fin - F2] = t; }
 }
 
+static int node_mix_finp(int Fin) { return Fin <= 16 ? 16 : (Fin <= 32 ? 32 : (Fin <= 48 ? 48 : (Fin <= 64 ? 64 : 0))); }
+
 static size_t node_mix_lds(int Fin, int F2, bool bwd) {
-    const int LDX = Fin | 1, C2 = 2 * F2, LDZ = C2 | 1;
-    return sizeof(float) * (size_t)(NM_TILE * LDX + C2 * LDX + C2 + (bwd ? NM_TILE * LDZ : 0));
+    const int FINP = node_mix_finp(Fin), C2 = 2 * F2, C2P = (C2 + 15) / 16 * 16;
+    return sizeof(float) * (size_t)(NM_ROWS * (FINP + 1) + C2 * FINP + (C2 + 3) / 4 * 4 + (bwd ? NM_ROWS * (C2P + 1) : 0));
 }
 
 static int node_mix_grid(int64_t num_rows) {
-    const int64_t nt = gml_cdiv(num_rows, NM_TILE);
-    return (int)(nt < GML_NUM_CU * 4 ? nt : GML_NUM_CU * 4);
+    const int64_t nt = gml_cdiv(num_rows, NM_ROWS);
+    return (int)(nt < GML_NUM_CU * 2 ? nt : GML_NUM_CU * 2);
+}
+
+static bool node_mix_supported(int Fin, int F2) { return node_mix_finp(Fin) != 0 && 2 * F2 <= 16 * NM_MAXCB; }
+
+template <bool BWD>
+static int node_mix_launch(int FINP, dim3 grid, size_t lds, hipStream_t st, const float* x, int64_t ldx, const float* w11,
+                           const float* b11, const float* w12, const float* b12, const float* gout, int64_t ldg,
+                           float* out, int64_t ldo, float* dx, int64_t lddx, float* partial, int64_t nrows, int Fin,
+                           int F2, int ntiles) {
+#define NM_GO(FP)                                                                                             \
+    if (FINP == FP) {                                                                                         \
+        static const hipError_t arc = hipFuncSetAttribute(reinterpret_cast<const void*>(&gml_k_node_mix<FP, BWD>), \
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        if (arc != hipSuccess) return (int)arc;                                                               \
+        hipLaunchKernelGGL((gml_k_node_mix<FP, BWD>), grid, dim3(256), lds, st, x, ldx, w11, b11, w12, b12, gout, ldg, \
+                           out, ldo, dx, lddx, partial, nrows, Fin, F2, ntiles);                              \
+        return gml_launch_status();                                                                           \
+    }
+    NM_GO(16) NM_GO(32) NM_GO(48) NM_GO(64)
+    return GML_E_UNSUPPORTED;
 }
 
 extern "C" int gml_node_mix_fwd(const float* x, int64_t ldx, const float* w11, const float* b11, const float* w12,
@@ -148,19 +218,15 @@ extern "C" int gml_node_mix_fwd(const float* x, int64_t ldx, const float* w11, c
     if (num_rows < 0 || Fin <= 0 || F2 <= 0 || ldx < Fin || ldo < F2) return GML_E_BADARG;
     if (num_rows == 0) return GML_OK;
     if (!x || !w11 || !w12 || !out) return GML_E_BADARG;
-    const size_t lds = node_mix_lds(Fin, F2, false);
-    if (lds > 64 * 1024) return GML_E_UNSUPPORTED;
-    hipLaunchKernelGGL((gml_k_node_mix<false>), dim3(node_mix_grid(num_rows)), dim3(256), lds, (hipStream_t)stream, x,
-                       ldx, w11, b11, w12, b12, (const float*)nullptr, (int64_t)0, out, ldo, (float*)nullptr,
-                       (int64_t)0, (float*)nullptr, num_rows, Fin, F2, (int)gml_cdiv(num_rows, NM_TILE));
-    return gml_launch_status();
+    if (!node_mix_supported(Fin, F2)) return GML_E_UNSUPPORTED;
+    return node_mix_launch<false>(node_mix_finp(Fin), dim3(node_mix_grid(num_rows)), node_mix_lds(Fin, F2, false),
+                                  (hipStream_t)stream, x, ldx, w11, b11, w12, b12, nullptr, 0, out, ldo, nullptr, 0,
+                                  nullptr, num_rows, Fin, F2, (int)gml_cdiv(num_rows, NM_ROWS));
 }
 
 extern "C" size_t gml_node_mix_bwd_workspace_bytes(int64_t num_rows, int32_t Fin, int32_t F2) {
-    if (num_rows <= 0 || Fin <= 0 || F2 <= 0) return 0;
-    const int npair = 2 * F2 * Fin + 2 * F2;
-    if (npair > 256 * NM_NA || node_mix_lds(Fin, F2, true) > 64 * 1024) return 0;   /* 0 = shape not supported */
-    return sizeof(float) * (size_t)node_mix_grid(num_rows) * npair;
+    if (num_rows <= 0 || Fin <= 0 || F2 <= 0 || !node_mix_supported(Fin, F2)) return 0;   /* 0 = not supported */
+    return sizeof(float) * (size_t)node_mix_grid(num_rows) * 4 * (2 * F2 * Fin + 2 * F2);
 }
 
 extern "C" int gml_node_mix_bwd(const float* x, int64_t ldx, const float* w11, const float* b11, const float* w12,
@@ -182,14 +248,13 @@ extern "C" int gml_node_mix_bwd(const float* x, int64_t ldx, const float* w11, c
     if (need == 0) return GML_E_UNSUPPORTED;
     if (!ws || ws_bytes < need) return GML_E_WORKSPACE;
     const int grid = node_mix_grid(num_rows);
-    hipLaunchKernelGGL((gml_k_node_mix<true>), dim3(grid), dim3(256), node_mix_lds(Fin, F2, true), st, x, ldx, w11,
-                       b11, w12, b12, gout, ldg, (float*)nullptr, (int64_t)0, dx, lddx, (float*)ws, num_rows, Fin,
-                       F2, (int)gml_cdiv(num_rows, NM_TILE));
-    int rc = gml_launch_status();
+    int rc = node_mix_launch<true>(node_mix_finp(Fin), dim3(grid), node_mix_lds(Fin, F2, true), st, x, ldx, w11, b11,
+                                   w12, b12, gout, ldg, nullptr, 0, dx, lddx, (float*)ws, num_rows, Fin, F2,
+                                   (int)gml_cdiv(num_rows, NM_ROWS));
     if (rc != GML_OK) return rc;
     const int n = 2 * F2 * Fin + 2 * F2;
-    hipLaunchKernelGGL(gml_k_node_mix_fold, dim3((unsigned)gml_cdiv(n, 256)), dim3(256), 0, st, (const float*)ws,
-                       (int64_t)grid, Fin, F2, dw11, db11, dw12, db12);
+    hipLaunchKernelGGL(gml_k_node_mix_fold, dim3((unsigned)gml_cdiv(n, 16)), dim3(256), 0, st, (const float*)ws,
+                       (int64_t)grid * 4, Fin, F2, dw11, db11, dw12, db12);
     return gml_launch_status();
 }
 

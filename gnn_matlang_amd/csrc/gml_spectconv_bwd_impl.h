@@ -262,6 +262,19 @@ __global__ __launch_bounds__(256, 2) void gml_k_spectconv_bwd(const GmlBwdParams
 
         // ---- dW += X^T P : contraction over the 64 rows of the group, slab of SE supports at a time
         if (p.dw_partial) {
+            // A fragments (X^T of the group's 64 rows) of the blocks this wave owns: loaded ONCE per group, before
+            // the slab loop -- a load placed after a barrier could not be hoisted and would stall every slab
+            float xa[C::IPS][16];
+#pragma unroll
+            for (int it = 0; it < C::IPS; ++it) {
+                const int fb = ((it * 4 + wave) / NOB) % NFB;
+                const int af = fb * 16 + r16;                                              // A[i = f][k = row]
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int ar = 4 * t + kq;
+                    xa[it][t] = (ar < nr && af < p.Fin) ? p.x[(r0 + ar) * p.ldx + af] : 0.f;
+                }
+            }
 #pragma unroll
             for (int sl = 0; sl < C::NSLAB; ++sl) {
                 float* pb = pex + (sl & 1) * (C::SE * 64 * LDP);
@@ -276,18 +289,16 @@ __global__ __launch_bounds__(256, 2) void gml_k_spectconv_bwd(const GmlBwdParams
 #pragma unroll
                 for (int it = 0; it < C::IPS; ++it) {
                     const int blk = it * 4 + wave;           // (se, fb, ob) block inside the slab
-                    const int ob = blk % NOB, fb = (blk / NOB) % NFB, se = blk / (NOB * NFB);
+                    const int ob = blk % NOB, se = blk / (NOB * NFB);
                     f32x4 d = dwacc[sl * C::IPS + it];
 #pragma unroll
                     for (int t = 0; t < 16; ++t) {
-                        const int ar = 4 * t + kq, af = fb * 16 + r16;                     // A[i = f][k = row]
-                        const float a = (ar < nr && af < p.Fin) ? p.x[(r0 + ar) * p.ldx + af] : 0.f;
                         const float b = pb[(se * 64 + 4 * t + kq) * LDP + ob * 16 + r16];  // B[k = row][j = o]
-                        d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[it][t], b, d, 0, 0, 0);
                     }
                     dwacc[sl * C::IPS + it] = d;
                 }
-                // the other half of the exchange buffer is free again after the NEXT barrier pair
+                // a slab buffer is rewritten two slabs later: every wave has passed the barrier in between
             }
         }
     }
