@@ -48,3 +48,12 @@ __device__ __forceinline__ void gml_load_row(const float* __restrict__ p, float 
         for (int i = 0; i < N; ++i) v[i] = p[i];
     }
 }
+
+// tanh for the edge / Hadamard branches: tanh(x) = 1 - 2 / (2^(2 log2(e) x) + 1), five instructions
+// (v_exp_f32, v_rcp_f32), branch-free, saturates correctly at +-inf.  Absolute error <= ~2e-7 (a few
+// ulp of 1.0); near 0 that is absolute, not relative, accuracy -- fp32-roundoff class for the sums and
+// products the layer forms from it (parity tolerance: 1e-4 of the tensor's max).
+__device__ __forceinline__ float gml_tanh(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+    return fmaf(-2.f, __builtin_amdgcn_rcpf(e + 1.f), 1.f);
+}

@@ -42,7 +42,7 @@ struct GmlEdgeMlp {
                 b = fmaf(w2[o * S + i], e[i], b);
                 c = fmaf(w3[o * S + i], e[i], c);
             }
-            z1[o] = a; t2[o] = tanhf(b); t3[o] = tanhf(c);
+            z1[o] = a; t2[o] = gml_tanh(b); t3[o] = gml_tanh(c);
         }
     }
 };

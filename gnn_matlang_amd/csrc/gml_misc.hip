@@ -62,11 +62,20 @@ __global__ __launch_bounds__(256) void gml_k_node_mix(const float* __restrict__ 
         const int64_t r0 = (int64_t)t * NM_ROWS;
         const int nr = (int)min((int64_t)NM_ROWS, nrows - r0);
         __syncthreads();
-        {                                                      // coalesced tile load, no runtime division:
-            const int f = tid % FINP;                          // lane <-> feature, 256/FINP rows per sweep
-#pragma unroll 4
-            for (int rr = tid / FINP; rr < NM_ROWS; rr += 256 / FINP)
-                xs[rr * LDX + f] = (rr < nr && f < Fin) ? x[(r0 + rr) * ldx + f] : 0.f;
+        {                                                      // coalesced tile load: lane <-> feature, 256/FINP rows
+            constexpr int RPS = 256 / FINP, NIT = (NM_ROWS + RPS - 1) / RPS;   // per sweep; ALL loads in flight
+            const int f = tid % FINP, rbase = tid / FINP;
+            float v[NIT];
+#pragma unroll
+            for (int j = 0; j < NIT; ++j) {
+                const int rr = rbase + j * RPS;
+                v[j] = (rr < nr && f < Fin) ? x[(r0 + rr) * ldx + f] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < NIT; ++j) {
+                const int rr = rbase + j * RPS;
+                if (rr < NM_ROWS) xs[rr * LDX + f] = v[j];
+            }
         }
         __syncthreads();
         const bool rv = tid < nr;
@@ -93,7 +102,7 @@ __global__ __launch_bounds__(256) void gml_k_node_mix(const float* __restrict__ 
                     b = fmaf(xr[4 * f4 + i], vb[i], b);
                 }
             }
-            const float ta = tanhf(a), tb = tanhf(b);
+            const float ta = gml_tanh(a), tb = gml_tanh(b);
             if constexpr (!BWD) {
                 if (rv) out[(r0 + tid) * ldo + o] = ta * tb;
             } else {
@@ -111,9 +120,14 @@ __global__ __launch_bounds__(256) void gml_k_node_mix(const float* __restrict__ 
             }
         }
         if constexpr (BWD) {
-            if (dx && rv) {
+            if (dx && rv) {                                    // read-modify-write of the lane's own row: all loads first
                 float* dr = dx + (r0 + tid) * lddx;
-                for (int f = 0; f < Fin; ++f) dr[f] += dxr[f];
+                float old[FINP];
+#pragma unroll
+                for (int f = 0; f < FINP; ++f) old[f] = (f < Fin) ? dr[f] : 0.f;
+#pragma unroll
+                for (int f = 0; f < FINP; ++f)
+                    if (f < Fin) dr[f] = old[f] + dxr[f];
             }
             // weight / bias gradients of this wave's 64 rows: D[c][f] += sum_rows dz[row][c] * [x | 1][row][f]
             const int rb = wave * 64;

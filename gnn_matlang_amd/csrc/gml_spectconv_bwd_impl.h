@@ -164,18 +164,22 @@ __global__ __launch_bounds__(256, 2) void gml_k_spectconv_bwd(const GmlBwdParams
                 }
             }
 #pragma unroll
-            for (int s = 0; s < S; ++s)
+            for (int s = 0; s < S; ++s) {
+                f32x4 d[NOB];                                // NOB independent accumulator chains, interleaved
 #pragma unroll
-                for (int ob = 0; ob < NOB; ++ob) {
-                    f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int ob = 0; ob < NOB; ++ob) d[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int t = 0; t < KF; ++t) {
+                for (int t = 0; t < KF; ++t)
+#pragma unroll
+                    for (int ob = 0; ob < NOB; ++ob) {
                         const float a = W_l[(s * FINP + KF * kq + t) * LDW + ob * 16 + r16];
-                        d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xb[t], d, 0, 0, 0);
+                        d[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xb[t], d[ob], 0, 0, 0);
                     }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { Z[s][ob][i] = d[i]; P[s][ob][i] = 0.f; }
-                }
+                for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { Z[s][ob][i] = d[ob][i]; P[s][ob][i] = 0.f; }
+            }
         }
 
         // ---- edge phase
@@ -232,18 +236,23 @@ __global__ __launch_bounds__(256, 2) void gml_k_spectconv_bwd(const GmlBwdParams
 
         // ---- dX = P W^T : contraction over (s, o), P registers are the A fragments
         if (p.dx) {
+            f32x4 dxa[NFB];                                  // NFB independent accumulator chains, interleaved
+#pragma unroll
+            for (int fb = 0; fb < NFB; ++fb) dxa[fb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int fb = 0; fb < NFB; ++fb) {
+                            const float b = W_l[(s * FINP + fb * 16 + r16) * LDW + ob * 16 + 4 * kq + i];
+                            dxa[fb] = __builtin_amdgcn_mfma_f32_16x16x4f32(P[s][ob][i], b, dxa[fb], 0, 0, 0);
+                        }
 #pragma unroll
             for (int fb = 0; fb < NFB; ++fb) {
-                f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 0; s < S; ++s)
-#pragma unroll
-                    for (int ob = 0; ob < NOB; ++ob)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const float b = W_l[(s * FINP + fb * 16 + r16) * LDW + ob * 16 + 4 * kq + i];
-                            d = __builtin_amdgcn_mfma_f32_16x16x4f32(P[s][ob][i], b, d, 0, 0, 0);
-                        }
+                const f32x4 d = dxa[fb];
                 const int f = fb * 16 + r16;
                 if (f < p.Fin) {
 #pragma unroll
@@ -290,13 +299,15 @@ __global__ __launch_bounds__(256, 2) void gml_k_spectconv_bwd(const GmlBwdParams
                 for (int it = 0; it < C::IPS; ++it) {
                     const int blk = it * 4 + wave;           // (se, fb, ob) block inside the slab
                     const int ob = blk % NOB, se = blk / (NOB * NFB);
-                    f32x4 d = dwacc[sl * C::IPS + it];
+                    f32x4 d0 = dwacc[sl * C::IPS + it], d1 = f32x4{0.f, 0.f, 0.f, 0.f};    // two chains: even / odd rows
 #pragma unroll
-                    for (int t = 0; t < 16; ++t) {
-                        const float b = pb[(se * 64 + 4 * t + kq) * LDP + ob * 16 + r16];  // B[k = row][j = o]
-                        d = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[it][t], b, d, 0, 0, 0);
+                    for (int t = 0; t < 16; t += 2) {
+                        const float b0 = pb[(se * 64 + 4 * t + kq) * LDP + ob * 16 + r16];       // B[k = row][j = o]
+                        const float b1 = pb[(se * 64 + 4 * (t + 1) + kq) * LDP + ob * 16 + r16];
+                        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[it][t], b0, d0, 0, 0, 0);
+                        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[it][t + 1], b1, d1, 0, 0, 0);
                     }
-                    dwacc[sl * C::IPS + it] = d;
+                    dwacc[sl * C::IPS + it] = d0 + d1;
                 }
                 // a slab buffer is rewritten two slabs later: every wave has passed the barrier in between
             }
