@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void gml_k_spectconv_bwd(const GmlBwdParams
         const int kend = rvalid ? rp_l[row + 1] - kb : 0;
 
         // ---- Z^T = W^T X^T : lane (r16, kq) gets Z[row][s][ob*16 + 4*kq + reg]
-        float Z[S][NOB][4], P[S][NOB][4];
+        f32x2 Z[S][NOB][2], P[S][NOB][2];        // o = ob*16 + 4*kq + 2*h + {x, y}: aligned register pairs for v_pk_fma_f32
         {
             // own X row, KF consecutive features per lane: the contraction index of step t is f = KF*kq + t
             float xb[KF];
@@ -178,7 +178,10 @@ __global__ __launch_bounds__(256, 2) void gml_k_spectconv_bwd(const GmlBwdParams
 #pragma unroll
                 for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { Z[s][ob][i] = d[ob][i]; P[s][ob][i] = 0.f; }
+                    for (int h = 0; h < 2; ++h) {
+                        Z[s][ob][h] = f32x2{d[ob][2 * h], d[ob][2 * h + 1]};
+                        P[s][ob][h] = f32x2{0.f, 0.f};
+                    }
             }
         }
 
@@ -187,24 +190,28 @@ __global__ __launch_bounds__(256, 2) void gml_k_spectconv_bwd(const GmlBwdParams
             const int dstl = col_l[k];
             float ev[S];
             gml_load_row<S, VAL_ALIGN>(ea_l + k * S, ev);
-            float gv[NOB][4];
+            f32x2 gv[NOB][2];
 #pragma unroll
             for (int ob = 0; ob < NOB; ++ob) {
                 const f32x4 t = *reinterpret_cast<const f32x4*>(gs + dstl * LDG + ob * 16 + 4 * kq);
-                gv[ob][0] = t.x; gv[ob][1] = t.y; gv[ob][2] = t.z; gv[ob][3] = t.w;
+                gv[ob][0] = f32x2{t.x, t.y};
+                gv[ob][1] = f32x2{t.z, t.w};
             }
+            // packed math (v_pk_fma_f32): both the P update and the Z.g dot run on float2 lanes; the dot keeps
+            // two partial sums (even / odd o) that are added once at the end
             float d[S];
 #pragma unroll
             for (int s = 0; s < S; ++s) {
-                float a = 0.f;
+                f32x2 a2 = f32x2{0.f, 0.f};
+                const f32x2 e2 = f32x2{ev[s], ev[s]};
 #pragma unroll
                 for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        P[s][ob][i] = fmaf(ev[s], gv[ob][i], P[s][ob][i]);
-                        a = fmaf(Z[s][ob][i], gv[ob][i], a);
+                    for (int h = 0; h < 2; ++h) {
+                        P[s][ob][h] = e2 * gv[ob][h] + P[s][ob][h];
+                        a2 = Z[s][ob][h] * gv[ob][h] + a2;
                     }
-                d[s] = a;
+                d[s] = a2.x + a2.y;
             }
             // the 4 lanes of a row (kq = 0..3) each hold a quarter of the o-sum: v_permlane16_swap /
             // v_permlane32_swap fold four values at a time so that lane kq ends up with the total of
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void gml_k_spectconv_bwd(const GmlBwdParams
 #pragma unroll
                         for (int fb = 0; fb < NFB; ++fb) {
                             const float b = W_l[(s * FINP + fb * 16 + r16) * LDW + ob * 16 + 4 * kq + i];
-                            dxa[fb] = __builtin_amdgcn_mfma_f32_16x16x4f32(P[s][ob][i], b, dxa[fb], 0, 0, 0);
+                            dxa[fb] = __builtin_amdgcn_mfma_f32_16x16x4f32(P[s][ob][i >> 1][i & 1], b, dxa[fb], 0, 0, 0);
                         }
 #pragma unroll
             for (int fb = 0; fb < NFB; ++fb) {
@@ -292,8 +299,8 @@ __global__ __launch_bounds__(256, 2) void gml_k_spectconv_bwd(const GmlBwdParams
 #pragma unroll
                     for (int ob = 0; ob < NOB; ++ob)
                         *reinterpret_cast<f32x4*>(pb + (se * 64 + row) * LDP + ob * 16 + 4 * kq) =
-                            f32x4{P[sl * C::SE + se][ob][0], P[sl * C::SE + se][ob][1], P[sl * C::SE + se][ob][2],
-                                  P[sl * C::SE + se][ob][3]};
+                            f32x4{P[sl * C::SE + se][ob][0].x, P[sl * C::SE + se][ob][0].y, P[sl * C::SE + se][ob][1].x,
+                                  P[sl * C::SE + se][ob][1].y};
                 __syncthreads();
 #pragma unroll
                 for (int it = 0; it < C::IPS; ++it) {
