@@ -198,6 +198,17 @@ def main():
                 cands.append(roof('spectconv_bwd', 'gml_k_spectconv_bwd (fused SpectConv backward: dX, dval, dW)'))
             if 'spectconv_fwd' in summ:
                 cands.append(roof('spectconv_fwd', 'gml_k_spectconv_fwd (fused SpectConv forward)'))
+            # HBM bytes per launch from the PMC counters (collected offline with the same command under rocprofv3,
+            # separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied -- profiles/r01_c_hbm_traffic.md);
+            # only valid for the workload it was measured on
+            tpath = os.path.join(ROOT, 'profiles', 'r01_c_hbm_traffic.json')
+            if os.path.exists(tpath) and data.num_graphs == 32768 and args.pool == 2048:
+                tk = json.load(open(tpath))['kernels']
+                for r, key in zip(cands, [('gml_k_spectconv_bwd<8, 2, 2>' if 'bwd' in c['kernel'] else
+                                           'gml_k_spectconv_fwd<8, 8, 2, true>') for c in cands]):
+                    if key in tk:
+                        r['traffic'] = tk[key]['hbm_bytes_per_launch']
+                        r['traffic_source'] = 'profiles/r01_c_hbm_traffic.json (rocprofv3 PMC, per launch)'
             cands.sort(key=lambda r: -r['ms_per_step'])
             res['roofline'] = cands[0]                   # the kernel with the largest share of the step
             res['roofline_other'] = cands[1:]
