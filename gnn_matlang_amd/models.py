@@ -43,17 +43,21 @@ class GNNML3(torch.nn.Module):
     """head 'mlp32': fc2(relu(fc1 x)), fc1: nin->32, fc2: 32->nclass;  'tanh10': tanh(fc1 x), fc1: nin->10."""
 
     def __init__(self, ninp, ne, nout1, nout2, nlayers, learnedge=True, bn=False, pool='add', head='mlp32',
-                 nclass=1):
+                 nclass=1, readout_bn=False):
         super().__init__()
-        nin = nout1 + nout2
-        self.nlayers, self.bn, self.pool, self.head = nlayers, bn, pool, head
+        widths = list(nout1) if isinstance(nout1, (list, tuple)) else [nout1] * nlayers    # per-layer nout1
+        self.nlayers, self.bn, self.pool, self.head, self.readout_bn = nlayers, bn, pool, head, readout_bn
+        fin = ninp
         for i in range(nlayers):
             setattr(self, 'conv%d' % (i + 1),
                     ML3Layer(learnedge=learnedge, nedgeinput=ne, nedgeoutput=ne,
-                             ninp=ninp if i == 0 else nin, nout1=nout1, nout2=nout2))
-        if bn:
-            for i in range(nlayers):
-                setattr(self, 'bn%d' % (i + 1), torch.nn.BatchNorm1d(nin))
+                             ninp=fin, nout1=widths[i], nout2=nout2))
+            fin = widths[i] + nout2
+            if bn:
+                setattr(self, 'bn%d' % (i + 1), torch.nn.BatchNorm1d(fin))
+        nin = fin
+        if readout_bn:                       # TF ReadoutLayer: batch_normalization of the pooled vector
+            self.bnr = torch.nn.BatchNorm1d(nin)
         if head == 'mlp32':
             self.fc1 = torch.nn.Linear(nin, 32)
             self.fc2 = torch.nn.Linear(32, nclass)
@@ -68,6 +72,8 @@ class GNNML3(torch.nn.Module):
             if self.bn:
                 x = getattr(self, 'bn%d' % (i + 1))(x)
         x = global_add_pool(x, data) if self.pool == 'add' else global_mean_pool(x, data)
+        if self.readout_bn:
+            x = self.bnr(x)
         if self.head == 'mlp32':
             return self.fc2(F.relu(self.fc1(x)))
         return torch.tanh(self.fc1(x))
@@ -113,6 +119,11 @@ def sr25_gnnml3(ninp=2, ne=6):             # sr25.py:252-262
     return GNNML3(ninp, ne, 32, 16, 3, head='tanh10')
 
 
+def mnist_gnnml3(ninp=2, ne=6):            # mnist75_gnnml3_tf.py:62, libs/models_tf.py:223-268 (DSGCNN)
+    return GNNML3(ninp, ne, [64, 128, 128], 0, 3, learnedge=False, pool='mean', head='mlp32', nclass=10,
+                  readout_bn=True)
+
+
 def mutag_gnnml3(ninp=8, ne=4):            # mutag.py:272-288
     return GNNML3(ninp, ne, 24, 24, 3, learnedge=False, bn=True, pool='mean')
 
@@ -123,6 +134,10 @@ def zinc_loss(pre, y):                     # Zinc12k.py:365
 
 def counting_loss(pre, y):                 # counting.py:411
     return torch.square(pre - y.view(-1, 1)).sum()
+
+
+def mnist_loss(pre, y):                    # libs/metrics_tf.py softmax cross entropy, batch mean
+    return F.cross_entropy(pre, y.long())
 
 
 def mutag_loss(pre, y):                    # mutag.py:345-348

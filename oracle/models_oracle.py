@@ -36,17 +36,21 @@ class OracleGNNML3(torch.nn.Module):
                  'tanh10' -> tanh(fc1) with fc1: nin->10 (sr25.py:262,276)."""
 
     def __init__(self, ninp, ne, nout1, nout2, nlayers, learnedge=True, bn=False,
-                 pool='add', head='mlp32', nclass=1, layer_cls=OracleML3Layer):
+                 pool='add', head='mlp32', nclass=1, readout_bn=False, layer_cls=OracleML3Layer):
         super().__init__()
-        nin = nout1 + nout2
-        self.nlayers, self.bn, self.pool, self.head = nlayers, bn, pool, head
+        widths = list(nout1) if isinstance(nout1, (list, tuple)) else [nout1] * nlayers    # per-layer nout1
+        self.nlayers, self.bn, self.pool, self.head, self.readout_bn = nlayers, bn, pool, head, readout_bn
+        fin = ninp
         for i in range(nlayers):
             setattr(self, 'conv%d' % (i + 1),
                     layer_cls(learnedge=learnedge, nedgeinput=ne, nedgeoutput=ne,
-                              ninp=ninp if i == 0 else nin, nout1=nout1, nout2=nout2))
-        if bn:
-            for i in range(nlayers):
-                setattr(self, 'bn%d' % (i + 1), torch.nn.BatchNorm1d(nin))
+                              ninp=fin, nout1=widths[i], nout2=nout2))
+            fin = widths[i] + nout2
+            if bn:
+                setattr(self, 'bn%d' % (i + 1), torch.nn.BatchNorm1d(fin))
+        nin = fin
+        if readout_bn:                       # TF ReadoutLayer: batch_normalization of the pooled vector
+            self.bnr = torch.nn.BatchNorm1d(nin)
         if head == 'mlp32':
             self.fc1 = torch.nn.Linear(nin, 32)
             self.fc2 = torch.nn.Linear(32, nclass)
@@ -60,6 +64,8 @@ class OracleGNNML3(torch.nn.Module):
                 x = getattr(self, 'bn%d' % (i + 1))(x)
         pool = global_add_pool if self.pool == 'add' else global_mean_pool
         x = pool(x, batch, num_graphs)
+        if self.readout_bn:
+            x = self.bnr(x)
         if self.head == 'mlp32':
             return self.fc2(F.relu(self.fc1(x)))
         return torch.tanh(self.fc1(x))
@@ -107,6 +113,14 @@ def sr25_gnnml3(ninp=2, ne=6, **kw):
     return OracleGNNML3(ninp, ne, 32, 16, 3, head='tanh10', **kw)
 
 
+def mnist_gnnml3(ninp=2, ne=6, **kw):
+    """mnist75_gnnml3_tf.py:62 + libs/models_tf.py:223-268 (DSGCNN): 3 graph convolutions 64/128/128 over
+    S=6 dense supports, no edge learning, no Hadamard branch, mean readout + batch norm, 128->32->10.
+    (dropout of the TF model is a training-time regulariser, not part of the path; omitted.)"""
+    return OracleGNNML3(ninp, ne, [64, 128, 128], 0, 3, learnedge=False, pool='mean', head='mlp32', nclass=10,
+                        readout_bn=True, **kw)
+
+
 def mutag_gnnml3(ninp=8, ne=4, **kw):
     return OracleGNNML3(ninp, ne, 24, 24, 3, learnedge=False, bn=True, pool='mean', **kw)
 
@@ -118,6 +132,10 @@ def zinc_loss(pre, y):            # Zinc12k.py:365
 
 def counting_loss(pre, y):        # counting.py:411 (y already the selected task column)
     return torch.square(pre - y.view(-1, 1)).sum()
+
+
+def mnist_loss(pre, y):           # libs/metrics_tf.py softmax_cross_entropy (mean over the batch)
+    return F.cross_entropy(pre, y.long())
 
 
 def mutag_loss(pre, y):           # mutag.py:345-348

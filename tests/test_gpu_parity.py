@@ -305,6 +305,34 @@ def test_sr25_isomorphism_golden(dev, golden):
         assert int(((Mcnt == 0).sum() - 15) / 2) == int(g['seed%d/similar' % seed])
 
 
+def test_mnist75_gnnml3_vs_oracle(dev):
+    """config 4 (TF DSGCNN: S=6 near-dense supports of 75-node graphs, widths 2->64->128->128, mean readout + BN):
+    the TF reference cannot run here, so this config is checked against the CPU oracle only (parity unpinned by
+    reference outputs); it exercises the wide-feature paths (multi-chunk forward, unfused backward)."""
+    from gnn_matlang_amd import SpectralDesign, collate, models, synthetic
+    from oracle import models_oracle as MO
+    raw = synthetic.make_graphs('mnist75', 6, seed=9)
+    host = collate(SpectralDesign(recfield=3, dv=10, nfreq=5).design_many(raw))      # prepareMnist_gnnml3_tf.py:14-17
+    assert host.edge_attr2.shape[1] == 6
+    data = host.to(dev)
+    torch.manual_seed(3)
+    ref = MO.mnist_gnnml3().train()
+    m = models.mnist_gnnml3()
+    m.load_state_dict(ref.state_dict())
+    m = m.to(dev).train()
+    pre_ref = ref(host.x, host.edge_index2, host.edge_attr2, host.batch, host.num_graphs)
+    l_ref = MO.mnist_loss(pre_ref, host.y)
+    l_ref.backward()
+    pre = m(data)
+    l = models.mnist_loss(pre, data.y)
+    l.backward()
+    close(pre, pre_ref, what='mnist logits')
+    assert abs(l.item() - l_ref.item()) <= TOL * abs(l_ref.item())
+    rp = dict(ref.named_parameters())
+    for n, p in m.named_parameters():
+        close(p.grad, rp[n].grad, tol=3e-4, what='mnist grad ' + n)
+
+
 # ------------------------------------------------------------------------------------------ full size
 def _big_zinc_batch(dev, ngraph_pool=512, reps=64):
     from gnn_matlang_amd import synthetic, SpectralDesign
