@@ -100,6 +100,9 @@ def main():
     ap.add_argument('--cpu-steps', type=int, default=3)
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-profile', action='store_true', help='skip the live per-kernel HIP-event timing')
+    ap.add_argument('--graph', action='store_true', help='capture the whole step in a HIP graph (launch-bound small batches)')
+    ap.add_argument('--ref-batch', type=int, default=64, help='also time the reference batch size (Zinc12k.py:20) as a '
+                    'HIP-graph-captured step; 0 = skip')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -135,6 +138,30 @@ def main():
         sync.sync()
         opt.step()
         return loss
+
+    def make_graph_step(mdl, dat, lr=1e-3):
+        """whole train step (fwd + loss + bwd + Adam) captured once in a HIP graph, replayed per step."""
+        o = torch.optim.Adam(mdl.parameters(), lr=lr, capturable=True)
+        for p_ in mdl.parameters():
+            p_.grad = torch.zeros_like(p_)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # warm-up on a side stream (allocator, lazy init)
+            for _ in range(3):
+                for p_ in mdl.parameters():
+                    p_.grad.zero_()
+                models.zinc_loss(mdl(dat), dat.y).backward()
+                o.step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g_ = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_):
+            for p_ in mdl.parameters():
+                p_.grad.zero_()
+            l_ = models.zinc_loss(mdl(dat), dat.y)
+            l_.backward()
+            o.step()
+        return g_, l_
 
     def fence():
         torch.cuda.synchronize()
@@ -213,6 +240,26 @@ def main():
             res['roofline'] = cands[0]                   # the kernel with the largest share of the step
             res['roofline_other'] = cands[1:]
             res['kernels_ms_per_step'] = {tag: round(v['ms'] * v['launches'] / args.steps, 4) for tag, v in summ.items()}
+        if world == 1 and args.ref_batch > 0:
+            # the reference's own batch size: launch-latency bound, so the step is replayed from a HIP graph
+            rb, _ = build_batch(args.ref_batch, args.ref_batch, seed=7, device=dev)
+            rb.csr('edge_index2')
+            torch.manual_seed(0)
+            rm = models.zinc_gnnml3().to(dev)
+            gr, gl = make_graph_step(rm, rb)
+            for _ in range(20):
+                gr.replay()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            nrep = 200
+            for _ in range(nrep):
+                gr.replay()
+            torch.cuda.synchronize()
+            dt1 = (time.perf_counter() - t1) / nrep
+            res['ref_batch'] = dict(graphs_per_step=rb.num_graphs, ms_per_step=dt1 * 1e3, value=rb.num_graphs / dt1,
+                                    unit='graphs/s', mode='whole step replayed from one HIP graph',
+                                    final_loss=float(gl.item()))
+            log('reference batch %d: %.3f ms/step (HIP graph)' % (rb.num_graphs, dt1 * 1e3))
         if world == 1 and not args.no_cpu:
             from gnn_matlang_amd import SpectralDesign, collate, synthetic
             raw = synthetic.make_graphs('zinc', args.cpu_graphs, seed=1000)
