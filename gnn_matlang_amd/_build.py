@@ -12,7 +12,7 @@ OBJDIR = os.path.join(CSRC, '_obj')
 LIB = os.path.join(PKG, 'libgml_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I', CSRC, '-I', INCLUDE,
-         '-Wno-unused-result']
+         '-Wno-unused-result'] + os.environ.get('GML_CXXFLAGS', '').split()
 
 
 def _sources():

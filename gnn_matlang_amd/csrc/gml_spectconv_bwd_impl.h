@@ -45,6 +45,10 @@ struct GmlBwdParams {
     int32_t xvec, gvec;      // x / g rows may be read as aligned float4
 };
 
+// static bounds of the register-batched staging (groups beyond them use the rolled loops)
+#define GML_BWD_ECAP_MAX 1024
+#define GML_BWD_XCAP_MAX 192
+
 template <int S, int NFB, int NOB>
 struct GmlBwdCfg {
     static constexpr int FINP = NFB * 16, FOUTP = NOB * 16;
@@ -115,26 +119,65 @@ __global__ __launch_bounds__(256, 2) void gml_k_spectconv_bwd(const GmlBwdParams
         const int kb = gi.x, ne = gi.y, lo = gi.z, nwin = gi.w;
         __syncthreads();                                     // previous group is done with every LDS region
 
-        // ---- stage (coalesced): rowptr slice, local column ids, value rows, G window, own X rows
+        // ---- stage (coalesced): rowptr slice, local column ids, value rows, G window.
+        // Fast path: every global load of the group is issued before the first LDS write (registers are free at
+        // this point: Z / P are dead), so the group pays ONE memory latency.  A rolled `lds[i] = g[i]` loop
+        // compiles to load / s_waitcnt vmcnt(0) / ds_write per iteration, i.e. a latency per element.
         if (tid <= nr) rp_l[tid] = p.rowptr[r0 + tid];
-        for (int i = tid; i < ne; i += 256) col_l[i] = p.col[kb + i] - lo;
-        if constexpr (S % 4 == 0) {
+        if ((S % 4 == 0) && p.gvec && ne <= GML_BWD_ECAP_MAX && nwin <= GML_BWD_XCAP_MAX) {
+            constexpr int NC = GML_BWD_ECAP_MAX / 256, NE4 = GML_BWD_ECAP_MAX * (S / 4) / 256;
+            constexpr int NG4 = (GML_BWD_XCAP_MAX * (C::FOUTP / 4) + 255) / 256;
+            int cv[NC];
+            f32x4 ev4[NE4], gv4[NG4];
             const f32x4* src = reinterpret_cast<const f32x4*>(p.val + (int64_t)kb * S);
-            for (int i = tid; i < ne * (S / 4); i += 256) reinterpret_cast<f32x4*>(ea_l)[i] = src[i];
-        } else {
-            for (int i = tid; i < ne * S; i += 256) ea_l[i] = p.val[(int64_t)kb * S + i];
-        }
-        if (p.gvec) {                                        // rows padded to a float4 multiple, 16-B aligned
-            for (int i = tid; i < nwin * (C::FOUTP / 4); i += 256) {
+#pragma unroll
+            for (int t = 0; t < NC; ++t) { const int i = tid + 256 * t; cv[t] = (i < ne) ? p.col[kb + i] : 0; }
+#pragma unroll
+            for (int t = 0; t < NE4; ++t) {
+                const int i = tid + 256 * t;
+                ev4[t] = (i < ne * (S / 4)) ? src[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int t = 0; t < NG4; ++t) {
+                const int i = tid + 256 * t;
                 const int rr = i / (C::FOUTP / 4), o4 = (i % (C::FOUTP / 4)) * 4;
-                f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (o4 < p.Fout) t = *reinterpret_cast<const f32x4*>(p.g + (int64_t)(lo + rr) * p.ldg + o4);   // pad cols are 0
-                *reinterpret_cast<f32x4*>(gs + rr * LDG + o4) = t;
+                gv4[t] = (i < nwin * (C::FOUTP / 4) && o4 < p.Fout)
+                             ? *reinterpret_cast<const f32x4*>(p.g + (int64_t)(lo + rr) * p.ldg + o4)
+                             : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int t = 0; t < NC; ++t) { const int i = tid + 256 * t; if (i < ne) col_l[i] = cv[t] - lo; }
+#pragma unroll
+            for (int t = 0; t < NE4; ++t) {
+                const int i = tid + 256 * t;
+                if (i < ne * (S / 4)) reinterpret_cast<f32x4*>(ea_l)[i] = ev4[t];
+            }
+#pragma unroll
+            for (int t = 0; t < NG4; ++t) {
+                const int i = tid + 256 * t;
+                const int rr = i / (C::FOUTP / 4), o4 = (i % (C::FOUTP / 4)) * 4;
+                if (i < nwin * (C::FOUTP / 4)) *reinterpret_cast<f32x4*>(gs + rr * LDG + o4) = gv4[t];
             }
         } else {
-            for (int i = tid; i < nwin * C::FOUTP; i += 256) {
-                const int rr = i / C::FOUTP, o = i % C::FOUTP;
-                gs[rr * LDG + o] = (o < p.Fout) ? p.g[(int64_t)(lo + rr) * p.ldg + o] : 0.f;
+            for (int i = tid; i < ne; i += 256) col_l[i] = p.col[kb + i] - lo;
+            if constexpr (S % 4 == 0) {
+                const f32x4* src = reinterpret_cast<const f32x4*>(p.val + (int64_t)kb * S);
+                for (int i = tid; i < ne * (S / 4); i += 256) reinterpret_cast<f32x4*>(ea_l)[i] = src[i];
+            } else {
+                for (int i = tid; i < ne * S; i += 256) ea_l[i] = p.val[(int64_t)kb * S + i];
+            }
+            if (p.gvec) {                                    // rows padded to a float4 multiple, 16-B aligned
+                for (int i = tid; i < nwin * (C::FOUTP / 4); i += 256) {
+                    const int rr = i / (C::FOUTP / 4), o4 = (i % (C::FOUTP / 4)) * 4;
+                    f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (o4 < p.Fout) t = *reinterpret_cast<const f32x4*>(p.g + (int64_t)(lo + rr) * p.ldg + o4);   // pad cols are 0
+                    *reinterpret_cast<f32x4*>(gs + rr * LDG + o4) = t;
+                }
+            } else {
+                for (int i = tid; i < nwin * C::FOUTP; i += 256) {
+                    const int rr = i / C::FOUTP, o = i % C::FOUTP;
+                    gs[rr * LDG + o] = (o < p.Fout) ? p.g[(int64_t)(lo + rr) * p.ldg + o] : 0.f;
+                }
             }
         }
         __syncthreads();
@@ -257,20 +300,30 @@ __global__ __launch_bounds__(256, 2) void gml_k_spectconv_bwd(const GmlBwdParams
                             const float b = W_l[(s * FINP + fb * 16 + r16) * LDW + ob * 16 + 4 * kq + i];
                             dxa[fb] = __builtin_amdgcn_mfma_f32_16x16x4f32(P[s][ob][i >> 1][i & 1], b, dxa[fb], 0, 0, 0);
                         }
+            if (p.flags & GML_ACCUM) {                       // own uniform branch: see the note in the forward epilogue
 #pragma unroll
-            for (int fb = 0; fb < NFB; ++fb) {
-                const f32x4 d = dxa[fb];
-                const int f = fb * 16 + r16;
-                if (f < p.Fin) {
+                for (int fb = 0; fb < NFB; ++fb) {
+                    const int f = fb * 16 + r16;
+                    float old[4];
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
                         const int lr = wave * 16 + 4 * kq + reg;
-                        if (lr < nr) {
-                            float* dst = p.dx + (r0 + lr) * p.lddx + f;
-                            float v = d[reg];
-                            if (p.flags & GML_ACCUM) v += *dst;
-                            *dst = v;
-                        }
+                        old[reg] = (f < p.Fin && lr < nr) ? p.dx[(r0 + lr) * p.lddx + f] : 0.f;
+                    }
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int lr = wave * 16 + 4 * kq + reg;
+                        if (f < p.Fin && lr < nr) p.dx[(r0 + lr) * p.lddx + f] = dxa[fb][reg] + old[reg];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int fb = 0; fb < NFB; ++fb) {
+                    const int f = fb * 16 + r16;
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int lr = wave * 16 + 4 * kq + reg;
+                        if (f < p.Fin && lr < nr) p.dx[(r0 + lr) * p.lddx + f] = dxa[fb][reg];
                     }
                 }
             }

@@ -114,7 +114,7 @@ __device__ __forceinline__ void gml_prefetch_issue(GmlPrefetch<SC, FPL>& q, cons
     q.nr = (int)min((int64_t)GML_GROUP, p.nrows - r0);
     const int4 gi = reinterpret_cast<const int4*>(p.ginfo)[g];                   // {kb, ne, lo, nwin}
     q.kb = gi.x; q.ne = gi.y; q.lo = gi.z; q.nwin = gi.w;
-    q.staged = (q.ne <= GML_ECAP) && (q.nwin <= GML_XCAP);
+    q.staged = (q.ne <= GML_ECAP) && (q.nwin <= GML_XCAP) && (p.epos == nullptr);
     q.rp = (tid <= q.nr) ? p.rowptr[r0 + tid] : 0;
     if (!q.staged) return;
 #pragma unroll
@@ -123,29 +123,30 @@ __device__ __forceinline__ void gml_prefetch_issue(GmlPrefetch<SC, FPL>& q, cons
         q.colv[t] = (i < q.ne) ? p.col[q.kb + i] : 0;
     }
     const int sbase = p.s0;
-    if (p.val_vec && (SC % 4 == 0)) {
+    // NOTE: indirect value rows (epos != NULL) never take the staged path (q.staged is false for them): folding
+    // `pk = epos ? epos[k] : k` into this loop makes hipcc emit a predicated load + s_waitcnt vmcnt(0) per
+    // element, which drains every load already in flight and serialises the whole prefetch (+3 us per group).
+    {
+        const float* vb = p.val + (int64_t)q.kb * p.S + sbase;
+        if (p.val_vec && (SC % 4 == 0)) {
 #pragma unroll
-        for (int t = 0; t < PF::EN / 4; ++t) {
-            const int idx4 = tid + 256 * t;                                      // float4 index inside [ne][SC]
-            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (idx4 < q.ne * (SC / 4)) {
-                const int i = idx4 / (SC / 4), s4 = (idx4 % (SC / 4)) * 4;
-                const int64_t pk = p.epos ? (int64_t)p.epos[q.kb + i] : (int64_t)(q.kb + i);
-                v = *reinterpret_cast<const f32x4*>(p.val + pk * p.S + sbase + s4);
+            for (int t = 0; t < PF::EN / 4; ++t) {
+                const int idx4 = tid + 256 * t;                                  // float4 index inside [ne][SC]
+                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (idx4 < q.ne * (SC / 4)) {
+                    const int i = idx4 / (SC / 4), s4 = (idx4 % (SC / 4)) * 4;
+                    v = *reinterpret_cast<const f32x4*>(vb + (int64_t)i * p.S + s4);
+                }
+                q.ev[4 * t] = v.x; q.ev[4 * t + 1] = v.y; q.ev[4 * t + 2] = v.z; q.ev[4 * t + 3] = v.w;
             }
-            q.ev[4 * t] = v.x; q.ev[4 * t + 1] = v.y; q.ev[4 * t + 2] = v.z; q.ev[4 * t + 3] = v.w;
-        }
-    } else {
+        } else {
 #pragma unroll
-        for (int t = 0; t < PF::EN; ++t) {
-            const int idx = tid + 256 * t;
-            float v = 0.f;
-            if (idx < q.ne * SC) {
-                const int i = idx / SC, s = idx % SC;
-                const int64_t pk = p.epos ? (int64_t)p.epos[q.kb + i] : (int64_t)(q.kb + i);
-                v = p.val[pk * p.S + sbase + s];
+            for (int t = 0; t < PF::EN; ++t) {
+                const int idx = tid + 256 * t;
+                float v = 0.f;
+                if (idx < q.ne * SC) v = vb[(int64_t)(idx / SC) * p.S + idx % SC];
+                q.ev[t] = v;
             }
-            q.ev[t] = v;
         }
     }
     if constexpr (XVEC) {
@@ -219,7 +220,7 @@ __device__ __forceinline__ void gml_prefetch_commit(const GmlPrefetch<SC, FPL>& 
 }
 
 template <int SC, int FPL, int NB, bool XVEC>
-__global__ __launch_bounds__(256) void gml_k_spectconv_fwd(const GmlFwdParams p) {
+__global__ __launch_bounds__(256, 2) void gml_k_spectconv_fwd(const GmlFwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using ST = GmlStage<SC, FPL>;
     constexpr int CH = 4 * FPL;
@@ -282,11 +283,8 @@ __global__ __launch_bounds__(256) void gml_k_spectconv_fwd(const GmlFwdParams p)
                     if (!p.allw) gml_stage_w<SC, FPL, NB>(lds_w, p, pass, c);
                     if (staged && !first) {
                         if (c == 0) {                        // value rows of this pass: [ne][SC]
-                            for (int idx = tid; idx < ne * SC; idx += 256) {
-                                const int i = idx / SC, s = idx % SC;
-                                const int64_t pk = p.epos ? (int64_t)p.epos[kb + i] : (int64_t)(kb + i);
-                                ea_l[idx] = p.val[pk * p.S + sbase + s];
-                            }
+                            for (int idx = tid; idx < ne * SC; idx += 256)     // staged => epos == NULL
+                                ea_l[idx] = p.val[(int64_t)(kb + idx / SC) * p.S + sbase + idx % SC];
                         }
                         for (int idx = tid; idx < nwin * CH; idx += 256) {
                             const int rr = idx / CH, f = idx % CH;
@@ -377,20 +375,38 @@ __global__ __launch_bounds__(256) void gml_k_spectconv_fwd(const GmlFwdParams p)
         if (!(p.flags & 0x800u))
 #endif
         {
+            // The accumulate variant lives in its own uniform branch: a per-element `if (accum) v += *dst` becomes a
+            // predicated load + s_waitcnt vmcnt(0) in front of EVERY store, and vmcnt also counts stores, so the
+            // stores of a tile would retire one round trip at a time.
+            const bool relu = (p.flags & GML_RELU) != 0;
+            if (p.flags & GML_ACCUM) {
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const int o = nb * 16 + r16;
-                if (o < p.Fout) {
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int o = nb * 16 + r16;
+                    float old[4];
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
                         const int lr = wave * 16 + 4 * kq + reg;
-                        if (lr < nr) {
-                            float* dst = p.out + (r0 + lr) * p.ldo + o;
-                            float v = oacc[nb][reg] + bias_r[nb];
-                            if (p.flags & GML_ACCUM) v += *dst;
-                            if (p.flags & GML_RELU) v = fmaxf(v, 0.f);
-                            *dst = v;
-                        }
+                        old[reg] = (o < p.Fout && lr < nr) ? p.out[(r0 + lr) * p.ldo + o] : 0.f;
+                    }
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int lr = wave * 16 + 4 * kq + reg;
+                        float v = oacc[nb][reg] + bias_r[nb] + old[reg];
+                        if (relu) v = fmaxf(v, 0.f);
+                        if (o < p.Fout && lr < nr) p.out[(r0 + lr) * p.ldo + o] = v;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int o = nb * 16 + r16;
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int lr = wave * 16 + 4 * kq + reg;
+                        float v = oacc[nb][reg] + bias_r[nb];
+                        if (relu) v = fmaxf(v, 0.f);
+                        if (o < p.Fout && lr < nr) p.out[(r0 + lr) * p.ldo + o] = v;
                     }
                 }
             }
