@@ -39,7 +39,7 @@ SIGNATURES = {
     'gml_segment_sum': (ctypes.c_int, [_p, _i64, _p, _p, _i64, _i64, _i32, _i32, _p]),
 }
 
-GML_RELU, GML_ACCUM = 1, 2
+GML_RELU, GML_ACCUM, GML_F32_MFMA = 1, 2, 4
 
 _lib = None
 

@@ -6,6 +6,8 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define GML_WAVE 64
 #define GML_NUM_CU 256
@@ -56,4 +58,26 @@ __device__ __forceinline__ void gml_load_row(const float* __restrict__ p, float 
 __device__ __forceinline__ float gml_tanh(float x) {
     const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
     return fmaf(-2.f, __builtin_amdgcn_rcpf(e + 1.f), 1.f);
+}
+
+// fp32 -> (hi, lo) bf16 pair with hi + lo = x to ~2^-17 relative (round-to-nearest both times).  Products of
+// two such splits, a_hi b_hi + a_hi b_lo + a_lo b_hi accumulated in fp32 by the bf16 matrix cores, carry a
+// relative error of ~2^-16 per term (the dropped a_lo b_lo and the lo roundings): fp32-class for the
+// K <= 768 contractions of this layer, at 1/5 of the f32 matrix-pipe time and -- unlike the f32-input MFMA,
+// which executes on the fp32 vector ALUs -- concurrently with the VALU work of the other waves.
+__device__ __forceinline__ void gml_split2(float x0, float x1, bf16x2& hi, bf16x2& lo) {
+    const f32x2 v = f32x2{x0, x1};
+    hi = __builtin_convertvector(v, bf16x2);
+    const f32x2 r = v - __builtin_convertvector(hi, f32x2);
+    lo = __builtin_convertvector(r, bf16x2);
+}
+
+__device__ __forceinline__ void gml_split8(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        bf16x2 h, l;
+        gml_split2(x[2 * i], x[2 * i + 1], h, l);
+        hi[2 * i] = h[0]; hi[2 * i + 1] = h[1];
+        lo[2 * i] = l[0]; lo[2 * i + 1] = l[1];
+    }
 }

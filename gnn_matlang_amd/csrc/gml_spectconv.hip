@@ -3,15 +3,15 @@
 
 // ---- families defined in gml_fwd_fam_*.hip ---------------------------------------------------
 #define GML_DECL_FAM(SC, FPL) \
-    template <> int gml_launch_fwd_family<SC, FPL>(const GmlFwdParams&, int, bool, dim3, size_t, hipStream_t);
+    template <> int gml_launch_fwd_family<SC, FPL>(const GmlFwdParams&, int, bool, bool, dim3, size_t, hipStream_t);
 GML_DECL_FAM(1, 8) GML_DECL_FAM(2, 8) GML_DECL_FAM(3, 8) GML_DECL_FAM(4, 8) GML_DECL_FAM(6, 8) GML_DECL_FAM(8, 8)
 GML_DECL_FAM(1, 4) GML_DECL_FAM(2, 4) GML_DECL_FAM(3, 4) GML_DECL_FAM(4, 4) GML_DECL_FAM(6, 4) GML_DECL_FAM(8, 4)
 GML_DECL_FAM(12, 4) GML_DECL_FAM(16, 4)
 
-static int launch_family(int SC, int FPL, const GmlFwdParams& p, int NB, bool xvec, dim3 grid, size_t lds,
+static int launch_family(int SC, int FPL, const GmlFwdParams& p, int NB, bool xvec, bool bf, dim3 grid, size_t lds,
                          hipStream_t st) {
 #define GML_FAM(SCV, FPLV) \
-    if (SC == SCV && FPL == FPLV) return gml_launch_fwd_family<SCV, FPLV>(p, NB, xvec, grid, lds, st);
+    if (SC == SCV && FPL == FPLV) return gml_launch_fwd_family<SCV, FPLV>(p, NB, xvec, bf, grid, lds, st);
     GML_FAM(1, 8) GML_FAM(2, 8) GML_FAM(3, 8) GML_FAM(4, 8) GML_FAM(6, 8) GML_FAM(8, 8)
     GML_FAM(1, 4) GML_FAM(2, 4) GML_FAM(3, 4) GML_FAM(4, 4) GML_FAM(6, 4) GML_FAM(8, 4)
     GML_FAM(12, 4) GML_FAM(16, 4)
@@ -91,7 +91,7 @@ extern "C" int gml_spectconv_fwd(const int32_t* rowptr, const int32_t* col, cons
             p.val_vec = (S % va == 0) && (p.s0 % va == 0);
             p.wfloats = (int)((p.allw ? all : wblk) / sizeof(float));
             const size_t lds = (size_t)p.wfloats * sizeof(float) + stage;
-            int rc = launch_family(SC, FPL, p, NB, xvec && FPL >= 4, dim3(grid), lds, st);
+            int rc = launch_family(SC, FPL, p, NB, xvec && FPL >= 4, (flags & GML_F32_MFMA) == 0, dim3(grid), lds, st);
             if (rc != GML_OK) return rc;
         }
     }

@@ -87,6 +87,28 @@ __device__ __forceinline__ void gml_stage_w(float* __restrict__ dst, const GmlFw
     }
 }
 
+// bf16x3 variant (FPL == 8): the W block is stored as MFMA B fragments of v_mfma_f32_16x16x32_bf16 -- 8 bf16
+// (16 bytes) per lane, k = 8*(lane>>4) + i <-> feature c*32 + 8*kq + i, column nb*16 + (lane&15) -- once as the
+// high parts and once as the low parts.  Same LDS footprint as the fp32 block (SC*NB*2 KiB).
+template <int SC, int NB>
+__device__ __forceinline__ void gml_stage_w_bf16(bf16x8* __restrict__ dst, const GmlFwdParams& p, int pass, int c) {
+    for (int e = threadIdx.x; e < SC * NB * 64; e += blockDim.x) {
+        const int lane = e & 63, nb = (e >> 6) % NB, s = (e >> 6) / NB;
+        const int o = nb * 16 + (lane & 15);
+        const float* ws = p.w + (int64_t)(p.s0 + pass * SC + s) * p.w_ss + (int64_t)o * p.w_so;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int f = c * 32 + 8 * (lane >> 4) + i;
+            v[i] = (f < p.Fin && o < p.Fout) ? ws[(int64_t)f * p.w_si] : 0.f;
+        }
+        bf16x8 hi, lo;
+        gml_split8(v, hi, lo);
+        dst[e] = hi;
+        dst[SC * NB * 64 + e] = lo;
+    }
+}
+
 // Per-thread registers that carry the NEXT group's CSR slice / value rows / X window while the
 // current group is being computed (global -> reg early, reg -> LDS late: the load latency hides
 // behind the aggregation + MFMA of the current group instead of stalling every group).
@@ -219,8 +241,9 @@ __device__ __forceinline__ void gml_prefetch_commit(const GmlPrefetch<SC, FPL>& 
     }
 }
 
-template <int SC, int FPL, int NB, bool XVEC>
+template <int SC, int FPL, int NB, bool XVEC, bool BF>
 __global__ __launch_bounds__(256, 2) void gml_k_spectconv_fwd(const GmlFwdParams p) {
+    static_assert(!BF || FPL == 8, "the bf16x3 projection needs 8 features per lane (K = 32 per MFMA)");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using ST = GmlStage<SC, FPL>;
     constexpr int CH = 4 * FPL;
@@ -248,8 +271,10 @@ __global__ __launch_bounds__(256, 2) void gml_k_spectconv_fwd(const GmlFwdParams
 
     if (p.allw) {
         for (int pass = 0; pass < p.npass; ++pass)
-            for (int c = 0; c < p.nchunks; ++c)
-                gml_stage_w<SC, FPL, NB>(lds_w + (pass * p.nchunks + c) * WBLK, p, pass, c);
+            for (int c = 0; c < p.nchunks; ++c) {
+                if constexpr (BF) gml_stage_w_bf16<SC, NB>(reinterpret_cast<bf16x8*>(lds_w + (pass * p.nchunks + c) * WBLK), p, pass, c);
+                else gml_stage_w<SC, FPL, NB>(lds_w + (pass * p.nchunks + c) * WBLK, p, pass, c);
+            }
     }
     float bias_r[NB];
 #pragma unroll
@@ -280,7 +305,10 @@ __global__ __launch_bounds__(256, 2) void gml_k_spectconv_fwd(const GmlFwdParams
                 if (p.allw) wl = lds_w + (pass * p.nchunks + c) * WBLK;
                 if (!first || !p.allw) {
                     __syncthreads();                         // LDS regions about to be overwritten are idle
-                    if (!p.allw) gml_stage_w<SC, FPL, NB>(lds_w, p, pass, c);
+                    if (!p.allw) {
+                        if constexpr (BF) gml_stage_w_bf16<SC, NB>(reinterpret_cast<bf16x8*>(lds_w), p, pass, c);
+                        else gml_stage_w<SC, FPL, NB>(lds_w, p, pass, c);
+                    }
                     if (staged && !first) {
                         if (c == 0) {                        // value rows of this pass: [ne][SC]
                             for (int idx = tid; idx < ne * SC; idx += 256)     // staged => epos == NULL
@@ -356,17 +384,36 @@ __global__ __launch_bounds__(256, 2) void gml_k_spectconv_fwd(const GmlFwdParams
                 } else
 #endif
                 {
+                    if constexpr (BF) {
+                        // acc[s][0..7] are exactly the 8 k-values of this lane's A fragment (k = 8*kq + j)
+                        const bf16x8* wh = reinterpret_cast<const bf16x8*>(wl);
+                        const bf16x8* wlo = wh + SC * NB * 64;
 #pragma unroll
-                    for (int s = 0; s < SC; ++s)
-#pragma unroll
-                        for (int j = 0; j < FPL; ++j) {
-                            const float a = acc[s][j];
+                        for (int s = 0; s < SC; ++s) {
+                            bf16x8 ah, al;
+                            gml_split8(acc[s], ah, al);
 #pragma unroll
                             for (int nb = 0; nb < NB; ++nb) {
-                                const float b = wl[((s * FPL + j) * NB + nb) * 64 + lane];
-                                oacc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, oacc[nb], 0, 0, 0);
+                                const bf16x8 bh = wh[(s * NB + nb) * 64 + lane];
+                                const bf16x8 bl = wlo[(s * NB + nb) * 64 + lane];
+                                oacc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, oacc[nb], 0, 0, 0);
+                                oacc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, oacc[nb], 0, 0, 0);
+                                oacc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, oacc[nb], 0, 0, 0);
                             }
                         }
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < SC; ++s)
+#pragma unroll
+                            for (int j = 0; j < FPL; ++j) {
+                                const float a = acc[s][j];
+#pragma unroll
+                                for (int nb = 0; nb < NB; ++nb) {
+                                    const float b = wl[((s * FPL + j) * NB + nb) * 64 + lane];
+                                    oacc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, oacc[nb], 0, 0, 0);
+                                }
+                            }
+                    }
                 }
             }
         }
@@ -417,19 +464,26 @@ __global__ __launch_bounds__(256, 2) void gml_k_spectconv_fwd(const GmlFwdParams
 
 // one (SC, FPL) family: NB in {1,2,4,8}, XVEC in {0,1}
 template <int SC, int FPL>
-int gml_launch_fwd_family(const GmlFwdParams& p, int NB, bool xvec, dim3 grid, size_t lds, hipStream_t st);
+int gml_launch_fwd_family(const GmlFwdParams& p, int NB, bool xvec, bool bf, dim3 grid, size_t lds, hipStream_t st);
 
+#define GML_FWD_GO(NBV, XV, BFV)                                                                      \
+    {                                                                                                 \
+        static const hipError_t attr_rc = hipFuncSetAttribute(                                        \
+            reinterpret_cast<const void*>(&gml_k_spectconv_fwd<SC, FPL, NBV, XV, BFV>),               \
+            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                  \
+        if (attr_rc != hipSuccess) return (int)attr_rc;                                               \
+        hipLaunchKernelGGL((gml_k_spectconv_fwd<SC, FPL, NBV, XV, BFV>), grid, dim3(256), lds, st, p); \
+        return gml_launch_status();                                                                   \
+    }
 #define GML_FWD_CASE(NBV, XV)                                                                         \
-    static const hipError_t attr_rc = hipFuncSetAttribute(                                            \
-        reinterpret_cast<const void*>(&gml_k_spectconv_fwd<SC, FPL, NBV, XV>),                        \
-        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                      \
-    if (attr_rc != hipSuccess) return (int)attr_rc;                                                   \
-    hipLaunchKernelGGL((gml_k_spectconv_fwd<SC, FPL, NBV, XV>), grid, dim3(256), lds, st, p);          \
-    return gml_launch_status();
+    if constexpr (FPL == 8) {                                                                         \
+        if (bf) GML_FWD_GO(NBV, XV, true)                                                             \
+    }                                                                                                 \
+    GML_FWD_GO(NBV, XV, false)
 
 #define GML_DEFINE_FWD_FAMILY(SCV, FPLV)                                                              \
     template <>                                                                                       \
-    int gml_launch_fwd_family<SCV, FPLV>(const GmlFwdParams& p, int NB, bool xvec, dim3 grid,         \
+    int gml_launch_fwd_family<SCV, FPLV>(const GmlFwdParams& p, int NB, bool xvec, bool bf, dim3 grid, \
                                          size_t lds, hipStream_t st) {                                \
         constexpr int SC = SCV, FPL = FPLV;                                                           \
         if (xvec) {                                                                                   \

@@ -21,6 +21,11 @@ from .graph import _ptr, _stream, _require_cuda
 # events recorded on the stream the kernel runs on, with its algorithmic bytes / flops.
 PROFILE = None
 
+# Projection arithmetic of the fused kernels: default = bf16x3 split on the bf16 matrix cores (fp32-class,
+# ~1e-6 of the output scale); F32_MFMA = True (or env GML_F32_MFMA=1) = f32-input MFMA, bit-identical to fmaf.
+import os as _os
+F32_MFMA = _os.environ.get('GML_F32_MFMA', '0') not in ('0', '')
+
 
 class _Timed(object):
     __slots__ = ('tag', 'q', 'f', 'e0')
@@ -90,7 +95,8 @@ def _fused_conv(rowptr, col, ginfo, epos, val, x, ldx, w, w_strides, bias, out, 
                 out_off):
     _lib.call('gml_spectconv_fwd', _ptr(rowptr), _ptr(col), _ptr(ginfo), _ptr(epos), _ptr(val), _ptr(x), int(ldx),
               _ptr(w), int(w_strides[0]), int(w_strides[1]), int(w_strides[2]), _ptr(bias),
-              _off(out, out_off), int(ldo), int(nrows), int(S), int(Fin), int(Fout), int(flags), _stream(x.device))
+              _off(out, out_off), int(ldo), int(nrows), int(S), int(Fin), int(Fout),
+              int(flags) | (_lib.GML_F32_MFMA if F32_MFMA else 0), _stream(x.device))
 
 
 def spmm(csr, val, x, S, Fin):

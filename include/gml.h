@@ -47,7 +47,9 @@ enum {
 /* flags of gml_spectconv_fwd */
 enum {
     GML_RELU = 1,   /* out = max(out, 0) in the epilogue          (ML3Layer: relu(conv1(..))) */
-    GML_ACCUM = 2   /* out += result instead of out = result      (gradient accumulation)     */
+    GML_ACCUM = 2,  /* out += result instead of out = result      (gradient accumulation)     */
+    GML_F32_MFMA = 4 /* project with the f32-input MFMA (bit-identical to an fmaf chain) instead of the default
+                        bf16x3 split on the bf16 matrix cores (fp32-class: ~1e-6 of the output scale)       */
 };
 
 int gml_version(void);
