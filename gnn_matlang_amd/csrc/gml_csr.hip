@@ -170,15 +170,15 @@ extern "C" int gml_csr_link_transpose(const int32_t* perm_fwd, const int32_t* pe
 }
 
 // ---------------------------------------------------------------------------------------------
-// Per 64-row group: {first edge, #edges, smallest column id, width of the column window}.  The fused
+// Per group of 64 (or 128) rows: {first edge, #edges, smallest column id, width of the column window}.  The fused
 // layer kernels read one 16-byte record per group and know at once which CSR slice / value rows / X
 // rows to prefetch (no dependent rowptr -> col -> min/max chain inside the hot kernel).
 __global__ __launch_bounds__(64) void gml_k_group_info(const int32_t* __restrict__ rowptr,
                                                       const int32_t* __restrict__ col, int64_t nrows,
-                                                      int32_t* __restrict__ ginfo) {
+                                                      int32_t group_rows, int32_t* __restrict__ ginfo) {
     const int64_t g = blockIdx.x;
-    const int64_t r0 = g * 64;
-    const int64_t r1 = min(r0 + 64, nrows);
+    const int64_t r0 = g * group_rows;
+    const int64_t r1 = min(r0 + group_rows, nrows);
     const int kb = rowptr[r0], ke = rowptr[r1];
     int mn = INT32_MAX, mx = -1;
     for (int k = kb + (int)threadIdx.x; k < ke; k += 64) {
@@ -198,12 +198,12 @@ __global__ __launch_bounds__(64) void gml_k_group_info(const int32_t* __restrict
     }
 }
 
-extern "C" int gml_csr_group_info(const int32_t* rowptr, const int32_t* col, int64_t num_rows, int32_t* ginfo,
-                                  gml_stream_t stream) {
-    if (num_rows < 0) return GML_E_BADARG;
+extern "C" int gml_csr_group_info(const int32_t* rowptr, const int32_t* col, int64_t num_rows, int32_t group_rows,
+                                  int32_t* ginfo, gml_stream_t stream) {
+    if (num_rows < 0 || (group_rows != 64 && group_rows != 128)) return GML_E_BADARG;
     if (num_rows == 0) return GML_OK;
     if (!rowptr || !ginfo) return GML_E_BADARG;
-    hipLaunchKernelGGL(gml_k_group_info, dim3((unsigned)gml_cdiv(num_rows, 64)), dim3(64), 0, (hipStream_t)stream,
-                       rowptr, col, num_rows, ginfo);
+    hipLaunchKernelGGL(gml_k_group_info, dim3((unsigned)gml_cdiv(num_rows, group_rows)), dim3(64), 0,
+                       (hipStream_t)stream, rowptr, col, num_rows, group_rows, ginfo);
     return gml_launch_status();
 }

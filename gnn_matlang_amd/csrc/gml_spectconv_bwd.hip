@@ -1,5 +1,5 @@
 // C-ABI dispatch of the fused backward kernel + the deterministic partial fold.
-#include "gml_spectconv_bwd_impl.h"
+#include "gml_spectconv_bwd2_impl.h"
 
 __global__ __launch_bounds__(256) void gml_k_reduce_rows(const float* __restrict__ partial, int64_t nparts, int64_t n,
                                                         float* __restrict__ out) {
@@ -25,8 +25,12 @@ GML_DECL_BWD(8, 2, 2) GML_DECL_BWD(8, 1, 2) GML_DECL_BWD(4, 2, 2) GML_DECL_BWD(4
 GML_DECL_BWD(12, 2, 1) GML_DECL_BWD(12, 1, 1) GML_DECL_BWD(6, 3, 2) GML_DECL_BWD(6, 1, 2)
 GML_DECL_BWD(4, 3, 2) GML_DECL_BWD(6, 2, 2) GML_DECL_BWD(8, 2, 1) GML_DECL_BWD(4, 4, 2)
 
+#define GML_DECL_BWD2(S, A) template <> int gml_launch_bwd2<S, A>(const GmlBwdParams&, dim3, size_t, hipStream_t);
+GML_DECL_BWD2(8, 2) GML_DECL_BWD2(8, 1) GML_DECL_BWD2(6, 2) GML_DECL_BWD2(6, 1)
+GML_DECL_BWD2(4, 2) GML_DECL_BWD2(4, 1) GML_DECL_BWD2(2, 2) GML_DECL_BWD2(2, 1)
+
 struct BwdPlan {
-    int ok, S, nfb, nob, grid, groups_per_wg, ecap, xcap;
+    int ok, S, nfb, nob, grid, groups_per_wg, ecap, xcap, rows;   /* rows: 64 (f32 MFMA kernel) or 128 (bf16x3 kernel) */
     size_t lds;
 };
 
@@ -37,15 +41,37 @@ struct BwdPlan {
         return pl;                                                                         \
     }
 
-static BwdPlan plan_bwd(int64_t num_rows, int S, int Fin, int Fout, int max_edges, int max_window) {
+static bool bwd2_shape(int S, int Fin, int Fout, uint32_t flags) {
+    return !(flags & GML_F32_MFMA) && (S == 2 || S == 4 || S == 6 || S == 8) && Fin <= 32 && Fout > 16 && Fout <= 32;
+}
+
+static BwdPlan plan_bwd(int64_t num_rows, int S, int Fin, int Fout, int max_edges, int max_window, uint32_t flags) {
     BwdPlan pl;
-    pl.ok = 0; pl.S = S;
+    pl.ok = 0; pl.S = S; pl.rows = 64;
     const int nfb = (Fin + 15) / 16, nob = (Fout + 15) / 16;
     pl.nfb = nfb; pl.nob = nob;
     pl.ecap = (max_edges + 15) / 16 * 16;
     if (pl.ecap < 64) pl.ecap = 64;
     pl.xcap = (max_window + 15) / 16 * 16;
     if (pl.xcap < 64) pl.xcap = 64;
+    if (bwd2_shape(S, Fin, Fout, flags)) {                 /* bf16x3 kernel: 128-row groups, one 8-wave workgroup per CU */
+        pl.rows = 128;
+        pl.nfb = (Fin + 15) / 16;
+        if (pl.ecap < 512) pl.ecap = 512;                  /* the value rows' region later holds the P^T slab */
+        const int ng = (int)gml_cdiv(num_rows, 128);
+        int grid2 = ng < GML_NUM_CU ? ng : GML_NUM_CU;
+        if (grid2 < 1) grid2 = 1;
+        pl.groups_per_wg = (int)gml_cdiv(ng, grid2);
+        pl.grid = pl.groups_per_wg > 0 ? (int)gml_cdiv(ng, pl.groups_per_wg) : 1;
+        switch (S) {
+            case 8: pl.lds = GmlBwd2Cfg<8, 2>::lds_bytes(pl.ecap, pl.xcap); break;
+            case 6: pl.lds = GmlBwd2Cfg<6, 2>::lds_bytes(pl.ecap, pl.xcap); break;
+            case 4: pl.lds = GmlBwd2Cfg<4, 2>::lds_bytes(pl.ecap, pl.xcap); break;
+            default: pl.lds = GmlBwd2Cfg<2, 2>::lds_bytes(pl.ecap, pl.xcap); break;
+        }
+        pl.ok = pl.lds <= 160 * 1024;
+        return pl;
+    }
     const int ngroups = (int)gml_cdiv(num_rows, 64);
     int grid = ngroups < GML_NUM_CU * 2 ? ngroups : GML_NUM_CU * 2;
     if (grid < 1) grid = 1;
@@ -58,10 +84,17 @@ static BwdPlan plan_bwd(int64_t num_rows, int S, int Fin, int Fout, int max_edge
     return pl;
 }
 
+extern "C" int gml_spectconv_bwd_group_rows(int32_t S, int32_t Fin, int32_t Fout, uint32_t flags) {
+    if (S <= 0 || Fin <= 0 || Fout <= 0) return 0;
+    if (bwd2_shape(S, Fin, Fout, flags)) return 128;
+    const BwdPlan pl = plan_bwd(64, S, Fin, Fout, 64, 64, flags | GML_F32_MFMA);
+    return pl.ok ? 64 : 0;
+}
+
 extern "C" size_t gml_spectconv_bwd_workspace_bytes(int64_t num_rows, int32_t S, int32_t Fin, int32_t Fout,
-                                                    int32_t max_group_edges, int32_t max_group_window) {
+                                                    int32_t max_group_edges, int32_t max_group_window, uint32_t flags) {
     if (num_rows <= 0 || S <= 0 || Fin <= 0 || Fout <= 0) return 0;
-    const BwdPlan pl = plan_bwd(num_rows, S, Fin, Fout, max_group_edges, max_group_window);
+    const BwdPlan pl = plan_bwd(num_rows, S, Fin, Fout, max_group_edges, max_group_window, flags);
     if (!pl.ok) return 0;                                     /* 0 = this shape has no fused backward */
     return (size_t)pl.grid * S * Fin * Fout * sizeof(float);
 }
@@ -81,7 +114,7 @@ extern "C" int gml_spectconv_bwd(const int32_t* rowptr, const int32_t* col, cons
     }
     if (!rowptr || !ginfo || !x || !g || !w) return GML_E_BADARG;
     if ((((uintptr_t)val | (uintptr_t)dval) & 15) != 0) return GML_E_BADARG;
-    const BwdPlan pl = plan_bwd(num_rows, S, Fin, Fout, max_group_edges, max_group_window);
+    const BwdPlan pl = plan_bwd(num_rows, S, Fin, Fout, max_group_edges, max_group_window, flags);
     if (!pl.ok) return GML_E_UNSUPPORTED;
     const size_t need = (size_t)pl.grid * S * Fin * Fout * sizeof(float);
     if (dw && (!ws || ws_bytes < need)) return GML_E_WORKSPACE;
@@ -93,14 +126,20 @@ extern "C" int gml_spectconv_bwd(const int32_t* rowptr, const int32_t* col, cons
     p.xvec = (Fin % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)x & 15) == 0);
     /* float4 groups up to roundup4(Fout) must exist in every row: true when ldg covers them (zero padded) */
     p.gvec = (ldg % 4 == 0) && ((Fout + 3) / 4 * 4 <= ldg) && (((uintptr_t)g & 15) == 0);
-    p.ngroups = (int)gml_cdiv(num_rows, 64); p.groups_per_wg = pl.groups_per_wg; p.ecap = pl.ecap; p.xcap = pl.xcap;
+    p.ngroups = (int)gml_cdiv(num_rows, pl.rows); p.groups_per_wg = pl.groups_per_wg; p.ecap = pl.ecap; p.xcap = pl.xcap;
     const int nfb = pl.nfb, nob = pl.nob;
     int rc = GML_E_UNSUPPORTED;
+    if (pl.rows == 128) {
+#define GML_BWD2_GO(SV, A) if (S == SV && nfb == A) rc = gml_launch_bwd2<SV, A>(p, dim3(pl.grid), pl.lds, st);
+        GML_BWD2_GO(8, 2) GML_BWD2_GO(8, 1) GML_BWD2_GO(6, 2) GML_BWD2_GO(6, 1)
+        GML_BWD2_GO(4, 2) GML_BWD2_GO(4, 1) GML_BWD2_GO(2, 2) GML_BWD2_GO(2, 1)
+    } else {
 #define GML_BWD_GO(SV, A, B) \
     if (S == SV && nfb == A && nob == B) rc = gml_launch_bwd<SV, A, B>(p, dim3(pl.grid), pl.lds, st);
     GML_BWD_GO(8, 2, 2) GML_BWD_GO(8, 1, 2) GML_BWD_GO(4, 2, 2) GML_BWD_GO(4, 1, 2)
     GML_BWD_GO(12, 2, 1) GML_BWD_GO(12, 1, 1) GML_BWD_GO(6, 3, 2) GML_BWD_GO(6, 1, 2)
     GML_BWD_GO(4, 3, 2) GML_BWD_GO(6, 2, 2) GML_BWD_GO(8, 2, 1) GML_BWD_GO(4, 4, 2)
+    }
     if (rc != GML_OK) return rc;
     if (dw) {
         const int64_t n = (int64_t)S * Fin * Fout;

@@ -1,0 +1,362 @@
+// Fused backward, bf16x3 variant (default for Fin <= 32, 16 < Fout <= 32): same outputs as
+// gml_k_spectconv_bwd (gml_spectconv_bwd_impl.h)
+//
+//   dX = sum_s A_s (G W_s^T),   dval[e,s] = < X[src] W_s, G[dst] >,   dW_s = X^T (A_s G)
+//
+// but all three projections run on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16) with both operands split
+// into bf16 (hi, lo) pairs and the three significant products accumulated in fp32 (fp32-class, see
+// gml_common.h).  Why: the f32-input MFMA executes on the fp32 vector ALUs, so in the f32 kernel the
+// 3 x 128 MFMAs of a tile serialise with its edge phase; the bf16 pipe is separate and asynchronous.
+//
+// Workgroup = 8 waves, group = 128 source rows (8 tiles of 16).  LDS: W twice as bf16 (hi, lo), once
+// f-contiguous [s][o][f] (A fragments of Z^T = W^T X^T) and once o-contiguous [s][f][o] (B fragments of
+// dX = P W^T) -- a bf16 MFMA fragment is 8 consecutive k per lane, so each contraction needs its own
+// layout; staging as in the f32 kernel.  Lane (r16, kq) of a tile owns row r16 and the 8 outputs
+// o = 8*kq .. 8*kq+7.  dW contracts over the 128 rows: X^T and P^T go through LDS as bf16 (hi, lo)
+// [f or o][row]; two supports per slab, wave w owns block (se, fb, ob) = w of the slab.
+#pragma once
+#include "gml_common.h"
+#include "gml_spectconv_bwd_impl.h"
+
+#define GML_BWD2_ROWS 128
+#define GML_BWD2_ECAP_MAX 2048     // register-batched staging bounds (per 128-row group)
+#define GML_BWD2_XCAP_MAX 320
+
+template <int S, int NFB>
+struct GmlBwd2Cfg {
+    static constexpr int FINP = 32, FOUTP = 32;             // K of one bf16 MFMA; NFB = live 16-wide Fin blocks
+    static constexpr int LDG = FOUTP + 4;                    // G window rows (floats, b128 aligned)
+    static constexpr int W_HALF = S * 32 * 32;               // bf16 elements of one (hi or lo) W image
+    static constexpr int W_BYTES = 4 * W_HALF * 2;           // fo-hi, fo-lo, of-hi, of-lo
+    static constexpr int SE = 2;                             // supports per dW slab (8 blocks -> 8 waves when NFB=2)
+    static constexpr int NSLAB = S / SE;
+    static constexpr int XT_BYTES = 2 * 32 * GML_BWD2_ROWS * 2;        // X^T hi, lo  [f][row]
+    static constexpr int PT_BYTES = 2 * SE * 32 * GML_BWD2_ROWS * 2;   // P^T hi, lo  [se][o][row]
+    static constexpr bool OK = (S % SE == 0);
+    __host__ __device__ static size_t ea_bytes(int ecap) {
+        const size_t a = (size_t)ecap * S * 4;
+        return a > (size_t)PT_BYTES ? a : (size_t)PT_BYTES;   // the value rows' region later holds the P^T slab
+    }
+    __host__ __device__ static size_t gs_bytes(int xcap) {
+        const size_t a = (size_t)xcap * LDG * 4;
+        return a > (size_t)XT_BYTES ? a : (size_t)XT_BYTES;   // the G window's region later holds X^T
+    }
+    __host__ __device__ static size_t lds_bytes(int ecap, int xcap) {
+        return (size_t)W_BYTES + 136 * 4 + (size_t)ecap * 4 + ea_bytes(ecap) + gs_bytes(xcap);
+    }
+};
+
+template <int S, int NFB>
+__global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p) {
+    using C = GmlBwd2Cfg<S, NFB>;
+    constexpr int LDG = C::LDG;
+    constexpr int ROWS = GML_BWD2_ROWS;
+    constexpr int VAL_ALIGN = (S % 4 == 0) ? 4 : ((S % 2 == 0) ? 2 : 1);
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __bf16* Wfo_h = reinterpret_cast<__bf16*>(lds_raw);     // [s][f][o]
+    __bf16* Wfo_l = Wfo_h + C::W_HALF;
+    __bf16* Wof_h = Wfo_l + C::W_HALF;                       // [s][o][f]
+    __bf16* Wof_l = Wof_h + C::W_HALF;
+    int* rp_l = reinterpret_cast<int*>(lds_raw + C::W_BYTES);
+    int* col_l = rp_l + 136;
+    float* ea_l = reinterpret_cast<float*>(col_l + p.ecap);
+    float* gs = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(ea_l) + C::ea_bytes(p.ecap));
+    __bf16* pT_h = reinterpret_cast<__bf16*>(ea_l);          // [se][o][row]   (after the dval rows left)
+    __bf16* pT_l = pT_h + C::SE * 32 * ROWS;
+    __bf16* xT_h = reinterpret_cast<__bf16*>(gs);            // [f][row]        (after the edge phase)
+    __bf16* xT_l = xT_h + 32 * ROWS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int wg = gml_xcd_remap(blockIdx.x, gridDim.x);
+    const int g0 = wg * p.groups_per_wg;
+    const int g1 = min(g0 + p.groups_per_wg, p.ngroups);
+
+    // W -> bf16 (hi, lo), both layouts, zero padded to 32 x 32
+    for (int e = tid; e < S * 32 * 32; e += 512) {
+        const int o = e & 31, f = (e >> 5) & 31, s = e >> 10;
+        const float v = (f < p.Fin && o < p.Fout) ? p.w[((int64_t)s * p.Fin + f) * p.Fout + o] : 0.f;
+        const __bf16 h = (__bf16)v;
+        const __bf16 l = (__bf16)(v - (float)h);
+        Wfo_h[e] = h; Wfo_l[e] = l;
+        Wof_h[(s * 32 + o) * 32 + f] = h; Wof_l[(s * 32 + o) * 32 + f] = l;
+    }
+
+    f32x4 dwacc[C::NSLAB];
+#pragma unroll
+    for (int i = 0; i < C::NSLAB; ++i) dwacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int g = g0; g < g1; ++g) {
+        const int64_t r0 = (int64_t)g * ROWS;
+        const int nr = (int)min((int64_t)ROWS, p.nrows - r0);
+        const int4 gi = reinterpret_cast<const int4*>(p.ginfo)[g];
+        const int kb = gi.x, ne = gi.y, lo = gi.z, nwin = gi.w;
+        __syncthreads();                                     // previous group is done with every LDS region
+
+        // ---- stage: every global load of the group is in flight before the first LDS write
+        if (tid <= nr) rp_l[tid] = p.rowptr[r0 + tid];
+        if ((S % 4 == 0) && p.gvec && ne <= GML_BWD2_ECAP_MAX && nwin <= GML_BWD2_XCAP_MAX) {
+            constexpr int NC = GML_BWD2_ECAP_MAX / 512, NE4 = (S % 4 == 0) ? GML_BWD2_ECAP_MAX * (S / 4) / 512 : 1;
+            constexpr int NG4 = (GML_BWD2_XCAP_MAX * 8 + 511) / 512;
+            int cv[NC];
+            f32x4 ev4[NE4], gv4[NG4];
+            const f32x4* src = reinterpret_cast<const f32x4*>(p.val + (int64_t)kb * S);
+#pragma unroll
+            for (int t = 0; t < NC; ++t) { const int i = tid + 512 * t; cv[t] = (i < ne) ? p.col[kb + i] : 0; }
+#pragma unroll
+            for (int t = 0; t < NE4; ++t) {
+                const int i = tid + 512 * t;
+                ev4[t] = (i < ne * (S / 4)) ? src[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int t = 0; t < NG4; ++t) {
+                const int i = tid + 512 * t;
+                const int rr = i >> 3, o4 = (i & 7) * 4;
+                gv4[t] = (i < nwin * 8 && o4 < p.Fout) ? *reinterpret_cast<const f32x4*>(p.g + (int64_t)(lo + rr) * p.ldg + o4)
+                                                        : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int t = 0; t < NC; ++t) { const int i = tid + 512 * t; if (i < ne) col_l[i] = cv[t] - lo; }
+#pragma unroll
+            for (int t = 0; t < NE4; ++t) {
+                const int i = tid + 512 * t;
+                if (i < ne * (S / 4)) reinterpret_cast<f32x4*>(ea_l)[i] = ev4[t];
+            }
+#pragma unroll
+            for (int t = 0; t < NG4; ++t) {
+                const int i = tid + 512 * t;
+                if (i < nwin * 8) *reinterpret_cast<f32x4*>(gs + (i >> 3) * LDG + (i & 7) * 4) = gv4[t];
+            }
+        } else {
+            for (int i = tid; i < ne; i += 512) col_l[i] = p.col[kb + i] - lo;
+            for (int i = tid; i < ne * S; i += 512) ea_l[i] = p.val[(int64_t)kb * S + i];
+            for (int i = tid; i < nwin * 32; i += 512) {
+                const int rr = i >> 5, o = i & 31;
+                gs[rr * LDG + o] = (o < p.Fout) ? p.g[(int64_t)(lo + rr) * p.ldg + o] : 0.f;
+            }
+        }
+        __syncthreads();
+
+        const int row = wave * 16 + r16;                     // row of the group owned by this lane
+        const bool rvalid = row < nr;
+        const int kbeg = rvalid ? rp_l[row] - kb : 0;
+        const int kend = rvalid ? rp_l[row + 1] - kb : 0;
+
+        // own X row, features 8*kq .. 8*kq+7  ->  bf16 (hi, lo) B fragment of Z^T, also the X^T tile of dW
+        bf16x8 xh, xl;
+        {
+            float xb[8];
+            const float* xr = p.x + (r0 + row) * p.ldx + 8 * kq;
+            if (p.xvec) {
+#pragma unroll
+                for (int q4 = 0; q4 < 2; ++q4) {
+                    f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (rvalid && 8 * kq + 4 * q4 < p.Fin) t = *reinterpret_cast<const f32x4*>(xr + 4 * q4);
+                    xb[4 * q4] = t.x; xb[4 * q4 + 1] = t.y; xb[4 * q4 + 2] = t.z; xb[4 * q4 + 3] = t.w;
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) xb[t] = (rvalid && 8 * kq + t < p.Fin) ? xr[t] : 0.f;
+            }
+            gml_split8(xb, xh, xl);
+        }
+
+        // ---- Z^T = W^T X^T: MFMA row i of block ob carries o = 8*(i>>2) + 4*ob + (i&3), so lane kq receives
+        //      o = 8*kq + 4*ob + reg: its 8 consecutive outputs
+        f32x2 Z[S][4], P[S][4];                              // pair h of block ob: o = 8*kq + 4*ob + 2*h + {0,1}
+        {
+            const int oa0 = 8 * (r16 >> 2) + (r16 & 3);      // A-fragment row -> output column (block 0); +4 for block 1
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+#pragma unroll
+                for (int ob = 0; ob < 2; ++ob) {
+                    const int off = (s * 32 + oa0 + 4 * ob) * 32 + 8 * kq;
+                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(Wof_h + off);
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(Wof_l + off);
+                    f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, xh, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xl, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xh, d, 0, 0, 0);
+                    Z[s][2 * ob] = f32x2{d[0], d[1]};
+                    Z[s][2 * ob + 1] = f32x2{d[2], d[3]};
+                    P[s][2 * ob] = f32x2{0.f, 0.f};
+                    P[s][2 * ob + 1] = f32x2{0.f, 0.f};
+                }
+            }
+        }
+
+        // ---- edge phase (fp32 VALU, packed): P += val * G[dst],  d[s] = <Z[s], G[dst]>
+        for (int k = kbeg; k < kend; ++k) {
+            const int dstl = col_l[k];
+            float ev[S];
+            gml_load_row<S, VAL_ALIGN>(ea_l + k * S, ev);
+            f32x2 gv[4];
+            {
+                const f32x4 t0 = *reinterpret_cast<const f32x4*>(gs + dstl * LDG + 8 * kq);
+                const f32x4 t1 = *reinterpret_cast<const f32x4*>(gs + dstl * LDG + 8 * kq + 4);
+                gv[0] = f32x2{t0.x, t0.y}; gv[1] = f32x2{t0.z, t0.w};
+                gv[2] = f32x2{t1.x, t1.y}; gv[3] = f32x2{t1.z, t1.w};
+            }
+            float d[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                f32x2 a2 = f32x2{0.f, 0.f};
+                const f32x2 e2 = f32x2{ev[s], ev[s]};
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    P[s][h] = e2 * gv[h] + P[s][h];
+                    a2 = Z[s][h] * gv[h] + a2;
+                }
+                d[s] = a2.x + a2.y;
+            }
+#pragma unroll
+            for (int c = 0; c < (S + 3) / 4; ++c) {
+                const float v0 = d[4 * c], v1 = (4 * c + 1 < S) ? d[4 * c + 1] : 0.f;
+                const float v2 = (4 * c + 2 < S) ? d[4 * c + 2] : 0.f, v3 = (4 * c + 3 < S) ? d[4 * c + 3] : 0.f;
+                const auto a01 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v0), __float_as_uint(v1), false, false);
+                const auto a23 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v2), __float_as_uint(v3), false, false);
+                const float c01 = __uint_as_float(a01[0]) + __uint_as_float(a01[1]);
+                const float c23 = __uint_as_float(a23[0]) + __uint_as_float(a23[1]);
+                const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(c01), __float_as_uint(c23), false, false);
+                const float tot = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+                if (4 * c + kq < S) ea_l[k * S + 4 * c + kq] = tot;
+            }
+        }
+        __syncthreads();                                     // dval rows complete; G window no longer needed
+
+        if (p.dval) {
+            if constexpr (S % 4 == 0) {
+                f32x4* dst = reinterpret_cast<f32x4*>(p.dval + (int64_t)kb * S);
+                for (int i = tid; i < ne * (S / 4); i += 512) dst[i] = reinterpret_cast<const f32x4*>(ea_l)[i];
+            } else {
+                for (int i = tid; i < ne * S; i += 512) p.dval[(int64_t)kb * S + i] = ea_l[i];
+            }
+        }
+
+        // ---- dX = P W^T: one K=32 step per support (k = o = 8*kq + i), P split on the fly
+        if (p.dx) {
+            f32x4 dxa[NFB];
+#pragma unroll
+            for (int fb = 0; fb < NFB; ++fb) dxa[fb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const float pv[8] = {P[s][0].x, P[s][0].y, P[s][1].x, P[s][1].y, P[s][2].x, P[s][2].y, P[s][3].x, P[s][3].y};
+                bf16x8 ph, pl;
+                gml_split8(pv, ph, pl);
+#pragma unroll
+                for (int fb = 0; fb < NFB; ++fb) {
+                    const int off = (s * 32 + fb * 16 + r16) * 32 + 8 * kq;   // B[k = o][j = f]: 8 consecutive o of row f
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(Wfo_h + off);
+                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Wfo_l + off);
+                    dxa[fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, bh, dxa[fb], 0, 0, 0);
+                    dxa[fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, bl, dxa[fb], 0, 0, 0);
+                    dxa[fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, bh, dxa[fb], 0, 0, 0);
+                }
+            }
+            if (p.flags & GML_ACCUM) {
+#pragma unroll
+                for (int fb = 0; fb < NFB; ++fb) {
+                    const int f = fb * 16 + r16;
+                    float old[4];
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int lr = wave * 16 + 4 * kq + reg;
+                        old[reg] = (f < p.Fin && lr < nr) ? p.dx[(r0 + lr) * p.lddx + f] : 0.f;
+                    }
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int lr = wave * 16 + 4 * kq + reg;
+                        if (f < p.Fin && lr < nr) p.dx[(r0 + lr) * p.lddx + f] = dxa[fb][reg] + old[reg];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int fb = 0; fb < NFB; ++fb) {
+                    const int f = fb * 16 + r16;
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int lr = wave * 16 + 4 * kq + reg;
+                        if (f < p.Fin && lr < nr) p.dx[(r0 + lr) * p.lddx + f] = dxa[fb][reg];
+                    }
+                }
+            }
+        }
+
+        // ---- dW += X^T P over the 128 rows of the group
+        if (p.dw_partial) {
+            // X^T tile (bf16 hi, lo) [f][row]: lane writes its 8 features of its row
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                xT_h[(8 * kq + t) * ROWS + row] = xh[t];
+                xT_l[(8 * kq + t) * ROWS + row] = xl[t];
+            }
+#pragma unroll
+            for (int sl = 0; sl < C::NSLAB; ++sl) {
+                __syncthreads();                             // slab buffer free: the dval copy-out (sl == 0) or the
+                                                             // previous slab's fragment reads are done in every wave
+#pragma unroll
+                for (int se = 0; se < C::SE; ++se) {
+                    const int s = sl * C::SE + se;
+                    const float pv[8] = {P[s][0].x, P[s][0].y, P[s][1].x, P[s][1].y, P[s][2].x, P[s][2].y, P[s][3].x, P[s][3].y};
+                    bf16x8 ph, pl;
+                    gml_split8(pv, ph, pl);
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        pT_h[(se * 32 + 8 * kq + t) * ROWS + row] = ph[t];
+                        pT_l[(se * 32 + 8 * kq + t) * ROWS + row] = pl[t];
+                    }
+                }
+                __syncthreads();
+                if (wave < C::SE * NFB * 2) {
+                    const int ob = wave & 1, fb = (wave >> 1) % NFB, se = (wave >> 1) / NFB;
+                    f32x4 d = dwacc[sl];
+#pragma unroll
+                    for (int st = 0; st < ROWS / 32; ++st) {
+                        const int xo = (fb * 16 + r16) * ROWS + 32 * st + 8 * kq;            // A[i = f][k = row]
+                        const int po = (se * 32 + ob * 16 + r16) * ROWS + 32 * st + 8 * kq;  // B[k = row][j = o]
+                        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(xT_h + xo);
+                        const bf16x8 al = *reinterpret_cast<const bf16x8*>(xT_l + xo);
+                        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(pT_h + po);
+                        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(pT_l + po);
+                        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, d, 0, 0, 0);
+                    }
+                    dwacc[sl] = d;
+                }
+            }
+        }
+    }
+
+    // ---- one dW partial per workgroup: wave w holds, per slab, block (se, fb, ob): D[i = f][j = o]
+    if (p.dw_partial && g0 < g1 && wave < C::SE * NFB * 2) {
+        float* out = p.dw_partial + (int64_t)wg * S * p.Fin * p.Fout;
+        const int ob = wave & 1, fb = (wave >> 1) % NFB, se = (wave >> 1) / NFB;
+        const int o = ob * 16 + r16;
+#pragma unroll
+        for (int sl = 0; sl < C::NSLAB; ++sl) {
+            const int s = sl * C::SE + se;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int f = fb * 16 + 4 * kq + reg;
+                if (f < p.Fin && o < p.Fout) out[((int64_t)s * p.Fin + f) * p.Fout + o] = dwacc[sl][reg];
+            }
+        }
+    }
+}
+
+template <int S, int NFB>
+int gml_launch_bwd2(const GmlBwdParams& p, dim3 grid, size_t lds, hipStream_t st);
+
+#define GML_DEFINE_BWD2(SV, NFBV)                                                                            \
+    template <>                                                                                              \
+    int gml_launch_bwd2<SV, NFBV>(const GmlBwdParams& p, dim3 grid, size_t lds, hipStream_t st) {            \
+        static_assert(GmlBwd2Cfg<SV, NFBV>::OK, "S must be even");                                           \
+        static const hipError_t attr_rc = hipFuncSetAttribute(                                               \
+            reinterpret_cast<const void*>(&gml_k_spectconv_bwd2<SV, NFBV>),                                  \
+            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                         \
+        if (attr_rc != hipSuccess) return (int)attr_rc;                                                      \
+        hipLaunchKernelGGL((gml_k_spectconv_bwd2<SV, NFBV>), grid, dim3(512), lds, st, p);                   \
+        return gml_launch_status();                                                                          \
+    }

@@ -155,25 +155,38 @@ def segment_sum(x, ptr, mean=False):
     return out
 
 
+def _bwd_plan(csr, S, Fin, Fout):
+    """(flags, ginfo, (max_edges, max_window), workspace bytes) of the fused backward for this shape, or None."""
+    L = _lib.lib()
+    for flags in ((_lib.GML_F32_MFMA,) if F32_MFMA else (0, _lib.GML_F32_MFMA)):
+        rows = int(L.gml_spectconv_bwd_group_rows(int(S), int(Fin), int(Fout), flags))
+        if rows == 0:
+            continue
+        ginfo, gmax = (csr.ginfo_t128, csr.gmax_t128) if rows == 128 else (csr.ginfo_t, csr.gmax_t)
+        nbytes = int(L.gml_spectconv_bwd_workspace_bytes(csr.N, int(S), int(Fin), int(Fout), gmax[0], gmax[1], flags))
+        if nbytes > 0:
+            return flags, ginfo, gmax, nbytes
+    return None
+
+
 def fused_bwd_available(csr, S, Fin, Fout):
-    return int(_lib.lib().gml_spectconv_bwd_workspace_bytes(csr.N, int(S), int(Fin), int(Fout), csr.gmax_t[0],
-                                                            csr.gmax_t[1])) > 0
+    return _bwd_plan(csr, S, Fin, Fout) is not None
 
 
 def fused_conv_bwd(csr, val_t, x, G, weight, need_x, need_val, need_w, dx_accum_into=None):
     """one launch: dX, dval (source order), dW.  val_t: supports in source order."""
     S, Fin, Fout = weight.shape
     dev = x.device
-    nbytes = int(_lib.lib().gml_spectconv_bwd_workspace_bytes(csr.N, S, Fin, Fout, csr.gmax_t[0], csr.gmax_t[1]))
+    flags, ginfo, gmax, nbytes = _bwd_plan(csr, S, Fin, Fout)
     ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=dev) if need_w else None
     dx = torch.empty(csr.N, Fin, dtype=torch.float32, device=dev) if need_x else None
     dval_t = torch.empty(csr.E, S, dtype=torch.float32, device=dev) if need_val else None
     dw = torch.empty(S, Fin, Fout, dtype=torch.float32, device=dev) if need_w else None
     q, f = conv_cost_bwd(csr.N, csr.E, S, Fin, Fout) if PROFILE is not None else (0, 0)
     with _Timed('spectconv_bwd', q, f):
-        _lib.call('gml_spectconv_bwd', _ptr(csr.rowptr_t), _ptr(csr.col_t), _ptr(csr.ginfo_t), _ptr(val_t),
+        _lib.call('gml_spectconv_bwd', _ptr(csr.rowptr_t), _ptr(csr.col_t), _ptr(ginfo), _ptr(val_t),
                   _ptr(x), int(x.stride(0)), _ptr(G), int(G.stride(0)), _ptr(weight), _ptr(dx), Fin, _ptr(dval_t),
-                  _ptr(dw), csr.N, S, Fin, Fout, csr.gmax_t[0], csr.gmax_t[1], 0, _ptr(ws),
+                  _ptr(dw), csr.N, S, Fin, Fout, gmax[0], gmax[1], flags, _ptr(ws),
                   ws.numel() if ws is not None else 0, _stream(dev))
     return dx, dval_t, dw
 

@@ -68,10 +68,11 @@ int gml_csr_from_coo(const int64_t* key, const int64_t* other_in, int64_t num_no
  * source-sorted edge keeps its values.  inv_scratch: E int32. */
 int gml_csr_link_transpose(const int32_t* perm_fwd, const int32_t* perm_t, int64_t num_edges,
                            int32_t* inv_scratch, int32_t* pos_t, gml_stream_t stream);
-/* ginfo[g] = {first edge, #edges, smallest column id, column-window width} of the 64-row group g
- * (int32 x 4 x ceil(num_rows/64)): the prefetch schedule of gml_spectconv_fwd. */
-int gml_csr_group_info(const int32_t* rowptr, const int32_t* col, int64_t num_rows, int32_t* ginfo,
-                       gml_stream_t stream);
+/* ginfo[g] = {first edge, #edges, smallest column id, column-window width} of the group g of `group_rows`
+ * (64 or 128) consecutive rows (int32 x 4 x ceil(num_rows/group_rows)): the staging schedule of the fused
+ * kernels (gml_spectconv_fwd: 64; gml_spectconv_bwd: gml_spectconv_bwd_group_rows()). */
+int gml_csr_group_info(const int32_t* rowptr, const int32_t* col, int64_t num_rows, int32_t group_rows,
+                       int32_t* ginfo, gml_stream_t stream);
 /* out[k, :] = in[perm[k], :]   (rows of `width` floats) */
 int gml_gather_rows(const float* in, const int32_t* perm, float* out, int64_t rows, int32_t width,
                     gml_stream_t stream);
@@ -102,9 +103,14 @@ int gml_spectconv_fwd(const int32_t* rowptr, const int32_t* col, const int32_t* 
  * = maxima of ginfo[:, 1] / ginfo[:, 3] (the caller reads them once per batch): they size the LDS
  * staging.  gml_spectconv_bwd_workspace_bytes returns 0 when the shape has no fused backward
  * (gml_spectconv_bwd then returns GML_E_UNSUPPORTED): the caller composes gml_spectconv_fwd on the
- * transposed view + gml_spmm_fwd + gml_sddmm instead.  flags: GML_ACCUM applies to dx. */
+ * transposed view + gml_spmm_fwd + gml_sddmm instead.  flags: GML_ACCUM applies to dx; GML_F32_MFMA forces the
+ * f32-input MFMA kernel (default: bf16x3 split on the bf16 matrix cores where the shape allows). */
+/* rows per staging group of the backward kernel this shape / flags selects: 128 (bf16x3 kernel), 64 (f32-MFMA
+ * kernel) or 0 (no fused backward).  ginfo, max_group_edges and max_group_window passed to the two functions
+ * below must be those of gml_csr_group_info(..., group_rows = this value). */
+int gml_spectconv_bwd_group_rows(int32_t S, int32_t Fin, int32_t Fout, uint32_t flags);
 size_t gml_spectconv_bwd_workspace_bytes(int64_t num_rows, int32_t S, int32_t Fin, int32_t Fout,
-                                         int32_t max_group_edges, int32_t max_group_window);
+                                         int32_t max_group_edges, int32_t max_group_window, uint32_t flags);
 int gml_spectconv_bwd(const int32_t* rowptr, const int32_t* col, const int32_t* ginfo, const float* val,
                       const float* x, int64_t ldx, const float* g, int64_t ldg, const float* w,
                       float* dx, int64_t lddx, float* dval, float* dw,
