@@ -30,8 +30,10 @@ struct GmlBwd2Cfg {
     static constexpr int W_BYTES = 4 * W_HALF * 2;           // fo-hi, fo-lo, of-hi, of-lo
     static constexpr int SE = 2;                             // supports per dW slab (8 blocks -> 8 waves when NFB=2)
     static constexpr int NSLAB = S / SE;
-    static constexpr int XT_BYTES = 2 * 32 * GML_BWD2_ROWS * 2;        // X^T hi, lo  [f][row]
-    static constexpr int PT_BYTES = 2 * SE * 32 * GML_BWD2_ROWS * 2;   // P^T hi, lo  [se][o][row]
+    static constexpr int LDT = GML_BWD2_ROWS + 8;           // row stride (bf16) of the transposed tiles: +16 B spreads
+                                                             // the 16 rows a fragment read touches over all 64 LDS banks
+    static constexpr int XT_BYTES = 2 * 32 * LDT * 2;                  // X^T hi, lo  [f][row]
+    static constexpr int PT_BYTES = 2 * SE * 32 * LDT * 2;             // P^T hi, lo  [se][o][row]
     static constexpr bool OK = (S % SE == 0);
     __host__ __device__ static size_t ea_bytes(int ecap) {
         const size_t a = (size_t)ecap * S * 4;
@@ -50,7 +52,7 @@ template <int S, int NFB>
 __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p) {
     using C = GmlBwd2Cfg<S, NFB>;
     constexpr int LDG = C::LDG;
-    constexpr int ROWS = GML_BWD2_ROWS;
+    constexpr int ROWS = GML_BWD2_ROWS, LDT = C::LDT;
     constexpr int VAL_ALIGN = (S % 4 == 0) ? 4 : ((S % 2 == 0) ? 2 : 1);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __bf16* Wfo_h = reinterpret_cast<__bf16*>(lds_raw);     // [s][f][o]
@@ -62,9 +64,9 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
     float* ea_l = reinterpret_cast<float*>(col_l + p.ecap);
     float* gs = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(ea_l) + C::ea_bytes(p.ecap));
     __bf16* pT_h = reinterpret_cast<__bf16*>(ea_l);          // [se][o][row]   (after the dval rows left)
-    __bf16* pT_l = pT_h + C::SE * 32 * ROWS;
+    __bf16* pT_l = pT_h + C::SE * 32 * LDT;
     __bf16* xT_h = reinterpret_cast<__bf16*>(gs);            // [f][row]        (after the edge phase)
-    __bf16* xT_l = xT_h + 32 * ROWS;
+    __bf16* xT_l = xT_h + 32 * LDT;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -79,8 +81,12 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
         const float v = (f < p.Fin && o < p.Fout) ? p.w[((int64_t)s * p.Fin + f) * p.Fout + o] : 0.f;
         const __bf16 h = (__bf16)v;
         const __bf16 l = (__bf16)(v - (float)h);
-        Wfo_h[e] = h; Wfo_l[e] = l;
-        Wof_h[(s * 32 + o) * 32 + f] = h; Wof_l[(s * 32 + o) * 32 + f] = l;
+        // 16-byte chunks of a 64-byte row are XOR-swizzled so that the 16 rows one fragment read touches
+        // (stride 64 B = 4-way conflict) land on distinct banks: key (f>>2)&3 for [s][f][o], (o>>3)&3 for [s][o][f]
+        const int ifo = (s * 32 + f) * 32 + ((((o >> 3) ^ (f >> 2)) & 3) << 3) + (o & 7);
+        const int iof = (s * 32 + o) * 32 + ((((f >> 3) ^ (o >> 3)) & 3) << 3) + (f & 7);
+        Wfo_h[ifo] = h; Wfo_l[ifo] = l;
+        Wof_h[iof] = h; Wof_l[iof] = l;
     }
 
     f32x4 dwacc[C::NSLAB];
@@ -171,7 +177,8 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
             for (int s = 0; s < S; ++s) {
 #pragma unroll
                 for (int ob = 0; ob < 2; ++ob) {
-                    const int off = (s * 32 + oa0 + 4 * ob) * 32 + 8 * kq;
+                    const int oa = oa0 + 4 * ob;
+                    const int off = (s * 32 + oa) * 32 + (((kq ^ (oa >> 3)) & 3) << 3);
                     const bf16x8 ah = *reinterpret_cast<const bf16x8*>(Wof_h + off);
                     const bf16x8 al = *reinterpret_cast<const bf16x8*>(Wof_l + off);
                     f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -246,7 +253,8 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
                 gml_split8(pv, ph, pl);
 #pragma unroll
                 for (int fb = 0; fb < NFB; ++fb) {
-                    const int off = (s * 32 + fb * 16 + r16) * 32 + 8 * kq;   // B[k = o][j = f]: 8 consecutive o of row f
+                    const int ff = fb * 16 + r16;                              // B[k = o][j = f]: 8 consecutive o of row f
+                    const int off = (s * 32 + ff) * 32 + (((kq ^ (ff >> 2)) & 3) << 3);
                     const bf16x8 bh = *reinterpret_cast<const bf16x8*>(Wfo_h + off);
                     const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Wfo_l + off);
                     dxa[fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, bh, dxa[fb], 0, 0, 0);
@@ -288,8 +296,8 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
             // X^T tile (bf16 hi, lo) [f][row]: lane writes its 8 features of its row
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
-                xT_h[(8 * kq + t) * ROWS + row] = xh[t];
-                xT_l[(8 * kq + t) * ROWS + row] = xl[t];
+                xT_h[(8 * kq + t) * LDT + row] = xh[t];
+                xT_l[(8 * kq + t) * LDT + row] = xl[t];
             }
 #pragma unroll
             for (int sl = 0; sl < C::NSLAB; ++sl) {
@@ -303,8 +311,8 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
                     gml_split8(pv, ph, pl);
 #pragma unroll
                     for (int t = 0; t < 8; ++t) {
-                        pT_h[(se * 32 + 8 * kq + t) * ROWS + row] = ph[t];
-                        pT_l[(se * 32 + 8 * kq + t) * ROWS + row] = pl[t];
+                        pT_h[(se * 32 + 8 * kq + t) * LDT + row] = ph[t];
+                        pT_l[(se * 32 + 8 * kq + t) * LDT + row] = pl[t];
                     }
                 }
                 __syncthreads();
@@ -313,8 +321,8 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
                     f32x4 d = dwacc[sl];
 #pragma unroll
                     for (int st = 0; st < ROWS / 32; ++st) {
-                        const int xo = (fb * 16 + r16) * ROWS + 32 * st + 8 * kq;            // A[i = f][k = row]
-                        const int po = (se * 32 + ob * 16 + r16) * ROWS + 32 * st + 8 * kq;  // B[k = row][j = o]
+                        const int xo = (fb * 16 + r16) * LDT + 32 * st + 8 * kq;             // A[i = f][k = row]
+                        const int po = (se * 32 + ob * 16 + r16) * LDT + 32 * st + 8 * kq;   // B[k = row][j = o]
                         const bf16x8 ah = *reinterpret_cast<const bf16x8*>(xT_h + xo);
                         const bf16x8 al = *reinterpret_cast<const bf16x8*>(xT_l + xo);
                         const bf16x8 bh = *reinterpret_cast<const bf16x8*>(pT_h + po);
