@@ -293,11 +293,14 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
 
         // ---- dW += X^T P over the 128 rows of the group
         if (p.dw_partial) {
-            // X^T tile (bf16 hi, lo) [f][row]: lane writes its 8 features of its row
+            // X^T tile (bf16 hi, lo) [f][row]: lane writes its 8 features of its row.  Inside a tile row the 128
+            // row positions are rotated by 16 * ((f or o) >> 3): the four kq lane groups, which write f (o) = 8*kq + t
+            // at the same time, then hit disjoint banks (un-rotated they are exactly 0 mod 32 banks apart).
+            const int rrow = (row + 16 * kq) & (ROWS - 1);
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
-                xT_h[(8 * kq + t) * LDT + row] = xh[t];
-                xT_l[(8 * kq + t) * LDT + row] = xl[t];
+                xT_h[(8 * kq + t) * LDT + rrow] = xh[t];
+                xT_l[(8 * kq + t) * LDT + rrow] = xl[t];
             }
 #pragma unroll
             for (int sl = 0; sl < C::NSLAB; ++sl) {
@@ -311,8 +314,8 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
                     gml_split8(pv, ph, pl);
 #pragma unroll
                     for (int t = 0; t < 8; ++t) {
-                        pT_h[(se * 32 + 8 * kq + t) * LDT + row] = ph[t];
-                        pT_l[(se * 32 + 8 * kq + t) * LDT + row] = pl[t];
+                        pT_h[(se * 32 + 8 * kq + t) * LDT + rrow] = ph[t];
+                        pT_l[(se * 32 + 8 * kq + t) * LDT + rrow] = pl[t];
                     }
                 }
                 __syncthreads();
@@ -321,8 +324,9 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
                     f32x4 d = dwacc[sl];
 #pragma unroll
                     for (int st = 0; st < ROWS / 32; ++st) {
-                        const int xo = (fb * 16 + r16) * LDT + 32 * st + 8 * kq;             // A[i = f][k = row]
-                        const int po = (se * 32 + ob * 16 + r16) * LDT + 32 * st + 8 * kq;   // B[k = row][j = o]
+                        const int rot = 16 * ((r16 >> 3) & 1);      // (f >> 3) & 3 = 2*fb + (r16 >> 3), likewise for o
+                        const int xo = (fb * 16 + r16) * LDT + ((32 * st + 8 * kq + 32 * fb + rot) & (ROWS - 1));            // A[i = f][k = row]
+                        const int po = (se * 32 + ob * 16 + r16) * LDT + ((32 * st + 8 * kq + 32 * ob + rot) & (ROWS - 1));  // B[k = row][j = o]
                         const bf16x8 ah = *reinterpret_cast<const bf16x8*>(xT_h + xo);
                         const bf16x8 al = *reinterpret_cast<const bf16x8*>(xT_l + xo);
                         const bf16x8 bh = *reinterpret_cast<const bf16x8*>(pT_h + po);
