@@ -204,38 +204,62 @@ def main():
         if prof:
             summ = Fn.profile_summary(prof)
 
-            def roof(tag, kernel):
+            bf16x3 = not Fn.F32_MFMA
+            BF16_PEAK_TFLOPS = 2500.0                       # dense bf16 MFMA (MI355X_MICROARCH.md)
+
+            def roof(tag, kernel, proj_flops, edge_flops):
+                """binding roof of one launch: HBM (algorithmic bytes), matrix pipe (projection flops: f32-input MFMA
+                at 157.3 TF, or 3 bf16 MFMAs per product at 2.5 PF in the default bf16x3 arithmetic) or -- never
+                binding here -- the fp32 VALU edge flops; achieved/peak are quoted for the binding one."""
                 k = summ[tag]
                 t = k['ms'] * 1e-3
-                gbs, tfs = k['bytes'] / t / 1e9, k['flops'] / t / 1e12
-                t_hbm, t_mfma = k['bytes'] / (HBM_PEAK_GBS * 1e9), k['flops'] / (MFMA_F32_PEAK_TFLOPS * 1e12)
-                if t_mfma >= t_hbm:
-                    r = dict(bound='mfma', achieved=tfs, peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
-                             frac=tfs / MFMA_F32_PEAK_TFLOPS)
+                nl = k['launches']
+                pf, ef = proj_flops / nl, edge_flops / nl
+                gbs = k['bytes'] / t / 1e9
+                t_hbm = k['bytes'] / (HBM_PEAK_GBS * 1e9)
+                if bf16x3:
+                    t_mat, mat_peak, mat_flops = 3 * pf / (BF16_PEAK_TFLOPS * 1e12), BF16_PEAK_TFLOPS, 3 * pf
+                else:
+                    t_mat, mat_peak, mat_flops = (pf + ef) / (MFMA_F32_PEAK_TFLOPS * 1e12), MFMA_F32_PEAK_TFLOPS, pf + ef
+                if t_mat > t_hbm:
+                    r = dict(bound='mfma', achieved=mat_flops / t / 1e12, peak=mat_peak, unit='TFLOP/s',
+                             frac=mat_flops / t / 1e12 / mat_peak)
                 else:
                     r = dict(bound='hbm', achieved=gbs, peak=HBM_PEAK_GBS, unit='GB/s', frac=gbs / HBM_PEAK_GBS)
-                r.update(traffic=None, kernel=kernel, launches=k['launches'], avg_launch_ms=k['ms'],
-                         ms_per_step=k['ms'] * k['launches'] / args.steps,
+                r.update(traffic=None, kernel=kernel, launches=nl, avg_launch_ms=k['ms'],
+                         ms_per_step=k['ms'] * nl / args.steps,
+                         projection_arith='bf16x3 split on the bf16 matrix cores, fp32 accumulate' if bf16x3
+                         else 'f32-input MFMA',
                          algorithmic_bytes_per_launch=k['bytes'], algorithmic_flops_per_launch=k['flops'],
-                         hbm_GBps=gbs, hbm_frac=gbs / HBM_PEAK_GBS, mfma_f32_TFLOPs=tfs,
-                         mfma_frac=tfs / MFMA_F32_PEAK_TFLOPS)
+                         t_hbm_ms=t_hbm * 1e3, t_matrix_ms=t_mat * 1e3, t_valu_edge_ms=ef / (MFMA_F32_PEAK_TFLOPS * 1e12) * 1e3,
+                         hbm_GBps=gbs, hbm_frac=gbs / HBM_PEAK_GBS,
+                         algorithmic_TFLOPs=k['flops'] / t / 1e12)
                 return r
+            # per-step flop split of the 4 layers (Fin = 25, 32, 32, 32; Fout = 30; S = 8): projections vs edge FMAs
+            N_, E_ = int(data.x.size(0)), int(data.edge_index2.size(1))
+            fins = [25, 32, 32, 32]
+            pj_f = sum(2 * N_ * 8 * f * 30 for f in fins) * args.steps
+            ed_f = sum(2 * E_ * 8 * f for f in fins) * args.steps
+            pj_b = sum(6 * N_ * 8 * f * 30 for f in fins) * args.steps          # Z, dX, dW
+            ed_b = sum(4 * E_ * 8 * 30 for f in fins) * args.steps              # P update + Z.g dot
             cands = []
             if 'spectconv_bwd' in summ:
-                cands.append(roof('spectconv_bwd', 'gml_k_spectconv_bwd (fused SpectConv backward: dX, dval, dW)'))
+                cands.append(roof('spectconv_bwd', 'gml_k_spectconv_bwd2 / gml_k_spectconv_bwd (fused SpectConv backward: dX, dval, dW)', pj_b, ed_b))
             if 'spectconv_fwd' in summ:
-                cands.append(roof('spectconv_fwd', 'gml_k_spectconv_fwd (fused SpectConv forward)'))
+                cands.append(roof('spectconv_fwd', 'gml_k_spectconv_fwd (fused SpectConv forward)', pj_f, ed_f))
             # HBM bytes per launch from the PMC counters (collected offline with the same command under rocprofv3,
-            # separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied -- profiles/r01_c_hbm_traffic.md);
+            # separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied -- profiles/r01_d_hbm_traffic.md);
             # only valid for the workload it was measured on
-            tpath = os.path.join(ROOT, 'profiles', 'r01_c_hbm_traffic.json')
+            tpath = os.path.join(ROOT, 'profiles', 'r01_d_hbm_traffic.json')
             if os.path.exists(tpath) and data.num_graphs == 32768 and args.pool == 2048:
                 tk = json.load(open(tpath))['kernels']
-                for r, key in zip(cands, [('gml_k_spectconv_bwd<8, 2, 2>' if 'bwd' in c['kernel'] else
-                                           'gml_k_spectconv_fwd<8, 8, 2, true>') for c in cands]):
-                    if key in tk:
-                        r['traffic'] = tk[key]['hbm_bytes_per_launch']
-                        r['traffic_source'] = 'profiles/r01_c_hbm_traffic.json (rocprofv3 PMC, per launch)'
+                for r in cands:
+                    pref = 'gml_k_spectconv_bwd' if 'backward' in r['kernel'] else 'gml_k_spectconv_fwd'
+                    hits = [v for kname, v in tk.items() if kname.startswith(pref)]
+                    if hits:                                  # launch-weighted mean over the instantiations used
+                        r['traffic'] = sum(h['hbm_bytes_per_launch'] * h.get('launches', 1) for h in hits) / \
+                            sum(h.get('launches', 1) for h in hits)
+                        r['traffic_source'] = 'profiles/r01_d_hbm_traffic.json (rocprofv3 PMC, per launch)'
             cands.sort(key=lambda r: -r['ms_per_step'])
             res['roofline'] = cands[0]                   # the kernel with the largest share of the step
             res['roofline_other'] = cands[1:]
