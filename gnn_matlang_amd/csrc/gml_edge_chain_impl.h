@@ -1,0 +1,464 @@
+// ML3Layer edge branch on the bf16 matrix cores, S = Sout <= 8 (reference: /root/reference/libs/spect_conv.py:190-194,
+// 205-207).  Same function as gml_edge_mlp_impl.h, different machine mapping:
+//
+//   out = relu( W4 . [ relu(W1 e) ; tanh(W2 e) * tanh(W3 e) ] )
+//
+// A wave works on tiles of 16 edges.  The edge index is ALWAYS the column (lane & 15) of a 16x16 MFMA tile and
+// the channel index the row, so the D registers of one v_mfma_f32_16x16x32_bf16 (lane (col, g = lane >> 4)
+// holds rows 4g..4g+3) are, after the elementwise step, directly the B operand of the next one: the k-slot
+// order of an MFMA is free as long as A (the weights, arranged once per wave in registers) uses the same
+// order.  No LDS, no scalar weight stream, nothing but e / gout is read per edge.
+//
+// fp32-class accuracy from bf16 inputs: every fp32 value is split x = hi + lo (two bf16, residual 2^-17 |x|)
+// and the split products are summed in the fp32 accumulator.  Where the contraction is short (K = S <= 8:
+// layer 1 and the W4^T back-projection) the four split products hi.hi, hi.lo, lo.hi, lo.lo occupy the four
+// 8-slot lane groups of ONE K = 32 instruction.
+//
+// Weight gradients contract over EDGES, i.e. over the column index: the tiles are transposed on the matrix
+// cores (tile^T = [hi | lo] x [I ; I], exact to the split residual), two transposed tiles (32 edges) form the
+// K = 32 operands of  dW += [h1; h23; gz1; gz2; gz3]^T-tiles x [go | e]^T-tile,  accumulated in registers over
+// the wave's whole edge range; one partial per workgroup, folded by gml_k_reduce_partials in fixed order.
+#pragma once
+#include "gml_common.h"
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t gml_pack2(float a, float b) {           // v_cvt_pk_bf16_f32 (RNE)
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
+__device__ __forceinline__ float gml_bf_lo(uint32_t p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float gml_bf_hi(uint32_t p) { return __uint_as_float(p & 0xffff0000u); }
+
+// x[0..3] -> packed bf16 pairs hi[2], lo[2] with hi + lo = x to 2^-17 relative
+__device__ __forceinline__ void gml_split4(const float (&x)[4], uint32_t (&hi)[2], uint32_t (&lo)[2]) {
+    hi[0] = gml_pack2(x[0], x[1]);
+    hi[1] = gml_pack2(x[2], x[3]);
+    lo[0] = gml_pack2(x[0] - gml_bf_lo(hi[0]), x[1] - gml_bf_hi(hi[0]));
+    lo[1] = gml_pack2(x[2] - gml_bf_lo(hi[1]), x[3] - gml_bf_hi(hi[1]));
+}
+__device__ __forceinline__ void gml_split4v(const f32x4 x, uint32_t (&hi)[2], uint32_t (&lo)[2]) {
+    const float t[4] = {x[0], x[1], x[2], x[3]};
+    gml_split4(t, hi, lo);
+}
+__device__ __forceinline__ bf16x8 gml_op(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    return __builtin_bit_cast(bf16x8, u32x4{a, b, c, d});
+}
+// 8 slot values of a weight operand -> the hi or the lo image
+__device__ __forceinline__ bf16x8 gml_wop(const float (&v)[8], bool lo_image) {
+    uint32_t h0[2], l0[2], h1[2], l1[2];
+    const float a[4] = {v[0], v[1], v[2], v[3]}, b[4] = {v[4], v[5], v[6], v[7]};
+    gml_split4(a, h0, l0);
+    gml_split4(b, h1, l1);
+    return lo_image ? gml_op(l0[0], l0[1], l1[0], l1[1]) : gml_op(h0[0], h0[1], h1[0], h1[1]);
+}
+#define GML_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+template <int S>
+struct GmlChainW {            // weight operands of one wave (registers)
+    bf16x8 a1[3];             // layer 1: W1, W2, W3 rows (k = in-channel; groups 0,1 hi / 2,3 lo)
+    bf16x8 a2h, a2l;          // layer 2: W4 (k = [h1 4g..4g+3 | h23 4g..4g+3]); rows 8..15 repeat rows 0..7
+};
+
+template <int S>
+__device__ __forceinline__ void gml_chain_load_fwd_weights(GmlChainW<S>& W, const float* __restrict__ w1,
+                                                           const float* __restrict__ w2, const float* __restrict__ w3,
+                                                           const float* __restrict__ w4, int c16, int g) {
+    constexpr int H2 = 2 * S, H4 = 4 * S;
+    const float* w123[3] = {w1, w2, w3};
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (c16 < H2 && j < S) ? w123[b][c16 * S + j] : 0.f;
+        W.a1[b] = gml_wop(v, g >= 2);
+    }
+    {
+        const int q = c16 & 7;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = 4 * g + j;
+            const bool ok = (q < S) && (c < H2);
+            v[j] = ok ? w4[q * H4 + c] : 0.f;
+            v[4 + j] = ok ? w4[q * H4 + H2 + c] : 0.f;
+        }
+        W.a2h = gml_wop(v, false);
+        W.a2l = gml_wop(v, true);
+    }
+}
+
+// per-tile forward state kept for the backward
+struct GmlChainT {
+    float e[8];               // the lane's edge row (all 4 lane groups of a column hold the same row)
+    f32x4 z1, t2, t3;         // W1 e ; tanh(W2 e) ; tanh(W3 e)      rows 4g..4g+3
+    u32x4 hh, hl;             // split [relu(z1) | t2*t3]: (h1 pair, h1 pair, h23 pair, h23 pair), hi and lo images
+    f32x4 out;                // W4 h (pre-activation), row r <-> q = 4(g&1) + r
+};
+
+template <int S>
+__device__ __forceinline__ void gml_chain_load_e(const float* __restrict__ ea, int64_t eid, bool valid, float (&e)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = 0.f;
+    if (valid) {
+        const float* p = ea + eid * S;
+        if constexpr (S % 4 == 0) {
+#pragma unroll
+            for (int j = 0; j < S / 4; ++j) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(p + 4 * j);
+                e[4 * j] = t.x; e[4 * j + 1] = t.y; e[4 * j + 2] = t.z; e[4 * j + 3] = t.w;
+            }
+        } else if constexpr (S % 2 == 0) {
+#pragma unroll
+            for (int j = 0; j < S / 2; ++j) {
+                const f32x2 t = *reinterpret_cast<const f32x2*>(p + 2 * j);
+                e[2 * j] = t.x; e[2 * j + 1] = t.y;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < S; ++j) e[j] = p[j];
+        }
+    }
+}
+
+template <int S>
+__device__ __forceinline__ void gml_chain_forward(const GmlChainW<S>& W, GmlChainT& T, int g) {
+    // layer 1 operand: even lane groups carry hi(e), odd ones lo(e)  ->  (Whi + Wlo)(ehi + elo) in one MFMA
+    uint32_t b1[4];
+    const bool odd = g & 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float x0 = T.e[2 * j], x1 = T.e[2 * j + 1];
+        const float t0 = __uint_as_float(__float_as_uint(x0) & 0xffff0000u);
+        const float t1 = __uint_as_float(__float_as_uint(x1) & 0xffff0000u);
+        b1[j] = gml_pack2(odd ? x0 - t0 : t0, odd ? x1 - t1 : t1);
+    }
+    const bf16x8 B1 = gml_op(b1[0], b1[1], b1[2], b1[3]);
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+    T.z1 = GML_MFMA(W.a1[0], B1, zero);
+    const f32x4 z2 = GML_MFMA(W.a1[1], B1, zero);
+    const f32x4 z3 = GML_MFMA(W.a1[2], B1, zero);
+    float h1[4], h23[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        T.t2[r] = gml_tanh(z2[r]);
+        T.t3[r] = gml_tanh(z3[r]);
+        h1[r] = fmaxf(T.z1[r], 0.f);
+        h23[r] = T.t2[r] * T.t3[r];
+    }
+    uint32_t h1h[2], h1l[2], h23h[2], h23l[2];
+    gml_split4(h1, h1h, h1l);
+    gml_split4(h23, h23h, h23l);
+    T.hh = u32x4{h1h[0], h1h[1], h23h[0], h23h[1]};
+    T.hl = u32x4{h1l[0], h1l[1], h23l[0], h23l[1]};
+    const bf16x8 B2h = __builtin_bit_cast(bf16x8, T.hh);
+    const bf16x8 B2l = __builtin_bit_cast(bf16x8, T.hl);
+    f32x4 o = GML_MFMA(W.a2l, B2h, zero);
+    o = GML_MFMA(W.a2h, B2l, o);
+    T.out = GML_MFMA(W.a2h, B2h, o);
+}
+
+// ------------------------------------------------------------------------------------------ forward kernel
+template <int S>
+__global__ __launch_bounds__(256, 2) void gml_k_edge_chain_fwd(const float* __restrict__ ea, const float* __restrict__ w1,
+                                                              const float* __restrict__ w2, const float* __restrict__ w3,
+                                                              const float* __restrict__ w4, float* __restrict__ out,
+                                                              const int32_t* __restrict__ tpos, float* __restrict__ out_t,
+                                                              int64_t E, int64_t ntiles) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c16 = lane & 15, g = lane >> 4;
+    GmlChainW<S> W;
+    gml_chain_load_fwd_weights<S>(W, w1, w2, w3, w4, c16, g);
+    const int q0 = 4 * (g & 1);
+    for (int64_t t = ((int64_t)blockIdx.x * 4 + wave) * 2; t < ntiles; t += (int64_t)gridDim.x * 8) {
+        GmlChainT T[2];
+        int64_t eid[2];
+        bool valid[2];
+        int32_t tp[2] = {0, 0};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            eid[u] = (t + u) * 16 + c16;
+            valid[u] = eid[u] < E;
+            gml_chain_load_e<S>(ea, eid[u], valid[u], T[u].e);
+            if (out_t != nullptr && valid[u] && g >= 2) tp[u] = tpos[eid[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) gml_chain_forward<S>(W, T[u], g);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!valid[u]) continue;
+            // lane groups 0,1 hold q = 0..3 / 4..7 and write `out`; groups 2,3 hold the same rows again and
+            // write the second (source-sorted) copy at tpos[e], so one store instruction serves both orders
+            float* dst;
+            if (g < 2) dst = out + eid[u] * S + q0;
+            else if (out_t != nullptr) dst = out_t + (int64_t)tp[u] * S + q0;
+            else continue;
+            if constexpr (S % 4 == 0) {
+                if (q0 < S)
+                    *reinterpret_cast<f32x4*>(dst) = f32x4{fmaxf(T[u].out[0], 0.f), fmaxf(T[u].out[1], 0.f),
+                                                          fmaxf(T[u].out[2], 0.f), fmaxf(T[u].out[3], 0.f)};
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (q0 + r < S) dst[r] = fmaxf(T[u].out[r], 0.f);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ backward kernel
+template <int S, bool GIN>
+struct GmlChainWB {
+    bf16x8 a3[2];             // W4^T blocks (h1 part, h23 part): k = q, groups 0,1 hi / 2,3 lo, slots [q | q]
+    bf16x8 a5[GIN ? 5 : 1];   // [W1|W2|W3]^T half-operands for d e (see below)
+    bf16x8 bIh, bIl;          // [I ; 0] and [0 ; I]: transposes of the hi / the lo image of a split tile
+};
+
+#ifndef GML_CHAIN_BWD_OCC
+#define GML_CHAIN_BWD_OCC 2
+#endif
+#define GML_CHAIN_NW(S) (6 * (S) * (S) + 4 * (S) * (S))
+
+// the lane's inputs of one 16-edge tile: the e row (all 8 values) and 4 values of the gout row
+template <int S>
+__device__ __forceinline__ void gml_chain_load_eg(const float* __restrict__ ea, const float* __restrict__ gout,
+                                                  int64_t eid, bool valid, int q0, float (&e)[8], float (&gq)[4]) {
+    gml_chain_load_e<S>(ea, eid, valid, e);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) gq[r] = 0.f;
+    if (valid) {
+        const float* gp = gout + eid * S + q0;
+        if constexpr (S % 4 == 0) {
+            if (q0 < S) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(gp);
+                gq[0] = t.x; gq[1] = t.y; gq[2] = t.z; gq[3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (q0 + r < S) gq[r] = gp[r];
+        }
+    }
+}
+
+template <int S, bool GIN>
+__global__ __launch_bounds__(256, GML_CHAIN_BWD_OCC) void gml_k_edge_chain_bwd(
+    const float* __restrict__ ea, const float* __restrict__ w1, const float* __restrict__ w2,
+    const float* __restrict__ w3, const float* __restrict__ w4, const float* __restrict__ gout,
+    float* __restrict__ gin, float* __restrict__ partial, int64_t E, int64_t ntiles) {
+    constexpr int H2 = 2 * S, H4 = 4 * S;
+    __shared__ float red[4][20][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c16 = lane & 15, g = lane >> 4;
+    const int q0 = 4 * (g & 1);
+    GmlChainW<S> W;
+    gml_chain_load_fwd_weights<S>(W, w1, w2, w3, w4, c16, g);
+    GmlChainWB<S, GIN> WB;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = q0 + j;
+            v[j] = v[4 + j] = (c16 < H2 && q < S) ? w4[q * H4 + blk * H2 + c16] : 0.f;
+        }
+        WB.a3[blk] = gml_wop(v, g >= 2);
+    }
+    if constexpr (GIN) {
+        // d e[in] = sum_b sum_z Wb[z][in] gz_b[z]: nine half-operand products (3 tiles x {hi.hi, hi.lo, lo.hi})
+        // packed into five K = 32 instructions:  [H1|H2] [H3|H1] [H2|H3] hi-weights, [L1|L2] [L3|0] lo-weights
+        const int in = c16 & 7;
+        float wv[3][4];
+        const float* w123[3] = {w1, w2, w3};
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int z = 4 * g + j;
+                wv[b][j] = (in < S && z < H2) ? w123[b][z * S + in] : 0.f;
+            }
+        constexpr int pa[5] = {0, 2, 1, 0, 2}, pb[5] = {1, 0, 2, 1, -1};
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = wv[pa[m]][j];
+                v[4 + j] = pb[m] >= 0 ? wv[pb[m] >= 0 ? pb[m] : 0][j] : 0.f;
+            }
+            WB.a5[m] = gml_wop(v, m >= 3);
+        }
+    }
+    {
+        float vh[8], vl[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float d = (c16 == 4 * g + (j & 3)) ? 1.f : 0.f;
+            vh[j] = j < 4 ? d : 0.f;
+            vl[j] = j < 4 ? 0.f : d;
+        }
+        WB.bIh = gml_wop(vh, false);
+        WB.bIl = gml_wop(vl, false);
+    }
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[5];
+#pragma unroll
+    for (int b = 0; b < 5; ++b) acc[b] = zero;
+
+    // transposed split tile: lane (channel = c16, g) gets [hi | lo] of edges 4g..4g+3 -- exact, the transposed
+    // values are bf16 numbers, so the repack is a plain conversion
+    auto transpose = [&](uint32_t h0, uint32_t h1, uint32_t l0, uint32_t l1) -> bf16x8 {
+        const bf16x8 A = gml_op(h0, h1, l0, l1);
+        const f32x4 th = GML_MFMA(A, WB.bIh, zero);
+        const f32x4 tl = GML_MFMA(A, WB.bIl, zero);
+        return gml_op(gml_pack2(th[0], th[1]), gml_pack2(th[2], th[3]), gml_pack2(tl[0], tl[1]), gml_pack2(tl[2], tl[3]));
+    };
+
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t t = (int64_t)blockIdx.x * 4 + wave;
+    float e_n[8], g_n[4];
+    gml_chain_load_eg<S>(ea, gout, t * 16 + c16, t < ntiles && t * 16 + c16 < E, q0, e_n, g_n);
+    for (; t < ntiles; t += stride) {
+        GmlChainT T;
+        float gq[4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) T.e[j] = e_n[j];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gq[r] = g_n[r];
+        const int64_t eid = t * 16 + c16;
+        const bool valid = eid < E;
+        {   // next tile's rows are in flight while this one is computed
+            const int64_t tn = t + stride, en = tn * 16 + c16;
+            gml_chain_load_eg<S>(ea, gout, en, tn < ntiles && en < E, q0, e_n, g_n);
+        }
+        gml_chain_forward<S>(W, T, g);
+        float go[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) go[r] = (T.out[r] > 0.f) ? gq[r] : 0.f;
+        uint32_t goh[2], gol[2];
+        gml_split4(go, goh, gol);
+        const bf16x8 B3 = gml_op(goh[0], goh[1], gol[0], gol[1]);
+        const f32x4 dh1 = GML_MFMA(WB.a3[0], B3, zero);
+        const f32x4 dh23 = GML_MFMA(WB.a3[1], B3, zero);
+        float gz[3][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            gz[0][r] = (T.z1[r] > 0.f) ? dh1[r] : 0.f;
+            gz[1][r] = dh23[r] * T.t3[r] * fmaf(-T.t2[r], T.t2[r], 1.f);
+            gz[2][r] = dh23[r] * T.t2[r] * fmaf(-T.t3[r], T.t3[r], 1.f);
+        }
+        uint32_t gh[3][2], gl[3][2];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) gml_split4(gz[b], gh[b], gl[b]);
+        if constexpr (GIN) {
+            f32x4 de = GML_MFMA(WB.a5[0], gml_op(gh[0][0], gh[0][1], gh[1][0], gh[1][1]), zero);
+            de = GML_MFMA(WB.a5[1], gml_op(gh[2][0], gh[2][1], gl[0][0], gl[0][1]), de);
+            de = GML_MFMA(WB.a5[2], gml_op(gl[1][0], gl[1][1], gl[2][0], gl[2][1]), de);
+            de = GML_MFMA(WB.a5[3], gml_op(gh[0][0], gh[0][1], gh[1][0], gh[1][1]), de);
+            de = GML_MFMA(WB.a5[4], gml_op(gh[2][0], gh[2][1], 0u, 0u), de);
+            if (valid && g < 2) {          // rows 4g + r = in-channel (rows 8..15 repeat 0..7)
+                float* dp = gin + eid * S + 4 * g;
+                if constexpr (S % 4 == 0) {
+                    if (4 * g < S) *reinterpret_cast<f32x4*>(dp) = de;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (4 * g + r < S) dp[r] = de[r];
+                }
+            }
+        }
+        // [go | e] tile: rows 0..7 = go (lane groups 0,1), rows 8..15 = e (lane groups 2,3)
+        float y[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[r] = (g < 2) ? go[r] : ((g & 1) ? T.e[4 + r] : T.e[r]);
+        uint32_t yh[2], yl[2];
+        gml_split4(y, yh, yl);
+        // weight gradients of the 16 edges: k-slots (g, j < 4) = hi, (g, j >= 4) = lo of edge 4g + (j & 3);
+        //   X.[Yh | Yh] = Xh Yh + Xl Yh ,  X.[Yl | 0] = Xh Yl
+        const u32x4 YT = __builtin_bit_cast(u32x4, transpose(yh[0], yh[1], yl[0], yl[1]));
+        const bf16x8 Bhh = gml_op(YT.x, YT.y, YT.x, YT.y);
+        const bf16x8 Bl0 = gml_op(YT.z, YT.w, 0u, 0u);
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+            bf16x8 XT;
+            if (b == 0) XT = transpose(T.hh.x, T.hh.y, T.hl.x, T.hl.y);
+            else if (b == 1) XT = transpose(T.hh.z, T.hh.w, T.hl.z, T.hl.w);
+            else XT = transpose(gh[b - 2][0], gh[b - 2][1], gl[b - 2][0], gl[b - 2][1]);
+            acc[b] = GML_MFMA(XT, Bl0, acc[b]);
+            acc[b] = GML_MFMA(XT, Bhh, acc[b]);
+        }
+    }
+
+    // one partial per workgroup: fixed-order sum of the 4 waves, then [dw1 (2S*S) | dw2 | dw3 | dw4 (S*4S)]
+#pragma unroll
+    for (int b = 0; b < 5; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][4 * b + r][lane] = acc[b][r];
+    __syncthreads();
+    float* P = partial + (int64_t)blockIdx.x * GML_CHAIN_NW(S);
+    for (int it = threadIdx.x; it < 20 * 64; it += 256) {
+        const int br = it >> 6, ln = it & 63;
+        const float v = ((red[0][br][ln] + red[1][br][ln]) + red[2][br][ln]) + red[3][br][ln];
+        const int b = br >> 2, row = 4 * (ln >> 4) + (br & 3), col = ln & 15;     // D: row = channel, col = [go | e]
+        if (row >= H2) continue;
+        if (b < 2) {
+            if (col < S) P[6 * S * S + col * H4 + b * H2 + row] = v;               // dW4[q][c]
+        } else {
+            if (col >= 8 && col < 8 + S) P[(b - 2) * H2 * S + row * S + (col - 8)] = v;   // dWb[z][in]
+        }
+    }
+}
+
+template <int S>
+int gml_launch_edge_chain_fwd(const float* ea, const float* w1, const float* w2, const float* w3, const float* w4,
+                              float* out, const int32_t* tpos, float* out_t, int64_t E, hipStream_t st);
+template <int S>
+int gml_launch_edge_chain_bwd(const float* ea, const float* w1, const float* w2, const float* w3, const float* w4,
+                              const float* gout, float* gin, float* dw1, float* dw2, float* dw3, float* dw4,
+                              int64_t E, void* ws, size_t ws_bytes, hipStream_t st);
+
+__global__ void gml_k_reduce_partials(const float* __restrict__ partial, int64_t nwaves, int nw,
+                                      float* __restrict__ d0, int n0, float* __restrict__ d1, int n1,
+                                      float* __restrict__ d2, int n2, float* __restrict__ d3, int n3);
+
+// persistent workgroups per CU: the register footprint allows 4 waves per SIMD without d e, 3 with it
+static inline int64_t gml_edge_chain_bwd_groups(int64_t E, int wgs_per_cu = 4) {
+    const int64_t ntiles = gml_cdiv(E, 16);
+    int64_t grid = gml_cdiv(ntiles, 4);
+    if (grid > wgs_per_cu * GML_NUM_CU) grid = wgs_per_cu * GML_NUM_CU;
+    return grid < 1 ? 1 : grid;
+}
+
+#define GML_DEFINE_EDGE_CHAIN(SV)                                                                               \
+    template <>                                                                                                 \
+    int gml_launch_edge_chain_fwd<SV>(const float* ea, const float* w1, const float* w2, const float* w3,       \
+                                      const float* w4, float* out, const int32_t* tpos, float* out_t,           \
+                                      int64_t E, hipStream_t st) {                                              \
+        const int64_t ntiles = gml_cdiv(E, 16);                                                                 \
+        int64_t grid = gml_cdiv(ntiles, 8);                                                                     \
+        if (grid > 8 * GML_NUM_CU) grid = 8 * GML_NUM_CU;                                                       \
+        hipLaunchKernelGGL((gml_k_edge_chain_fwd<SV>), dim3((unsigned)grid), dim3(256), 0, st, ea, w1, w2, w3,  \
+                           w4, out, tpos, out_t, E, ntiles);                                                    \
+        return gml_launch_status();                                                                             \
+    }                                                                                                           \
+    template <>                                                                                                 \
+    int gml_launch_edge_chain_bwd<SV>(const float* ea, const float* w1, const float* w2, const float* w3,       \
+                                      const float* w4, const float* gout, float* gin, float* dw1, float* dw2,   \
+                                      float* dw3, float* dw4, int64_t E, void* ws, size_t ws_bytes,             \
+                                      hipStream_t st) {                                                         \
+        const int64_t npairs = gml_cdiv(E, 16); /* 16-edge tiles */                                             \
+        const int64_t grid = gml_edge_chain_bwd_groups(E, gin != nullptr ? 3 : 4);                                                      \
+        constexpr int NW = GML_CHAIN_NW(SV);                                                                    \
+        if (ws_bytes < (size_t)grid * NW * sizeof(float)) return GML_E_WORKSPACE;                               \
+        if (gin != nullptr)                                                                                     \
+            hipLaunchKernelGGL((gml_k_edge_chain_bwd<SV, true>), dim3((unsigned)grid), dim3(256), 0, st, ea,    \
+                               w1, w2, w3, w4, gout, gin, (float*)ws, E, npairs);                               \
+        else                                                                                                    \
+            hipLaunchKernelGGL((gml_k_edge_chain_bwd<SV, false>), dim3((unsigned)grid), dim3(256), 0, st, ea,   \
+                               w1, w2, w3, w4, gout, gin, (float*)ws, E, npairs);                               \
+        int rc = gml_launch_status();                                                                           \
+        if (rc != GML_OK) return rc;                                                                            \
+        const int n123 = 2 * SV * SV, n4 = SV * 4 * SV;                                                         \
+        hipLaunchKernelGGL(gml_k_reduce_partials, dim3((unsigned)gml_cdiv(NW, 16)), dim3(256), 0, st,           \
+                           (const float*)ws, grid, NW, dw1, n123, dw2, n123, dw3, n123, dw4, n4);               \
+        return gml_launch_status();                                                                             \
+    }

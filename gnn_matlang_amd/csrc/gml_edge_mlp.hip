@@ -1,5 +1,29 @@
 // C-ABI dispatch of the ML3Layer edge-branch kernels + the partial-sum fold.
 #include "gml_edge_mlp_impl.h"
+#include "gml_edge_chain_impl.h"
+#include <stdlib.h>
+
+// S <= 8 runs on the bf16 matrix cores (gml_edge_chain_impl.h); GML_EDGE_VALU=1 in the environment keeps the
+// one-edge-per-lane fp32 VALU kernels for every S (ablation / exact-fp32 arithmetic).
+static bool emlp_use_chain(int S) {
+    static const bool valu = [] { const char* e = getenv("GML_EDGE_VALU"); return e && e[0] == '1'; }();
+    return S <= 8 && !valu;
+}
+#define GML_DECL_ECHAIN(SV)                                                                                  \
+    template <> int gml_launch_edge_chain_fwd<SV>(const float*, const float*, const float*, const float*,    \
+                                                  const float*, float*, const int32_t*, float*, int64_t,     \
+                                                  hipStream_t);                                              \
+    template <> int gml_launch_edge_chain_bwd<SV>(const float*, const float*, const float*, const float*,    \
+                                                  const float*, const float*, float*, float*, float*,        \
+                                                  float*, float*, int64_t, void*, size_t, hipStream_t);
+GML_DECL_ECHAIN(1) GML_DECL_ECHAIN(2) GML_DECL_ECHAIN(3) GML_DECL_ECHAIN(4)
+GML_DECL_ECHAIN(5) GML_DECL_ECHAIN(6) GML_DECL_ECHAIN(7) GML_DECL_ECHAIN(8)
+#define GML_ECHAIN_SWITCH(CALL)                                                                 \
+    switch (S) {                                                                                \
+        case 1: return CALL(1); case 2: return CALL(2); case 3: return CALL(3);                 \
+        case 4: return CALL(4); case 5: return CALL(5); case 6: return CALL(6);                 \
+        case 7: return CALL(7); case 8: return CALL(8);                                         \
+    }
 
 // dst[j] = sum_w partial[w][j] in a fixed order: 16 lanes split the partial index, LDS tree in fixed order
 __global__ __launch_bounds__(256) void gml_k_reduce_partials(const float* __restrict__ partial, int64_t nwaves, int nw,
@@ -56,6 +80,10 @@ extern "C" int gml_edge_mlp_fwd(const float* ea, const float* w1, const float* w
     if ((((uintptr_t)ea | (uintptr_t)out | (uintptr_t)out_t) & 15) != 0) return GML_E_BADARG;
     if (out_t && !tpos) return GML_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
+    if (emlp_use_chain(S)) {
+#define GML_CALL_CF(SV) gml_launch_edge_chain_fwd<SV>(ea, w1, w2, w3, w4, out, tpos, out_t, num_edges, st)
+        GML_ECHAIN_SWITCH(GML_CALL_CF)
+    }
 #define GML_CALL_F(SV) gml_launch_edge_mlp_fwd<SV, SV>(ea, w1, w2, w3, w4, out, tpos, out_t, num_edges, st)
     GML_EMLP_SWITCH(GML_CALL_F)
 }
@@ -69,7 +97,10 @@ static int64_t emlp_bwd_waves(int64_t E, int S) {
 
 extern "C" size_t gml_edge_mlp_bwd_workspace_bytes(int64_t num_edges, int32_t S, int32_t Sout) {
     if (num_edges <= 0 || S <= 0 || Sout != S) return 0;
-    return (size_t)emlp_bwd_waves(num_edges, S) * (size_t)(6 * S * S + Sout * 4 * S) * sizeof(float);
+    // both kernel families are covered, so the size does not depend on the environment switch
+    int64_t parts = emlp_bwd_waves(num_edges, S);
+    if (S <= 8 && gml_edge_chain_bwd_groups(num_edges) > parts) parts = gml_edge_chain_bwd_groups(num_edges);
+    return (size_t)parts * (size_t)(6 * S * S + Sout * 4 * S) * sizeof(float);
 }
 
 extern "C" int gml_edge_mlp_bwd(const float* ea, const float* w1, const float* w2, const float* w3,
@@ -89,6 +120,11 @@ extern "C" int gml_edge_mlp_bwd(const float* ea, const float* w1, const float* w
     }
     if (!ea || !gout || !ws) return GML_E_BADARG;
     if ((((uintptr_t)ea | (uintptr_t)gout | (uintptr_t)gin) & 15) != 0) return GML_E_BADARG;
+    if (emlp_use_chain(S)) {
+#define GML_CALL_CB(SV) \
+    gml_launch_edge_chain_bwd<SV>(ea, w1, w2, w3, w4, gout, gin, dw1, dw2, dw3, dw4, num_edges, ws, ws_bytes, st)
+        GML_ECHAIN_SWITCH(GML_CALL_CB)
+    }
 #define GML_CALL_B(SV) \
     gml_launch_edge_mlp_bwd<SV, SV>(ea, w1, w2, w3, w4, gout, gin, dw1, dw2, dw3, dw4, num_edges, ws, ws_bytes, st)
     GML_EMLP_SWITCH(GML_CALL_B)
