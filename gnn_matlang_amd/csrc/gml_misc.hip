@@ -320,6 +320,33 @@ extern "C" int gml_segment_sum(const float* x, int64_t ldx, const int32_t* ptr, 
     return gml_launch_status();
 }
 
+// gradient of the pooling: every row of a segment receives the segment's gradient row.  One wave per
+// segment sweep: lanes <-> (row offset, column), coalesced stores.
+__global__ void gml_k_segment_bcast(const float* __restrict__ g, int64_t ldg, const int32_t* __restrict__ ptr,
+                                    float* __restrict__ out, int64_t ldo, int64_t nseg, int F, int mean) {
+    const int64_t seg = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (seg >= nseg) return;
+    const int lane = threadIdx.x & 63;
+    const int r0 = ptr[seg], r1 = ptr[seg + 1];
+    const float sc = mean ? 1.f / (float)max(r1 - r0, 1) : 1.f;
+    const int64_t n = (int64_t)(r1 - r0) * F;
+    for (int64_t i = lane; i < n; i += 64) {
+        const int64_t r = i / F;
+        const int c = (int)(i - r * F);
+        out[(r0 + r) * ldo + c] = g[seg * ldg + c] * sc;
+    }
+}
+
+extern "C" int gml_segment_bcast(const float* g, int64_t ldg, const int32_t* ptr, float* out, int64_t ldo,
+                                 int64_t num_segments, int32_t F, int32_t mean, gml_stream_t stream) {
+    if (num_segments < 0 || F <= 0 || ldg < F || ldo < F) return GML_E_BADARG;
+    if (num_segments == 0) return GML_OK;
+    if (!g || !ptr || !out) return GML_E_BADARG;
+    hipLaunchKernelGGL(gml_k_segment_bcast, dim3((unsigned)gml_cdiv(num_segments, 4)), dim3(256), 0,
+                       (hipStream_t)stream, g, ldg, ptr, out, ldo, num_segments, F, mean);
+    return gml_launch_status();
+}
+
 // ---------------------------------------------------------------------------------------------
 template <bool SCATTER>
 __global__ void gml_k_perm_rows(const float* __restrict__ in, const int32_t* __restrict__ perm,

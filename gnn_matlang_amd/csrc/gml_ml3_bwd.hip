@@ -1,0 +1,372 @@
+// Backward of the ML3Layer output stage, one pass over the rows (libs/spect_conv.py:209-212 and their autograd):
+//
+//   out = cat[ relu(conv(x)) , tanh(fc11 x) * tanh(fc12 x) ]
+//
+//   G[:, :nout1]   = gy[:, :nout1] * (out[:, :nout1] > 0)      (gradient at the conv output; cols [nout1, ldg) = 0)
+//   dcb            = column sums of G                           (conv bias gradient)
+//   dz1, dz2       = gy[:, nout1:] * tanh' terms                (recomputed from x)
+//   dx             = dz1 w11 + dz2 w12                          (WRITTEN; the conv backward then accumulates into it)
+//   dw11, dw12, db11, db12 = dz^T [x | 1]
+//
+// Replaces three passes (relu mask, Hadamard-branch backward with a strided read-modify-write of dx, bias
+// column sums) by one whose global accesses are all coalesced: SB_ROWS-row tiles, the x / dx tile goes through LDS
+// (row-per-lane compute in between), the weight gradients are contracted on the matrix cores as in
+// gml_k_node_mix, every sum is formed in a fixed order (per-workgroup partials + fold).
+#include "gml_common.h"
+
+#ifndef SB_ROWS
+#define SB_ROWS 128      /* rows per tile = threads per workgroup: small groups, several per CU, overlap phases */
+#endif
+#define SB_WAVES (SB_ROWS / 64)
+#ifndef SB_WGS_PER_CU
+#define SB_WGS_PER_CU 4
+#endif
+#define SB_MAXCB 3        /* 2*F2 <= 48 */
+
+struct GmlSplitBwdParams {
+    const float* gy; int64_t ldgy;
+    const float* y; int64_t ldy;
+    const float* x; int64_t ldx;
+    const float* w11; const float* b11; const float* w12; const float* b12;
+    float* G; int64_t ldg;
+    float* dx; int64_t lddx;
+    float* part;
+    int64_t nrows;
+    int Fin, nout1, F2, ntiles, CP, npart;      // CP: power of two >= ldg (<= 256); npart: floats per partial
+};
+
+// FINP = 0: no Hadamard branch (plain SpectConv + relu): mask and bias sums only
+// VEC / VX = 4: the leading dimensions of gy, y, G / of x, dx are multiples of 4 floats and the bases 16-byte
+// aligned (float4 accesses); 1 otherwise
+template <int FINP, int VEC, int VX>
+__global__ __launch_bounds__(SB_ROWS, (FINP <= 32 ? 2 : 1)) void gml_k_ml3_split_bwd(const GmlSplitBwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int LDX = FINP + 1;                              // odd: row-per-lane accesses are conflict free
+    constexpr int NFB = FINP / 16;
+    const int F2 = p.F2, Fin = p.Fin, nout1 = p.nout1;
+    const int C2 = 2 * F2, C2P = (C2 + 15) / 16 * 16, LDZ = C2P + 1, ncb = C2P / 16, LDI = F2 | 1;
+    float* xs = lds;                                           // [SB_ROWS][LDX]   x tile, later the dx tile
+    float* wc = xs + SB_ROWS * LDX;                            // [C2][FINP]   w11 rows then w12 rows, zero padded
+    float* bc = wc + C2 * FINP;                                // [C2]
+    float* gz = bc + ((C2 + 3) / 4 * 4);                       // [SB_ROWS][LDZ]   dz1 | dz2
+    float* gi = gz + (FINP ? SB_ROWS * LDZ : 0);               // [SB_ROWS][LDI]   gy[:, nout1:]
+    float* red = FINP ? gi + SB_ROWS * LDI : lds;              // [SB_ROWS]    bias partial fold
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    // pass A: lane <-> VEC consecutive columns, RPS rows per sweep
+    const int CPV = p.CP / VEC, RPS = SB_ROWS / CPV, NIT = SB_ROWS / RPS;
+    const int fa = (tid & (CPV - 1)) * VEC, ra = tid / CPV;
+    const int Cy = nout1 + F2;                                 // live columns of gy
+    const int fa_y = min(fa, (Cy - 1) / VEC * VEC), fa_o = min(fa, (nout1 - 1) / VEC * VEC);   // clamped: loads stay inside
+    const int ldgy = (int)p.ldgy, ldy = (int)p.ldy, ldg = (int)p.ldg, ldx = (int)p.ldx, lddx = (int)p.lddx;
+    if constexpr (FINP > 0) {
+        for (int i = tid; i < C2 * FINP; i += SB_ROWS) {
+            const int c = i / FINP, f = i % FINP;
+            wc[i] = (f < Fin) ? ((c < F2) ? p.w11[c * Fin + f] : p.w12[(c - F2) * Fin + f]) : 0.f;
+        }
+        for (int i = tid; i < C2; i += SB_ROWS) bc[i] = (i < F2) ? (p.b11 ? p.b11[i] : 0.f) : (p.b12 ? p.b12[i - F2] : 0.f);
+    }
+    float bacc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) bacc[k] = 0.f;
+    f32x4 acc[SB_MAXCB][NFB + 1];
+#pragma unroll
+    for (int a = 0; a < SB_MAXCB; ++a)
+#pragma unroll
+        for (int b = 0; b <= NFB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
+        const int64_t r0 = (int64_t)t * SB_ROWS;
+        const int nr = (int)min((int64_t)SB_ROWS, p.nrows - r0);
+        __syncthreads();                                       // previous tile's readers of xs / gz / gi are done
+        // tile-relative 32-bit element offsets from uniform bases (row < 2^8, ld < 2^24: 24-bit multiply-add)
+        const float* gyb = p.gy + r0 * p.ldgy;
+        const float* yb = p.y + r0 * p.ldy;
+        float* Gb = p.G + r0 * p.ldg;
+        if constexpr (FINP > 0) {                              // x tile: lane <-> VX features, 8 / 16 loads in flight
+            constexpr int FV = FINP / VX, RPX = SB_ROWS / FV, NIX = (SB_ROWS + RPX - 1) / RPX;
+            constexpr int XCH = 8;
+            const float* xb = p.x + r0 * p.ldx;
+            const int f = (tid % FV) * VX, rb = tid / FV, fc = min(f, (Fin - 1) / VX * VX);
+#pragma unroll
+            for (int j0 = 0; j0 < NIX; j0 += XCH) {
+                float v[XCH][VX];
+#pragma unroll
+                for (int j = 0; j < XCH; ++j) {
+                    const int off = __umul24(min(rb + (j0 + j) * RPX, nr - 1), ldx) + fc;
+                    if constexpr (VX == 4) {
+                        const f32x4 t4 = *reinterpret_cast<const f32x4*>(xb + off);
+                        v[j][0] = t4.x; v[j][1] = t4.y; v[j][2] = t4.z; v[j][3] = t4.w;
+                    } else {
+                        v[j][0] = xb[off];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < XCH; ++j) {
+                    const int rr = rb + (j0 + j) * RPX;
+                    if (j0 + j < NIX && rr < SB_ROWS) {
+#pragma unroll
+                        for (int k = 0; k < VX; ++k) xs[rr * LDX + f + k] = (rr < nr && f + k < Fin) ? v[j][k] : 0.f;
+                    }
+                }
+            }
+        }
+        // ---- pass A: relu mask, G tile, bias sums, Hadamard-branch gradient columns -> LDS
+        constexpr int SB_CHUNK = VEC == 4 ? 8 : 16;            // NIT = CP / VEC is a multiple of it
+        for (int j0 = 0; j0 < NIT; j0 += SB_CHUNK) {
+            float vg[SB_CHUNK][VEC], vo[SB_CHUNK][VEC];
+#pragma unroll
+            for (int j = 0; j < SB_CHUNK; ++j) {               // clamped addresses: unconditional, batched loads
+                {
+                    const int rr = min(ra + (j0 + j) * RPS, nr - 1);
+                    const int og = __umul24(rr, ldgy) + fa_y, oy = __umul24(rr, ldy) + fa_o;
+                    if constexpr (VEC == 4) {
+                        const f32x4 a4 = *reinterpret_cast<const f32x4*>(gyb + og);
+                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(yb + oy);
+                        vg[j][0] = a4.x; vg[j][1] = a4.y; vg[j][2] = a4.z; vg[j][3] = a4.w;
+                        vo[j][0] = b4.x; vo[j][1] = b4.y; vo[j][2] = b4.z; vo[j][3] = b4.w;
+                    } else {
+                        vg[j][0] = gyb[og];
+                        vo[j][0] = yb[oy];
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < SB_CHUNK; ++j) {
+                {
+                    const int rr = ra + (j0 + j) * RPS;
+                    const bool rv = rr < nr;
+                    float gm[VEC];
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        gm[k] = (rv && fa + k < nout1 && vo[j][k] > 0.f) ? vg[j][k] : 0.f;
+                        bacc[k] += gm[k];
+                        if constexpr (FINP > 0)
+                            if (fa + k >= nout1 && fa + k < Cy) gi[rr * LDI + (fa + k - nout1)] = rv ? vg[j][k] : 0.f;
+                    }
+                    if (rv && fa < ldg) {
+                        const int off = __umul24(rr, ldg) + fa;
+                        if constexpr (VEC == 4) *reinterpret_cast<f32x4*>(Gb + off) = f32x4{gm[0], gm[1], gm[2], gm[3]};
+                        else Gb[off] = gm[0];
+                    }
+                }
+            }
+        }
+        if constexpr (FINP > 0) {
+            __syncthreads();
+            // ---- pass B: one row per lane
+            float xr[FINP], dxr[FINP];
+#pragma unroll
+            for (int f = 0; f < FINP; ++f) { xr[f] = xs[tid * LDX + f]; dxr[f] = 0.f; }
+            for (int c = C2; c < C2P; ++c) gz[tid * LDZ + c] = 0.f;
+            for (int o = 0; o < F2; ++o) {
+                float a = bc[o], b = bc[F2 + o];
+                const float* wa = wc + o * FINP;
+                const float* wb = wc + (F2 + o) * FINP;
+#pragma unroll
+                for (int f4 = 0; f4 < FINP / 4; ++f4) {
+                    const f32x4 va = *reinterpret_cast<const f32x4*>(wa + 4 * f4);
+                    const f32x4 vb = *reinterpret_cast<const f32x4*>(wb + 4 * f4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        a = fmaf(xr[4 * f4 + i], va[i], a);
+                        b = fmaf(xr[4 * f4 + i], vb[i], b);
+                    }
+                }
+                const float ta = gml_tanh(a), tb = gml_tanh(b);
+                const float g = gi[tid * LDI + o];
+                const float g1 = g * tb * (1.f - ta * ta), g2 = g * ta * (1.f - tb * tb);
+                gz[tid * LDZ + o] = g1;
+                gz[tid * LDZ + F2 + o] = g2;
+#pragma unroll
+                for (int f4 = 0; f4 < FINP / 4; ++f4) {
+                    const f32x4 va = *reinterpret_cast<const f32x4*>(wa + 4 * f4);
+                    const f32x4 vb = *reinterpret_cast<const f32x4*>(wb + 4 * f4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dxr[4 * f4 + i] = fmaf(g1, va[i], fmaf(g2, vb[i], dxr[4 * f4 + i]));
+                }
+            }
+            // weight / bias gradients of this wave's 64 rows: D[c][f] += sum_rows dz[row][c] * [x | 1][row][f]
+            // (the wave reads only its own rows of gz and xs, written by its own lanes above)
+            const int rb = wave * 64;
+#pragma unroll
+            for (int t16 = 0; t16 < 16; ++t16) {
+                const int rr = rb + 4 * t16 + kq;
+#pragma unroll
+                for (int cb = 0; cb < SB_MAXCB; ++cb) {
+                    if (cb < ncb) {
+                        const float a = gz[rr * LDZ + cb * 16 + r16];
+#pragma unroll
+                        for (int fb = 0; fb < NFB; ++fb)
+                            acc[cb][fb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xs[rr * LDX + fb * 16 + r16], acc[cb][fb], 0, 0, 0);
+                        acc[cb][NFB] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, (r16 == 0) ? 1.f : 0.f, acc[cb][NFB], 0, 0, 0);
+                    }
+                }
+            }
+            if (p.dx != nullptr) {                             // dx tile through LDS: row-per-lane in, coalesced out
+#pragma unroll
+                for (int f = 0; f < FINP; ++f) xs[tid * LDX + f] = dxr[f];
+                __syncthreads();
+                constexpr int FV = FINP / VX, RPX = SB_ROWS / FV, NIX = (SB_ROWS + RPX - 1) / RPX;
+                float* dxb = p.dx + r0 * p.lddx;
+                const int f = (tid % FV) * VX, rbx = tid / FV;
+#pragma unroll 8
+                for (int j = 0; j < NIX; ++j) {
+                    const int rr = rbx + j * RPX;
+                    if (rr < nr && f < Fin) {
+                        const int off = __umul24(rr, lddx) + f;
+                        if constexpr (VX == 4)
+                            *reinterpret_cast<f32x4*>(dxb + off) = f32x4{xs[rr * LDX + f], xs[rr * LDX + f + 1],
+                                                                         xs[rr * LDX + f + 2], xs[rr * LDX + f + 3]};
+                        else dxb[off] = xs[rr * LDX + f];
+                    }
+                }
+            }
+        }
+    }
+    // ---- one partial per workgroup:  [dw11 | dw12 | db11 | db12 | dcb], fixed-order sums
+    __syncthreads();
+    float* P = p.part + (int64_t)blockIdx.x * p.npart;
+    if constexpr (FINP > 0) {
+        // D layout: lane (col j = r16, rows i = 4*kq + reg): i = c index, j = f index;  4 waves folded through xs
+        constexpr int NA = SB_MAXCB * (NFB + 1) * 4;
+        float* wred = xs;                                      // [SB_WAVES][NA][64]
+#pragma unroll
+        for (int cb = 0; cb < SB_MAXCB; ++cb)
+#pragma unroll
+            for (int fb = 0; fb <= NFB; ++fb)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) wred[(wave * NA + (cb * (NFB + 1) + fb) * 4 + reg) * 64 + lane] = acc[cb][fb][reg];
+        __syncthreads();
+        for (int it = tid; it < NA * 64; it += SB_ROWS) {
+            const int a = it >> 6, ln = it & 63;
+            float v = wred[a * 64 + ln];
+#pragma unroll
+            for (int w = 1; w < SB_WAVES; ++w) v += wred[(w * NA + a) * 64 + ln];
+            const int reg = a & 3, fb = (a >> 2) % (NFB + 1), cb = (a >> 2) / (NFB + 1);
+            const int c = cb * 16 + 4 * (ln >> 4) + reg, j = ln & 15;
+            if (c >= C2) continue;
+            if (fb < NFB) {
+                const int f = fb * 16 + j;
+                if (f < Fin) P[c * Fin + f] = v;               // rows c < F2: dw11, then dw12
+            } else if (j == 0) {
+                P[C2 * Fin + c] = v;                           // db11 | db12
+            }
+        }
+        __syncthreads();
+    }
+    // thread (ra, fa) holds the sums of columns fa .. fa+VEC-1 over its rows: red[ra][column]
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) red[ra * p.CP + fa + k] = bacc[k];
+    __syncthreads();
+    if (tid < nout1) {                                         // nout1 <= CP <= SB_ROWS
+        float s = 0.f;
+        for (int k = 0; k < RPS; ++k) s += red[k * p.CP + tid];
+        P[C2 * Fin + C2 + tid] = s;
+    }
+}
+
+// fold [nparts][n] partials in fixed order and split into the five destinations
+__global__ __launch_bounds__(256) void gml_k_split_fold(const float* __restrict__ partial, int64_t nparts, int n,
+                                                       float* __restrict__ d0, int n0, float* __restrict__ d1, int n1,
+                                                       float* __restrict__ d2, int n2, float* __restrict__ d3, int n3,
+                                                       float* __restrict__ d4, int n4) {
+    __shared__ float red[16][17];
+    const int jl = threadIdx.x & 15, wl = threadIdx.x >> 4;
+    const int j = blockIdx.x * 16 + jl;
+    float a = 0.f;
+    if (j < n)
+        for (int64_t w = wl; w < nparts; w += 16) a += partial[w * n + j];
+    red[wl][jl] = a;
+    __syncthreads();
+    if (wl != 0 || j >= n) return;
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][jl];
+    int q = j;
+    if (q < n0) { if (d0) d0[q] = t; return; }
+    q -= n0;
+    if (q < n1) { if (d1) d1[q] = t; return; }
+    q -= n1;
+    if (q < n2) { if (d2) d2[q] = t; return; }
+    q -= n2;
+    if (q < n3) { if (d3) d3[q] = t; return; }
+    q -= n3;
+    if (q < n4 && d4) d4[q] = t;
+}
+
+static int sb_finp(int Fin, int F2) {
+    if (F2 == 0) return 0;
+    return Fin <= 16 ? 16 : (Fin <= 32 ? 32 : (Fin <= 48 ? 48 : (Fin <= 64 ? 64 : -1)));
+}
+static int sb_cp(int64_t ldg) { return ldg <= 32 ? 32 : (ldg <= 64 ? 64 : (ldg <= 128 ? 128 : ((ldg <= 256 && SB_ROWS >= 256) ? 256 : 0))); }
+static int sb_grid(int64_t num_rows) {
+    const int64_t nt = gml_cdiv(num_rows, SB_ROWS);
+    return (int)(nt < GML_NUM_CU * SB_WGS_PER_CU ? nt : GML_NUM_CU * SB_WGS_PER_CU);
+}
+static int sb_npart(int Fin, int nout1, int F2) { return 2 * F2 * Fin + 2 * F2 + nout1; }
+static size_t sb_lds(int FINP, int F2) {
+    const int C2 = 2 * F2, C2P = (C2 + 15) / 16 * 16;
+    size_t fl = SB_ROWS * 4;                                                // red (VEC <= 4 columns per thread)
+    if (FINP > 0) fl += (size_t)SB_ROWS * (FINP + 1) + (size_t)C2 * FINP + (C2 + 3) / 4 * 4 + (size_t)SB_ROWS * (C2P + 1) +
+                        (size_t)SB_ROWS * (F2 | 1);
+    const size_t fold = FINP > 0 ? (size_t)SB_WAVES * SB_MAXCB * (FINP / 16 + 1) * 4 * 64 : 0;   // wred aliases xs.. : must fit
+    return sizeof(float) * (fl > fold ? fl : fold);
+}
+
+extern "C" size_t gml_ml3_split_bwd_workspace_bytes(int64_t num_rows, int32_t Fin, int32_t nout1, int32_t F2) {
+    if (num_rows <= 0 || nout1 <= 0 || F2 < 0 || (F2 > 0 && (Fin <= 0 || sb_finp(Fin, F2) < 0 || 2 * F2 > 16 * SB_MAXCB)))
+        return 0;                                                            /* 0 = not supported */
+    return sizeof(float) * (size_t)sb_grid(num_rows) * sb_npart(F2 ? Fin : 0, nout1, F2);
+}
+
+extern "C" int gml_ml3_split_bwd(const float* gy, int64_t ldgy, const float* y, int64_t ldy, const float* x, int64_t ldx,
+                                 const float* w11, const float* b11, const float* w12, const float* b12, float* G,
+                                 int64_t ldg, float* dx, int64_t lddx, float* dcb, float* dw11, float* db11, float* dw12,
+                                 float* db12, int64_t num_rows, int32_t Fin, int32_t nout1, int32_t F2, void* ws,
+                                 size_t ws_bytes, gml_stream_t stream) {
+    if (num_rows < 0 || nout1 <= 0 || F2 < 0 || ldgy < nout1 + F2 || ldy < nout1 || ldg < nout1) return GML_E_BADARG;
+    if (F2 > 0 && (Fin <= 0 || ldx < Fin || (dx && lddx < Fin) || !w11 || !w12 || !dw11 || !dw12)) return GML_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (F2 == 0) Fin = 0;
+    if (num_rows == 0) {
+        if (dcb) hipMemsetAsync(dcb, 0, sizeof(float) * nout1, st);
+        if (F2 > 0) {
+            hipMemsetAsync(dw11, 0, sizeof(float) * F2 * Fin, st);
+            hipMemsetAsync(dw12, 0, sizeof(float) * F2 * Fin, st);
+            if (db11) hipMemsetAsync(db11, 0, sizeof(float) * F2, st);
+            if (db12) hipMemsetAsync(db12, 0, sizeof(float) * F2, st);
+        }
+        return gml_launch_status();
+    }
+    if (!gy || !y || !G || (F2 > 0 && !x)) return GML_E_BADARG;
+    const int FINP = sb_finp(Fin, F2), CP = sb_cp(ldg > nout1 + F2 ? ldg : nout1 + F2);
+    if (FINP < 0 || CP == 0 || 2 * F2 > 16 * SB_MAXCB) return GML_E_UNSUPPORTED;
+    const size_t need = gml_ml3_split_bwd_workspace_bytes(num_rows, Fin, nout1, F2);
+    if (!ws || ws_bytes < need) return GML_E_WORKSPACE;
+    GmlSplitBwdParams p;
+    p.gy = gy; p.ldgy = ldgy; p.y = y; p.ldy = ldy; p.x = x; p.ldx = ldx;
+    p.w11 = w11; p.b11 = b11; p.w12 = w12; p.b12 = b12;
+    p.G = G; p.ldg = ldg; p.dx = dx; p.lddx = lddx; p.part = (float*)ws; p.nrows = num_rows;
+    p.Fin = Fin; p.nout1 = nout1; p.F2 = F2; p.ntiles = (int)gml_cdiv(num_rows, SB_ROWS); p.CP = CP;
+    p.npart = sb_npart(Fin, nout1, F2);
+    const int grid = sb_grid(num_rows);
+    const size_t lds = sb_lds(FINP, F2);
+    const int va = (((ldgy | ldy | ldg) & 3) == 0 && (((uintptr_t)gy | (uintptr_t)y | (uintptr_t)G) & 15) == 0) ? 4 : 1;
+    const int vx = (F2 == 0 || (((ldx | (dx ? lddx : 0)) & 3) == 0 && (((uintptr_t)x | (uintptr_t)dx) & 15) == 0)) ? 4 : 1;
+#define SB_GO(FP, VA, VXX)                                                                                       \
+    if (FINP == FP && va == VA && vx == VXX) {                                                                   \
+        static const hipError_t arc = hipFuncSetAttribute(                                                       \
+            reinterpret_cast<const void*>(&gml_k_ml3_split_bwd<FP, VA, VXX>),                                    \
+            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                             \
+        if (arc != hipSuccess) return (int)arc;                                                                  \
+        hipLaunchKernelGGL((gml_k_ml3_split_bwd<FP, VA, VXX>), dim3(grid), dim3(SB_ROWS), lds, st, p);           \
+    }
+#define SB_GO4(FP) SB_GO(FP, 1, 1) SB_GO(FP, 1, 4) SB_GO(FP, 4, 1) SB_GO(FP, 4, 4)
+    SB_GO(0, 1, 4) SB_GO(0, 4, 4) SB_GO4(16) SB_GO4(32) SB_GO4(48) SB_GO4(64)
+    int rc = gml_launch_status();
+    if (rc != GML_OK) return rc;
+    hipLaunchKernelGGL(gml_k_split_fold, dim3((unsigned)gml_cdiv(p.npart, 16)), dim3(256), 0, st, (const float*)ws,
+                       (int64_t)grid, p.npart, dw11, F2 * Fin, dw12, F2 * Fin, db11, F2, db12, F2, dcb, nout1);
+    return gml_launch_status();
+}

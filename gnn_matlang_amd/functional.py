@@ -146,6 +146,43 @@ def edge_mlp_bwd(ea, w1, w2, w3, w4, gout, need_gin):
     return gin, dw1, dw2, dw3, dw4
 
 
+def ml3_split_bwd(gy, y, nout1, x=None, w11=None, b11=None, w12=None, b12=None, need_dx=False, need_dcb=False):
+    """One pass over the rows for the backward of  cat[relu(conv), tanh(fc11 x) * tanh(fc12 x)]  (or of a plain
+    relu(conv) when w11 is None): returns G [N, nout1] (view of a zero-padded buffer), dx (Hadamard-branch part
+    only, or None), dcb, dw11, db11, dw12, db12."""
+    N = gy.size(0)
+    F2 = 0 if w11 is None else int(w11.size(0))
+    Fin = int(x.size(1)) if F2 else 0
+    dev = gy.device
+    nbytes = int(_lib.lib().gml_ml3_split_bwd_workspace_bytes(int(N), Fin, int(nout1), F2))
+    if nbytes == 0 and N > 0:
+        return None
+    ld = (nout1 + 3) // 4 * 4                                # zero padded: float4-readable rows
+    G = torch.empty(N, ld, dtype=torch.float32, device=dev)
+    ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=dev)
+    dx = torch.empty(N, Fin, dtype=torch.float32, device=dev) if (need_dx and F2) else None
+    dcb = torch.empty(nout1, dtype=torch.float32, device=dev) if need_dcb else None
+    dw11 = torch.empty_like(w11) if F2 else None
+    dw12 = torch.empty_like(w12) if F2 else None
+    db11 = torch.empty_like(b11) if (F2 and b11 is not None) else None
+    db12 = torch.empty_like(b12) if (F2 and b12 is not None) else None
+    with _Timed('ml3_split_bwd', 4 * N * (3 * (nout1 + F2) + (2 * Fin if dx is not None else Fin))):
+        _lib.call('gml_ml3_split_bwd', _ptr(gy), int(gy.stride(0)), _ptr(y), int(y.stride(0)), _ptr(x),
+                  int(x.stride(0)) if F2 else 0, _ptr(w11), _ptr(b11), _ptr(w12), _ptr(b12), _ptr(G), ld, _ptr(dx), Fin,
+                  _ptr(dcb), _ptr(dw11), _ptr(db11), _ptr(dw12), _ptr(db12), int(N), Fin, int(nout1), F2, _ptr(ws),
+                  ws.numel(), _stream(dev))
+    return G[:, :nout1], dx, dcb, dw11, db11, dw12, db12
+
+
+def segment_bcast(g, ptr, nrows, mean=False):
+    """gradient of segment_sum: row r of segment s receives g[s] (divided by the segment length for the mean)."""
+    B, F = int(ptr.numel() - 1), int(g.size(1))
+    out = torch.empty(nrows, F, dtype=torch.float32, device=g.device)
+    _lib.call('gml_segment_bcast', _ptr(g), int(g.stride(0)), _ptr(ptr), _ptr(out), F, B, F, 1 if mean else 0,
+              _stream(g.device))
+    return out
+
+
 def segment_sum(x, ptr, mean=False):
     """global_add_pool / global_mean_pool over a batch whose nodes are grouped per graph (ptr [B+1] int32)."""
     B, F = int(ptr.numel() - 1), int(x.size(1))
@@ -179,7 +216,10 @@ def fused_conv_bwd(csr, val_t, x, G, weight, need_x, need_val, need_w, dx_accum_
     dev = x.device
     flags, ginfo, gmax, nbytes = _bwd_plan(csr, S, Fin, Fout)
     ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=dev) if need_w else None
-    dx = torch.empty(csr.N, Fin, dtype=torch.float32, device=dev) if need_x else None
+    if need_x and dx_accum_into is not None:                 # dx already holds another branch's contribution
+        dx, flags = dx_accum_into, flags | _lib.GML_ACCUM
+    else:
+        dx = torch.empty(csr.N, Fin, dtype=torch.float32, device=dev) if need_x else None
     dval_t = torch.empty(csr.E, S, dtype=torch.float32, device=dev) if need_val else None
     dw = torch.empty(S, Fin, Fout, dtype=torch.float32, device=dev) if need_w else None
     q, f = conv_cost_bwd(csr.N, csr.E, S, Fin, Fout) if PROFILE is not None else (0, 0)
@@ -192,9 +232,11 @@ def fused_conv_bwd(csr, val_t, x, G, weight, need_x, need_val, need_w, dx_accum_
 
 
 # ---------------------------------------------------------------------------- shared backward pieces
-def _conv_backward(csr, x, val, weight, G, need_x, need_val, need_w, val_t=None, want_source_order=False):
+def _conv_backward(csr, x, val, weight, G, need_x, need_val, need_w, val_t=None, want_source_order=False,
+                   dx_accum_into=None):
     """G [N,Fout] contiguous = gradient at the (pre-activation) conv output.
-    Returns dx, dval, dw; dval is in source order when want_source_order (and the fused kernel ran)."""
+    Returns dx, dval, dw; dval is in source order when want_source_order (and the fused kernel ran).
+    dx_accum_into: [N,Fin] buffer that already holds a partial dx; the conv contribution is added to it."""
     S, Fin, Fout = weight.shape
     N = csr.N
     dx = dval = dw = None
@@ -204,7 +246,7 @@ def _conv_backward(csr, x, val, weight, G, need_x, need_val, need_w, val_t=None,
         if val_t is None:
             with _Timed('val_to_source_order'):
                 val_t = csr.to_source_order(val)
-        dx, dval_t, dw = fused_conv_bwd(csr, val_t, x, G, weight, need_x, need_val, need_w)
+        dx, dval_t, dw = fused_conv_bwd(csr, val_t, x, G, weight, need_x, need_val, need_w, dx_accum_into)
         if need_val and not want_source_order:
             with _Timed('dval_from_source_order'):
                 dval_t = csr.from_source_order(dval_t)
@@ -212,13 +254,13 @@ def _conv_backward(csr, x, val, weight, G, need_x, need_val, need_w, val_t=None,
     if not G.is_contiguous():
         G = G.contiguous()
     if need_x:
-        dx = torch.empty(N, Fin, dtype=torch.float32, device=x.device)
+        dx = dx_accum_into if dx_accum_into is not None else torch.empty(N, Fin, dtype=torch.float32, device=x.device)
         # dX = sum_s A_s (G W_s^T): rows keyed by SOURCE, features = G, weight element (s, o, f) = W[s, f, o]
         if val_t is None:
             with _Timed('val_to_source_order'):
                 val_t = csr.to_source_order(val)
         fused_conv(csr.rowptr_t, csr.col_t, csr.ginfo_t, None, val_t, G, Fout, weight, (Fin * Fout, 1, Fout), None,
-                   dx, Fin, N, S, Fout, Fin, tag='spectconv_dx')
+                   dx, Fin, N, S, Fout, Fin, _lib.GML_ACCUM if dx_accum_into is not None else 0, tag='spectconv_dx')
     if need_w:
         with _Timed('dw_spmm'):
             h = spmm(csr, val, x, S, Fin)                                # [N, S*Fin]
@@ -261,10 +303,17 @@ class SpectConvFunction(torch.autograd.Function):
         gout = _f32c(gout, 'grad_out')
         with torch.cuda.device(x.device):
             Fout = weight.size(2)
-            G = relu_bwd(gout, 0, Fout, out, Fout, csr.N, Fout) if ctx.relu else gout
             need = ctx.needs_input_grad
+            want_db = ctx.has_bias and need[3]
+            db = None
+            r = ml3_split_bwd(gout, out, Fout, need_dcb=want_db) if ctx.relu else None
+            if r is not None:
+                G, db = r[0], r[2]
+            else:
+                G = relu_bwd(gout, 0, Fout, out, Fout, csr.N, Fout) if ctx.relu else gout
             dx, dval, dw, _ = _conv_backward(csr, x, val, weight, G, need[0], need[1], need[2])
-            db = G.sum(0) if (ctx.has_bias and need[3]) else None
+            if want_db and db is None:
+                db = G.sum(0)
         return dx, dval, dw, db, None, None
 
 
@@ -321,27 +370,37 @@ class ML3LayerFunction(torch.autograd.Function):
             ea = val
         g = [None] * 15
         with torch.cuda.device(x.device):
-            G = relu_bwd(gy, 0, C, out, C, N, nout1)
             need_val = need[1] or (learnedge and any(need[2:6]))
             if not learnedge and fused_bwd_available(csr, S, Fin, nout1):
                 ea_t = csr.to_source_order(val, cache=True)              # raw supports: per-batch data
-            dx, dea, dcw, dea_src = _conv_backward(csr, x, ea, cw, G, need[0], need_val, need[6], val_t=ea_t,
-                                                   want_source_order=learnedge)
-            g[6] = dcw
-            if ctx.has_cb and need[7]:
-                g[7] = G.sum(0)
-            if nout2 > 0:
-                nbytes = int(_lib.lib().gml_node_mix_bwd_workspace_bytes(N, Fin, nout2))
-                if nbytes == 0:
-                    raise NotImplementedError('Hadamard branch backward: ninp=%d, nout2=%d outside the compiled '
-                                              'kernel range' % (Fin, nout2))
-                ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-                g[8], g[9], g[10], g[11] = (torch.empty_like(w11), torch.empty_like(b11), torch.empty_like(w12),
-                                            torch.empty_like(b12))
-                with _Timed('node_mix_bwd'):
-                    _lib.call('gml_node_mix_bwd', _ptr(x), Fin, _ptr(w11), _ptr(b11), _ptr(w12), _ptr(b12),
-                              _off(gy, nout1), C, _ptr(dx) if need[0] else _ptr(None), Fin, _ptr(g[8]), _ptr(g[9]),
-                              _ptr(g[10]), _ptr(g[11]), N, Fin, nout2, _ptr(ws), ws.numel(), _stream(x.device))
+            want_cb = ctx.has_cb and need[7]
+            r = ml3_split_bwd(gy, out, nout1, x, w11, b11, w12, b12, need_dx=need[0], need_dcb=want_cb) \
+                if nout2 > 0 else ml3_split_bwd(gy, out, nout1, need_dcb=want_cb)
+            if r is not None:
+                # one pass: relu mask, conv1.bias gradient, Hadamard branch (its dx written, conv adds to it)
+                G, dx0, g[7], g[8], g[9], g[10], g[11] = r
+                dx, dea, dcw, dea_src = _conv_backward(csr, x, ea, cw, G, need[0], need_val, need[6], val_t=ea_t,
+                                                       want_source_order=learnedge, dx_accum_into=dx0)
+                g[6] = dcw
+            else:
+                G = relu_bwd(gy, 0, C, out, C, N, nout1)
+                dx, dea, dcw, dea_src = _conv_backward(csr, x, ea, cw, G, need[0], need_val, need[6], val_t=ea_t,
+                                                       want_source_order=learnedge)
+                g[6] = dcw
+                if want_cb:
+                    g[7] = G.sum(0)
+                if nout2 > 0:
+                    nbytes = int(_lib.lib().gml_node_mix_bwd_workspace_bytes(N, Fin, nout2))
+                    if nbytes == 0:
+                        raise NotImplementedError('Hadamard branch backward: ninp=%d, nout2=%d outside the compiled '
+                                                  'kernel range' % (Fin, nout2))
+                    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+                    g[8], g[9], g[10], g[11] = (torch.empty_like(w11), torch.empty_like(b11), torch.empty_like(w12),
+                                                torch.empty_like(b12))
+                    with _Timed('node_mix_bwd'):
+                        _lib.call('gml_node_mix_bwd', _ptr(x), Fin, _ptr(w11), _ptr(b11), _ptr(w12), _ptr(b12),
+                                  _off(gy, nout1), C, _ptr(dx) if need[0] else _ptr(None), Fin, _ptr(g[8]), _ptr(g[9]),
+                                  _ptr(g[10]), _ptr(g[11]), N, Fin, nout2, _ptr(ws), ws.numel(), _stream(x.device))
             g[0] = dx
             if learnedge:
                 if need_val:

@@ -9,7 +9,7 @@ edge_index2, edge_attr2, batch, ptr, y).
 import torch
 import torch.nn.functional as F
 
-from .functional import segment_sum
+from .functional import segment_bcast, segment_sum
 from .spect_conv import ML3Layer, SpectConv
 
 
@@ -25,10 +25,7 @@ class _SegmentPool(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         ptr, batch = ctx.saved_tensors
-        if ctx.mean:
-            cnt = (ptr[1:] - ptr[:-1]).clamp(min=1).to(g.dtype).unsqueeze(-1)
-            g = g / cnt
-        return g.index_select(0, batch), None, None, None
+        return segment_bcast(g.contiguous(), ptr, batch.numel(), ctx.mean), None, None, None
 
 
 def global_add_pool(x, data):

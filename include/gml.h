@@ -159,6 +159,22 @@ int gml_node_mix_bwd(const float* x, int64_t ldx, const float* w11, const float*
                      float* dx, int64_t lddx, float* dw11, float* db11, float* dw12, float* db12,
                      int64_t num_rows, int32_t Fin, int32_t F2, void* ws, size_t ws_bytes, gml_stream_t stream);
 
+/* ---------------------------------------------------------------- ML3Layer output stage, backward in one pass
+ * (autograd of libs/spect_conv.py:209-212: the relu on the conv part, the concat, the Hadamard branch, conv1.bias)
+ *   G[:, :nout1] = gy[:, :nout1] * (y[:, :nout1] > 0), G[:, nout1:ldg] = 0      gradient at the conv output
+ *   dcb          = column sums of G                                             (NULL: not wanted)
+ *   dx           = dz11 w11 + dz12 w12  -- WRITTEN (follow with gml_spectconv_bwd + GML_ACCUM); NULL: not wanted
+ *   dw11, db11, dw12, db12 as gml_node_mix_bwd, from gy[:, nout1:nout1+F2].
+ * F2 == 0: no Hadamard branch (x, w*, dw*, dx ignored) -- relu mask + bias sums of a plain SpectConv.
+ * workspace_bytes == 0: shape not supported (caller uses gml_relu_bwd + gml_node_mix_bwd). */
+size_t gml_ml3_split_bwd_workspace_bytes(int64_t num_rows, int32_t Fin, int32_t nout1, int32_t F2);
+int gml_ml3_split_bwd(const float* gy, int64_t ldgy, const float* y, int64_t ldy, const float* x, int64_t ldx,
+                      const float* w11, const float* b11, const float* w12, const float* b12,
+                      float* G, int64_t ldg, float* dx, int64_t lddx, float* dcb,
+                      float* dw11, float* db11, float* dw12, float* db12,
+                      int64_t num_rows, int32_t Fin, int32_t nout1, int32_t F2,
+                      void* ws, size_t ws_bytes, gml_stream_t stream);
+
 /* ---------------------------------------------------------------- glue
  * g[r, c] = (y[r, c] > 0) ? gy[r, c] : 0   for c < F, and 0 for F <= c < ldg (relu backward on a strided
  * slice; the zero padding lets consumers read aligned float4 groups) */
@@ -168,6 +184,9 @@ int gml_relu_bwd(const float* gy, int64_t ldgy, const float* y, int64_t ldy, flo
  * mean != 0 divides by the segment length: global_mean_pool) */
 int gml_segment_sum(const float* x, int64_t ldx, const int32_t* ptr, float* out, int64_t ldo,
                     int64_t num_segments, int32_t F, int32_t mean, gml_stream_t stream);
+/* its gradient: out[r, :] = g[seg(r), :] (/ segment length when mean != 0) for r in [ptr[seg], ptr[seg+1]) */
+int gml_segment_bcast(const float* g, int64_t ldg, const int32_t* ptr, float* out, int64_t ldo,
+                      int64_t num_segments, int32_t F, int32_t mean, gml_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -226,6 +226,52 @@ def test_spmm_sddmm_edge_mlp_node_mix_vs_oracle(dev):
             close(got, w.grad, what='edge mlp %s S=%d' % (n, S))
 
 
+@pytest.mark.gpu
+def test_ml3_output_stage_backward_vs_autograd(dev):
+    """gml_ml3_split_bwd (relu mask + conv bias sums + Hadamard-branch backward in one pass) and
+    gml_segment_bcast against torch autograd of the same expressions on the CPU (fp32)."""
+    from gnn_matlang_amd import functional as Fn
+    torch.manual_seed(11)
+    for N, Fin, nout1, F2 in ((1000, 25, 30, 2), (257, 32, 30, 2), (513, 2, 16, 16), (300, 48, 32, 16),
+                              (777, 48, 24, 24), (1, 7, 5, 3), (900, 0, 64, 0), (333, 0, 128, 0)):
+        C = nout1 + F2
+        y = torch.randn(N, C)
+        gy = torch.randn(N, C)
+        G_ref = gy[:, :nout1] * (y[:, :nout1] > 0)
+        if F2:
+            x = torch.randn(N, Fin, requires_grad=True)
+            lin = [torch.nn.Linear(Fin, F2) for _ in range(2)]
+            h = torch.tanh(lin[0](x)) * torch.tanh(lin[1](x))
+            (h * gy[:, nout1:]).sum().backward()
+            args = (x.detach().to(dev), lin[0].weight.detach().to(dev), lin[0].bias.detach().to(dev),
+                    lin[1].weight.detach().to(dev), lin[1].bias.detach().to(dev))
+            r = Fn.ml3_split_bwd(gy.to(dev), y.to(dev), nout1, *args, need_dx=True, need_dcb=True)
+        else:
+            r = Fn.ml3_split_bwd(gy.to(dev), y.to(dev), nout1, need_dcb=True)
+        assert r is not None, (N, Fin, nout1, F2)
+        G, dx, dcb, dw11, db11, dw12, db12 = r
+        what = 'N=%d Fin=%d nout1=%d F2=%d ' % (N, Fin, nout1, F2)
+        assert torch.equal(G.cpu(), G_ref), what + 'G'                      # a select: bit-exact
+        if G._base is not None and G._base.size(1) > nout1:
+            assert float(G._base[:, nout1:].abs().sum()) == 0., what + "padding"
+        close(dcb, G_ref.sum(0), what=what + 'dcb')
+        if F2:
+            close(dx, x.grad, what=what + 'dx')
+            close(dw11, lin[0].weight.grad, what=what + 'dw11')
+            close(db11, lin[0].bias.grad, what=what + 'db11')
+            close(dw12, lin[1].weight.grad, what=what + 'dw12')
+            close(db12, lin[1].bias.grad, what=what + 'db12')
+    # pooling gradient
+    sizes = torch.tensor([3, 1, 0, 7, 64, 2, 129])
+    ptr = torch.cat([torch.zeros(1, dtype=torch.long), sizes.cumsum(0)]).int()
+    g = torch.randn(len(sizes), 32)
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), sizes)
+    for mean in (False, True):
+        ref = g[batch] / (sizes[batch].clamp(min=1).float().unsqueeze(-1) if mean else 1.)
+        got = Fn.segment_bcast(g.to(dev), ptr.to(dev), int(sizes.sum()), mean)
+        close(got, ref, tol=1e-6, what='segment_bcast mean=%s' % mean)
+
+
 # ------------------------------------------------------------------------------------------ ML3Layer
 def test_ml3layer_golden(dev, golden):
     from gnn_matlang_amd import ML3Layer
