@@ -142,22 +142,18 @@ def main():
     def make_graph_step(mdl, dat, lr=1e-3):
         """whole train step (fwd + loss + bwd + Adam) captured once in a HIP graph, replayed per step."""
         o = torch.optim.Adam(mdl.parameters(), lr=lr, capturable=True)
-        for p_ in mdl.parameters():
-            p_.grad = torch.zeros_like(p_)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                      # warm-up on a side stream (allocator, lazy init)
             for _ in range(3):
-                for p_ in mdl.parameters():
-                    p_.grad.zero_()
+                o.zero_grad(set_to_none=True)
                 models.zinc_loss(mdl(dat), dat.y).backward()
                 o.step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g_ = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g_):
-            for p_ in mdl.parameters():
-                p_.grad.zero_()
+            o.zero_grad(set_to_none=True)               # gradients are handed over, not accumulated
             l_ = models.zinc_loss(mdl(dat), dat.y)
             l_.backward()
             o.step()

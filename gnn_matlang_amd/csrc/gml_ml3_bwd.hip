@@ -370,3 +370,118 @@ extern "C" int gml_ml3_split_bwd(const float* gy, int64_t ldgy, const float* y, 
                        (int64_t)grid, p.npart, dw11, F2 * Fin, dw12, F2 * Fin, db11, F2, db12, F2, dcb, nout1);
     return gml_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------
+// out[i][j] = sum_r A[r][i] * B[r][j]   (a, b <= 64; n rows in the millions): the weight gradient of a small
+// dense layer applied to every row (readout head fc1 / fc2 of Zinc12k.py:343-345).  A library GEMM maps this
+// M = a, N = b, K = n problem onto ONE workgroup; here the rows are split over the chip, each wave contracts
+// its 64 rows on the matrix cores (v_mfma_f32_16x16x4_f32, both tiles staged coalesced through LDS) and the
+// per-workgroup partials are folded in fixed order.
+// ---------------------------------------------------------------------------------------------
+#define XTY_ROWS 256
+static __host__ __device__ inline int xty_ld(int a) { return a <= 16 ? 16 : (a <= 48 ? 48 : 80); }   // = 16 or 48 mod 64
+
+__global__ __launch_bounds__(256) void gml_k_xty(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
+                                                 int64_t ldb, float* __restrict__ part, int64_t n, int a, int b,
+                                                 int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int LDA = xty_ld(a), LDB = xty_ld(b);
+    float* As = lds;                         // [256][LDA]
+    float* Bs = As + XTY_ROWS * LDA;         // [256][LDB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int nab = (a + 15) / 16, nbb = (b + 15) / 16;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) acc[x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int64_t r0 = (int64_t)t * XTY_ROWS;
+        const int nr = (int)min((int64_t)XTY_ROWS, n - r0);
+        __syncthreads();
+        for (int i = tid; i < XTY_ROWS * LDA; i += 256) {
+            const int r = i / LDA, c = i - r * LDA;
+            As[i] = (r < nr && c < a) ? A[(r0 + r) * lda + c] : 0.f;
+        }
+        for (int i = tid; i < XTY_ROWS * LDB; i += 256) {
+            const int r = i / LDB, c = i - r * LDB;
+            Bs[i] = (r < nr && c < b) ? B[(r0 + r) * ldb + c] : 0.f;
+        }
+        __syncthreads();
+        const int rb = wave * 64;
+#pragma unroll 4
+        for (int t16 = 0; t16 < 16; ++t16) {
+            const int rr = rb + 4 * t16 + kq;
+            float av[4], bv[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) av[x] = (x < nab) ? As[rr * LDA + x * 16 + i16] : 0.f;
+#pragma unroll
+            for (int y = 0; y < 4; ++y) bv[y] = (y < nbb) ? Bs[rr * LDB + y * 16 + i16] : 0.f;
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 4; ++y)
+                    if (x < nab && y < nbb) acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[x], bv[y], acc[x][y], 0, 0, 0);
+        }
+    }
+    // D[x][y]: lane (col = i16, rows 4*kq + reg): row = A column, col = B column; fold the 4 waves through LDS
+    __syncthreads();
+    float* red = lds;                        // [4 waves][16 blocks][4 regs][64 lanes] = 64 KB max; only live blocks used
+    const int nblk = nab * nbb;
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+            if (x < nab && y < nbb)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) red[((wave * nblk + x * nbb + y) * 4 + reg) * 64 + lane] = acc[x][y][reg];
+    __syncthreads();
+    float* P = part + (int64_t)blockIdx.x * a * b;
+    for (int it = tid; it < nblk * 4 * 64; it += 256) {
+        const int ln = it & 63, reg = (it >> 6) & 3, blk = it >> 8;
+        const float v = ((red[((0 * nblk + blk) * 4 + reg) * 64 + ln] + red[((1 * nblk + blk) * 4 + reg) * 64 + ln]) +
+                         red[((2 * nblk + blk) * 4 + reg) * 64 + ln]) + red[((3 * nblk + blk) * 4 + reg) * 64 + ln];
+        const int x = blk / nbb, y = blk - x * nbb;
+        const int i = x * 16 + 4 * (ln >> 4) + reg, j = y * 16 + (ln & 15);
+        if (i < a && j < b) P[i * b + j] = v;
+    }
+}
+
+static int xty_grid(int64_t n) {
+    const int64_t nt = gml_cdiv(n, XTY_ROWS);
+    return (int)(nt < GML_NUM_CU * 2 ? nt : GML_NUM_CU * 2);
+}
+
+extern "C" size_t gml_xty_workspace_bytes(int64_t n, int32_t a, int32_t b) {
+    if (n <= 0 || a <= 0 || b <= 0 || a > 64 || b > 64) return 0;
+    return sizeof(float) * (size_t)xty_grid(n) * a * b;
+}
+
+extern "C" int gml_xty(const float* A, int64_t lda, const float* B, int64_t ldb, float* out, int64_t n, int32_t a,
+                       int32_t b, void* ws, size_t ws_bytes, gml_stream_t stream) {
+    if (n < 0 || a <= 0 || b <= 0 || lda < a || ldb < b || !out) return GML_E_BADARG;
+    if (a > 64 || b > 64) return GML_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) {
+        hipMemsetAsync(out, 0, sizeof(float) * a * b, st);
+        return gml_launch_status();
+    }
+    if (!A || !B) return GML_E_BADARG;
+    if (!ws || ws_bytes < gml_xty_workspace_bytes(n, a, b)) return GML_E_WORKSPACE;
+    const int grid = xty_grid(n);
+    size_t lds = sizeof(float) * (size_t)XTY_ROWS * (xty_ld(a) + xty_ld(b));
+    const size_t fold = sizeof(float) * (size_t)4 * ((a + 15) / 16) * ((b + 15) / 16) * 4 * 64;
+    if (fold > lds) lds = fold;
+    static const hipError_t arc = hipFuncSetAttribute(reinterpret_cast<const void*>(&gml_k_xty),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (arc != hipSuccess) return (int)arc;
+    hipLaunchKernelGGL(gml_k_xty, dim3(grid), dim3(256), lds, st, A, lda, B, ldb, (float*)ws, n, a, b,
+                       (int)gml_cdiv(n, XTY_ROWS));
+    int rc = gml_launch_status();
+    if (rc != GML_OK) return rc;
+    hipLaunchKernelGGL(gml_k_split_fold, dim3((unsigned)gml_cdiv(a * b, 16)), dim3(256), 0, st, (const float*)ws,
+                       (int64_t)grid, a * b, out, a * b, (float*)nullptr, 0, (float*)nullptr, 0, (float*)nullptr, 0,
+                       (float*)nullptr, 0);
+    return gml_launch_status();
+}

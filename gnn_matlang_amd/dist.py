@@ -10,25 +10,35 @@ import torch.distributed as dist
 
 
 class FlatGradSync(object):
-    """Keeps every parameter's .grad as a view into one flat buffer; ``sync()`` = one all-reduce."""
+    """One all-reduce per step over a flat fp32 gradient buffer.
+
+    ``zero()`` drops the gradients (``.grad = None``), so the backward pass hands each parameter's freshly
+    written gradient tensor over without an accumulate kernel per parameter; ``sync()`` packs them into one
+    flat buffer (a single concatenation), all-reduces it and gives every parameter its slice back as ``.grad``
+    (views, no copies).  With one rank nothing is launched at all."""
 
     def __init__(self, params, group=None):
         self.params = [p for p in params if p.requires_grad]
         self.group = group
-        n = sum(p.numel() for p in self.params)
-        ref = self.params[0]
-        self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
+        self.flat = None
+
+    def _world(self):
+        return dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
+
+    def zero(self):
+        for p in self.params:
+            p.grad = None
+
+    def sync(self):
+        if self._world() == 1:
+            return None
+        self.flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+                               for p in self.params])
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
         off = 0
         for p in self.params:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
             off += p.numel()
-
-    def zero(self):
-        self.flat.zero_()
-
-    def sync(self):
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
         return self.flat
 
 

@@ -174,6 +174,48 @@ def ml3_split_bwd(gy, y, nout1, x=None, w11=None, b11=None, w12=None, b12=None, 
     return G[:, :nout1], dx, dcb, dw11, db11, dw12, db12
 
 
+def xty(a, b):
+    """a^T b for two tall matrices with <= 64 columns each ([n,p], [n,q] -> [p,q]); None if outside the kernel range."""
+    n, p, q = int(a.size(0)), int(a.size(1)), int(b.size(1))
+    nbytes = int(_lib.lib().gml_xty_workspace_bytes(n, p, q))
+    if nbytes == 0 and n > 0:
+        return None
+    out = torch.empty(p, q, dtype=torch.float32, device=a.device)
+    ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=a.device)
+    _lib.call('gml_xty', _ptr(a), int(a.stride(0)), _ptr(b), int(b.stride(0)), _ptr(out), n, p, q, _ptr(ws), ws.numel(),
+              _stream(a.device))
+    return out
+
+
+class TallLinearFunction(torch.autograd.Function):
+    """F.linear for a small layer applied to many rows; only the weight gradient g^T x differs from autograd's
+    (a K = rows contraction that a library GEMM runs on a single workgroup)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_b = b is not None
+        return torch.nn.functional.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = g.contiguous()
+        gx = g.mm(w) if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            with torch.cuda.device(x.device):
+                gw = xty(g, x.contiguous()) if (x.is_cuda and x.dtype == torch.float32) else None
+            if gw is None:
+                gw = g.t().mm(x)
+        gb = g.sum(0) if (ctx.has_b and ctx.needs_input_grad[2]) else None
+        return gx, gw, gb
+
+
+def tall_linear(x, lin):
+    return TallLinearFunction.apply(x, lin.weight, lin.bias)
+
+
 def segment_bcast(g, ptr, nrows, mean=False):
     """gradient of segment_sum: row r of segment s receives g[s] (divided by the segment length for the mean)."""
     B, F = int(ptr.numel() - 1), int(g.size(1))

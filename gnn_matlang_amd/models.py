@@ -9,7 +9,7 @@ edge_index2, edge_attr2, batch, ptr, y).
 import torch
 import torch.nn.functional as F
 
-from .functional import segment_bcast, segment_sum
+from .functional import segment_bcast, segment_sum, tall_linear
 from .spect_conv import ML3Layer, SpectConv
 
 
@@ -72,8 +72,8 @@ class GNNML3(torch.nn.Module):
         if self.readout_bn:
             x = self.bnr(x)
         if self.head == 'mlp32':
-            return self.fc2(F.relu(self.fc1(x)))
-        return torch.tanh(self.fc1(x))
+            return tall_linear(F.relu(tall_linear(x, self.fc1)), self.fc2)
+        return torch.tanh(tall_linear(x, self.fc1))
 
 
 class GNNML1Mutag(torch.nn.Module):
@@ -101,7 +101,7 @@ class GNNML1Mutag(torch.nn.Module):
                            F.relu(g('fc%d2')(x)) * F.relu(g('fc%d3')(x))], 1)
             x = g('bn%d')(x)
         x = global_mean_pool(x, data)
-        return self.fc2(F.relu(self.fc1(x)))
+        return tall_linear(F.relu(tall_linear(x, self.fc1)), self.fc2)
 
 
 def zinc_gnnml3(ninp=25, ne=8):            # Zinc12k.py:316-329

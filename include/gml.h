@@ -188,6 +188,12 @@ int gml_segment_sum(const float* x, int64_t ldx, const int32_t* ptr, float* out,
 int gml_segment_bcast(const float* g, int64_t ldg, const int32_t* ptr, float* out, int64_t ldo,
                       int64_t num_segments, int32_t F, int32_t mean, gml_stream_t stream);
 
+/* out[i, j] = sum_r A[r, i] * B[r, j]  (a, b <= 64): weight gradient g^T x of a small dense layer over n rows
+ * (readout head fc1 / fc2, Zinc12k.py:343-345), rows split over the chip, fixed summation order */
+size_t gml_xty_workspace_bytes(int64_t n, int32_t a, int32_t b);
+int gml_xty(const float* A, int64_t lda, const float* B, int64_t ldb, float* out, int64_t n, int32_t a, int32_t b,
+            void* ws, size_t ws_bytes, gml_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -261,6 +261,10 @@ def test_ml3_output_stage_backward_vs_autograd(dev):
             close(db11, lin[0].bias.grad, what=what + 'db11')
             close(dw12, lin[1].weight.grad, what=what + 'dw12')
             close(db12, lin[1].bias.grad, what=what + 'db12')
+    # weight gradient of a small dense layer over many rows
+    for n, pa, q in ((1000, 32, 32), (257, 1, 32), (5000, 10, 48), (3, 64, 64), (70000, 32, 32)):
+        a, b = torch.randn(n, pa), torch.randn(n, q)
+        close(Fn.xty(a.to(dev), b.to(dev)), a.double().t().mm(b.double()).float(), what='xty %d %d %d' % (n, pa, q))
     # pooling gradient
     sizes = torch.tensor([3, 1, 0, 7, 64, 2, 129])
     ptr = torch.cat([torch.zeros(1, dtype=torch.long), sizes.cumsum(0)]).int()
