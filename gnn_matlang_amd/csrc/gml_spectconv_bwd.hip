@@ -25,6 +25,9 @@ GML_DECL_BWD(8, 2, 2) GML_DECL_BWD(8, 1, 2) GML_DECL_BWD(4, 2, 2) GML_DECL_BWD(4
 GML_DECL_BWD(12, 2, 1) GML_DECL_BWD(12, 1, 1) GML_DECL_BWD(6, 3, 2) GML_DECL_BWD(6, 1, 2)
 GML_DECL_BWD(4, 3, 2) GML_DECL_BWD(6, 2, 2) GML_DECL_BWD(8, 2, 1) GML_DECL_BWD(4, 4, 2)
 
+#ifdef GML_BWD2_TIMING
+static unsigned long long* bwd2_prof_buf();
+#endif
 #define GML_DECL_BWD2(S, A) template <> int gml_launch_bwd2<S, A>(const GmlBwdParams&, dim3, size_t, hipStream_t);
 GML_DECL_BWD2(8, 2) GML_DECL_BWD2(8, 1) GML_DECL_BWD2(6, 2) GML_DECL_BWD2(6, 1)
 GML_DECL_BWD2(4, 2) GML_DECL_BWD2(4, 1) GML_DECL_BWD2(2, 2) GML_DECL_BWD2(2, 1)
@@ -123,6 +126,9 @@ extern "C" int gml_spectconv_bwd(const int32_t* rowptr, const int32_t* col, cons
     p.rowptr = rowptr; p.col = col; p.ginfo = ginfo; p.val = val; p.x = x; p.ldx = ldx; p.g = g; p.ldg = ldg;
     p.w = w; p.dx = dx; p.lddx = lddx; p.dval = dval; p.dw_partial = dw ? (float*)ws : nullptr;
     p.nrows = num_rows; p.S = S; p.Fin = Fin; p.Fout = Fout; p.flags = flags;
+#ifdef GML_BWD2_TIMING
+    p.prof = bwd2_prof_buf();
+#endif
     p.xvec = (Fin % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)x & 15) == 0);
     /* float4 groups up to roundup4(Fout) must exist in every row: true when ldg covers them (zero padded) */
     p.gvec = (ldg % 4 == 0) && ((Fout + 3) / 4 * 4 <= ldg) && (((uintptr_t)g & 15) == 0);
@@ -149,3 +155,17 @@ extern "C" int gml_spectconv_bwd(const int32_t* rowptr, const int32_t* col, cons
     }
     return GML_OK;
 }
+
+#ifdef GML_BWD2_TIMING
+// debug build only: per-phase cycle sums of thread 0 of every workgroup
+// (0 dW of the previous group + barrier, 1 stage, 2 Z projection, 3 edge, 4 barrier, 5 dval + dX, 6 tail)
+static unsigned long long* bwd2_prof_buf() {
+    static unsigned long long* b = [] { unsigned long long* q = nullptr; hipMalloc(&q, 64); hipMemset(q, 0, 64); return q; }();
+    return b;
+}
+extern "C" int gml_debug_bwd2_prof(unsigned long long* out, int reset) {
+    hipError_t e = hipMemcpy(out, bwd2_prof_buf(), 64, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && reset) e = hipMemset(bwd2_prof_buf(), 0, 64);
+    return (int)e;
+}
+#endif

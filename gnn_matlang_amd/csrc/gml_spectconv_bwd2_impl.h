@@ -18,6 +18,8 @@
 #include "gml_common.h"
 #include "gml_spectconv_bwd_impl.h"
 
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
 #define GML_BWD2_ROWS 128
 #define GML_BWD2_ECAP_MAX 2048     // register-batched staging bounds (per 128-row group)
 #define GML_BWD2_XCAP_MAX 320
@@ -47,6 +49,13 @@ struct GmlBwd2Cfg {
         return (size_t)W_BYTES + 136 * 4 + (size_t)ecap * 4 + ea_bytes(ecap) + gs_bytes(xcap);
     }
 };
+
+#ifdef GML_BWD2_TIMING      // debug build: per-phase cycle sums of thread 0 of every workgroup (tools/bwd2_phases.py)
+#define GML_T(i) do { if (tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); \
+                      atomicAdd(&p.prof[i], t_ - tprev_); tprev_ = t_; } } while (0)
+#else
+#define GML_T(i)
+#endif
 
 template <int S, int NFB>
 __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p) {
@@ -93,14 +102,35 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
 #pragma unroll
     for (int i = 0; i < C::NSLAB; ++i) dwacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+#ifdef GML_BWD2_TIMING
+    unsigned long long tprev_ = __builtin_readcyclecounter();
+#endif
     for (int g = g0; g < g1; ++g) {
         const int64_t r0 = (int64_t)g * ROWS;
         const int nr = (int)min((int64_t)ROWS, p.nrows - r0);
         const int4 gi = reinterpret_cast<const int4*>(p.ginfo)[g];
         const int kb = gi.x, ne = gi.y, lo = gi.z, nwin = gi.w;
         __syncthreads();                                     // previous group is done with every LDS region
+        GML_T(0);                                            // = previous group's dW phase + this barrier
 
         // ---- stage: every global load of the group is in flight before the first LDS write
+        const int row = wave * 16 + r16;                     // row of the group owned by this lane
+        const bool rvalid = row < nr;
+        float xb[8];
+        {
+            const float* xr = p.x + (r0 + row) * p.ldx + 8 * kq;
+            if (p.xvec) {
+#pragma unroll
+                for (int q4 = 0; q4 < 2; ++q4) {
+                    f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (rvalid && 8 * kq + 4 * q4 < p.Fin) t = *reinterpret_cast<const f32x4*>(xr + 4 * q4);
+                    xb[4 * q4] = t.x; xb[4 * q4 + 1] = t.y; xb[4 * q4 + 2] = t.z; xb[4 * q4 + 3] = t.w;
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) xb[t] = (rvalid && 8 * kq + t < p.Fin) ? xr[t] : 0.f;
+            }
+        }
         if (tid <= nr) rp_l[tid] = p.rowptr[r0 + tid];
         if ((S % 4 == 0) && p.gvec && ne <= GML_BWD2_ECAP_MAX && nwin <= GML_BWD2_XCAP_MAX) {
             constexpr int NC = GML_BWD2_ECAP_MAX / 512, NE4 = (S % 4 == 0) ? GML_BWD2_ECAP_MAX * (S / 4) / 512 : 1;
@@ -143,30 +173,15 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
             }
         }
         __syncthreads();
+        GML_T(1);
 
-        const int row = wave * 16 + r16;                     // row of the group owned by this lane
-        const bool rvalid = row < nr;
         const int kbeg = rvalid ? rp_l[row] - kb : 0;
         const int kend = rvalid ? rp_l[row + 1] - kb : 0;
 
-        // own X row, features 8*kq .. 8*kq+7  ->  bf16 (hi, lo) B fragment of Z^T, also the X^T tile of dW
+        // own X row (its load was issued ahead of the staging loads), features 8*kq .. 8*kq+7  ->  bf16 (hi, lo)
+        // B fragment of Z^T, also the X^T tile of dW
         bf16x8 xh, xl;
-        {
-            float xb[8];
-            const float* xr = p.x + (r0 + row) * p.ldx + 8 * kq;
-            if (p.xvec) {
-#pragma unroll
-                for (int q4 = 0; q4 < 2; ++q4) {
-                    f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (rvalid && 8 * kq + 4 * q4 < p.Fin) t = *reinterpret_cast<const f32x4*>(xr + 4 * q4);
-                    xb[4 * q4] = t.x; xb[4 * q4 + 1] = t.y; xb[4 * q4 + 2] = t.z; xb[4 * q4 + 3] = t.w;
-                }
-            } else {
-#pragma unroll
-                for (int t = 0; t < 8; ++t) xb[t] = (rvalid && 8 * kq + t < p.Fin) ? xr[t] : 0.f;
-            }
-            gml_split8(xb, xh, xl);
-        }
+        gml_split8(xb, xh, xl);
 
         // ---- Z^T = W^T X^T: MFMA row i of block ob carries o = 8*(i>>2) + 4*ob + (i&3), so lane kq receives
         //      o = 8*kq + 4*ob + reg: its 8 consecutive outputs
@@ -193,6 +208,7 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
             }
         }
 
+        GML_T(2);
         // ---- edge phase (fp32 VALU, packed): P += val * G[dst],  d[s] = <Z[s], G[dst]>
         for (int k = kbeg; k < kend; ++k) {
             const int dstl = col_l[k];
@@ -230,7 +246,9 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
                 if (4 * c + kq < S) ea_l[k * S + 4 * c + kq] = tot;
             }
         }
+        GML_T(3);
         __syncthreads();                                     // dval rows complete; G window no longer needed
+        GML_T(4);
 
         if (p.dval) {
             if constexpr (S % 4 == 0) {
@@ -246,6 +264,17 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
             f32x4 dxa[NFB];
 #pragma unroll
             for (int fb = 0; fb < NFB; ++fb) dxa[fb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.flags & GML_ACCUM) {                       // accumulate: the old values travel while the MFMAs run
+#pragma unroll
+                for (int fb = 0; fb < NFB; ++fb) {
+                    const int f = fb * 16 + r16;
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {      // clamped, unconditional loads (lanes outside are never stored)
+                        const int lr = min(wave * 16 + 4 * kq + reg, nr - 1);
+                        dxa[fb][reg] = p.dx[(r0 + lr) * p.lddx + min(f, p.Fin - 1)];
+                    }
+                }
+            }
 #pragma unroll
             for (int s = 0; s < S; ++s) {
                 const float pv[8] = {P[s][0].x, P[s][0].y, P[s][1].x, P[s][1].y, P[s][2].x, P[s][2].y, P[s][3].x, P[s][3].y};
@@ -262,46 +291,48 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
                     dxa[fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, bh, dxa[fb], 0, 0, 0);
                 }
             }
-            if (p.flags & GML_ACCUM) {
 #pragma unroll
-                for (int fb = 0; fb < NFB; ++fb) {
-                    const int f = fb * 16 + r16;
-                    float old[4];
+            for (int fb = 0; fb < NFB; ++fb) {
+                const int f = fb * 16 + r16;
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) {
-                        const int lr = wave * 16 + 4 * kq + reg;
-                        old[reg] = (f < p.Fin && lr < nr) ? p.dx[(r0 + lr) * p.lddx + f] : 0.f;
-                    }
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) {
-                        const int lr = wave * 16 + 4 * kq + reg;
-                        if (f < p.Fin && lr < nr) p.dx[(r0 + lr) * p.lddx + f] = dxa[fb][reg] + old[reg];
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int fb = 0; fb < NFB; ++fb) {
-                    const int f = fb * 16 + r16;
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) {
-                        const int lr = wave * 16 + 4 * kq + reg;
-                        if (f < p.Fin && lr < nr) p.dx[(r0 + lr) * p.lddx + f] = dxa[fb][reg];
-                    }
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int lr = wave * 16 + 4 * kq + reg;
+                    if (f < p.Fin && lr < nr) p.dx[(r0 + lr) * p.lddx + f] = dxa[fb][reg];
                 }
             }
         }
 
+        GML_T(5);
         // ---- dW += X^T P over the 128 rows of the group
         if (p.dw_partial) {
-            // X^T tile (bf16 hi, lo) [f][row]: lane writes its 8 features of its row.  Inside a tile row the 128
-            // row positions are rotated by 16 * ((f or o) >> 3): the four kq lane groups, which write f (o) = 8*kq + t
-            // at the same time, then hit disjoint banks (un-rotated they are exactly 0 mod 32 banks apart).
-            const int rrow = (row + 16 * kq) & (ROWS - 1);
+            // X^T / P^T tiles (bf16 hi, lo) [f or o][row] for the row contraction.  The 16 x 32 register tile of a wave
+            // (lane (row, kq): 8 consecutive features) is transposed ON THE MATRIX CORES: tile x [0/1 selection of one
+            // 16-wide block] leaves, in lane (column n, g), rows 4g..4g+3 of feature 16*blk + n -- exact (the values
+            // are bf16 numbers) -- which go to LDS as ONE 8-byte store per block and image instead of eight 2-byte ones.
+            bf16x8 sel[2];
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                xT_h[(8 * kq + t) * LDT + rrow] = xh[t];
-                xT_l[(8 * kq + t) * LDT + rrow] = xl[t];
+            for (int blk = 0; blk < 2; ++blk) {
+                uint32_t u[4];
+#pragma unroll
+                for (int j2 = 0; j2 < 4; ++j2) {
+                    const int f0 = 8 * kq + 2 * j2 - 16 * blk;
+                    u[j2] = (f0 == r16 ? 0x3F80u : 0u) | (f0 + 1 == r16 ? 0x3F800000u : 0u);
+                }
+                sel[blk] = __builtin_bit_cast(bf16x8, u32x4_t{u[0], u[1], u[2], u[3]});
             }
+            auto put_t = [&](const bf16x8 a, __bf16* dst_row0) {     // dst_row0: image + first channel row of block 0
+                const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) {
+                    const f32x4 t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, sel[blk], z4, 0, 0, 0);
+                    const bf16x2 p01 = __builtin_convertvector(f32x2{t[0], t[1]}, bf16x2);
+                    const bf16x2 p23 = __builtin_convertvector(f32x2{t[2], t[3]}, bf16x2);
+                    uint32_t w2[2] = {__builtin_bit_cast(uint32_t, p01), __builtin_bit_cast(uint32_t, p23)};
+                    *reinterpret_cast<uint2*>(dst_row0 + (16 * blk + r16) * LDT + wave * 16 + 4 * kq) = uint2{w2[0], w2[1]};
+                }
+            };
+            put_t(xh, xT_h);
+            put_t(xl, xT_l);
 #pragma unroll
             for (int sl = 0; sl < C::NSLAB; ++sl) {
                 __syncthreads();                             // slab buffer free: the dval copy-out (sl == 0) or the
@@ -312,11 +343,8 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
                     const float pv[8] = {P[s][0].x, P[s][0].y, P[s][1].x, P[s][1].y, P[s][2].x, P[s][2].y, P[s][3].x, P[s][3].y};
                     bf16x8 ph, pl;
                     gml_split8(pv, ph, pl);
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-                        pT_h[(se * 32 + 8 * kq + t) * LDT + rrow] = ph[t];
-                        pT_l[(se * 32 + 8 * kq + t) * LDT + rrow] = pl[t];
-                    }
+                    put_t(ph, pT_h + se * 32 * LDT);
+                    put_t(pl, pT_l + se * 32 * LDT);
                 }
                 __syncthreads();
                 if (wave < C::SE * NFB * 2) {
@@ -324,9 +352,8 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
                     f32x4 d = dwacc[sl];
 #pragma unroll
                     for (int st = 0; st < ROWS / 32; ++st) {
-                        const int rot = 16 * ((r16 >> 3) & 1);      // (f >> 3) & 3 = 2*fb + (r16 >> 3), likewise for o
-                        const int xo = (fb * 16 + r16) * LDT + ((32 * st + 8 * kq + 32 * fb + rot) & (ROWS - 1));            // A[i = f][k = row]
-                        const int po = (se * 32 + ob * 16 + r16) * LDT + ((32 * st + 8 * kq + 32 * ob + rot) & (ROWS - 1));  // B[k = row][j = o]
+                        const int xo = (fb * 16 + r16) * LDT + 32 * st + 8 * kq;                 // A[i = f][k = row]
+                        const int po = (se * 32 + ob * 16 + r16) * LDT + 32 * st + 8 * kq;       // B[k = row][j = o]
                         const bf16x8 ah = *reinterpret_cast<const bf16x8*>(xT_h + xo);
                         const bf16x8 al = *reinterpret_cast<const bf16x8*>(xT_l + xo);
                         const bf16x8 bh = *reinterpret_cast<const bf16x8*>(pT_h + po);
@@ -341,6 +368,7 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
         }
     }
 
+    GML_T(6);
     // ---- one dW partial per workgroup: wave w holds, per slab, block (se, fb, ob): D[i = f][j = o]
     if (p.dw_partial && g0 < g1 && wave < C::SE * NFB * 2) {
         float* out = p.dw_partial + (int64_t)wg * S * p.Fin * p.Fout;
