@@ -81,3 +81,22 @@ __device__ __forceinline__ void gml_split8(const float (&x)[8], bf16x8& hi, bf16
         lo[2 * i] = l[0]; lo[2 * i + 1] = l[1];
     }
 }
+
+// sum of partial[w * n + j] over w = wl, wl + 16, ... < nparts in ascending order (the fixed order of every
+// partial fold), eight clamped, unconditional loads in flight per step instead of one dependent load per add
+__device__ __forceinline__ float gml_fold_column(const float* __restrict__ partial, int64_t nparts, int64_t n,
+                                                 int64_t j, int wl) {
+    float a = 0.f;
+    for (int64_t w = wl; w < nparts; w += 16 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t w2 = w + 16 * u;
+            v[u] = partial[(w2 < nparts ? w2 : nparts - 1) * n + j];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (w + 16 * u < nparts) a += v[u];
+    }
+    return a;
+}

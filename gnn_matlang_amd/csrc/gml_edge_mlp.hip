@@ -33,8 +33,7 @@ __global__ __launch_bounds__(256) void gml_k_reduce_partials(const float* __rest
     const int jl = threadIdx.x & 15, wl = threadIdx.x >> 4;
     const int j = blockIdx.x * 16 + jl;
     float a = 0.f;
-    if (j < nw)
-        for (int64_t w = wl; w < nwaves; w += 16) a += partial[w * nw + j];
+    if (j < nw) a = gml_fold_column(partial, nwaves, nw, j, wl);
     red[wl][jl] = a;
     __syncthreads();
     if (wl == 0 && j < nw) {

@@ -180,8 +180,7 @@ __global__ __launch_bounds__(256) void gml_k_node_mix_fold(const float* __restri
     const int jl = threadIdx.x & 15, wl = threadIdx.x >> 4;
     const int j = blockIdx.x * 16 + jl;
     float a = 0.f;
-    if (j < n)
-        for (int64_t w = wl; w < nparts; w += 16) a += partial[w * n + j];
+    if (j < n) a = gml_fold_column(partial, nparts, n, j, wl);
     red[wl][jl] = a;
     __syncthreads();
     if (wl != 0 || j >= n) return;

@@ -275,8 +275,7 @@ __global__ __launch_bounds__(256) void gml_k_split_fold(const float* __restrict_
     const int jl = threadIdx.x & 15, wl = threadIdx.x >> 4;
     const int j = blockIdx.x * 16 + jl;
     float a = 0.f;
-    if (j < n)
-        for (int64_t w = wl; w < nparts; w += 16) a += partial[w * n + j];
+    if (j < n) a = gml_fold_column(partial, nparts, n, j, wl);
     red[wl][jl] = a;
     __syncthreads();
     if (wl != 0 || j >= n) return;
