@@ -53,10 +53,46 @@ __device__ __forceinline__ bf16x8 gml_wop(const float (&v)[8], bool lo_image) {
 }
 #define GML_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
+// Splitting is the VALU cost of this design (convert, unpack, subtract, convert per value); the subtraction is moved
+// to the matrix pipe: for two tiles xa, xb in D layout, H = (hi(xa) pairs, hi(xb) pairs) is at once the B operand
+// k-slots [tile a rows | tile b rows], so  xa - hi(xa) = [-I | 0] x H + xa  and  xb - hi(xb) = [0 | -I] x H + xb  are two
+// MFMAs with constant A operands (exact: the products are single bf16 values, the sum is representable).
+struct GmlNegI {
+    bf16x8 first, second;     // [-I | 0], [0 | -I]: A[row][slot (g, j)] = -1 iff row = 4g + (j & 3) in that half
+};
+__device__ __forceinline__ void gml_chain_make_negI(GmlNegI& N, int c16, int g) {
+    float va[8], vb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float d = (c16 == 4 * g + (j & 3)) ? -1.f : 0.f;
+        va[j] = j < 4 ? d : 0.f;
+        vb[j] = j < 4 ? 0.f : d;
+    }
+    N.first = gml_wop(va, false);
+    N.second = gml_wop(vb, false);
+}
+// (xa, xb) -> hi = (a01, a23, b01, b23), lo likewise
+__device__ __forceinline__ void gml_split_pair(const GmlNegI& N, const f32x4 xa, const f32x4 xb, u32x4& hi, u32x4& lo) {
+    hi = u32x4{gml_pack2(xa[0], xa[1]), gml_pack2(xa[2], xa[3]), gml_pack2(xb[0], xb[1]), gml_pack2(xb[2], xb[3])};
+    const bf16x8 H = __builtin_bit_cast(bf16x8, hi);
+    const f32x4 ra = GML_MFMA(N.first, H, xa);
+    const f32x4 rb = GML_MFMA(N.second, H, xb);
+    lo = u32x4{gml_pack2(ra[0], ra[1]), gml_pack2(ra[2], ra[3]), gml_pack2(rb[0], rb[1]), gml_pack2(rb[2], rb[3])};
+}
+// one tile -> [hi | lo] (the k-slot layout of the short-contraction operands and of the transposes)
+__device__ __forceinline__ u32x4 gml_split_one(const GmlNegI& N, const f32x4 x) {
+    u32x4 t = u32x4{gml_pack2(x[0], x[1]), gml_pack2(x[2], x[3]), 0u, 0u};
+    const f32x4 r = GML_MFMA(N.first, __builtin_bit_cast(bf16x8, t), x);
+    t.z = gml_pack2(r[0], r[1]);
+    t.w = gml_pack2(r[2], r[3]);
+    return t;
+}
+
 template <int S>
 struct GmlChainW {            // weight operands of one wave (registers)
     bf16x8 a1[3];             // layer 1: W1, W2, W3 rows (k = in-channel; groups 0,1 hi / 2,3 lo)
     bf16x8 a2h, a2l;          // layer 2: W4 (k = [h1 4g..4g+3 | h23 4g..4g+3]); rows 8..15 repeat rows 0..7
+    GmlNegI negI;
 };
 
 template <int S>
@@ -68,8 +104,10 @@ __device__ __forceinline__ void gml_chain_load_fwd_weights(GmlChainW<S>& W, cons
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
         float v[8];
+        // W2, W3 carry the 2 log2(e) of tanh(z) = 1 - 2 / (2^(2 log2(e) z) + 1): one multiply less per tanh
+        const float sc = b == 0 ? 1.f : 2.8853900817779268f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (c16 < H2 && j < S) ? w123[b][c16 * S + j] : 0.f;
+        for (int j = 0; j < 8; ++j) v[j] = (c16 < H2 && j < S) ? w123[b][c16 * S + j] * sc : 0.f;
         W.a1[b] = gml_wop(v, g >= 2);
     }
     {
@@ -85,6 +123,7 @@ __device__ __forceinline__ void gml_chain_load_fwd_weights(GmlChainW<S>& W, cons
         W.a2h = gml_wop(v, false);
         W.a2l = gml_wop(v, true);
     }
+    gml_chain_make_negI(W.negI, c16, g);
 }
 
 // per-tile forward state kept for the backward
@@ -120,7 +159,10 @@ __device__ __forceinline__ void gml_chain_load_e(const float* __restrict__ ea, i
     }
 }
 
-template <int S>
+// RES: residuals of the h split on the matrix pipe (backward kernel, VALU-issue-bound) or on the VALU (forward kernel,
+// store-bound: the extra MFMA round trip only lengthens its dependency chain).  Both give the same bits (the
+// subtraction is exact either way), so the relu mask recomputed by the backward matches the forward's.
+template <int S, bool RES>
 __device__ __forceinline__ void gml_chain_forward(const GmlChainW<S>& W, GmlChainT& T, int g) {
     // layer 1 operand: even lane groups carry hi(e), odd ones lo(e)  ->  (Whi + Wlo)(ehi + elo) in one MFMA
     uint32_t b1[4];
@@ -137,19 +179,23 @@ __device__ __forceinline__ void gml_chain_forward(const GmlChainW<S>& W, GmlChai
     T.z1 = GML_MFMA(W.a1[0], B1, zero);
     const f32x4 z2 = GML_MFMA(W.a1[1], B1, zero);
     const f32x4 z3 = GML_MFMA(W.a1[2], B1, zero);
-    float h1[4], h23[4];
+    f32x4 h1, h23;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        T.t2[r] = gml_tanh(z2[r]);
-        T.t3[r] = gml_tanh(z3[r]);
+    for (int r = 0; r < 4; ++r) {                            // z2, z3 arrive pre-scaled by 2 log2(e)
+        T.t2[r] = fmaf(-2.f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(z2[r]) + 1.f), 1.f);
+        T.t3[r] = fmaf(-2.f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(z3[r]) + 1.f), 1.f);
         h1[r] = fmaxf(T.z1[r], 0.f);
         h23[r] = T.t2[r] * T.t3[r];
     }
-    uint32_t h1h[2], h1l[2], h23h[2], h23l[2];
-    gml_split4(h1, h1h, h1l);
-    gml_split4(h23, h23h, h23l);
-    T.hh = u32x4{h1h[0], h1h[1], h23h[0], h23h[1]};
-    T.hl = u32x4{h1l[0], h1l[1], h23l[0], h23l[1]};
+    if constexpr (RES) {
+        gml_split_pair(W.negI, h1, h23, T.hh, T.hl);
+    } else {
+        uint32_t h1h[2], h1l[2], h23h[2], h23l[2];
+        gml_split4v(h1, h1h, h1l);
+        gml_split4v(h23, h23h, h23l);
+        T.hh = u32x4{h1h[0], h1h[1], h23h[0], h23h[1]};
+        T.hl = u32x4{h1l[0], h1l[1], h23l[0], h23l[1]};
+    }
     const bf16x8 B2h = __builtin_bit_cast(bf16x8, T.hh);
     const bf16x8 B2l = __builtin_bit_cast(bf16x8, T.hl);
     f32x4 o = GML_MFMA(W.a2l, B2h, zero);
@@ -182,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void gml_k_edge_chain_fwd(const float* __re
             if (out_t != nullptr && valid[u] && g >= 2) tp[u] = tpos[eid[u]];
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) gml_chain_forward<S>(W, T[u], g);
+        for (int u = 0; u < 2; ++u) gml_chain_forward<S, false>(W, T[u], g);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             if (!valid[u]) continue;
@@ -209,13 +255,10 @@ __global__ __launch_bounds__(256, 2) void gml_k_edge_chain_fwd(const float* __re
 template <int S, bool GIN>
 struct GmlChainWB {
     bf16x8 a3[2];             // W4^T blocks (h1 part, h23 part): k = q, groups 0,1 hi / 2,3 lo, slots [q | q]
-    bf16x8 a5[GIN ? 5 : 1];   // [W1|W2|W3]^T half-operands for d e (see below)
+    bf16x8 a5[GIN ? 4 : 1];   // [W1|W2|W3]^T operands for d e: [H1|H2], [L1|L2], [H3|0], [L3|0]
     bf16x8 bIh, bIl;          // [I ; 0] and [0 ; I]: transposes of the hi / the lo image of a split tile
 };
 
-#ifndef GML_CHAIN_BWD_OCC
-#define GML_CHAIN_BWD_OCC 2
-#endif
 #define GML_CHAIN_NW(S) (6 * (S) * (S) + 4 * (S) * (S))
 
 // the lane's inputs of one 16-edge tile: the e row (all 8 values) and 4 values of the gout row
@@ -241,7 +284,7 @@ __device__ __forceinline__ void gml_chain_load_eg(const float* __restrict__ ea, 
 }
 
 template <int S, bool GIN>
-__global__ __launch_bounds__(256, GML_CHAIN_BWD_OCC) void gml_k_edge_chain_bwd(
+__global__ __launch_bounds__(256, 3) void gml_k_edge_chain_bwd(
     const float* __restrict__ ea, const float* __restrict__ w1, const float* __restrict__ w2,
     const float* __restrict__ w3, const float* __restrict__ w4, const float* __restrict__ gout,
     float* __restrict__ gin, float* __restrict__ partial, int64_t E, int64_t ntiles) {
@@ -264,8 +307,9 @@ __global__ __launch_bounds__(256, GML_CHAIN_BWD_OCC) void gml_k_edge_chain_bwd(
         WB.a3[blk] = gml_wop(v, g >= 2);
     }
     if constexpr (GIN) {
-        // d e[in] = sum_b sum_z Wb[z][in] gz_b[z]: nine half-operand products (3 tiles x {hi.hi, hi.lo, lo.hi})
-        // packed into five K = 32 instructions:  [H1|H2] [H3|H1] [H2|H3] hi-weights, [L1|L2] [L3|0] lo-weights
+        // d e[in] = sum_b sum_z Wb[z][in] gz_b[z]: the gz tiles are split in pairs (gz1, gz2), (gz3, y), so the nine
+        // significant products take six K = 32 instructions:  [H1|H2].(hi12, lo12), [L1|L2].hi12, [H3|0].(hi3y, lo3y),
+        // [L3|0].hi3y   (the zero half ignores the y slots)
         const int in = c16 & 7;
         float wv[3][4];
         const float* w123[3] = {w1, w2, w3};
@@ -276,17 +320,16 @@ __global__ __launch_bounds__(256, GML_CHAIN_BWD_OCC) void gml_k_edge_chain_bwd(
                 const int z = 4 * g + j;
                 wv[b][j] = (in < S && z < H2) ? w123[b][z * S + in] : 0.f;
             }
-        constexpr int pa[5] = {0, 2, 1, 0, 2}, pb[5] = {1, 0, 2, 1, -1};
+        float v12[8], v3[8];
 #pragma unroll
-        for (int m = 0; m < 5; ++m) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v[j] = wv[pa[m]][j];
-                v[4 + j] = pb[m] >= 0 ? wv[pb[m] >= 0 ? pb[m] : 0][j] : 0.f;
-            }
-            WB.a5[m] = gml_wop(v, m >= 3);
+        for (int j = 0; j < 4; ++j) {
+            v12[j] = wv[0][j]; v12[4 + j] = wv[1][j];
+            v3[j] = wv[2][j]; v3[4 + j] = 0.f;
         }
+        WB.a5[0] = gml_wop(v12, false);
+        WB.a5[1] = gml_wop(v12, true);
+        WB.a5[2] = gml_wop(v3, false);
+        WB.a5[3] = gml_wop(v3, true);
     }
     {
         float vh[8], vl[8];
@@ -304,13 +347,16 @@ __global__ __launch_bounds__(256, GML_CHAIN_BWD_OCC) void gml_k_edge_chain_bwd(
 #pragma unroll
     for (int b = 0; b < 5; ++b) acc[b] = zero;
 
-    // transposed split tile: lane (channel = c16, g) gets [hi | lo] of edges 4g..4g+3 -- exact, the transposed
-    // values are bf16 numbers, so the repack is a plain conversion
-    auto transpose = [&](uint32_t h0, uint32_t h1, uint32_t l0, uint32_t l1) -> bf16x8 {
-        const bf16x8 A = gml_op(h0, h1, l0, l1);
-        const f32x4 th = GML_MFMA(A, WB.bIh, zero);
-        const f32x4 tl = GML_MFMA(A, WB.bIl, zero);
+    // transposed split tiles: lane (channel = c16, g) gets [hi | lo] of edges 4g..4g+3 -- exact, the transposed values
+    // are bf16 numbers, so the repack is a plain conversion.  The operands are the pair tuples as they are:
+    // [I ; 0] selects the first tile of a tuple, [0 ; I] the second.
+    auto repack = [&](const f32x4 th, const f32x4 tl) -> bf16x8 {
         return gml_op(gml_pack2(th[0], th[1]), gml_pack2(th[2], th[3]), gml_pack2(tl[0], tl[1]), gml_pack2(tl[2], tl[3]));
+    };
+    auto transpose_pair = [&](const u32x4 hi, const u32x4 lo, bf16x8& xa, bf16x8& xb) {
+        const bf16x8 H = __builtin_bit_cast(bf16x8, hi), L = __builtin_bit_cast(bf16x8, lo);
+        xa = repack(GML_MFMA(H, WB.bIh, zero), GML_MFMA(L, WB.bIh, zero));
+        xb = repack(GML_MFMA(H, WB.bIl, zero), GML_MFMA(L, WB.bIl, zero));
     };
 
     const int64_t stride = (int64_t)gridDim.x * 4;
@@ -330,31 +376,34 @@ __global__ __launch_bounds__(256, GML_CHAIN_BWD_OCC) void gml_k_edge_chain_bwd(
             const int64_t tn = t + stride, en = tn * 16 + c16;
             gml_chain_load_eg<S>(ea, gout, en, tn < ntiles && en < E, q0, e_n, g_n);
         }
-        gml_chain_forward<S>(W, T, g);
-        float go[4];
+        gml_chain_forward<S, true>(W, T, g);
+        f32x4 go;
 #pragma unroll
         for (int r = 0; r < 4; ++r) go[r] = (T.out[r] > 0.f) ? gq[r] : 0.f;
-        uint32_t goh[2], gol[2];
-        gml_split4(go, goh, gol);
-        const bf16x8 B3 = gml_op(goh[0], goh[1], gol[0], gol[1]);
+        const bf16x8 B3 = __builtin_bit_cast(bf16x8, gml_split_one(W.negI, go));      // [go hi | go lo]
         const f32x4 dh1 = GML_MFMA(WB.a3[0], B3, zero);
         const f32x4 dh23 = GML_MFMA(WB.a3[1], B3, zero);
-        float gz[3][4];
+        f32x4 gz1, gz2, gz3, y;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            gz[0][r] = (T.z1[r] > 0.f) ? dh1[r] : 0.f;
-            gz[1][r] = dh23[r] * T.t3[r] * fmaf(-T.t2[r], T.t2[r], 1.f);
-            gz[2][r] = dh23[r] * T.t2[r] * fmaf(-T.t3[r], T.t3[r], 1.f);
+            gz1[r] = (T.z1[r] > 0.f) ? dh1[r] : 0.f;
+            gz2[r] = dh23[r] * T.t3[r] * fmaf(-T.t2[r], T.t2[r], 1.f);
+            gz3[r] = dh23[r] * T.t2[r] * fmaf(-T.t3[r], T.t3[r], 1.f);
+            // [go | e] tile: rows 0..7 = go (lane groups 0,1), rows 8..15 = e (lane groups 2,3)
+            y[r] = (g < 2) ? go[r] : ((g & 1) ? T.e[4 + r] : T.e[r]);
         }
-        uint32_t gh[3][2], gl[3][2];
-#pragma unroll
-        for (int b = 0; b < 3; ++b) gml_split4(gz[b], gh[b], gl[b]);
+        u32x4 g12h, g12l, g3yh, g3yl;
+        gml_split_pair(W.negI, gz1, gz2, g12h, g12l);
+        gml_split_pair(W.negI, gz3, y, g3yh, g3yl);
         if constexpr (GIN) {
-            f32x4 de = GML_MFMA(WB.a5[0], gml_op(gh[0][0], gh[0][1], gh[1][0], gh[1][1]), zero);
-            de = GML_MFMA(WB.a5[1], gml_op(gh[2][0], gh[2][1], gl[0][0], gl[0][1]), de);
-            de = GML_MFMA(WB.a5[2], gml_op(gl[1][0], gl[1][1], gl[2][0], gl[2][1]), de);
-            de = GML_MFMA(WB.a5[3], gml_op(gh[0][0], gh[0][1], gh[1][0], gh[1][1]), de);
-            de = GML_MFMA(WB.a5[4], gml_op(gh[2][0], gh[2][1], 0u, 0u), de);
+            const bf16x8 H12 = __builtin_bit_cast(bf16x8, g12h), L12 = __builtin_bit_cast(bf16x8, g12l);
+            const bf16x8 H3y = __builtin_bit_cast(bf16x8, g3yh), L3y = __builtin_bit_cast(bf16x8, g3yl);
+            f32x4 de = GML_MFMA(WB.a5[1], H12, zero);
+            de = GML_MFMA(WB.a5[3], H3y, de);
+            de = GML_MFMA(WB.a5[0], L12, de);
+            de = GML_MFMA(WB.a5[2], L3y, de);
+            de = GML_MFMA(WB.a5[0], H12, de);
+            de = GML_MFMA(WB.a5[2], H3y, de);
             if (valid && g < 2) {          // rows 4g + r = in-channel (rows 8..15 repeat 0..7)
                 float* dp = gin + eid * S + 4 * g;
                 if constexpr (S % 4 == 0) {
@@ -366,25 +415,19 @@ __global__ __launch_bounds__(256, GML_CHAIN_BWD_OCC) void gml_k_edge_chain_bwd(
                 }
             }
         }
-        // [go | e] tile: rows 0..7 = go (lane groups 0,1), rows 8..15 = e (lane groups 2,3)
-        float y[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) y[r] = (g < 2) ? go[r] : ((g & 1) ? T.e[4 + r] : T.e[r]);
-        uint32_t yh[2], yl[2];
-        gml_split4(y, yh, yl);
         // weight gradients of the 16 edges: k-slots (g, j < 4) = hi, (g, j >= 4) = lo of edge 4g + (j & 3);
         //   X.[Yh | Yh] = Xh Yh + Xl Yh ,  X.[Yl | 0] = Xh Yl
-        const u32x4 YT = __builtin_bit_cast(u32x4, transpose(yh[0], yh[1], yl[0], yl[1]));
+        bf16x8 XT[5], YTb;
+        transpose_pair(T.hh, T.hl, XT[0], XT[1]);            // h1, h23
+        transpose_pair(g12h, g12l, XT[2], XT[3]);            // gz1, gz2
+        transpose_pair(g3yh, g3yl, XT[4], YTb);              // gz3, [go | e]
+        const u32x4 YT = __builtin_bit_cast(u32x4, YTb);
         const bf16x8 Bhh = gml_op(YT.x, YT.y, YT.x, YT.y);
         const bf16x8 Bl0 = gml_op(YT.z, YT.w, 0u, 0u);
 #pragma unroll
         for (int b = 0; b < 5; ++b) {
-            bf16x8 XT;
-            if (b == 0) XT = transpose(T.hh.x, T.hh.y, T.hl.x, T.hl.y);
-            else if (b == 1) XT = transpose(T.hh.z, T.hh.w, T.hl.z, T.hl.w);
-            else XT = transpose(gh[b - 2][0], gh[b - 2][1], gl[b - 2][0], gl[b - 2][1]);
-            acc[b] = GML_MFMA(XT, Bl0, acc[b]);
-            acc[b] = GML_MFMA(XT, Bhh, acc[b]);
+            acc[b] = GML_MFMA(XT[b], Bl0, acc[b]);
+            acc[b] = GML_MFMA(XT[b], Bhh, acc[b]);
         }
     }
 
@@ -420,7 +463,7 @@ __global__ void gml_k_reduce_partials(const float* __restrict__ partial, int64_t
                                       float* __restrict__ d0, int n0, float* __restrict__ d1, int n1,
                                       float* __restrict__ d2, int n2, float* __restrict__ d3, int n3);
 
-// persistent workgroups per CU: the register footprint allows 4 waves per SIMD without d e, 3 with it
+// persistent workgroups per CU: the register footprint (130..162) allows 3 waves per SIMD
 static inline int64_t gml_edge_chain_bwd_groups(int64_t E, int wgs_per_cu = 4) {
     const int64_t ntiles = gml_cdiv(E, 16);
     int64_t grid = gml_cdiv(ntiles, 4);
@@ -446,7 +489,7 @@ static inline int64_t gml_edge_chain_bwd_groups(int64_t E, int wgs_per_cu = 4) {
                                       float* dw3, float* dw4, int64_t E, void* ws, size_t ws_bytes,             \
                                       hipStream_t st) {                                                         \
         const int64_t npairs = gml_cdiv(E, 16); /* 16-edge tiles */                                             \
-        const int64_t grid = gml_edge_chain_bwd_groups(E, gin != nullptr ? 3 : 4);                                                      \
+        const int64_t grid = gml_edge_chain_bwd_groups(E, 3);                                                      \
         constexpr int NW = GML_CHAIN_NW(SV);                                                                    \
         if (ws_bytes < (size_t)grid * NW * sizeof(float)) return GML_E_WORKSPACE;                               \
         if (gin != nullptr)                                                                                     \
