@@ -259,7 +259,14 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
             }
         }
 
-        // ---- dX = P W^T: one K=32 step per support (k = o = 8*kq + i), P split on the fly
+        // P -> bf16 (hi, lo) once; the pairs are the A fragments of dX and the inputs of the dW transposes
+        bf16x8 PH[S], PL[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const float pv[8] = {P[s][0].x, P[s][0].y, P[s][1].x, P[s][1].y, P[s][2].x, P[s][2].y, P[s][3].x, P[s][3].y};
+            gml_split8(pv, PH[s], PL[s]);
+        }
+        // ---- dX = P W^T: one K=32 step per support (k = o = 8*kq + i)
         if (p.dx) {
             f32x4 dxa[NFB];
 #pragma unroll
@@ -277,9 +284,7 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
             }
 #pragma unroll
             for (int s = 0; s < S; ++s) {
-                const float pv[8] = {P[s][0].x, P[s][0].y, P[s][1].x, P[s][1].y, P[s][2].x, P[s][2].y, P[s][3].x, P[s][3].y};
-                bf16x8 ph, pl;
-                gml_split8(pv, ph, pl);
+                const bf16x8 ph = PH[s], pl = PL[s];
 #pragma unroll
                 for (int fb = 0; fb < NFB; ++fb) {
                     const int ff = fb * 16 + r16;                              // B[k = o][j = f]: 8 consecutive o of row f
@@ -340,11 +345,8 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
 #pragma unroll
                 for (int se = 0; se < C::SE; ++se) {
                     const int s = sl * C::SE + se;
-                    const float pv[8] = {P[s][0].x, P[s][0].y, P[s][1].x, P[s][1].y, P[s][2].x, P[s][2].y, P[s][3].x, P[s][3].y};
-                    bf16x8 ph, pl;
-                    gml_split8(pv, ph, pl);
-                    put_t(ph, pT_h + se * 32 * LDT);
-                    put_t(pl, pT_l + se * 32 * LDT);
+                    put_t(PH[s], pT_h + se * 32 * LDT);
+                    put_t(PL[s], pT_l + se * 32 * LDT);
                 }
                 __syncthreads();
                 if (wave < C::SE * NFB * 2) {
