@@ -62,19 +62,31 @@ __global__ __launch_bounds__(256) void gml_k_node_mix(const float* __restrict__ 
         const int64_t r0 = (int64_t)t * NM_ROWS;
         const int nr = (int)min((int64_t)NM_ROWS, nrows - r0);
         __syncthreads();
-        {                                                      // coalesced tile load: lane <-> feature, 256/FINP rows
+        if ((ldx & 3) == 0 && (((uintptr_t)x) & 15) == 0) {    // float4 rows: lane <-> 4 features, clamped unconditional loads
+            constexpr int FV = FINP / 4, RPS = 256 / FV, NIT = (NM_ROWS + RPS - 1) / RPS;
+            const int f = (tid % FV) * 4, rbase = tid / FV, fc = min(f, (Fin - 1) / 4 * 4);
+            f32x4 v[NIT];
+#pragma unroll
+            for (int j = 0; j < NIT; ++j)
+                v[j] = *reinterpret_cast<const f32x4*>(x + (r0 + min(rbase + j * RPS, nr - 1)) * ldx + fc);
+#pragma unroll
+            for (int j = 0; j < NIT; ++j) {
+                const int rr = rbase + j * RPS;
+                if (rr < NM_ROWS) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) xs[rr * LDX + f + k] = (rr < nr && f + k < Fin) ? v[j][k] : 0.f;
+                }
+            }
+        } else {                                               // coalesced tile load: lane <-> feature, 256/FINP rows
             constexpr int RPS = 256 / FINP, NIT = (NM_ROWS + RPS - 1) / RPS;   // per sweep; ALL loads in flight
-            const int f = tid % FINP, rbase = tid / FINP;
+            const int f = tid % FINP, rbase = tid / FINP, fc = min(f, Fin - 1);
             float v[NIT];
 #pragma unroll
-            for (int j = 0; j < NIT; ++j) {
-                const int rr = rbase + j * RPS;
-                v[j] = (rr < nr && f < Fin) ? x[(r0 + rr) * ldx + f] : 0.f;
-            }
+            for (int j = 0; j < NIT; ++j) v[j] = x[(r0 + min(rbase + j * RPS, nr - 1)) * ldx + fc];
 #pragma unroll
             for (int j = 0; j < NIT; ++j) {
                 const int rr = rbase + j * RPS;
-                if (rr < NM_ROWS) xs[rr * LDX + f] = v[j];
+                if (rr < NM_ROWS) xs[rr * LDX + f] = (rr < nr && f < Fin) ? v[j] : 0.f;
             }
         }
         __syncthreads();
@@ -304,7 +316,14 @@ __global__ void gml_k_segment_sum(const float* __restrict__ x, int64_t ldx, cons
     const int c = (int)(i % F);
     const int r0 = ptr[g], r1 = ptr[g + 1];
     float a = 0.f;
-    for (int r = r0; r < r1; ++r) a += x[(int64_t)r * ldx + c];
+    for (int r = r0; r < r1; r += 8) {                       // same ascending order, eight clamped loads in flight
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = x[(int64_t)min(r + u, r1 - 1) * ldx + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (r + u < r1) a += v[u];
+    }
     if (mean) a = a / (float)max(r1 - r0, 1);
     out[g * ldo + c] = a;
 }

@@ -399,13 +399,32 @@ __global__ __launch_bounds__(256) void gml_k_xty(const float* __restrict__ A, in
         const int64_t r0 = (int64_t)t * XTY_ROWS;
         const int nr = (int)min((int64_t)XTY_ROWS, n - r0);
         __syncthreads();
-        for (int i = tid; i < XTY_ROWS * LDA; i += 256) {
-            const int r = i / LDA, c = i - r * LDA;
-            As[i] = (r < nr && c < a) ? A[(r0 + r) * lda + c] : 0.f;
+        // coalesced tile loads, eight (clamped, unconditional) loads in flight per thread and operand
+        for (int i0 = tid; i0 < XTY_ROWS * LDA; i0 += 256 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + 256 * u, r = i / LDA, c = i - r * LDA;
+                v[u] = A[(r0 + min(r, nr - 1)) * lda + min(c, a - 1)];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + 256 * u, r = i / LDA, c = i - r * LDA;
+                if (i < XTY_ROWS * LDA) As[i] = (r < nr && c < a) ? v[u] : 0.f;
+            }
         }
-        for (int i = tid; i < XTY_ROWS * LDB; i += 256) {
-            const int r = i / LDB, c = i - r * LDB;
-            Bs[i] = (r < nr && c < b) ? B[(r0 + r) * ldb + c] : 0.f;
+        for (int i0 = tid; i0 < XTY_ROWS * LDB; i0 += 256 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + 256 * u, r = i / LDB, c = i - r * LDB;
+                v[u] = B[(r0 + min(r, nr - 1)) * ldb + min(c, b - 1)];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + 256 * u, r = i / LDB, c = i - r * LDB;
+                if (i < XTY_ROWS * LDB) Bs[i] = (r < nr && c < b) ? v[u] : 0.f;
+            }
         }
         __syncthreads();
         const int rb = wave * 64;
