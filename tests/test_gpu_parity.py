@@ -1,6 +1,8 @@
 """GPU parity: the HIP path (through the C ABI of libgml_hip.so) against the oracle and the golden
 vectors captured from the reference.  Tolerance: north_star's 1e-4 relative fp32
 (max|got-ref| / max|ref| <= 1e-4, conftest.rel_err); integer/index work bit-exact."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -167,6 +169,69 @@ def test_fused_forward_and_grads_vs_oracle(dev, S, fin, fout):
     close(eg.grad, eo.grad, what='g_edge_attr')
     close(m.weight.grad, wo.grad, what='g_weight')
     close(m.bias.grad, bo.grad, what='g_bias')
+
+
+def test_exact_fp32_mode_is_closer_to_the_oracle(dev):
+    """GML_F32_MFMA (f32-input MFMA: exact fp32 products) must agree with the oracle at fp32-roundoff level, an
+    order of magnitude tighter than the default bf16 hi/lo split is asked to."""
+    from gnn_matlang_amd import SpectConv, functional as Fn
+    from oracle import spect_conv_oracle as O
+    rng = np.random.default_rng(77)
+    torch.manual_seed(77)
+    N, S, fin, fout = 300, 8, 32, 30
+    ei = _random_graph(rng, N, 6)
+    ea, x = torch.randn(ei.shape[1], S), torch.randn(N, fin)
+    m = SpectConv(fin, fout, S, selfconn=False).to(dev)
+    w, b = m.weight.detach().cpu(), m.bias.detach().cpu()
+    xo, eo, wo = (t.clone().requires_grad_(True) for t in (x, ea, w))
+    yo = O.spectconv_forward(xo, T(ei), eo, wo, b, False)
+    gout = torch.randn_like(yo)
+    (yo * gout).sum().backward()
+    errs = {}
+    old = Fn.F32_MFMA
+    try:
+        for mode in (False, True):
+            Fn.F32_MFMA = mode
+            m.zero_grad()
+            xg, eg = x.to(dev).requires_grad_(True), ea.to(dev).requires_grad_(True)
+            y = m(xg, T(ei).to(dev), eg)
+            (y * gout.to(dev)).sum().backward()
+            errs[mode] = max(rel_err(y.detach().cpu().numpy(), yo.detach().numpy()),
+                             rel_err(xg.grad.cpu().numpy(), xo.grad.numpy()),
+                             rel_err(eg.grad.cpu().numpy(), eo.grad.numpy()),
+                             rel_err(m.weight.grad.cpu().numpy(), wo.grad.numpy()))
+    finally:
+        Fn.F32_MFMA = old
+    assert errs[True] <= 2e-6, errs
+    assert errs[False] <= TOL, errs
+
+
+def test_edge_branch_valu_kernels_via_environment(dev):
+    """GML_EDGE_VALU=1 (read once per process) routes S <= 8 to the one-edge-per-lane fp32 kernels: same results."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, torch, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from gnn_matlang_amd import functional as Fn\n"
+        "from oracle import spect_conv_oracle as O\n"
+        "torch.manual_seed(3)\n"
+        "S, E = 8, 3000\n"
+        "ea = torch.randn(E, S)\n"
+        "ws = [torch.randn(2 * S, S) * 0.7 for _ in range(3)] + [torch.randn(S, 4 * S) * 0.5]\n"
+        "eo = ea.clone().requires_grad_(True); wo = [w.clone().requires_grad_(True) for w in ws]\n"
+        "yo = O.edge_mlp_forward(eo, *wo); g = torch.randn_like(yo); (yo * g).sum().backward()\n"
+        "d = torch.device('cuda:0'); wd = [w.to(d) for w in ws]\n"
+        "y, _ = Fn.edge_mlp_fwd(ea.to(d), *wd)\n"
+        "r = Fn.edge_mlp_bwd(ea.to(d), *wd, g.to(d), True)\n"
+        "def rel(a, b): return float((a.cpu() - b).abs().max() / b.abs().max())\n"
+        "e = max([rel(y, yo.detach()), rel(r[0], eo.grad)] + [rel(r[i + 1], wo[i].grad) for i in range(4)])\n"
+        "print('MAXERR', e)\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, GML_EDGE_VALU='1')
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    err = float(out.stdout.strip().split('MAXERR')[-1])
+    assert err <= 2e-5, out.stdout
 
 
 def test_empty_and_tiny_inputs(dev):
