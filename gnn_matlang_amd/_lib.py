@@ -18,6 +18,7 @@ SIGNATURES = {
     'gml_csr_workspace_bytes': (_sz, [_i64, _i64]),
     'gml_csr_from_coo': (ctypes.c_int, [_p, _p, _i64, _i64, _p, _p, _p, _p, _sz, _p]),
     'gml_csr_link_transpose': (ctypes.c_int, [_p, _p, _i64, _p, _p, _p]),
+    'gml_csr_group_record_ints': (ctypes.c_int32, [_i32]),
     'gml_csr_group_info': (ctypes.c_int, [_p, _p, _i64, _i32, _p, _p]),
     'gml_gather_rows': (ctypes.c_int, [_p, _p, _p, _i64, _i32, _p]),
     'gml_scatter_rows': (ctypes.c_int, [_p, _p, _p, _i64, _i32, _p]),

@@ -170,18 +170,31 @@ extern "C" int gml_csr_link_transpose(const int32_t* perm_fwd, const int32_t* pe
 }
 
 // ---------------------------------------------------------------------------------------------
-// Per group of 64 (or 128) rows: {first edge, #edges, smallest column id, width of the column window}.  The fused
-// layer kernels read one 16-byte record per group and know at once which CSR slice / value rows / X
-// rows to prefetch (no dependent rowptr -> col -> min/max chain inside the hot kernel).
-__global__ __launch_bounds__(64) void gml_k_group_info(const int32_t* __restrict__ rowptr,
-                                                      const int32_t* __restrict__ col, int64_t nrows,
-                                                      int32_t group_rows, int32_t* __restrict__ ginfo) {
+// Per group of 64 (or 128) rows one record of GML_GREC_INTS(group_rows) ints:
+//   {first edge, #edges, smallest column id, width of the column window}  -- the fused layer kernels read these 16
+//   bytes and know at once which CSR slice / value rows / X rows to prefetch (no dependent rowptr -> col -> min/max
+//   chain inside the hot kernel);
+//   128-row groups only: order[128] bytes -- the row (local index) each lane position of the consuming kernel works on.  Rows are
+//   ranked by degree (descending, ties by index) so the 16 rows of a tile run near-equal edge loops (lane utilisation
+//   of the edge phase 0.59 -> 0.90 on ZINC-like supports); rank blocks are dealt to the waves so that the SIMDs
+//   stay balanced: 128-row groups (backward, 8 waves, waves w and w+4 share a SIMD) pair block a with block 7-a
+//   and rotate a with the group index.  64-row groups (forward: 4 waves, one tile per SIMD, a barrier per group)
+//   carry no order: concentrating the long rows in one tile lengthens the group's critical path by more than the
+//   shorter tiles save (measured +2.6 %).
+//   Which row a lane serves does not change any row's result (each row keeps its own edge order).
+__global__ __launch_bounds__(128) void gml_k_group_info(const int32_t* __restrict__ rowptr,
+                                                       const int32_t* __restrict__ col, int64_t nrows,
+                                                       int32_t group_rows, int32_t* __restrict__ ginfo) {
+    __shared__ int deg[128];
+    __shared__ int red[4];
+    __shared__ unsigned char row_of_rank[128];
+    const int t = threadIdx.x;
     const int64_t g = blockIdx.x;
     const int64_t r0 = g * group_rows;
     const int64_t r1 = min(r0 + group_rows, nrows);
     const int kb = rowptr[r0], ke = rowptr[r1];
     int mn = INT32_MAX, mx = -1;
-    for (int k = kb + (int)threadIdx.x; k < ke; k += 64) {
+    for (int k = kb + t; k < ke; k += 128) {
         const int c = col[k];
         mn = min(mn, c);
         mx = max(mx, c);
@@ -191,11 +204,36 @@ __global__ __launch_bounds__(64) void gml_k_group_info(const int32_t* __restrict
         mn = min(mn, __shfl_xor(mn, off));
         mx = max(mx, __shfl_xor(mx, off));
     }
-    if (threadIdx.x == 0) {
+    if ((t & 63) == 0) { red[2 * (t >> 6)] = mn; red[2 * (t >> 6) + 1] = mx; }
+    if (t < group_rows) deg[t] = (r0 + t < nrows) ? rowptr[r0 + t + 1] - rowptr[r0 + t] : -1;   // rows past the end rank last
+    __syncthreads();
+    int32_t* rec = ginfo + g * GML_GREC_INTS(group_rows);
+    if (t == 0) {
+        mn = min(red[0], red[2]);
+        mx = max(red[1], red[3]);
         int4 o;
         o.x = kb; o.y = ke - kb; o.z = (ke > kb) ? mn : 0; o.w = (ke > kb) ? mx - mn + 1 : 0;
-        reinterpret_cast<int4*>(ginfo)[g] = o;
+        *reinterpret_cast<int4*>(rec) = o;
     }
+    if (t < group_rows) {
+        const int d = deg[t];
+        int rank = 0;
+        for (int u = 0; u < group_rows; ++u) rank += (deg[u] > d || (deg[u] == d && u < t)) ? 1 : 0;
+        row_of_rank[rank] = (unsigned char)t;
+    }
+    __syncthreads();
+    if (t < group_rows) {
+        const int wave = t >> 4, i = t & 15;
+        if (group_rows == 128) {
+            const int a = ((wave & 3) + (int)g) & 3;
+            const int blk = (wave < 4) ? a : 7 - a;
+            reinterpret_cast<unsigned char*>(rec + 4)[t] = row_of_rank[blk * 16 + i];
+        }
+    }
+}
+
+extern "C" int32_t gml_csr_group_record_ints(int32_t group_rows) {
+    return (group_rows == 64 || group_rows == 128) ? GML_GREC_INTS(group_rows) : 0;
 }
 
 extern "C" int gml_csr_group_info(const int32_t* rowptr, const int32_t* col, int64_t num_rows, int32_t group_rows,
@@ -203,7 +241,7 @@ extern "C" int gml_csr_group_info(const int32_t* rowptr, const int32_t* col, int
     if (num_rows < 0 || (group_rows != 64 && group_rows != 128)) return GML_E_BADARG;
     if (num_rows == 0) return GML_OK;
     if (!rowptr || !ginfo) return GML_E_BADARG;
-    hipLaunchKernelGGL(gml_k_group_info, dim3((unsigned)gml_cdiv(num_rows, group_rows)), dim3(64), 0,
+    hipLaunchKernelGGL(gml_k_group_info, dim3((unsigned)gml_cdiv(num_rows, group_rows)), dim3(128), 0,
                        (hipStream_t)stream, rowptr, col, num_rows, group_rows, ginfo);
     return gml_launch_status();
 }

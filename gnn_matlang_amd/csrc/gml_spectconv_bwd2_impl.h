@@ -108,13 +108,16 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
     for (int g = g0; g < g1; ++g) {
         const int64_t r0 = (int64_t)g * ROWS;
         const int nr = (int)min((int64_t)ROWS, p.nrows - r0);
-        const int4 gi = reinterpret_cast<const int4*>(p.ginfo)[g];
+        const int32_t* rec = p.ginfo + (int64_t)g * GML_GREC_INTS(ROWS);
+        const int4 gi = *reinterpret_cast<const int4*>(rec);
         const int kb = gi.x, ne = gi.y, lo = gi.z, nwin = gi.w;
+        // degree-sorted row assignment: this lane's row, and the rows of its 4 dX output registers (one byte each)
+        const int row = reinterpret_cast<const unsigned char*>(rec + 4)[wave * 16 + r16];
+        const uint32_t out_rows = reinterpret_cast<const uint32_t*>(rec + 4)[wave * 4 + kq];
         __syncthreads();                                     // previous group is done with every LDS region
         GML_T(0);                                            // = previous group's dW phase + this barrier
 
         // ---- stage: every global load of the group is in flight before the first LDS write
-        const int row = wave * 16 + r16;                     // row of the group owned by this lane
         const bool rvalid = row < nr;
         float xb[8];
         {
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
                     const int f = fb * 16 + r16;
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {      // clamped, unconditional loads (lanes outside are never stored)
-                        const int lr = min(wave * 16 + 4 * kq + reg, nr - 1);
+                        const int lr = min((int)((out_rows >> (8 * reg)) & 255u), nr - 1);
                         dxa[fb][reg] = p.dx[(r0 + lr) * p.lddx + min(f, p.Fin - 1)];
                     }
                 }
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
                 const int f = fb * 16 + r16;
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
-                    const int lr = wave * 16 + 4 * kq + reg;
+                    const int lr = (int)((out_rows >> (8 * reg)) & 255u);
                     if (f < p.Fin && lr < nr) p.dx[(r0 + lr) * p.lddx + f] = dxa[fb][reg];
                 }
             }

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void gml_k_spectconv_bwd(const GmlBwdParams
     for (int g = g0; g < g1; ++g) {
         const int64_t r0 = (int64_t)g * 64;
         const int nr = (int)min((int64_t)64, p.nrows - r0);
-        const int4 gi = reinterpret_cast<const int4*>(p.ginfo)[g];
+        const int4 gi = *reinterpret_cast<const int4*>(p.ginfo + (int64_t)g * GML_GREC_INTS(64));   // row order unused here
         const int kb = gi.x, ne = gi.y, lo = gi.z, nwin = gi.w;
         __syncthreads();                                     // previous group is done with every LDS region
 

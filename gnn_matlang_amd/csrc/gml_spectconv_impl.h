@@ -42,7 +42,7 @@ struct GmlFwdParams {
     int32_t allw;        // whole W of this launch resident in LDS
     int32_t val_vec;     // value rows (S floats apart, starting at s0) keep the SC alignment class
     int32_t wfloats;     // floats of LDS reserved for W in front of the staging area
-    const int32_t* ginfo; // [ngroups][4] = {first edge, #edges, first column, column window} per 64-row group
+    const int32_t* ginfo; // [ngroups][GML_GREC_INTS(64)] records of gml_csr_group_info (64-row groups)
 };
 
 // Per-group staging capacities.  A group = 64 consecutive output rows = the 4 tiles a workgroup
@@ -134,7 +134,8 @@ __device__ __forceinline__ void gml_prefetch_issue(GmlPrefetch<SC, FPL>& q, cons
     constexpr int CH = PF::CH;
     const int64_t r0 = (int64_t)g * GML_GROUP;
     q.nr = (int)min((int64_t)GML_GROUP, p.nrows - r0);
-    const int4 gi = reinterpret_cast<const int4*>(p.ginfo)[g];                   // {kb, ne, lo, nwin}
+    const int32_t* rec = p.ginfo + (int64_t)g * GML_GREC_INTS(GML_GROUP);
+    const int4 gi = *reinterpret_cast<const int4*>(rec);                         // {kb, ne, lo, nwin}
     q.kb = gi.x; q.ne = gi.y; q.lo = gi.z; q.nwin = gi.w;
     q.staged = (q.ne <= GML_ECAP) && (q.nwin <= GML_XCAP) && (p.epos == nullptr);
     q.rp = (tid <= q.nr) ? p.rowptr[r0 + tid] : 0;

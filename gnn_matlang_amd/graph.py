@@ -71,9 +71,11 @@ class GraphCSR(object):
             g.tpos = torch.empty(E, **i32)
             _lib.call('gml_csr_link_transpose', _ptr(g.pos_t), _ptr(g.pos_t), E, _ptr(g.tpos), _ptr(inv), st)
             ng = max((N + 63) // 64, 1)
-            g.ginfo, g.ginfo_t = torch.zeros(ng, 4, **i32), torch.zeros(ng, 4, **i32)
+            rec64 = int(_lib.lib().gml_csr_group_record_ints(64))    # int32 per group record
+            rec128 = int(_lib.lib().gml_csr_group_record_ints(128))
+            g.ginfo, g.ginfo_t = torch.zeros(ng, rec64, **i32), torch.zeros(ng, rec64, **i32)
             ng2 = max((N + 127) // 128, 1)
-            g.ginfo_t128 = torch.zeros(ng2, 4, **i32)
+            g.ginfo_t128 = torch.zeros(ng2, rec128, **i32)
             _lib.call('gml_csr_group_info', _ptr(g.rowptr), _ptr(g.col), N, 64, _ptr(g.ginfo), st)
             _lib.call('gml_csr_group_info', _ptr(g.rowptr_t), _ptr(g.col_t), N, 64, _ptr(g.ginfo_t), st)
             _lib.call('gml_csr_group_info', _ptr(g.rowptr_t), _ptr(g.col_t), N, 128, _ptr(g.ginfo_t128), st)

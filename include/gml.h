@@ -68,9 +68,15 @@ int gml_csr_from_coo(const int64_t* key, const int64_t* other_in, int64_t num_no
  * source-sorted edge keeps its values.  inv_scratch: E int32. */
 int gml_csr_link_transpose(const int32_t* perm_fwd, const int32_t* perm_t, int64_t num_edges,
                            int32_t* inv_scratch, int32_t* pos_t, gml_stream_t stream);
-/* ginfo[g] = {first edge, #edges, smallest column id, column-window width} of the group g of `group_rows`
- * (64 or 128) consecutive rows (int32 x 4 x ceil(num_rows/group_rows)): the staging schedule of the fused
- * kernels (gml_spectconv_fwd: 64; gml_spectconv_bwd: gml_spectconv_bwd_group_rows()). */
+/* Group records: the staging schedule of the fused kernels (gml_spectconv_fwd: group_rows = 64;
+ * gml_spectconv_bwd: gml_spectconv_bwd_group_rows()).  One record of gml_csr_group_record_ints(group_rows) int32
+ * per group of `group_rows` (64 or 128) consecutive rows, ceil(num_rows / group_rows) records:
+ *   {first edge, #edges, smallest column id, column-window width},
+ *   128-row groups: then 128 bytes, the local row each lane position of the backward kernel works on -- rows ranked
+ *   by degree so that the 16 rows of a tile run near-equal edge loops, rank blocks dealt to the waves so the SIMDs
+ *   stay balanced (which lane serves a row never changes the row's result).
+ * Callers size LDS with the maxima of ints 1 and 3 over the records.  gml_csr_group_record_ints = int32 per record. */
+int32_t gml_csr_group_record_ints(int32_t group_rows);
 int gml_csr_group_info(const int32_t* rowptr, const int32_t* col, int64_t num_rows, int32_t group_rows,
                        int32_t* ginfo, gml_stream_t stream);
 /* out[k, :] = in[perm[k], :]   (rows of `width` floats) */
