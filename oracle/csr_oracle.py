@@ -43,3 +43,31 @@ def transpose_view(src, dst, num_nodes, perm):
     inv = np.empty(len(src), dtype=np.int64)
     inv[np.asarray(perm, dtype=np.int64)] = np.arange(len(src))
     return rowptr_t.astype(np.int32), dst[perm_t].astype(np.int32), inv[perm_t].astype(np.int32)
+
+
+def group_records(rowptr, col, num_rows, group_rows):
+    """Per-group staging records of gml_csr_group_info (include/gml.h): {first edge, #edges, smallest column id,
+    column-window width}; for 128-row groups also the degree-ranked row order the backward kernel's lane positions use:
+    rows ranked by (degree descending, index ascending), rows past the end last; rank block `a` goes to wave a's
+    position block and block 7-a to wave a+4's, with a = ((wave & 3) + group) & 3."""
+    rowptr, col = np.asarray(rowptr), np.asarray(col)
+    ng = max((num_rows + group_rows - 1) // group_rows, 1) if num_rows > 0 else 0
+    info = np.zeros((ng, 4), np.int64)
+    order = np.zeros((ng, group_rows), np.int64)
+    for g in range(ng):
+        r0, r1 = g * group_rows, min((g + 1) * group_rows, num_rows)
+        kb, ke = int(rowptr[r0]), int(rowptr[r1])
+        c = col[kb:ke]
+        info[g] = (kb, ke - kb, c.min() if ke > kb else 0, c.max() - c.min() + 1 if ke > kb else 0)
+        deg = np.full(group_rows, -1, np.int64)
+        deg[:r1 - r0] = rowptr[r0 + 1:r1 + 1] - rowptr[r0:r1]
+        row_of_rank = np.lexsort((np.arange(group_rows), -deg))
+        for pos in range(group_rows):
+            wave, i = pos >> 4, pos & 15
+            if group_rows == 128:
+                a = ((wave & 3) + g) & 3
+                blk = a if wave < 4 else 7 - a
+                order[g, pos] = row_of_rank[blk * 16 + i]
+            else:
+                order[g, pos] = pos
+    return info, order

@@ -46,6 +46,16 @@ def _csr_check(ei, N, dev):
     for got, ref, name in ((g.rowptr, rowptr, 'rowptr'), (g.col, col, 'col'), (g.perm, perm, 'perm'),
                            (g.rowptr_t, rp_t, 'rowptr_t'), (g.col_t, col_t, 'col_t'), (g.pos_t, pos_t, 'pos_t')):
         assert np.array_equal(got.cpu().numpy(), ref), name          # integer work: bit-exact
+    from oracle.csr_oracle import group_records
+    for rec, rp, cl, rows, name in ((g.ginfo, rowptr, col, 64, 'ginfo'), (g.ginfo_t, rp_t, col_t, 64, 'ginfo_t'),
+                                    (g.ginfo_t128, rp_t, col_t, 128, 'ginfo_t128')):
+        info, order = group_records(rp, cl, N, rows)
+        got = rec.cpu().numpy()
+        assert np.array_equal(got[:, :4], info), name
+        if rows == 128:                                               # lane position -> row bytes: a permutation per group
+            ob = got[:, 4:].astype(np.int32).view(np.uint8).reshape(got.shape[0], -1)[:, :128]
+            assert np.array_equal(ob, order), name + ' order'
+            assert all(sorted(r.tolist()) == list(range(128)) for r in ob), name + ' not a permutation'
 
 
 def test_csr_bit_exact(dev, golden):
