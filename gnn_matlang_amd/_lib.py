@@ -40,6 +40,9 @@ SIGNATURES = {
     'gml_relu_bwd': (ctypes.c_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i32, _p]),
     'gml_segment_sum': (ctypes.c_int, [_p, _i64, _p, _p, _i64, _i64, _i32, _i32, _p]),
     'gml_segment_bcast': (ctypes.c_int, [_p, _i64, _p, _p, _i64, _i64, _i32, _i32, _p]),
+    'gml_spectral_count': (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i32, _i32, _p, _p]),
+    'gml_spectral_design': (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i32, _i32, _i32, ctypes.c_double, _i32, ctypes.c_double,
+                                           _i32, _i32, _p, _i64, _p, _p, _p, _p]),
     'gml_xty_workspace_bytes': (_sz, [_i64, _i32, _i32]),
     'gml_xty': (ctypes.c_int, [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _p, _sz, _p]),
     'gml_ml3_split_bwd_workspace_bytes': (_sz, [_i64, _i32, _i32, _i32]),

@@ -95,6 +95,57 @@ class SpectralDesign(object):
                               lmax=lmax[k], y=graphs[i][2] if len(graphs[i]) > 2 else 0)
         return out
 
+    # ------------------------------------------------------------------ device path (whole batch, one launch pair)
+    MAX_DEVICE_NODES = 80
+
+    def design_device(self, x, edge_index, ptr):
+        """Supports of a collated batch on the GPU (libgml_hip.so: gml_spectral_count / gml_spectral_design).
+        x [N,f] float32, edge_index [2,e] int64 (global ids, each graph's edges contiguous, graphs in order),
+        ptr [B+1] node offsets -- all CUDA tensors.  Returns dict(x, edge_index2 [2,m] int64, edge_attr2 [m,S] float32,
+        lmax [B] float32); same values as the host path to float64 roundoff of the eigen-solver, same mask and order."""
+        from . import _lib
+        from .functional import _ptr, _stream
+        dev = x.device
+        if dev.type != 'cuda':
+            raise RuntimeError('design_device needs CUDA tensors (the host path is design_many / __call__)')
+        with torch.cuda.device(dev):
+            ptr32 = ptr.to(device=dev, dtype=torch.int32).contiguous()
+            B = int(ptr32.numel() - 1)
+            ei = edge_index.to(device=dev, dtype=torch.int64).contiguous()
+            e = int(ei.size(1))
+            sizes = (ptr32[1:] - ptr32[:-1])
+            nmax = int(sizes.max().item()) if B else 0
+            if nmax > self.MAX_DEVICE_NODES or self.nfreq > 16:
+                raise NotImplementedError('graphs with more than %d nodes (or nfreq > 16): use the host path'
+                                          % self.MAX_DEVICE_NODES)
+            # edges per graph: graph id of each edge's source, counted
+            gid = torch.bucketize(ei[0], ptr32[1:].to(torch.int64), right=True) if e else ei.new_zeros(0)
+            eptr = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+            if e:
+                eptr[1:] = torch.bincount(gid, minlength=B).cumsum(0).to(torch.int32)
+            nnz = torch.empty(B, dtype=torch.int32, device=dev)
+            st = _stream(dev)
+            _lib.call('gml_spectral_count', _ptr(ptr32), _ptr(eptr), _ptr(ei), e, B, nmax, int(self.recfield), _ptr(nnz), st)
+            out_ptr = torch.zeros(B + 1, dtype=torch.int64, device=dev)
+            out_ptr[1:] = nnz.to(torch.int64).cumsum(0)
+            m = int(out_ptr[-1].item())
+            S = self.nsup
+            ei2 = torch.empty(2, m, dtype=torch.int64, device=dev)
+            ea2 = torch.empty(m, S, dtype=torch.float32, device=dev)
+            lmax = torch.empty(B, dtype=torch.float32, device=dev)
+            _lib.call('gml_spectral_design', _ptr(ptr32), _ptr(eptr), _ptr(ei), e, B, nmax, int(self.recfield),
+                      int(self.nfreq), float(self.dv), 0 if self.vmax is None else 1,
+                      float(0.0 if self.vmax is None else self.vmax), 1 if self.laplacien else 0,
+                      1 if self.addadj else 0, _ptr(out_ptr), m, _ptr(ei2), _ptr(ea2), _ptr(lmax), st)
+            xo = x
+            if self.adddegree:
+                deg = torch.zeros(x.size(0), dtype=torch.float32, device=dev)
+                if e:                                               # column sums of the 0/1 adjacency (duplicate edges count once)
+                    key = torch.unique(ei[0] * x.size(0) + ei[1])
+                    deg.index_add_(0, key % x.size(0), torch.ones_like(key, dtype=torch.float32))
+                xo = torch.cat([x.float(), deg[:, None]], 1)
+        return dict(x=xo, edge_index2=ei2, edge_attr2=ea2, lmax=lmax)
+
     # ------------------------------------------------------------------ reference call convention
     def __call__(self, data):
         """``data``: any object with ``x`` [n,f] and ``edge_index`` [2,e] tensors (a PyG ``Data`` works).

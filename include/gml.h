@@ -194,6 +194,23 @@ int gml_segment_sum(const float* x, int64_t ldx, const int32_t* ptr, float* out,
 int gml_segment_bcast(const float* g, int64_t ldg, const int32_t* ptr, float* out, int64_t ldo,
                       int64_t num_segments, int32_t F, int32_t mean, gml_stream_t stream);
 
+/* ---------------------------------------------------------------- support precompute on the device (adjacent step, P1)
+ * SpectralDesign.__call__ (libs/utils.py:546-610) for a batch of graphs with at most 80 nodes each (larger: host
+ * implementation).  node_ptr [B+1], edge_ptr [B+1]: graph b owns nodes [node_ptr[b], node_ptr[b+1]) and the edges
+ * [edge_ptr[b], edge_ptr[b+1]) of edge_index [2, e_total] (int64, global node ids).
+ *   gml_spectral_count : nnz[b] = number of entries of the mask M_b (A or (A+I) squared recfield-1 times, > 0);
+ *   gml_spectral_design: with out_ptr = exclusive scan of nnz ([B+1], int64) writes, at out_ptr[b], the row-major COO of
+ *     M_b (edge_index2 [2, m_total] int64, global ids) and per entry the S = nfreq + 1 (+1) support values
+ *     (edge_attr2 [m_total, S]: nfreq Gaussian band-pass filters of the normalised-Laplacian spectrum -- or of A's when
+ *     laplacien == 0 --, the identity, and A when addadj), plus lmax[b] = largest Laplacian eigenvalue.
+ * Eigenproblems in float64 (cyclic Jacobi in LDS); has_vmax/vmax = fixed upper end of the frequency grid. */
+int gml_spectral_count(const int32_t* node_ptr, const int32_t* edge_ptr, const int64_t* edge_index, int64_t e_total,
+                       int64_t num_graphs, int32_t max_nodes, int32_t recfield, int32_t* nnz, gml_stream_t stream);
+int gml_spectral_design(const int32_t* node_ptr, const int32_t* edge_ptr, const int64_t* edge_index, int64_t e_total,
+                        int64_t num_graphs, int32_t max_nodes, int32_t recfield, int32_t nfreq, double dv,
+                        int32_t has_vmax, double vmax, int32_t laplacien, int32_t addadj, const int64_t* out_ptr,
+                        int64_t m_total, int64_t* edge_index2, float* edge_attr2, float* lmax, gml_stream_t stream);
+
 /* out[i, j] = sum_r A[r, i] * B[r, j]  (a, b <= 64): weight gradient g^T x of a small dense layer over n rows
  * (readout head fc1 / fc2, Zinc12k.py:343-345), rows split over the chip, fixed summation order */
 size_t gml_xty_workspace_bytes(int64_t n, int32_t a, int32_t b);

@@ -351,6 +351,50 @@ def test_ml3_output_stage_backward_vs_autograd(dev):
         close(got, ref, tol=1e-6, what='segment_bcast mean=%s' % mean)
 
 
+def test_spectral_design_on_device(dev, golden):
+    """gml_spectral_count / gml_spectral_design (batched Jacobi eigh in LDS) against the reference's own vectors
+    (every golden SpectralDesign case that fits the 80-node kernel) and, batched, against the host implementation:
+    mask and its row-major order bit-exact, support values to 5e-6 absolute (float64 solver roundoff, float32 output;
+    laplacien=False cases: the reference solves A in float32, 5e-5)."""
+    import ast
+    from gnn_matlang_amd import SpectralDesign, synthetic
+    g = golden('spectral_design.npz')
+    ran = 0
+    for k in range(int(g['ncases'])):
+        c = g.sub('case%02d/' % k)
+        kw = ast.literal_eval(str(c['kw']))
+        n = c['in_x'].shape[0]
+        if n > SpectralDesign.MAX_DEVICE_NODES:
+            continue
+        sd = SpectralDesign(**kw)
+        d = sd.design_device(T(c['in_x']).to(dev), T(c['in_edge_index']).long().to(dev),
+                             torch.tensor([0, n], dtype=torch.int32, device=dev))
+        assert np.array_equal(d['edge_index2'].cpu().numpy(), c['edge_index2']), str(c['name'])
+        assert np.array_equal(d['x'].cpu().numpy(), c['x']), str(c['name'])
+        tol = 5e-6 if kw.get('laplacien', True) else 5e-5
+        np.testing.assert_allclose(d['edge_attr2'].cpu().numpy(), c['edge_attr2'], rtol=0, atol=tol, err_msg=str(c['name']))
+        np.testing.assert_allclose(d['lmax'].cpu().numpy()[0], c['lmax'], rtol=2e-6)
+        ran += 1
+    assert ran >= 40, ran
+    # a collated batch of mixed sizes (incl. an edgeless graph) against the host path
+    raw = synthetic.make_graphs('zinc', 60, seed=11) + synthetic.make_graphs('counting', 20, seed=12)
+    raw.append((np.ones((3, raw[0][0].shape[1]), np.float32), np.zeros((2, 0), np.int64), 0.0))
+    raw = [(np.asarray(x, np.float32)[:, :1], ei, y) for x, ei, y in raw]       # one feature column for all
+    sd = SpectralDesign(recfield=2, dv=2, nfreq=7, adddegree=True)
+    host = sd.design_many(raw)
+    sizes = np.array([x.shape[0] for x, _, _ in raw])
+    ptr = np.concatenate([[0], np.cumsum(sizes)])
+    X = np.concatenate([x for x, _, _ in raw])
+    EI = np.concatenate([np.asarray(ei, np.int64) + ptr[i] for i, (_, ei, _) in enumerate(raw)], 1)
+    d = sd.design_device(T(X).to(dev), T(EI).to(dev), torch.tensor(ptr, dtype=torch.int32, device=dev))
+    ei2 = np.concatenate([h['edge_index2'] + ptr[i] for i, h in enumerate(host)], 1)
+    ea2 = np.concatenate([h['edge_attr2'] for h in host])
+    assert np.array_equal(d['edge_index2'].cpu().numpy(), ei2)
+    np.testing.assert_allclose(d['edge_attr2'].cpu().numpy(), ea2, rtol=0, atol=5e-6)
+    np.testing.assert_allclose(d['lmax'].cpu().numpy(), np.array([h['lmax'] for h in host]), rtol=2e-6, atol=1e-6)
+    assert np.array_equal(d['x'].cpu().numpy(), np.concatenate([h['x'] for h in host]))
+
+
 # ------------------------------------------------------------------------------------------ ML3Layer
 def test_ml3layer_golden(dev, golden):
     from gnn_matlang_amd import ML3Layer
