@@ -22,6 +22,7 @@ SIGNATURES = {
     'gml_csr_group_info': (ctypes.c_int, [_p, _p, _i64, _i32, _p, _p]),
     'gml_gather_rows': (ctypes.c_int, [_p, _p, _p, _i64, _i32, _p]),
     'gml_scatter_rows': (ctypes.c_int, [_p, _p, _p, _i64, _i32, _p]),
+    'gml_spectconv_fwd_group_rows': (ctypes.c_int32, [_i32, _i32, _i32, ctypes.c_uint32]),
     'gml_spectconv_fwd': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _p, _p, _i64,
                                          _i64, _i32, _i32, _i32, _u32, _p]),
     'gml_spectconv_bwd_group_rows': (ctypes.c_int, [_i32, _i32, _i32, _u32]),
@@ -50,7 +51,7 @@ SIGNATURES = {
                                          _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _sz, _p]),
 }
 
-GML_RELU, GML_ACCUM, GML_F32_MFMA = 1, 2, 4
+GML_RELU, GML_ACCUM, GML_F32_MFMA, GML_GROUPS128 = 1, 2, 4, 8
 
 _lib = None
 

@@ -1,5 +1,21 @@
 // Dispatch of the fused forward kernel families + the unfused SpMM / SDDMM kernels.
 #include "gml_spectconv_impl.h"
+#include "gml_spectconv_fwd2_impl.h"
+
+#define GML_DECL_FWD2(S, B) template <> int gml_launch_fwd2<S, B>(const GmlFwdParams&, dim3, hipStream_t, bool);
+GML_DECL_FWD2(8, 2) GML_DECL_FWD2(8, 1) GML_DECL_FWD2(6, 2) GML_DECL_FWD2(6, 1)
+GML_DECL_FWD2(4, 2) GML_DECL_FWD2(4, 1) GML_DECL_FWD2(2, 2) GML_DECL_FWD2(2, 1)
+
+static bool fwd2_shape(int S, int Fin, int Fout, uint32_t flags) {
+#ifdef GML_NO_FWD2
+    return false;
+#endif
+    return (flags & GML_F32_MFMA) == 0 && (S == 2 || S == 4 || S == 6 || S == 8) && Fin <= 32 && Fout <= 32;
+}
+
+extern "C" int32_t gml_spectconv_fwd_group_rows(int32_t S, int32_t Fin, int32_t Fout, uint32_t flags) {
+    return fwd2_shape(S, Fin, Fout, flags) ? 128 : 64;
+}
 
 // ---- families defined in gml_fwd_fam_*.hip ---------------------------------------------------
 #define GML_DECL_FAM(SC, FPL) \
@@ -32,6 +48,27 @@ extern "C" int gml_spectconv_fwd(const int32_t* rowptr, const int32_t* col, cons
     if (!rowptr || !ginfo || !x || !w || !out) return GML_E_BADARG;   /* col/val may be null when there are no edges */
     if (num_rows > (int64_t)INT32_MAX - 16) return GML_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
+
+    if (flags & GML_GROUPS128) {
+        // 128-row / 8-wave kernel: the caller passes 128-row group records (gml_spectconv_fwd_group_rows said 128)
+        const bool xv = (ldx % 4 == 0) && (((uintptr_t)x & 15) == 0);
+        if (!fwd2_shape(S, Fin, Fout, flags) || epos != nullptr || (((uintptr_t)val & 15) != 0)) return GML_E_BADARG;
+        GmlFwdParams p = {};
+        p.rowptr = rowptr; p.col = col; p.ginfo = ginfo; p.epos = nullptr; p.val = val; p.x = x; p.ldx = ldx;
+        p.w = w; p.w_ss = w_ss; p.w_si = w_si; p.w_so = w_so; p.bias = bias; p.out = out; p.ldo = ldo;
+        p.nrows = num_rows; p.S = S; p.Fin = Fin; p.Fout = Fout; p.flags = flags; p.s0 = 0; p.npass = 1; p.nchunks = 1;
+        p.val_vec = 1;
+        p.ngroups = (int)gml_cdiv(num_rows, GML_FWD2_ROWS);
+        int grid = p.ngroups < GML_NUM_CU ? p.ngroups : GML_NUM_CU;      // one 512-thread workgroup per CU
+        p.groups_per_wg = (int)gml_cdiv(p.ngroups, grid);
+        grid = (int)gml_cdiv(p.ngroups, p.groups_per_wg);
+        const int nob = Fout > 16 ? 2 : 1;
+        int rc = GML_E_UNSUPPORTED;
+#define GML_FWD2_GO(SV, B) if (S == SV && nob == B) rc = gml_launch_fwd2<SV, B>(p, dim3(grid), st, xv);
+        GML_FWD2_GO(8, 2) GML_FWD2_GO(8, 1) GML_FWD2_GO(6, 2) GML_FWD2_GO(6, 1)
+        GML_FWD2_GO(4, 2) GML_FWD2_GO(4, 1) GML_FWD2_GO(2, 2) GML_FWD2_GO(2, 1)
+        return rc;
+    }
 
     // features per lane per chunk: 8 unless 4 pads the contraction less
     const int pad8 = (Fin + 31) / 32 * 32, pad4 = (Fin + 15) / 16 * 16;

@@ -1,0 +1,259 @@
+// Fused forward, 128-row / 8-wave geometry (bf16x3 projection; Fin <= 32, Fout <= 32, S in {2,4,6,8}): same function as
+// gml_k_spectconv_fwd (gml_spectconv_impl.h)
+//
+//   out[r, :] = act( sum_s (sum_{k in row r} val[k, s] x[col[k], :]) W_s + b )
+//
+// organised like the backward kernel (gml_spectconv_bwd2_impl.h): one 512-thread workgroup per CU, groups of 128 target
+// rows, one 16-row tile per wave, the group record's degree-ranked row order (rows of a tile run near-equal edge
+// loops; rank blocks a and 7-a on the two waves of a SIMD).  With 64 accumulators per lane instead of the backward's
+// 128 there is room to keep the NEXT group's CSR slice, value rows and X window in flight in registers while this
+// group is aggregated and projected (unconditional, clamped loads: see the note in the kernel).
+#pragma once
+#include "gml_common.h"
+#include "gml_spectconv_impl.h"
+
+#define GML_FWD2_ROWS 128
+#define GML_FWD2_ECAP 1024      // staged edges per group
+#define GML_FWD2_XCAP 208       // staged window rows of X (128 rows + 2 x the largest graph of a block-diagonal batch)
+
+template <int S>
+struct GmlFwd2Cfg {
+    static constexpr int LDX = 36;                             // X window rows (floats, b128 aligned)
+    static constexpr int W_HALF = S * 32 * 32;                 // bf16 elements of one (hi or lo) W image [s][o][f]
+    static constexpr int W_BYTES = 2 * W_HALF * 2;
+    static constexpr size_t lds_bytes() {
+        return (size_t)W_BYTES + 136 * 4 + (size_t)GML_FWD2_ECAP * 4 + (size_t)GML_FWD2_ECAP * S * 4 +
+               (size_t)GML_FWD2_XCAP * LDX * 4;
+    }
+};
+
+// XVEC: the X rows are float4-addressable (ldx % 4 == 0, aligned base); else the window is staged element-wise
+template <int S, int NOB, bool XVEC>
+__global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p) {
+    using C = GmlFwd2Cfg<S>;
+    constexpr int LDX = C::LDX, ROWS = GML_FWD2_ROWS;
+    constexpr int VAL_ALIGN = (S % 4 == 0) ? 4 : ((S % 2 == 0) ? 2 : 1);
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __bf16* Wof_h = reinterpret_cast<__bf16*>(lds_raw);       // [s][o][f], 16-byte chunks XOR-swizzled by (o >> 3) & 3
+    __bf16* Wof_l = Wof_h + C::W_HALF;
+    int* rp_l = reinterpret_cast<int*>(lds_raw + C::W_BYTES);
+    int* col_l = rp_l + 136;
+    float* ea_l = reinterpret_cast<float*>(col_l + GML_FWD2_ECAP);
+    float* xs = ea_l + GML_FWD2_ECAP * S;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int wg = gml_xcd_remap(blockIdx.x, gridDim.x);
+    const int g0 = wg * p.groups_per_wg;
+    const int g1 = min(g0 + p.groups_per_wg, p.ngroups);
+    if (g0 >= g1) return;
+
+    for (int e = tid; e < S * 32 * 32; e += 512) {
+        const int f = e & 31, o = (e >> 5) & 31, s = e >> 10;
+        const float v = (f < p.Fin && o < p.Fout) ? p.w[(int64_t)(p.s0 + s) * p.w_ss + (int64_t)f * p.w_si + (int64_t)o * p.w_so] : 0.f;
+        const __bf16 h = (__bf16)v;
+        const __bf16 l = (__bf16)(v - (float)h);
+        const int iof = (s * 32 + o) * 32 + ((((f >> 3) ^ (o >> 3)) & 3) << 3) + (f & 7);
+        Wof_h[iof] = h;
+        Wof_l[iof] = l;
+    }
+    float bias_r[NOB];
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) bias_r[ob] = (p.bias && ob * 16 + r16 < p.Fout) ? p.bias[ob * 16 + r16] : 0.f;
+
+    // ---- software-pipelined staging.  Every prefetch load is unconditional with indices clamped into the arrays (lanes
+    //      outside fetch a valid, unused element): with a load under a predicate or branch the compiler cannot count the
+    //      loads in flight and waits for all of them at the next vmcnt it needs.
+    constexpr int NC = GML_FWD2_ECAP / 512, NE4 = (S % 4 == 0) ? GML_FWD2_ECAP * (S / 4) / 512 : 1;
+    constexpr int NX4 = XVEC ? (GML_FWD2_XCAP * 8 + 511) / 512 : 1;
+    constexpr int NX1 = XVEC ? 1 : (GML_FWD2_XCAP * 32 + 511) / 512;
+    const int etot = p.rowptr[p.nrows];
+    const int* colb = etot > 0 ? p.col : p.ginfo;              // an edgeless graph reads the (always present) group records
+    const f32x4* valb = etot > 0 ? reinterpret_cast<const f32x4*>(p.val) : reinterpret_cast<const f32x4*>(p.ginfo);
+    const int emax = max(etot, 1) - 1;
+    const int64_t emax4 = (S % 4 == 0) ? max((int64_t)etot * (S / 4), (int64_t)1) - 1 : 0;
+    const bool vec_ok = (S % 4 == 0) && p.val_vec && (p.S == S);
+    const int f4max = ((p.Fin + 3) / 4 * 4 - 4);
+    int cv[NC], rpv = 0;
+    f32x4 ev4[NE4], xv4[NX4];
+    float xv1[NX1];
+    int4 gi_n = int4{0, 0, 0, 0};
+    int row_n = 0;
+    uint32_t outrows_n = 0;
+    auto issue = [&](int g) {
+        const int32_t* rec = p.ginfo + (int64_t)g * GML_GREC_INTS(ROWS);
+        gi_n = *reinterpret_cast<const int4*>(rec);
+        row_n = reinterpret_cast<const unsigned char*>(rec + 4)[wave * 16 + r16];
+        outrows_n = reinterpret_cast<const uint32_t*>(rec + 4)[wave * 4 + kq];
+        const int64_t r0 = (int64_t)g * ROWS;
+        rpv = p.rowptr[min(r0 + tid, p.nrows)];
+        if (vec_ok) {
+            const int kb = gi_n.x, lo = gi_n.z;
+#pragma unroll
+            for (int t = 0; t < NC; ++t) cv[t] = colb[min(kb + tid + 512 * t, emax)];
+#pragma unroll
+            for (int t = 0; t < NE4; ++t) ev4[t] = valb[min((int64_t)kb * (S / 4) + tid + 512 * t, emax4)];
+            if constexpr (XVEC) {
+#pragma unroll
+                for (int t = 0; t < NX4; ++t) {
+                    const int i = tid + 512 * t;
+                    const int64_t rr = min((int64_t)lo + (i >> 3), p.nrows - 1);
+                    xv4[t] = *reinterpret_cast<const f32x4*>(p.x + rr * p.ldx + min((i & 7) * 4, f4max));
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < NX1; ++t) {
+                    const int i = tid + 512 * t;
+                    const int64_t rr = min((int64_t)lo + (i >> 5), p.nrows - 1);
+                    xv1[t] = p.x[rr * p.ldx + min(i & 31, p.Fin - 1)];
+                }
+            }
+        }
+    };
+    issue(g0);
+    __syncthreads();                                           // W images complete
+
+    for (int g = g0; g < g1; ++g) {
+        const int64_t r0 = (int64_t)g * ROWS;
+        const int nr = (int)min((int64_t)ROWS, p.nrows - r0);
+        const int kb = gi_n.x, ne = gi_n.y, lo = gi_n.z, nwin = gi_n.w;
+        const int row = row_n;
+        const uint32_t out_rows = outrows_n;
+        const bool staged = vec_ok && ne <= GML_FWD2_ECAP && nwin <= GML_FWD2_XCAP;
+
+        // ---- commit the prefetched registers
+        if (tid <= nr) rp_l[tid] = rpv;
+        if (staged) {
+#pragma unroll
+            for (int t = 0; t < NC; ++t) { const int i = tid + 512 * t; if (i < ne) col_l[i] = cv[t] - lo; }
+#pragma unroll
+            for (int t = 0; t < NE4; ++t) {
+                const int i = tid + 512 * t;
+                if (i < ne * (S / 4)) reinterpret_cast<f32x4*>(ea_l)[i] = ev4[t];
+            }
+            if constexpr (XVEC) {
+#pragma unroll
+                for (int t = 0; t < NX4; ++t) {
+                    const int i = tid + 512 * t;
+                    const int f4 = (i & 7) * 4;
+                    if (i < nwin * 8)
+                        *reinterpret_cast<f32x4*>(xs + (i >> 3) * LDX + f4) = (f4 < p.Fin) ? xv4[t] : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < NX1; ++t) {
+                    const int i = tid + 512 * t;
+                    if (i < nwin * 32) xs[(i >> 5) * LDX + (i & 31)] = ((i & 31) < p.Fin) ? xv1[t] : 0.f;
+                }
+            }
+        }
+        __syncthreads();
+        if (g + 1 < g1) issue(g + 1);                          // in flight during this group's compute
+
+        const bool rvalid = row < nr;
+        const int kbeg = rvalid ? rp_l[row] : 0;
+        const int kend = rvalid ? rp_l[row + 1] : 0;
+
+        // ---- aggregation (fp32 VALU, packed): acc[s][f] += val[k, s] * x[col[k], f], f = 8*kq .. 8*kq+7
+        f32x2 acc[S][4];
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int h = 0; h < 4; ++h) acc[s][h] = f32x2{0.f, 0.f};
+        if (staged) {
+            for (int k = kbeg - kb; k < kend - kb; ++k) {
+                const int srcl = col_l[k];
+                float ev[S];
+                gml_load_row<S, VAL_ALIGN>(ea_l + k * S, ev);
+                const f32x4 t0 = *reinterpret_cast<const f32x4*>(xs + srcl * LDX + 8 * kq);
+                const f32x4 t1 = *reinterpret_cast<const f32x4*>(xs + srcl * LDX + 8 * kq + 4);
+                const f32x2 xv[4] = {f32x2{t0.x, t0.y}, f32x2{t0.z, t0.w}, f32x2{t1.x, t1.y}, f32x2{t1.z, t1.w}};
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const f32x2 e2 = f32x2{ev[s], ev[s]};
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) acc[s][h] = e2 * xv[h] + acc[s][h];
+                }
+            }
+        } else {                                               // group outside the LDS capacities (or unaligned rows): global gathers
+            for (int k = kbeg; k < kend; ++k) {
+                const int src = p.col[k];
+                float xb[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) xb[t] = (8 * kq + t < p.Fin) ? p.x[(int64_t)src * p.ldx + 8 * kq + t] : 0.f;
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const float e = p.val[(int64_t)k * p.S + p.s0 + s];
+                    const f32x2 e2 = f32x2{e, e};
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) acc[s][h] = e2 * f32x2{xb[2 * h], xb[2 * h + 1]} + acc[s][h];
+                }
+            }
+        }
+
+        // ---- projection: out tile = sum_s acc_s W_s (acc split on the fly = A fragments, k = f = 8*kq + j)
+        f32x4 oacc[NOB];
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob) oacc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.flags & GML_ACCUM) {                             // the old values travel while the MFMAs run (clamped loads)
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int lr = min((int)((out_rows >> (8 * reg)) & 255u), nr - 1);
+                    oacc[ob][reg] = p.out[(r0 + lr) * p.ldo + min(ob * 16 + r16, p.Fout - 1)];
+                }
+        }
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const float av[8] = {acc[s][0].x, acc[s][0].y, acc[s][1].x, acc[s][1].y, acc[s][2].x, acc[s][2].y, acc[s][3].x, acc[s][3].y};
+            bf16x8 ah, al;
+            gml_split8(av, ah, al);
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob) {
+                const int o = ob * 16 + r16;                   // B[k = f][n = o]: 8 consecutive f of column o
+                const int off = (s * 32 + o) * 32 + (((kq ^ (o >> 3)) & 3) << 3);
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(Wof_h + off);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Wof_l + off);
+                oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, oacc[ob], 0, 0, 0);
+                oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, oacc[ob], 0, 0, 0);
+                oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, oacc[ob], 0, 0, 0);
+            }
+        }
+        const bool relu = (p.flags & GML_RELU) != 0;
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob) {
+            const int o = ob * 16 + r16;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int lr = (int)((out_rows >> (8 * reg)) & 255u);
+                float v = oacc[ob][reg] + bias_r[ob];
+                if (relu) v = fmaxf(v, 0.f);
+                if (o < p.Fout && lr < nr) p.out[(r0 + lr) * p.ldo + o] = v;
+            }
+        }
+        __syncthreads();                                       // this group's LDS reads are done
+    }
+}
+
+template <int S, int NOB>
+int gml_launch_fwd2(const GmlFwdParams& p, dim3 grid, hipStream_t st, bool xvec);
+
+#define GML_DEFINE_FWD2(SV, NOBV)                                                                            \
+    template <>                                                                                              \
+    int gml_launch_fwd2<SV, NOBV>(const GmlFwdParams& p, dim3 grid, hipStream_t st, bool xvec) {             \
+        static const hipError_t rc1 = hipFuncSetAttribute(                                                   \
+            reinterpret_cast<const void*>(&gml_k_spectconv_fwd2<SV, NOBV, true>),                            \
+            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                         \
+        static const hipError_t rc0 = hipFuncSetAttribute(                                                   \
+            reinterpret_cast<const void*>(&gml_k_spectconv_fwd2<SV, NOBV, false>),                           \
+            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                         \
+        if (rc1 != hipSuccess) return (int)rc1;                                                              \
+        if (rc0 != hipSuccess) return (int)rc0;                                                              \
+        if (xvec) hipLaunchKernelGGL((gml_k_spectconv_fwd2<SV, NOBV, true>), grid, dim3(512),                \
+                                     GmlFwd2Cfg<SV>::lds_bytes(), st, p);                                    \
+        else hipLaunchKernelGGL((gml_k_spectconv_fwd2<SV, NOBV, false>), grid, dim3(512),                    \
+                                GmlFwd2Cfg<SV>::lds_bytes(), st, p);                                         \
+        return gml_launch_status();                                                                          \
+    }

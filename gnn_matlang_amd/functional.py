@@ -99,6 +99,15 @@ def _fused_conv(rowptr, col, ginfo, epos, val, x, ldx, w, w_strides, bias, out, 
               int(flags) | (_lib.GML_F32_MFMA if F32_MFMA else 0), _stream(x.device))
 
 
+def fwd_groups(csr, x, S, Fin, Fout):
+    """(group records, extra flags) the forward kernel wants for this shape: the 8-wave kernel on 128-row records when
+    the shape is compiled for it, else the 64-row kernel."""
+    flags = _lib.GML_F32_MFMA if F32_MFMA else 0
+    if int(_lib.lib().gml_spectconv_fwd_group_rows(int(S), int(Fin), int(Fout), flags)) == 128:
+        return csr.ginfo128, _lib.GML_GROUPS128
+    return csr.ginfo, 0
+
+
 def spmm(csr, val, x, S, Fin):
     h = torch.empty(csr.N, S * Fin, dtype=torch.float32, device=x.device)
     _lib.call('gml_spmm_fwd', _ptr(csr.rowptr), _ptr(csr.col), _ptr(None), _ptr(val), _ptr(x), int(x.stride(0)),
@@ -332,8 +341,9 @@ class SpectConvFunction(torch.autograd.Function):
             bias = _f32c(bias, 'bias')
         with torch.cuda.device(x.device):
             out = torch.empty(csr.N, Fout, dtype=torch.float32, device=x.device)
-            fused_conv(csr.rowptr, csr.col, csr.ginfo, None, val, x, Fin, weight, (Fin * Fout, Fout, 1), bias, out,
-                       Fout, csr.N, S, Fin, Fout, _lib.GML_RELU if relu else 0)
+            gi, gflag = fwd_groups(csr, x, S, Fin, Fout)
+            fused_conv(csr.rowptr, csr.col, gi, None, val, x, Fin, weight, (Fin * Fout, Fout, 1), bias, out,
+                       Fout, csr.N, S, Fin, Fout, (_lib.GML_RELU if relu else 0) | gflag)
         ctx.csr, ctx.relu, ctx.has_bias = csr, relu, bias is not None
         ctx.save_for_backward(x, val, weight, out if relu else None)
         return out
@@ -389,8 +399,9 @@ class ML3LayerFunction(torch.autograd.Function):
                 raise ValueError('conv1 expects %d supports, edge branch produced %d' % (S, ea.size(1)))
             out = torch.empty(N, C, dtype=torch.float32, device=x.device)
             cb_ = _f32c(cb, 'conv1.bias') if cb is not None else None
-            fused_conv(csr.rowptr, csr.col, csr.ginfo, None, ea, x, Fin, cw, (Fin * nout1, nout1, 1), cb_, out, C, N,
-                       S, Fin, nout1, _lib.GML_RELU)
+            gi, gflag = fwd_groups(csr, x, S, Fin, nout1)
+            fused_conv(csr.rowptr, csr.col, gi, None, ea, x, Fin, cw, (Fin * nout1, nout1, 1), cb_, out, C, N,
+                       S, Fin, nout1, _lib.GML_RELU | gflag)
             if nout2 > 0:
                 w11, b11, w12, b12 = (_f32c(w11, 'fc11.weight'), _f32c(b11, 'fc11.bias'), _f32c(w12, 'fc12.weight'),
                                       _f32c(b12, 'fc12.bias'))

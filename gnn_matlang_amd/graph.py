@@ -36,7 +36,7 @@ def _require_cuda(t, name):
 
 class GraphCSR(object):
     __slots__ = ('N', 'E', 'device', 'rowptr', 'col', 'perm', 'rowptr_t', 'col_t', 'pos_t', 'perm_t',
-                 'ginfo', 'ginfo_t', 'gmax', 'gmax_t', 'ginfo_t128', 'gmax_t128', 'tpos', '_val_cache', '_keep')
+                 'ginfo', 'ginfo_t', 'gmax', 'gmax_t', 'ginfo_t128', 'gmax_t128', 'ginfo128', 'tpos', '_val_cache', '_keep')
 
     def __init__(self):
         self._val_cache = OrderedDict()
@@ -76,9 +76,11 @@ class GraphCSR(object):
             g.ginfo, g.ginfo_t = torch.zeros(ng, rec64, **i32), torch.zeros(ng, rec64, **i32)
             ng2 = max((N + 127) // 128, 1)
             g.ginfo_t128 = torch.zeros(ng2, rec128, **i32)
+            g.ginfo128 = torch.zeros(ng2, rec128, **i32)
             _lib.call('gml_csr_group_info', _ptr(g.rowptr), _ptr(g.col), N, 64, _ptr(g.ginfo), st)
             _lib.call('gml_csr_group_info', _ptr(g.rowptr_t), _ptr(g.col_t), N, 64, _ptr(g.ginfo_t), st)
             _lib.call('gml_csr_group_info', _ptr(g.rowptr_t), _ptr(g.col_t), N, 128, _ptr(g.ginfo_t128), st)
+            _lib.call('gml_csr_group_info', _ptr(g.rowptr), _ptr(g.col), N, 128, _ptr(g.ginfo128), st)
             # per-batch maxima (edges per 64-row group, column window): they size the LDS staging of the fused
             # backward kernel.  One device->host read per batch, at index-build time (not in the step).
             mx = torch.stack([g.ginfo[:, 1].max(), g.ginfo[:, 3].max(), g.ginfo_t[:, 1].max(),

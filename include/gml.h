@@ -48,8 +48,10 @@ enum {
 enum {
     GML_RELU = 1,   /* out = max(out, 0) in the epilogue          (ML3Layer: relu(conv1(..))) */
     GML_ACCUM = 2,  /* out += result instead of out = result      (gradient accumulation)     */
-    GML_F32_MFMA = 4 /* project with the f32-input MFMA (bit-identical to an fmaf chain) instead of the default
-                        bf16x3 split on the bf16 matrix cores (fp32-class: ~1e-6 of the output scale)       */
+    GML_F32_MFMA = 4, /* project with the f32-input MFMA (bit-identical to an fmaf chain) instead of the default
+                         bf16x3 split on the bf16 matrix cores (fp32-class: ~1e-6 of the output scale)       */
+    GML_GROUPS128 = 8 /* gml_spectconv_fwd: `ginfo` holds 128-row group records (gml_spectconv_fwd_group_rows() = 128,
+                         epos NULL): the 8-wave forward kernel                                                 */
 };
 
 int gml_version(void);
@@ -93,6 +95,9 @@ int gml_scatter_rows(const float* in, const int32_t* perm, float* out, int64_t r
  * W element (s, i, o) lives at w[s*w_ss + i*w_si + o*w_so] so the transposed weights of the
  * backward pass need no copy.  bias may be NULL.  Used for: forward (CSR by target, x = X),
  * d/dX (CSR by source, x = dOut, W transposed view, epos = pos_t). */
+/* group size (64 | 128) whose records the forward wants for this shape and arithmetic; 128 additionally needs
+ * epos == NULL -- the caller then passes those records and GML_GROUPS128 */
+int32_t gml_spectconv_fwd_group_rows(int32_t S, int32_t Fin, int32_t Fout, uint32_t flags);
 int gml_spectconv_fwd(const int32_t* rowptr, const int32_t* col, const int32_t* ginfo, const int32_t* epos,
                       const float* val, const float* x, int64_t ldx,
                       const float* w, int64_t w_ss, int64_t w_si, int64_t w_so,
