@@ -2,9 +2,5 @@
 #include "gml_spectconv_fwd2_impl.h"
 GML_DEFINE_FWD2(8, 2)
 GML_DEFINE_FWD2(8, 1)
-GML_DEFINE_FWD2(6, 2)
-GML_DEFINE_FWD2(6, 1)
 GML_DEFINE_FWD2(4, 2)
 GML_DEFINE_FWD2(4, 1)
-GML_DEFINE_FWD2(2, 2)
-GML_DEFINE_FWD2(2, 1)

@@ -3,14 +3,14 @@
 #include "gml_spectconv_fwd2_impl.h"
 
 #define GML_DECL_FWD2(S, B) template <> int gml_launch_fwd2<S, B>(const GmlFwdParams&, dim3, hipStream_t, bool);
-GML_DECL_FWD2(8, 2) GML_DECL_FWD2(8, 1) GML_DECL_FWD2(6, 2) GML_DECL_FWD2(6, 1)
-GML_DECL_FWD2(4, 2) GML_DECL_FWD2(4, 1) GML_DECL_FWD2(2, 2) GML_DECL_FWD2(2, 1)
+GML_DECL_FWD2(8, 2) GML_DECL_FWD2(8, 1) GML_DECL_FWD2(4, 2) GML_DECL_FWD2(4, 1)
 
 static bool fwd2_shape(int S, int Fin, int Fout, uint32_t flags) {
 #ifdef GML_NO_FWD2
     return false;
 #endif
-    return (flags & GML_F32_MFMA) == 0 && (S == 2 || S == 4 || S == 6 || S == 8) && Fin <= 32 && Fout <= 32;
+    // S % 4 == 0: the register-staged value rows are float4 (other S keep the 64-row kernel, which stages any S)
+    return (flags & GML_F32_MFMA) == 0 && (S == 4 || S == 8) && Fin <= 32 && Fout <= 32;
 }
 
 extern "C" int32_t gml_spectconv_fwd_group_rows(int32_t S, int32_t Fin, int32_t Fout, uint32_t flags) {
@@ -65,8 +65,7 @@ extern "C" int gml_spectconv_fwd(const int32_t* rowptr, const int32_t* col, cons
         const int nob = Fout > 16 ? 2 : 1;
         int rc = GML_E_UNSUPPORTED;
 #define GML_FWD2_GO(SV, B) if (S == SV && nob == B) rc = gml_launch_fwd2<SV, B>(p, dim3(grid), st, xv);
-        GML_FWD2_GO(8, 2) GML_FWD2_GO(8, 1) GML_FWD2_GO(6, 2) GML_FWD2_GO(6, 1)
-        GML_FWD2_GO(4, 2) GML_FWD2_GO(4, 1) GML_FWD2_GO(2, 2) GML_FWD2_GO(2, 1)
+        GML_FWD2_GO(8, 2) GML_FWD2_GO(8, 1) GML_FWD2_GO(4, 2) GML_FWD2_GO(4, 1)
         return rc;
     }
 

@@ -181,6 +181,32 @@ def test_fused_forward_and_grads_vs_oracle(dev, S, fin, fout):
     close(m.bias.grad, bo.grad, what='g_bias')
 
 
+@pytest.mark.parametrize('S,fin,fout,deg', [(8, 32, 30, 5), (8, 25, 30, 24), (4, 32, 16, 24), (8, 32, 32, 40)])
+def test_eight_wave_forward_staged_and_global_paths(dev, S, fin, fout, deg):
+    """the 128-row forward kernel on groups inside its LDS capacities (deg 5) and far outside (deg >= 24: > 1024 edges
+    per group -> global-gather path), aligned and unaligned x rows, against the oracle; backward rides along."""
+    from gnn_matlang_amd import SpectConv
+    from oracle import spect_conv_oracle as O
+    rng = np.random.default_rng(S * 100 + deg)
+    torch.manual_seed(deg)
+    N = 517
+    ei = _random_graph(rng, N, deg)
+    ea, x = torch.randn(ei.shape[1], S), torch.randn(N, fin)
+    m = SpectConv(fin, fout, S, selfconn=False).to(dev)
+    w, b = m.weight.detach().cpu(), m.bias.detach().cpu()
+    xo, eo, wo = (t.clone().requires_grad_(True) for t in (x, ea, w))
+    yo = O.spectconv_forward(xo, T(ei), eo, wo, b, False)
+    gout = torch.randn_like(yo)
+    (yo * gout).sum().backward()
+    xg, eg = x.to(dev).requires_grad_(True), ea.to(dev).requires_grad_(True)
+    y = m(xg, T(ei).to(dev), eg)
+    close(y, yo, what='out')
+    (y * gout.to(dev)).sum().backward()
+    close(xg.grad, xo.grad, what='g_x')
+    close(eg.grad, eo.grad, what='g_edge_attr')
+    close(m.weight.grad, wo.grad, what='g_weight')
+
+
 def test_exact_fp32_mode_is_closer_to_the_oracle(dev):
     """GML_F32_MFMA (f32-input MFMA: exact fp32 products) must agree with the oracle at fp32-roundoff level, an
     order of magnitude tighter than the default bf16 hi/lo split is asked to."""
