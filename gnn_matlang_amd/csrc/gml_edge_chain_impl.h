@@ -162,19 +162,28 @@ __device__ __forceinline__ void gml_chain_load_e(const float* __restrict__ ea, i
 // RES: residuals of the h split on the matrix pipe (backward kernel, VALU-issue-bound) or on the VALU (forward kernel,
 // store-bound: the extra MFMA round trip only lengthens its dependency chain).  Both give the same bits (the
 // subtraction is exact either way), so the relu mask recomputed by the backward matches the forward's.
-template <int S, bool RES>
-__device__ __forceinline__ void gml_chain_forward(const GmlChainW<S>& W, GmlChainT& T, int g) {
-    // layer 1 operand: even lane groups carry hi(e), odd ones lo(e)  ->  (Whi + Wlo)(ehi + elo) in one MFMA
+// layer 1 operand from the fp32 row: even lane groups carry hi(e), odd ones lo(e)  ->  (Whi + Wlo)(ehi + elo) in one MFMA
+__device__ __forceinline__ bf16x8 gml_chain_b1(const float (&e)[8], int g) {
     uint32_t b1[4];
     const bool odd = g & 1;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const float x0 = T.e[2 * j], x1 = T.e[2 * j + 1];
+        const float x0 = e[2 * j], x1 = e[2 * j + 1];
         const float t0 = __uint_as_float(__float_as_uint(x0) & 0xffff0000u);
         const float t1 = __uint_as_float(__float_as_uint(x1) & 0xffff0000u);
         b1[j] = gml_pack2(odd ? x0 - t0 : t0, odd ? x1 - t1 : t1);
     }
-    const bf16x8 B1 = gml_op(b1[0], b1[1], b1[2], b1[3]);
+    return gml_op(b1[0], b1[1], b1[2], b1[3]);
+}
+
+// The raw supports are per-batch constants, so their split can be made once (gml_edge_presplit): per edge 32 bytes,
+// hi[8] then lo[8] (bf16, the same truncate / round-the-residual split as gml_chain_b1, channels >= S zero).  A lane
+// then loads its layer-1 operand with one 16-byte load and no arithmetic.
+__global__ __launch_bounds__(256) void gml_k_edge_presplit(const float* __restrict__ ea, uint32_t* __restrict__ es,
+                                                          int64_t E, int S);
+
+template <int S, bool RES>
+__device__ __forceinline__ void gml_chain_forward(const GmlChainW<S>& W, GmlChainT& T, const bf16x8 B1, int g) {
     const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
     T.z1 = GML_MFMA(W.a1[0], B1, zero);
     const f32x4 z2 = GML_MFMA(W.a1[1], B1, zero);
@@ -204,8 +213,9 @@ __device__ __forceinline__ void gml_chain_forward(const GmlChainW<S>& W, GmlChai
 }
 
 // ------------------------------------------------------------------------------------------ forward kernel
-template <int S>
-__global__ __launch_bounds__(256, 2) void gml_k_edge_chain_fwd(const float* __restrict__ ea, const float* __restrict__ w1,
+template <int S, bool PRE>
+__global__ __launch_bounds__(256, 2) void gml_k_edge_chain_fwd(const float* __restrict__ ea, const uint32_t* __restrict__ es,
+                                                              const float* __restrict__ w1,
                                                               const float* __restrict__ w2, const float* __restrict__ w3,
                                                               const float* __restrict__ w4, float* __restrict__ out,
                                                               const int32_t* __restrict__ tpos, float* __restrict__ out_t,
@@ -220,15 +230,23 @@ __global__ __launch_bounds__(256, 2) void gml_k_edge_chain_fwd(const float* __re
         int64_t eid[2];
         bool valid[2];
         int32_t tp[2] = {0, 0};
+        u32x4 b1[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             eid[u] = (t + u) * 16 + c16;
             valid[u] = eid[u] < E;
-            gml_chain_load_e<S>(ea, eid[u], valid[u], T[u].e);
+            if constexpr (PRE) {
+                b1[u] = valid[u] ? *reinterpret_cast<const u32x4*>(es + eid[u] * 8 + 4 * (g & 1)) : u32x4{0u, 0u, 0u, 0u};
+            } else {
+                gml_chain_load_e<S>(ea, eid[u], valid[u], T[u].e);
+            }
             if (out_t != nullptr && valid[u] && g >= 2) tp[u] = tpos[eid[u]];
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) gml_chain_forward<S, false>(W, T[u], g);
+        for (int u = 0; u < 2; ++u) {
+            if constexpr (PRE) gml_chain_forward<S, false>(W, T[u], __builtin_bit_cast(bf16x8, b1[u]), g);
+            else gml_chain_forward<S, false>(W, T[u], gml_chain_b1(T[u].e, g), g);
+        }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             if (!valid[u]) continue;
@@ -261,31 +279,29 @@ struct GmlChainWB {
 
 #define GML_CHAIN_NW(S) (6 * (S) * (S) + 4 * (S) * (S))
 
-// the lane's inputs of one 16-edge tile: the e row (all 8 values) and 4 values of the gout row
+// 4 consecutive floats of a row of S starting at channel q0 (zero beyond S / for invalid lanes)
 template <int S>
-__device__ __forceinline__ void gml_chain_load_eg(const float* __restrict__ ea, const float* __restrict__ gout,
-                                                  int64_t eid, bool valid, int q0, float (&e)[8], float (&gq)[4]) {
-    gml_chain_load_e<S>(ea, eid, valid, e);
+__device__ __forceinline__ void gml_chain_load_q(const float* __restrict__ base, int64_t eid, bool valid, int q0, float (&v)[4]) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) gq[r] = 0.f;
+    for (int r = 0; r < 4; ++r) v[r] = 0.f;
     if (valid) {
-        const float* gp = gout + eid * S + q0;
+        const float* gp = base + eid * S + q0;
         if constexpr (S % 4 == 0) {
             if (q0 < S) {
                 const f32x4 t = *reinterpret_cast<const f32x4*>(gp);
-                gq[0] = t.x; gq[1] = t.y; gq[2] = t.z; gq[3] = t.w;
+                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
             }
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (q0 + r < S) gq[r] = gp[r];
+                if (q0 + r < S) v[r] = gp[r];
         }
     }
 }
 
-template <int S, bool GIN>
+template <int S, bool GIN, bool PRE>
 __global__ __launch_bounds__(256, 3) void gml_k_edge_chain_bwd(
-    const float* __restrict__ ea, const float* __restrict__ w1, const float* __restrict__ w2,
+    const float* __restrict__ ea, const uint32_t* __restrict__ es, const float* __restrict__ w1, const float* __restrict__ w2,
     const float* __restrict__ w3, const float* __restrict__ w4, const float* __restrict__ gout,
     float* __restrict__ gin, float* __restrict__ partial, int64_t E, int64_t ntiles) {
     constexpr int H2 = 2 * S, H4 = 4 * S;
@@ -361,22 +377,43 @@ __global__ __launch_bounds__(256, 3) void gml_k_edge_chain_bwd(
 
     const int64_t stride = (int64_t)gridDim.x * 4;
     int64_t t = (int64_t)blockIdx.x * 4 + wave;
-    float e_n[8], g_n[4];
-    gml_chain_load_eg<S>(ea, gout, t * 16 + c16, t < ntiles && t * 16 + c16 < E, q0, e_n, g_n);
+    // prefetched inputs of the next tile: fp32 row (or, with the presplit buffer, the ready layer-1 operand + the 4 raw
+    // values of the [go | e] tile) and 4 values of the gout row
+    float e_n[PRE ? 1 : 8], ye_n[4], g_n[4];
+    u32x4 b1_n = u32x4{0u, 0u, 0u, 0u};
+    auto fetch = [&](int64_t tt) {
+        const int64_t en = tt * 16 + c16;
+        const bool ok = tt < ntiles && en < E;
+        if constexpr (PRE) {
+            b1_n = ok ? *reinterpret_cast<const u32x4*>(es + en * 8 + 4 * (g & 1)) : u32x4{0u, 0u, 0u, 0u};
+            gml_chain_load_q<S>(ea, en, ok, q0, ye_n);
+        } else {
+            gml_chain_load_e<S>(ea, en, ok, e_n);
+        }
+        gml_chain_load_q<S>(gout, en, ok, q0, g_n);
+    };
+    fetch(t);
     for (; t < ntiles; t += stride) {
         GmlChainT T;
-        float gq[4];
+        float gq[4], ye[4];
+        bf16x8 B1;
+        if constexpr (PRE) {
+            B1 = __builtin_bit_cast(bf16x8, b1_n);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) T.e[j] = e_n[j];
+            for (int r = 0; r < 4; ++r) ye[r] = ye_n[r];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) T.e[j] = e_n[j];
+            B1 = gml_chain_b1(T.e, g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ye[r] = (g & 1) ? T.e[4 + r] : T.e[r];
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) gq[r] = g_n[r];
         const int64_t eid = t * 16 + c16;
         const bool valid = eid < E;
-        {   // next tile's rows are in flight while this one is computed
-            const int64_t tn = t + stride, en = tn * 16 + c16;
-            gml_chain_load_eg<S>(ea, gout, en, tn < ntiles && en < E, q0, e_n, g_n);
-        }
-        gml_chain_forward<S, true>(W, T, g);
+        fetch(t + stride);                                     // next tile's rows are in flight while this one is computed
+        gml_chain_forward<S, true>(W, T, B1, g);
         f32x4 go;
 #pragma unroll
         for (int r = 0; r < 4; ++r) go[r] = (T.out[r] > 0.f) ? gq[r] : 0.f;
@@ -390,7 +427,7 @@ __global__ __launch_bounds__(256, 3) void gml_k_edge_chain_bwd(
             gz2[r] = dh23[r] * T.t3[r] * fmaf(-T.t2[r], T.t2[r], 1.f);
             gz3[r] = dh23[r] * T.t2[r] * fmaf(-T.t3[r], T.t3[r], 1.f);
             // [go | e] tile: rows 0..7 = go (lane groups 0,1), rows 8..15 = e (lane groups 2,3)
-            y[r] = (g < 2) ? go[r] : ((g & 1) ? T.e[4 + r] : T.e[r]);
+            y[r] = (g < 2) ? go[r] : ye[r];
         }
         u32x4 g12h, g12l, g3yh, g3yl;
         gml_split_pair(W.negI, gz1, gz2, g12h, g12l);
@@ -452,10 +489,10 @@ __global__ __launch_bounds__(256, 3) void gml_k_edge_chain_bwd(
 }
 
 template <int S>
-int gml_launch_edge_chain_fwd(const float* ea, const float* w1, const float* w2, const float* w3, const float* w4,
-                              float* out, const int32_t* tpos, float* out_t, int64_t E, hipStream_t st);
+int gml_launch_edge_chain_fwd(const float* ea, const uint32_t* es, const float* w1, const float* w2, const float* w3,
+                              const float* w4, float* out, const int32_t* tpos, float* out_t, int64_t E, hipStream_t st);
 template <int S>
-int gml_launch_edge_chain_bwd(const float* ea, const float* w1, const float* w2, const float* w3, const float* w4,
+int gml_launch_edge_chain_bwd(const float* ea, const uint32_t* es, const float* w1, const float* w2, const float* w3, const float* w4,
                               const float* gout, float* gin, float* dw1, float* dw2, float* dw3, float* dw4,
                               int64_t E, void* ws, size_t ws_bytes, hipStream_t st);
 
@@ -473,31 +510,43 @@ static inline int64_t gml_edge_chain_bwd_groups(int64_t E, int wgs_per_cu = 4) {
 
 #define GML_DEFINE_EDGE_CHAIN(SV)                                                                               \
     template <>                                                                                                 \
-    int gml_launch_edge_chain_fwd<SV>(const float* ea, const float* w1, const float* w2, const float* w3,       \
-                                      const float* w4, float* out, const int32_t* tpos, float* out_t,           \
-                                      int64_t E, hipStream_t st) {                                              \
+    int gml_launch_edge_chain_fwd<SV>(const float* ea, const uint32_t* es, const float* w1, const float* w2,    \
+                                      const float* w3, const float* w4, float* out, const int32_t* tpos,        \
+                                      float* out_t, int64_t E, hipStream_t st) {                                \
         const int64_t ntiles = gml_cdiv(E, 16);                                                                 \
         int64_t grid = gml_cdiv(ntiles, 8);                                                                     \
         if (grid > 8 * GML_NUM_CU) grid = 8 * GML_NUM_CU;                                                       \
-        hipLaunchKernelGGL((gml_k_edge_chain_fwd<SV>), dim3((unsigned)grid), dim3(256), 0, st, ea, w1, w2, w3,  \
-                           w4, out, tpos, out_t, E, ntiles);                                                    \
+        if (es != nullptr)                                                                                      \
+            hipLaunchKernelGGL((gml_k_edge_chain_fwd<SV, true>), dim3((unsigned)grid), dim3(256), 0, st, ea,    \
+                               es, w1, w2, w3, w4, out, tpos, out_t, E, ntiles);                                \
+        else                                                                                                    \
+            hipLaunchKernelGGL((gml_k_edge_chain_fwd<SV, false>), dim3((unsigned)grid), dim3(256), 0, st, ea,   \
+                               es, w1, w2, w3, w4, out, tpos, out_t, E, ntiles);                                \
         return gml_launch_status();                                                                             \
     }                                                                                                           \
     template <>                                                                                                 \
-    int gml_launch_edge_chain_bwd<SV>(const float* ea, const float* w1, const float* w2, const float* w3,       \
-                                      const float* w4, const float* gout, float* gin, float* dw1, float* dw2,   \
-                                      float* dw3, float* dw4, int64_t E, void* ws, size_t ws_bytes,             \
-                                      hipStream_t st) {                                                         \
-        const int64_t npairs = gml_cdiv(E, 16); /* 16-edge tiles */                                             \
-        const int64_t grid = gml_edge_chain_bwd_groups(E, 3);                                                      \
+    int gml_launch_edge_chain_bwd<SV>(const float* ea, const uint32_t* es, const float* w1, const float* w2,    \
+                                      const float* w3, const float* w4, const float* gout, float* gin,          \
+                                      float* dw1, float* dw2, float* dw3, float* dw4, int64_t E, void* ws,      \
+                                      size_t ws_bytes, hipStream_t st) {                                        \
+        const int64_t ntiles = gml_cdiv(E, 16);                                                                 \
+        const int64_t grid = gml_edge_chain_bwd_groups(E, 3);                                                   \
         constexpr int NW = GML_CHAIN_NW(SV);                                                                    \
         if (ws_bytes < (size_t)grid * NW * sizeof(float)) return GML_E_WORKSPACE;                               \
-        if (gin != nullptr)                                                                                     \
-            hipLaunchKernelGGL((gml_k_edge_chain_bwd<SV, true>), dim3((unsigned)grid), dim3(256), 0, st, ea,    \
-                               w1, w2, w3, w4, gout, gin, (float*)ws, E, npairs);                               \
+        const dim3 gd((unsigned)grid), bd(256);                                                                 \
+        float* wsf = (float*)ws;                                                                                \
+        if (gin != nullptr && es != nullptr)                                                                    \
+            hipLaunchKernelGGL((gml_k_edge_chain_bwd<SV, true, true>), gd, bd, 0, st, ea, es, w1, w2, w3, w4,   \
+                               gout, gin, wsf, E, ntiles);                                                      \
+        else if (gin != nullptr)                                                                                \
+            hipLaunchKernelGGL((gml_k_edge_chain_bwd<SV, true, false>), gd, bd, 0, st, ea, es, w1, w2, w3, w4,  \
+                               gout, gin, wsf, E, ntiles);                                                      \
+        else if (es != nullptr)                                                                                 \
+            hipLaunchKernelGGL((gml_k_edge_chain_bwd<SV, false, true>), gd, bd, 0, st, ea, es, w1, w2, w3, w4,  \
+                               gout, gin, wsf, E, ntiles);                                                      \
         else                                                                                                    \
-            hipLaunchKernelGGL((gml_k_edge_chain_bwd<SV, false>), dim3((unsigned)grid), dim3(256), 0, st, ea,   \
-                               w1, w2, w3, w4, gout, gin, (float*)ws, E, npairs);                               \
+            hipLaunchKernelGGL((gml_k_edge_chain_bwd<SV, false, false>), gd, bd, 0, st, ea, es, w1, w2, w3, w4, \
+                               gout, gin, wsf, E, ntiles);                                                      \
         int rc = gml_launch_status();                                                                           \
         if (rc != GML_OK) return rc;                                                                            \
         const int n123 = 2 * SV * SV, n4 = SV * 4 * SV;                                                         \

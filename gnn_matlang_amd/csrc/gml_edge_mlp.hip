@@ -10,12 +10,12 @@ static bool emlp_use_chain(int S) {
     return S <= 8 && !valu;
 }
 #define GML_DECL_ECHAIN(SV)                                                                                  \
-    template <> int gml_launch_edge_chain_fwd<SV>(const float*, const float*, const float*, const float*,    \
-                                                  const float*, float*, const int32_t*, float*, int64_t,     \
-                                                  hipStream_t);                                              \
-    template <> int gml_launch_edge_chain_bwd<SV>(const float*, const float*, const float*, const float*,    \
-                                                  const float*, const float*, float*, float*, float*,        \
-                                                  float*, float*, int64_t, void*, size_t, hipStream_t);
+    template <> int gml_launch_edge_chain_fwd<SV>(const float*, const uint32_t*, const float*, const float*, \
+                                                  const float*, const float*, float*, const int32_t*, float*, \
+                                                  int64_t, hipStream_t);                                     \
+    template <> int gml_launch_edge_chain_bwd<SV>(const float*, const uint32_t*, const float*, const float*, \
+                                                  const float*, const float*, const float*, float*, float*,  \
+                                                  float*, float*, float*, int64_t, void*, size_t, hipStream_t);
 GML_DECL_ECHAIN(1) GML_DECL_ECHAIN(2) GML_DECL_ECHAIN(3) GML_DECL_ECHAIN(4)
 GML_DECL_ECHAIN(5) GML_DECL_ECHAIN(6) GML_DECL_ECHAIN(7) GML_DECL_ECHAIN(8)
 #define GML_ECHAIN_SWITCH(CALL)                                                                 \
@@ -69,18 +69,51 @@ GML_DECL_EMLP(13) GML_DECL_EMLP(14) GML_DECL_EMLP(15) GML_DECL_EMLP(16)
     }                                                                                           \
     return GML_E_UNSUPPORTED;
 
-extern "C" int gml_edge_mlp_fwd(const float* ea, const float* w1, const float* w2, const float* w3,
+// hi[8] | lo[8] bf16 per edge (32 bytes): the layer-1 operand of the matrix-core kernels, made once per batch
+__global__ __launch_bounds__(256) void gml_k_edge_presplit(const float* __restrict__ ea, uint32_t* __restrict__ es,
+                                                          int64_t E, int S) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    uint32_t hi[4], lo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float x0 = (2 * j < S) ? ea[e * S + 2 * j] : 0.f, x1 = (2 * j + 1 < S) ? ea[e * S + 2 * j + 1] : 0.f;
+        const float t0 = __uint_as_float(__float_as_uint(x0) & 0xffff0000u);
+        const float t1 = __uint_as_float(__float_as_uint(x1) & 0xffff0000u);
+        hi[j] = gml_pack2(t0, t1);
+        lo[j] = gml_pack2(x0 - t0, x1 - t1);
+    }
+    u32x4* o = reinterpret_cast<u32x4*>(es + e * 8);
+    o[0] = u32x4{hi[0], hi[1], hi[2], hi[3]};
+    o[1] = u32x4{lo[0], lo[1], lo[2], lo[3]};
+}
+
+extern "C" int gml_edge_presplit(const float* ea, void* ea_split, int64_t num_edges, int32_t S, gml_stream_t stream) {
+    if (num_edges < 0 || S <= 0) return GML_E_BADARG;
+    if (S > 8) return GML_E_UNSUPPORTED;
+    if (num_edges == 0) return GML_OK;
+    if (!ea || !ea_split || (((uintptr_t)ea_split) & 15) != 0) return GML_E_BADARG;
+    hipLaunchKernelGGL(gml_k_edge_presplit, dim3((unsigned)gml_cdiv(num_edges, 256)), dim3(256), 0, (hipStream_t)stream, ea,
+                       (uint32_t*)ea_split, num_edges, S);
+    return gml_launch_status();
+}
+
+extern "C" int gml_edge_mlp_fwd(const float* ea, const void* ea_split, const float* w1, const float* w2, const float* w3,
                                 const float* w4, float* out, const int32_t* tpos, float* out_t,
                                 int64_t num_edges, int32_t S, int32_t Sout, gml_stream_t stream) {
     if (num_edges < 0 || S <= 0 || Sout <= 0) return GML_E_BADARG;
     if (num_edges == 0) return GML_OK;
     if (!ea || !w1 || !w2 || !w3 || !w4 || !out) return GML_E_BADARG;
     if (S != Sout) return GML_E_UNSUPPORTED;   // every reference script uses nedgeoutput == nedgeinput
-    if ((((uintptr_t)ea | (uintptr_t)out | (uintptr_t)out_t) & 15) != 0) return GML_E_BADARG;
+    if ((((uintptr_t)ea | (uintptr_t)out | (uintptr_t)out_t | (uintptr_t)ea_split) & 15) != 0) return GML_E_BADARG;
+#ifdef GML_NO_PRESPLIT
+    ea_split = nullptr;
+#endif
     if (out_t && !tpos) return GML_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     if (emlp_use_chain(S)) {
-#define GML_CALL_CF(SV) gml_launch_edge_chain_fwd<SV>(ea, w1, w2, w3, w4, out, tpos, out_t, num_edges, st)
+#define GML_CALL_CF(SV) \
+    gml_launch_edge_chain_fwd<SV>(ea, (const uint32_t*)ea_split, w1, w2, w3, w4, out, tpos, out_t, num_edges, st)
         GML_ECHAIN_SWITCH(GML_CALL_CF)
     }
 #define GML_CALL_F(SV) gml_launch_edge_mlp_fwd<SV, SV>(ea, w1, w2, w3, w4, out, tpos, out_t, num_edges, st)
@@ -102,7 +135,7 @@ extern "C" size_t gml_edge_mlp_bwd_workspace_bytes(int64_t num_edges, int32_t S,
     return (size_t)parts * (size_t)(6 * S * S + Sout * 4 * S) * sizeof(float);
 }
 
-extern "C" int gml_edge_mlp_bwd(const float* ea, const float* w1, const float* w2, const float* w3,
+extern "C" int gml_edge_mlp_bwd(const float* ea, const void* ea_split, const float* w1, const float* w2, const float* w3,
                                 const float* w4, const float* gout, float* gin, float* dw1, float* dw2,
                                 float* dw3, float* dw4, int64_t num_edges, int32_t S, int32_t Sout,
                                 void* ws, size_t ws_bytes, gml_stream_t stream) {
@@ -118,10 +151,14 @@ extern "C" int gml_edge_mlp_bwd(const float* ea, const float* w1, const float* w
         return gml_launch_status();
     }
     if (!ea || !gout || !ws) return GML_E_BADARG;
-    if ((((uintptr_t)ea | (uintptr_t)gout | (uintptr_t)gin) & 15) != 0) return GML_E_BADARG;
+    if ((((uintptr_t)ea | (uintptr_t)gout | (uintptr_t)gin | (uintptr_t)ea_split) & 15) != 0) return GML_E_BADARG;
+#ifdef GML_NO_PRESPLIT
+    ea_split = nullptr;
+#endif
     if (emlp_use_chain(S)) {
 #define GML_CALL_CB(SV) \
-    gml_launch_edge_chain_bwd<SV>(ea, w1, w2, w3, w4, gout, gin, dw1, dw2, dw3, dw4, num_edges, ws, ws_bytes, st)
+    gml_launch_edge_chain_bwd<SV>(ea, (const uint32_t*)ea_split, w1, w2, w3, w4, gout, gin, dw1, dw2, dw3, dw4, \
+                                  num_edges, ws, ws_bytes, st)
         GML_ECHAIN_SWITCH(GML_CALL_CB)
     }
 #define GML_CALL_B(SV) \

@@ -131,18 +131,28 @@ def relu_bwd(gy, gy_off, ldgy, y, ldy, nrows, F):
     return g[:, :F]
 
 
-def edge_mlp_fwd(ea, w1, w2, w3, w4, tpos=None):
+def edge_presplit(ea):
+    """bf16 hi | lo image of the rows of ea (S <= 8) for the matrix-core edge kernels; None when not applicable."""
+    E, S = ea.shape
+    if S > 8 or E == 0:
+        return None
+    es = torch.empty(E, 8, dtype=torch.int32, device=ea.device)
+    _lib.call('gml_edge_presplit', _ptr(ea), _ptr(es), int(E), int(S), _stream(ea.device))
+    return es
+
+
+def edge_mlp_fwd(ea, w1, w2, w3, w4, tpos=None, ea_split=None):
     """returns out (same edge order as ea) and, when tpos is given, the same rows at out_t[tpos[e]]."""
     E, S = ea.shape
     So = w4.size(0)
     out = torch.empty(E, So, dtype=torch.float32, device=ea.device)
     out_t = torch.empty(E, So, dtype=torch.float32, device=ea.device) if tpos is not None else None
-    _lib.call('gml_edge_mlp_fwd', _ptr(ea), _ptr(w1), _ptr(w2), _ptr(w3), _ptr(w4), _ptr(out), _ptr(tpos),
+    _lib.call('gml_edge_mlp_fwd', _ptr(ea), _ptr(ea_split), _ptr(w1), _ptr(w2), _ptr(w3), _ptr(w4), _ptr(out), _ptr(tpos),
               _ptr(out_t), int(E), int(S), int(So), _stream(ea.device))
     return out, out_t
 
 
-def edge_mlp_bwd(ea, w1, w2, w3, w4, gout, need_gin):
+def edge_mlp_bwd(ea, w1, w2, w3, w4, gout, need_gin, ea_split=None):
     E, S = ea.shape
     So = w4.size(0)
     dev = ea.device
@@ -150,7 +160,7 @@ def edge_mlp_bwd(ea, w1, w2, w3, w4, gout, need_gin):
     ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=dev)
     gin = torch.empty_like(ea) if need_gin else None
     dw1, dw2, dw3, dw4 = torch.empty_like(w1), torch.empty_like(w2), torch.empty_like(w3), torch.empty_like(w4)
-    _lib.call('gml_edge_mlp_bwd', _ptr(ea), _ptr(w1), _ptr(w2), _ptr(w3), _ptr(w4), _ptr(gout), _ptr(gin),
+    _lib.call('gml_edge_mlp_bwd', _ptr(ea), _ptr(ea_split), _ptr(w1), _ptr(w2), _ptr(w3), _ptr(w4), _ptr(gout), _ptr(gin),
               _ptr(dw1), _ptr(dw2), _ptr(dw3), _ptr(dw4), int(E), int(S), int(So), _ptr(ws), ws.numel(), _stream(dev))
     return gin, dw1, dw2, dw3, dw4
 
@@ -392,7 +402,7 @@ class ML3LayerFunction(torch.autograd.Function):
                 # when the fused backward will run, the edge branch also emits its output in source order
                 dual = any(ctx.needs_input_grad) and fused_bwd_available(csr, S, Fin, nout1)
                 with _Timed('edge_mlp_fwd', 4 * val.numel() * (3 if dual else 2), 20 * val.size(0) * val.size(1) ** 2):
-                    ea, ea_t = edge_mlp_fwd(val, w1, w2, w3, w4, csr.tpos if dual else None)
+                    ea, ea_t = edge_mlp_fwd(val, w1, w2, w3, w4, csr.tpos if dual else None, csr.presplit(val))
             else:
                 ea, ea_t = val, None
             if ea.size(1) != S:
@@ -460,7 +470,8 @@ class ML3LayerFunction(torch.autograd.Function):
                     # the edge MLP is per-edge, so it can run in whichever order dea arrived in
                     val_in = csr.to_source_order(val, cache=True) if dea_src else val
                     with _Timed('edge_mlp_bwd', 4 * val.numel() * 2, 60 * val.size(0) * val.size(1) ** 2):
-                        gin, g[2], g[3], g[4], g[5] = edge_mlp_bwd(val_in, w1, w2, w3, w4, dea, need[1])
+                        gin, g[2], g[3], g[4], g[5] = edge_mlp_bwd(val_in, w1, w2, w3, w4, dea, need[1],
+                                                                   csr.presplit(val_in))
                     if gin is not None and dea_src:
                         gin = csr.from_source_order(gin)
                     g[1] = gin

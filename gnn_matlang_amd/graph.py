@@ -98,7 +98,7 @@ class GraphCSR(object):
         _lib.call('gml_gather_rows', _ptr(ea), _ptr(self.perm), _ptr(out), self.E, int(ea.size(1)), _stream(ea.device))
         if cache:
             self._val_cache[key] = (edge_attr, out)        # keep the source alive: its address is the key
-            while len(self._val_cache) > 4:
+            while len(self._val_cache) > 8:
                 self._val_cache.popitem(last=False)
         return out
 
@@ -113,7 +113,24 @@ class GraphCSR(object):
                   _stream(val_sorted.device))
         if cache:
             self._val_cache[key] = (val_sorted, out)
-            while len(self._val_cache) > 4:
+            while len(self._val_cache) > 8:
+                self._val_cache.popitem(last=False)
+        return out
+
+    def presplit(self, val):
+        """bf16 hi | lo image of a per-batch value array (cached on the tensor's identity like the other derived
+        arrays); None when the edge kernels do not use one (S > 8)."""
+        from .functional import edge_presplit
+        if val.requires_grad or val.size(1) > 8:
+            return None
+        key = ('p', val.data_ptr(), val._version, tuple(val.shape))
+        hit = self._val_cache.get(key)
+        if hit is not None:
+            return hit[1]
+        out = edge_presplit(val)
+        if out is not None:
+            self._val_cache[key] = (val, out)
+            while len(self._val_cache) > 8:
                 self._val_cache.popitem(last=False)
         return out
 

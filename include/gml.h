@@ -143,15 +143,19 @@ int gml_sddmm(const int32_t* rowptr, const int32_t* col, const int32_t* epos,
  *   out = relu( W4 . [ relu(W1 . e) ; tanh(W2 . e) * tanh(W3 . e) ] )      per edge e in R^S
  * w1,w2,w3: [2S, S]; w4: [Sout, 4S]  (torch.nn.Linear layout, bias-free).  S = Sout <= 16.
  * If out_t != NULL the row of edge e is also written to out_t[tpos[e], :] (the same values in a second
- * edge order: the backward kernel walks the source-sorted order). */
-int gml_edge_mlp_fwd(const float* ea, const float* w1, const float* w2, const float* w3, const float* w4,
-                     float* out, const int32_t* tpos, float* out_t,
+ * edge order: the backward kernel walks the source-sorted order).
+ * ea_split (optional, S <= 8): the rows of ea split once into bf16 hi[8] | lo[8] (32 bytes per edge, 16-byte aligned)
+ * by gml_edge_presplit -- the raw supports are per-batch constants, so the matrix-core kernels load their first
+ * operand ready-made instead of splitting it per layer and per step.  Must describe the same ea (same edge order). */
+int gml_edge_presplit(const float* ea, void* ea_split, int64_t num_edges, int32_t S, gml_stream_t stream);
+int gml_edge_mlp_fwd(const float* ea, const void* ea_split, const float* w1, const float* w2, const float* w3,
+                     const float* w4, float* out, const int32_t* tpos, float* out_t,
                      int64_t num_edges, int32_t S, int32_t Sout, gml_stream_t stream);
 size_t gml_edge_mlp_bwd_workspace_bytes(int64_t num_edges, int32_t S, int32_t Sout);
 /* gout: dL/dout [E, Sout].  Writes dw1..dw4 (same shapes as the weights) and, if gin != NULL,
  * dL/dea [E, S].  Intermediates are recomputed from ea. */
-int gml_edge_mlp_bwd(const float* ea, const float* w1, const float* w2, const float* w3, const float* w4,
-                     const float* gout, float* gin, float* dw1, float* dw2, float* dw3, float* dw4,
+int gml_edge_mlp_bwd(const float* ea, const void* ea_split, const float* w1, const float* w2, const float* w3,
+                     const float* w4, const float* gout, float* gin, float* dw1, float* dw2, float* dw3, float* dw4,
                      int64_t num_edges, int32_t S, int32_t Sout,
                      void* ws, size_t ws_bytes, gml_stream_t stream);
 

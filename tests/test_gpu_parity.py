@@ -325,6 +325,15 @@ def test_spmm_sddmm_edge_mlp_node_mix_vs_oracle(dev):
         close(gin, eo.grad, what='edge mlp gin S=%d' % S)
         for got, w, n in ((d1, wo[0], 'dw1'), (d2, wo[1], 'dw2'), (d3, wo[2], 'dw3'), (d4, wo[3], 'dw4')):
             close(got, w.grad, what='edge mlp %s S=%d' % (n, S))
+        if S <= 8:                                         # ready-made bf16 hi | lo operand: the same bits
+            es = Fn.edge_presplit(ea.to(dev))
+            y3, yt3 = Fn.edge_mlp_fwd(ea.to(dev), *wd, tpos=tp, ea_split=es)
+            assert torch.equal(y3, y) and torch.equal(yt3, yt)
+            r3 = Fn.edge_mlp_bwd(ea.to(dev), *wd, gout.to(dev), True, ea_split=es)
+            for a_, b_ in zip(r3, (gin, d1, d2, d3, d4)):
+                assert torch.equal(a_, b_)
+            r4 = Fn.edge_mlp_bwd(ea.to(dev), *wd, gout.to(dev), False, ea_split=es)
+            assert r4[0] is None and all(torch.equal(a_, b_) for a_, b_ in zip(r4[1:], (d1, d2, d3, d4)))
 
 
 @pytest.mark.gpu
