@@ -28,7 +28,9 @@ struct GmlFwd2Cfg {
 };
 
 // XVEC: the X rows are float4-addressable (ldx % 4 == 0, aligned base); else the window is staged element-wise
-template <int S, int NOB, bool XVEC>
+// MIX: the ML3Layer Hadamard branch (F2 <= 8 outputs) of the group's own rows rides along: one more K = 32 MFMA triple
+// per tile against the [w11; w12] rows instead of a second pass over x by another kernel
+template <int S, int NOB, bool XVEC, bool MIX>
 __global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p) {
     using C = GmlFwd2Cfg<S>;
     constexpr int LDX = C::LDX, ROWS = GML_FWD2_ROWS;
@@ -61,6 +63,21 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p
     float bias_r[NOB];
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob) bias_r[ob] = (p.bias && ob * 16 + r16 < p.Fout) ? p.bias[ob * 16 + r16] : 0.f;
+
+    bf16x8 mwh, mwl;                                           // B[k = f][n = c]: c < F2 -> w11 row c, F2 <= c < 2 F2 -> w12 row c - F2
+    float mbias = 0.f;
+    if constexpr (MIX) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int f = 8 * kq + j;
+            const bool ok = f < p.Fin && r16 < 2 * p.F2;
+            v[j] = ok ? (r16 < p.F2 ? p.w11[r16 * p.Fin + f] : p.w12[(r16 - p.F2) * p.Fin + f]) : 0.f;
+        }
+        gml_split8(v, mwh, mwl);
+        if (r16 < p.F2) mbias = p.b11 ? p.b11[r16] : 0.f;
+        else if (r16 < 2 * p.F2) mbias = p.b12 ? p.b12[r16 - p.F2] : 0.f;
+    }
 
     // ---- software-pipelined staging.  Every prefetch load is unconditional with indices clamped into the arrays (lanes
     //      outside fetch a valid, unused element): with a load under a predicate or branch the compiler cannot count the
@@ -154,6 +171,20 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p
         const bool rvalid = row < nr;
         const int kbeg = rvalid ? rp_l[row] : 0;
         const int kend = rvalid ? rp_l[row + 1] : 0;
+        float xrow[MIX ? 8 : 1];                              // the lane's own x row, features 8*kq..8*kq+7 (Hadamard branch)
+        if constexpr (MIX) {
+            const float* xr = p.x + min(r0 + row, p.nrows - 1) * p.ldx;
+            if constexpr (XVEC) {
+#pragma unroll
+                for (int q4 = 0; q4 < 2; ++q4) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(xr + min(8 * kq + 4 * q4, f4max));
+                    xrow[4 * q4] = t.x; xrow[4 * q4 + 1] = t.y; xrow[4 * q4 + 2] = t.z; xrow[4 * q4 + 3] = t.w;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xrow[j] = xr[min(8 * kq + j, p.Fin - 1)];
+            }
+        }
 
         // ---- aggregation (fp32 VALU, packed): acc[s][f] += val[k, s] * x[col[k], f], f = 8*kq .. 8*kq+7
         f32x2 acc[S][4];
@@ -233,27 +264,47 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p
                 if (o < p.Fout && lr < nr) p.out[(r0 + lr) * p.ldo + o] = v;
             }
         }
+        if constexpr (MIX) {
+            // z[row][c] = x[row] . wmix[c]: A = the lane's row (k = f), D: lane (c = r16, kq) holds rows 4*kq + reg
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (8 * kq + j >= p.Fin) xrow[j] = 0.f;        // clamped loads fetched a neighbour: outside Fin -> 0
+            bf16x8 xh, xl;
+            gml_split8(xrow, xh, xl);
+            f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+            z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, mwh, z, 0, 0, 0);
+            z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, mwl, z, 0, 0, 0);
+            z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, mwh, z, 0, 0, 0);
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const float t = gml_tanh(z[reg] + mbias);
+                const float u = __shfl(t, lane + p.F2);        // partner column c + F2 of the same 16-lane row group
+                const int lr = (int)((out_rows >> (8 * reg)) & 255u);
+                if (r16 < p.F2 && lr < nr) p.out[(r0 + lr) * p.ldo + p.mix_col + r16] = t * u;
+            }
+        }
         __syncthreads();                                       // this group's LDS reads are done
     }
 }
 
 template <int S, int NOB>
-int gml_launch_fwd2(const GmlFwdParams& p, dim3 grid, hipStream_t st, bool xvec);
+int gml_launch_fwd2(const GmlFwdParams& p, dim3 grid, hipStream_t st, bool xvec, bool mix);
 
+#define GML_FWD2_LAUNCH(SV, NOBV, XV, MX)                                                                    \
+    {                                                                                                        \
+        static const hipError_t rc_ = hipFuncSetAttribute(                                                   \
+            reinterpret_cast<const void*>(&gml_k_spectconv_fwd2<SV, NOBV, XV, MX>),                          \
+            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                         \
+        if (rc_ != hipSuccess) return (int)rc_;                                                              \
+        hipLaunchKernelGGL((gml_k_spectconv_fwd2<SV, NOBV, XV, MX>), grid, dim3(512),                        \
+                           GmlFwd2Cfg<SV>::lds_bytes(), st, p);                                              \
+        return gml_launch_status();                                                                          \
+    }
 #define GML_DEFINE_FWD2(SV, NOBV)                                                                            \
     template <>                                                                                              \
-    int gml_launch_fwd2<SV, NOBV>(const GmlFwdParams& p, dim3 grid, hipStream_t st, bool xvec) {             \
-        static const hipError_t rc1 = hipFuncSetAttribute(                                                   \
-            reinterpret_cast<const void*>(&gml_k_spectconv_fwd2<SV, NOBV, true>),                            \
-            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                         \
-        static const hipError_t rc0 = hipFuncSetAttribute(                                                   \
-            reinterpret_cast<const void*>(&gml_k_spectconv_fwd2<SV, NOBV, false>),                           \
-            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                         \
-        if (rc1 != hipSuccess) return (int)rc1;                                                              \
-        if (rc0 != hipSuccess) return (int)rc0;                                                              \
-        if (xvec) hipLaunchKernelGGL((gml_k_spectconv_fwd2<SV, NOBV, true>), grid, dim3(512),                \
-                                     GmlFwd2Cfg<SV>::lds_bytes(), st, p);                                    \
-        else hipLaunchKernelGGL((gml_k_spectconv_fwd2<SV, NOBV, false>), grid, dim3(512),                    \
-                                GmlFwd2Cfg<SV>::lds_bytes(), st, p);                                         \
-        return gml_launch_status();                                                                          \
+    int gml_launch_fwd2<SV, NOBV>(const GmlFwdParams& p, dim3 grid, hipStream_t st, bool xvec, bool mix) {   \
+        if (xvec && mix) GML_FWD2_LAUNCH(SV, NOBV, true, true)                                               \
+        if (xvec) GML_FWD2_LAUNCH(SV, NOBV, true, false)                                                     \
+        if (mix) GML_FWD2_LAUNCH(SV, NOBV, false, true)                                                      \
+        GML_FWD2_LAUNCH(SV, NOBV, false, false)                                                              \
     }

@@ -43,6 +43,9 @@ struct GmlFwdParams {
     int32_t val_vec;     // value rows (S floats apart, starting at s0) keep the SC alignment class
     int32_t wfloats;     // floats of LDS reserved for W in front of the staging area
     const int32_t* ginfo; // [ngroups][GML_GREC_INTS(64)] records of gml_csr_group_info (64-row groups)
+    // Hadamard branch fused into the 8-wave kernel (gml_ml3_fwd): out[r, mix_col + o] = tanh(x w11_o + b11_o) tanh(x w12_o + b12_o)
+    const float* w11; const float* b11; const float* w12; const float* b12;
+    int32_t F2, mix_col;
 };
 
 // Per-group staging capacities.  A group = 64 consecutive output rows = the 4 tiles a workgroup

@@ -410,13 +410,16 @@ class ML3LayerFunction(torch.autograd.Function):
             out = torch.empty(N, C, dtype=torch.float32, device=x.device)
             cb_ = _f32c(cb, 'conv1.bias') if cb is not None else None
             gi, gflag = fwd_groups(csr, x, S, Fin, nout1)
-            fused_conv(csr.rowptr, csr.col, gi, None, ea, x, Fin, cw, (Fin * nout1, nout1, 1), cb_, out, C, N,
-                       S, Fin, nout1, _lib.GML_RELU | gflag)
             if nout2 > 0:
                 w11, b11, w12, b12 = (_f32c(w11, 'fc11.weight'), _f32c(b11, 'fc11.bias'), _f32c(w12, 'fc12.weight'),
                                       _f32c(b12, 'fc12.bias'))
-                _lib.call('gml_node_mix_fwd', _ptr(x), Fin, _ptr(w11), _ptr(b11), _ptr(w12), _ptr(b12),
-                          _off(out, nout1), C, N, Fin, nout2, _stream(x.device))
+            q, f = conv_cost(N, int(ea.size(0)), S, Fin, nout1) if PROFILE is not None else (0, 0)
+            with _Timed('spectconv_fwd', q, f):                    # conv (+ Hadamard branch of the same rows)
+                _lib.call('gml_ml3_fwd', _ptr(csr.rowptr), _ptr(csr.col), _ptr(gi), _ptr(ea), _ptr(x), Fin, _ptr(cw),
+                          Fin * nout1, nout1, 1, _ptr(cb_), _ptr(w11 if nout2 > 0 else None),
+                          _ptr(b11 if nout2 > 0 else None), _ptr(w12 if nout2 > 0 else None),
+                          _ptr(b12 if nout2 > 0 else None), _ptr(out), C, N, S, Fin, nout1, int(nout2),
+                          _lib.GML_RELU | gflag | (_lib.GML_F32_MFMA if F32_MFMA else 0), _stream(x.device))
         ctx.csr, ctx.learnedge, ctx.nout2, ctx.has_cb = csr, learnedge, nout2, cb is not None
         ctx.save_for_backward(x, val, ea if learnedge else None, w1, w2, w3, w4, cw, w11, b11, w12, b12, out, ea_t)
         return out

@@ -159,6 +159,16 @@ int gml_edge_mlp_bwd(const float* ea, const void* ea_split, const float* w1, con
                      int64_t num_edges, int32_t S, int32_t Sout,
                      void* ws, size_t ws_bytes, gml_stream_t stream);
 
+/* ---------------------------------------------------------------- ML3Layer forward without the edge branch
+ * (libs/spect_conv.py:204-212): out[:, :nout1] = act(SpectConv(x)), out[:, nout1:nout1+F2] = tanh(fc11 x) * tanh(fc12 x).
+ * Same arguments as gml_spectconv_fwd (epos = NULL) + the Hadamard weights; one launch on the 8-wave kernel when
+ * GML_GROUPS128 applies and F2 <= 8, else gml_spectconv_fwd followed by gml_node_mix_fwd.  F2 = 0: conv only. */
+int gml_ml3_fwd(const int32_t* rowptr, const int32_t* col, const int32_t* ginfo, const float* val,
+                const float* x, int64_t ldx, const float* w, int64_t w_ss, int64_t w_si, int64_t w_so,
+                const float* bias, const float* w11, const float* b11, const float* w12, const float* b12,
+                float* out, int64_t ldo, int64_t num_rows, int32_t S, int32_t Fin, int32_t nout1, int32_t F2,
+                uint32_t flags, gml_stream_t stream);
+
 /* ---------------------------------------------------------------- ML3Layer Hadamard branch
  *   out[r, 0:F2] = tanh(x[r] . w11^T + b11) * tanh(x[r] . w12^T + b12)      w1x: [F2, Fin] */
 int gml_node_mix_fwd(const float* x, int64_t ldx, const float* w11, const float* b11,
