@@ -121,8 +121,10 @@ class GraphCSR(object):
         """bf16 hi | lo image of a per-batch value array (cached on the tensor's identity like the other derived
         arrays); None when the edge kernels do not use one (S > 8)."""
         from .functional import edge_presplit
-        if val.requires_grad or val.size(1) > 8:
+        if val.size(1) > 8:
             return None
+        if val.requires_grad:                                  # trained supports change every step: split, do not cache
+            return edge_presplit(val.detach())
         key = ('p', val.data_ptr(), val._version, tuple(val.shape))
         hit = self._val_cache.get(key)
         if hit is not None:
