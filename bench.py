@@ -242,11 +242,11 @@ def main():
             if 'spectconv_bwd' in summ:
                 cands.append(roof('spectconv_bwd', 'gml_k_spectconv_bwd2 / gml_k_spectconv_bwd (fused SpectConv backward: dX, dval, dW)', pj_b, ed_b))
             if 'spectconv_fwd' in summ:
-                cands.append(roof('spectconv_fwd', 'gml_k_spectconv_fwd (fused SpectConv forward)', pj_f, ed_f))
+                cands.append(roof('spectconv_fwd', 'gml_k_spectconv_fwd2 / gml_k_spectconv_fwd (fused SpectConv forward; the 8-wave kernel also carries the Hadamard branch)', pj_f, ed_f))
             # HBM bytes per launch from the PMC counters (collected offline with the same command under rocprofv3,
-            # separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied -- profiles/r01_g_hbm_traffic.md);
+            # separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied -- profiles/r01_h_hbm_traffic.md);
             # only valid for the workload it was measured on
-            tpath = os.path.join(ROOT, 'profiles', 'r01_g_hbm_traffic.json')
+            tpath = os.path.join(ROOT, 'profiles', 'r01_h_hbm_traffic.json')
             if os.path.exists(tpath) and data.num_graphs == 32768 and args.pool == 2048:
                 tk = json.load(open(tpath))['kernels']
                 for r in cands:
@@ -255,7 +255,7 @@ def main():
                     if hits:                                  # launch-weighted mean over the instantiations used
                         r['traffic'] = sum(h['hbm_bytes_per_launch'] * h.get('launches', 1) for h in hits) / \
                             sum(h.get('launches', 1) for h in hits)
-                        r['traffic_source'] = 'profiles/r01_g_hbm_traffic.json (rocprofv3 PMC, per launch)'
+                        r['traffic_source'] = 'profiles/r01_h_hbm_traffic.json (rocprofv3 PMC, per launch)'
             cands.sort(key=lambda r: -r['ms_per_step'])
             res['roofline'] = cands[0]                   # the kernel with the largest share of the step
             res['roofline_other'] = cands[1:]
