@@ -214,13 +214,27 @@ static int launch_spmm(const int32_t* rowptr, const int32_t* col, const int32_t*
     return gml_launch_status();
 }
 
-extern "C" int gml_spmm_fwd(const int32_t* rowptr, const int32_t* col, const int32_t* epos, const float* val,
-                            const float* x, int64_t ldx, float* h, int64_t num_rows, int32_t S, int32_t Fin,
-                            gml_stream_t stream) {
+extern "C" int gml_spmm_fwd(const int32_t* rowptr, const int32_t* col, const int32_t* ginfo128, const int32_t* epos,
+                            const float* val, const float* x, int64_t ldx, float* h, int64_t num_rows, int32_t S,
+                            int32_t Fin, gml_stream_t stream) {
     if (num_rows < 0 || S <= 0 || Fin <= 0 || ldx < Fin) return GML_E_BADARG;
     if (num_rows == 0) return GML_OK;
     if (!rowptr || !x || !h) return GML_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
+    if (ginfo128 != nullptr && epos == nullptr && fwd2_shape(S, Fin, 16, 0) && (((uintptr_t)val & 15) == 0) &&
+        (((uintptr_t)h & 15) == 0)) {
+        // the 8-wave kernel's staged, degree-ranked aggregation; H written straight from the accumulators
+        const bool xv = (ldx % 4 == 0) && (((uintptr_t)x & 15) == 0);
+        GmlFwdParams p = {};
+        p.rowptr = rowptr; p.col = col; p.ginfo = ginfo128; p.val = val; p.x = x; p.ldx = ldx;
+        p.nrows = num_rows; p.S = S; p.Fin = Fin; p.Fout = 16; p.npass = 1; p.nchunks = 1; p.val_vec = 1; p.hout = h;
+        p.ngroups = (int)gml_cdiv(num_rows, GML_FWD2_ROWS);
+        int grid = p.ngroups < GML_NUM_CU ? p.ngroups : GML_NUM_CU;
+        p.groups_per_wg = (int)gml_cdiv(p.ngroups, grid);
+        grid = (int)gml_cdiv(p.ngroups, p.groups_per_wg);
+        if (S == 8) return gml_launch_fwd2<8, 1>(p, dim3(grid), st, xv, false);
+        if (S == 4) return gml_launch_fwd2<4, 1>(p, dim3(grid), st, xv, false);
+    }
     int s0 = 0;
     while (s0 < S) {
         const int rem = S - s0;

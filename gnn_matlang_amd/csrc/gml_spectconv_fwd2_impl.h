@@ -51,7 +51,7 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p
     const int g1 = min(g0 + p.groups_per_wg, p.ngroups);
     if (g0 >= g1) return;
 
-    for (int e = tid; e < S * 32 * 32; e += 512) {
+    for (int e = tid; e < S * 32 * 32 && p.hout == nullptr; e += 512) {
         const int f = e & 31, o = (e >> 5) & 31, s = e >> 10;
         const float v = (f < p.Fin && o < p.Fout) ? p.w[(int64_t)(p.s0 + s) * p.w_ss + (int64_t)f * p.w_si + (int64_t)o * p.w_so] : 0.f;
         const __bf16 h = (__bf16)v;
@@ -221,6 +221,38 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p
                     for (int h = 0; h < 4; ++h) acc[s][h] = e2 * f32x2{xb[2 * h], xb[2 * h + 1]} + acc[s][h];
                 }
             }
+        }
+
+        if (p.hout != nullptr) {                               // stand-alone SpMM: the aggregate is the output
+            // H[row][s][0..Fin) is 4 * Fin bytes: a lane's 8 features are a quarter of it.  Through a per-wave LDS tile
+            // ([16 rows][36], reusing the idle W area) every store instruction writes whole 128-byte (row, s) segments:
+            // lane l -> segment l >> 3 (row 2*j + ...), 16 bytes each
+            float* tile = reinterpret_cast<float*>(lds_raw) + wave * (16 * 36);
+            const bool v4 = (p.Fin == 32);
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                if (v4) {
+                    *reinterpret_cast<f32x4*>(tile + r16 * 36 + 8 * kq) = f32x4{acc[s][0].x, acc[s][0].y, acc[s][1].x, acc[s][1].y};
+                    *reinterpret_cast<f32x4*>(tile + r16 * 36 + 8 * kq + 4) = f32x4{acc[s][2].x, acc[s][2].y, acc[s][3].x, acc[s][3].y};
+                    // (LDS ops of one wave execute in order: no barrier inside the wave's private tile)
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const int pos = half * 8 + (lane >> 3), c4 = (lane & 7) * 4;      // tile position -> its row
+                        const f32x4 t = *reinterpret_cast<const f32x4*>(tile + pos * 36 + c4);
+                        const int rr = __shfl(row, pos);                                      // lane `pos` of this wave owns tile row pos
+                        if (rr < nr) *reinterpret_cast<f32x4*>(p.hout + (r0 + rr) * ((int64_t)S * 32) + s * 32 + c4) = t;
+                    }
+                } else if (rvalid) {
+                    float* hr = p.hout + (r0 + row) * ((int64_t)S * p.Fin) + s * p.Fin + 8 * kq;
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        if (8 * kq + 2 * h < p.Fin) hr[2 * h] = acc[s][h].x;
+                        if (8 * kq + 2 * h + 1 < p.Fin) hr[2 * h + 1] = acc[s][h].y;
+                    }
+                }
+            }
+            __syncthreads();                                   // this group's LDS reads are done
+            continue;
         }
 
         // ---- projection: out tile = sum_s acc_s W_s (acc split on the fly = A fragments, k = f = 8*kq + j)

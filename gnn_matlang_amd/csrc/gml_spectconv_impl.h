@@ -46,6 +46,7 @@ struct GmlFwdParams {
     // Hadamard branch fused into the 8-wave kernel (gml_ml3_fwd): out[r, mix_col + o] = tanh(x w11_o + b11_o) tanh(x w12_o + b12_o)
     const float* w11; const float* b11; const float* w12; const float* b12;
     int32_t F2, mix_col;
+    float* hout;          // stand-alone SpMM on the 8-wave kernel: H [N, S, Fin] receives the aggregate, no projection
 };
 
 // Per-group staging capacities.  A group = 64 consecutive output rows = the 4 tiles a workgroup

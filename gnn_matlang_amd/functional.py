@@ -110,7 +110,7 @@ def fwd_groups(csr, x, S, Fin, Fout):
 
 def spmm(csr, val, x, S, Fin):
     h = torch.empty(csr.N, S * Fin, dtype=torch.float32, device=x.device)
-    _lib.call('gml_spmm_fwd', _ptr(csr.rowptr), _ptr(csr.col), _ptr(None), _ptr(val), _ptr(x), int(x.stride(0)),
+    _lib.call('gml_spmm_fwd', _ptr(csr.rowptr), _ptr(csr.col), _ptr(csr.ginfo128), _ptr(None), _ptr(val), _ptr(x), int(x.stride(0)),
               _ptr(h), csr.N, int(S), int(Fin), _stream(x.device))
     return h
 
