@@ -40,8 +40,13 @@ class GNNML3(torch.nn.Module):
     """head 'mlp32': fc2(relu(fc1 x)), fc1: nin->32, fc2: 32->nclass;  'tanh10': tanh(fc1 x), fc1: nin->10."""
 
     def __init__(self, ninp, ne, nout1, nout2, nlayers, learnedge=True, bn=False, pool='add', head='mlp32',
-                 nclass=1, readout_bn=False):
+                 nclass=1, readout_bn=False, dense_n=0):
         super().__init__()
+        # dense_n > 0: equal-size graphs of dense_n nodes with near-dense masks (MNIST-75) are evaluated as dense
+        # blocks with batched library GEMMs (dense_block.py); same parameters, same values
+        if dense_n and (learnedge or nout2):
+            raise ValueError('the dense-block path covers plain SpectConv stacks (learnedge=False, nout2=0)')
+        self.dense_n = int(dense_n)
         widths = list(nout1) if isinstance(nout1, (list, tuple)) else [nout1] * nlayers    # per-layer nout1
         self.nlayers, self.bn, self.pool, self.head, self.readout_bn = nlayers, bn, pool, head, readout_bn
         fin = ninp
@@ -63,9 +68,18 @@ class GNNML3(torch.nn.Module):
 
     def forward(self, data):
         x = data.x
-        csr = data.csr('edge_index2')
+        if self.dense_n:
+            from .dense_block import dense_supports, spectconv_dense
+            if getattr(data, '_spT', None) is None:             # per-batch data, like the CSR
+                data._spT = dense_supports(data.edge_index2, data.edge_attr2, data.ptr, self.dense_n)
+        else:
+            csr = data.csr('edge_index2')
         for i in range(self.nlayers):
-            x = getattr(self, 'conv%d' % (i + 1))(x, csr, data.edge_attr2)
+            layer = getattr(self, 'conv%d' % (i + 1))
+            if self.dense_n:
+                x = F.relu(spectconv_dense(x, data._spT, layer.conv1.weight, layer.conv1.bias, self.dense_n))
+            else:
+                x = layer(x, csr, data.edge_attr2)
             if self.bn:
                 x = getattr(self, 'bn%d' % (i + 1))(x)
         x = global_add_pool(x, data) if self.pool == 'add' else global_mean_pool(x, data)
@@ -116,9 +130,9 @@ def sr25_gnnml3(ninp=2, ne=6):             # sr25.py:252-262
     return GNNML3(ninp, ne, 32, 16, 3, head='tanh10')
 
 
-def mnist_gnnml3(ninp=2, ne=6):            # mnist75_gnnml3_tf.py:62, libs/models_tf.py:223-268 (DSGCNN)
+def mnist_gnnml3(ninp=2, ne=6, dense_n=0):  # mnist75_gnnml3_tf.py:62, libs/models_tf.py:223-268 (DSGCNN)
     return GNNML3(ninp, ne, [64, 128, 128], 0, 3, learnedge=False, pool='mean', head='mlp32', nclass=10,
-                  readout_bn=True)
+                  readout_bn=True, dense_n=dense_n)
 
 
 def mutag_gnnml3(ninp=8, ne=4):            # mutag.py:272-288

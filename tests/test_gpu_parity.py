@@ -535,6 +535,16 @@ def test_mnist75_gnnml3_vs_oracle(dev):
     rp = dict(ref.named_parameters())
     for n, p in m.named_parameters():
         close(p.grad, rp[n].grad, tol=3e-4, what='mnist grad ' + n)
+    # dense-block evaluation (batched library GEMMs over [B, S*75, 75] support blocks): same parameters, same values
+    md = models.mnist_gnnml3(dense_n=75)
+    md.load_state_dict(ref.state_dict())
+    md = md.to(dev).train()
+    pre_d = md(data)
+    ld = models.mnist_loss(pre_d, data.y)
+    ld.backward()
+    close(pre_d, pre_ref, what='mnist logits (dense blocks)')
+    for n, p in md.named_parameters():
+        close(p.grad, rp[n].grad, tol=3e-4, what='mnist dense grad ' + n)
 
 
 # ------------------------------------------------------------------------------------------ full size

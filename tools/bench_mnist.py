@@ -1,0 +1,40 @@
+"""MNIST-75 GNNML3 (config 4) train step: sparse (block-CSR HIP kernels) vs dense-block (batched library GEMMs) path.
+python tools/bench_mnist.py [graphs]"""
+import json
+import os
+import sys
+import time
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gnn_matlang_amd import SpectralDesign, collate, models, synthetic
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+dev = torch.device('cuda:0')
+raw = synthetic.make_graphs('mnist75', 64, seed=1)
+pool = SpectralDesign(recfield=3, dv=10, nfreq=5).design_many(raw)
+data = collate([pool[i % 64] for i in range(B)]).to(dev)
+data.y = torch.randint(0, 10, (B,), device=dev)
+out = {}
+for name, dn in (('sparse', 0), ('dense', 75)):
+    torch.manual_seed(0)
+    m = models.mnist_gnnml3(dense_n=dn).to(dev).train()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, fused=True)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        l = models.mnist_loss(m(data), data.y)
+        l.backward()
+        opt.step()
+        return l
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 10
+    for _ in range(n):
+        l = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    out[name] = dict(ms_per_step=dt * 1e3, graphs_per_s=B / dt, loss=float(l))
+print(json.dumps(dict(graphs=B, nodes=int(data.x.size(0)), support_edges=int(data.edge_index2.size(1)), **out)))
