@@ -24,6 +24,7 @@ PROFILE = None
 # Projection arithmetic of the fused kernels: default = bf16x3 split on the bf16 matrix cores (fp32-class,
 # ~1e-6 of the output scale); F32_MFMA = True (or env GML_F32_MFMA=1) = f32-input MFMA, bit-identical to fmaf.
 import os as _os
+_linear = torch.nn.functional.linear
 F32_MFMA = _os.environ.get('GML_F32_MFMA', '0') not in ('0', '')
 
 
@@ -141,10 +142,31 @@ def edge_presplit(ea):
     return es
 
 
+def _edge_mlp_pad(ea, w1, w2, w3, w4):
+    """nedgeoutput != nedgeinput (spect_conv.py:66-71 allows it, no reference script uses it): the kernels are compiled
+    for square shapes, and zero-padded operands of size P = max(S, Sout) give the identical result — a padded hidden
+    unit is relu(0) = 0 resp. tanh(0)^2 = 0, a padded output column is dropped."""
+    S, So = ea.size(1), w4.size(0)
+    P = max(S, So)
+
+    def pad_in(w):
+        z = w.new_zeros(2 * P, P)
+        z[:2 * S, :S] = w
+        return z
+    w4p = w4.new_zeros(P, 4 * P)
+    w4p[:So, :2 * S] = w4[:, :2 * S]
+    w4p[:So, 2 * P:2 * P + 2 * S] = w4[:, 2 * S:]
+    return torch.nn.functional.pad(ea, (0, P - S)), pad_in(w1), pad_in(w2), pad_in(w3), w4p, P
+
+
 def edge_mlp_fwd(ea, w1, w2, w3, w4, tpos=None, ea_split=None):
     """returns out (same edge order as ea) and, when tpos is given, the same rows at out_t[tpos[e]]."""
     E, S = ea.shape
     So = w4.size(0)
+    if So != S:
+        eap, w1p, w2p, w3p, w4p, _ = _edge_mlp_pad(ea, w1, w2, w3, w4)
+        out, out_t = edge_mlp_fwd(eap, w1p, w2p, w3p, w4p, tpos, edge_presplit(eap))
+        return out[:, :So].contiguous(), (out_t[:, :So].contiguous() if out_t is not None else None)
     out = torch.empty(E, So, dtype=torch.float32, device=ea.device)
     out_t = torch.empty(E, So, dtype=torch.float32, device=ea.device) if tpos is not None else None
     _lib.call('gml_edge_mlp_fwd', _ptr(ea), _ptr(ea_split), _ptr(w1), _ptr(w2), _ptr(w3), _ptr(w4), _ptr(out), _ptr(tpos),
@@ -156,6 +178,13 @@ def edge_mlp_bwd(ea, w1, w2, w3, w4, gout, need_gin, ea_split=None):
     E, S = ea.shape
     So = w4.size(0)
     dev = ea.device
+    if So != S:
+        eap, w1p, w2p, w3p, w4p, P = _edge_mlp_pad(ea, w1, w2, w3, w4)
+        gin, d1, d2, d3, d4 = edge_mlp_bwd(eap, w1p, w2p, w3p, w4p, torch.nn.functional.pad(gout, (0, P - So)), need_gin,
+                                           edge_presplit(eap))
+        return (gin[:, :S].contiguous() if gin is not None else None, d1[:2 * S, :S].contiguous(),
+                d2[:2 * S, :S].contiguous(), d3[:2 * S, :S].contiguous(),
+                torch.cat([d4[:So, :2 * S], d4[:So, 2 * P:2 * P + 2 * S]], 1))
     nbytes = int(_lib.lib().gml_edge_mlp_bwd_workspace_bytes(int(E), int(S), int(So)))
     ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=dev)
     gin = torch.empty_like(ea) if need_gin else None
@@ -163,6 +192,11 @@ def edge_mlp_bwd(ea, w1, w2, w3, w4, gout, need_gin, ea_split=None):
     _lib.call('gml_edge_mlp_bwd', _ptr(ea), _ptr(ea_split), _ptr(w1), _ptr(w2), _ptr(w3), _ptr(w4), _ptr(gout), _ptr(gin),
               _ptr(dw1), _ptr(dw2), _ptr(dw3), _ptr(dw4), int(E), int(S), int(So), _ptr(ws), ws.numel(), _stream(dev))
     return gin, dw1, dw2, dw3, dw4
+
+
+def node_mix_native(Fin, F2):
+    """True when the Hadamard branch tanh(fc11 x) * tanh(fc12 x) of this shape runs on the fused HIP kernels."""
+    return int(_lib.lib().gml_node_mix_bwd_workspace_bytes(1, int(Fin), int(F2))) != 0
 
 
 def ml3_split_bwd(gy, y, nout1, x=None, w11=None, b11=None, w12=None, b12=None, need_dx=False, need_dcb=False):
@@ -414,12 +448,16 @@ class ML3LayerFunction(torch.autograd.Function):
                 w11, b11, w12, b12 = (_f32c(w11, 'fc11.weight'), _f32c(b11, 'fc11.bias'), _f32c(w12, 'fc12.weight'),
                                       _f32c(b12, 'fc12.bias'))
             q, f = conv_cost(N, int(ea.size(0)), S, Fin, nout1) if PROFILE is not None else (0, 0)
+            mixk = nout2 > 0 and node_mix_native(Fin, nout2)
             with _Timed('spectconv_fwd', q, f):                    # conv (+ Hadamard branch of the same rows)
                 _lib.call('gml_ml3_fwd', _ptr(csr.rowptr), _ptr(csr.col), _ptr(gi), _ptr(ea), _ptr(x), Fin, _ptr(cw),
-                          Fin * nout1, nout1, 1, _ptr(cb_), _ptr(w11 if nout2 > 0 else None),
-                          _ptr(b11 if nout2 > 0 else None), _ptr(w12 if nout2 > 0 else None),
-                          _ptr(b12 if nout2 > 0 else None), _ptr(out), C, N, S, Fin, nout1, int(nout2),
+                          Fin * nout1, nout1, 1, _ptr(cb_), _ptr(w11 if mixk else None),
+                          _ptr(b11 if mixk else None), _ptr(w12 if mixk else None),
+                          _ptr(b12 if mixk else None), _ptr(out), C, N, S, Fin, nout1, int(nout2) if mixk else 0,
                           _lib.GML_RELU | gflag | (_lib.GML_F32_MFMA if F32_MFMA else 0), _stream(x.device))
+            if nout2 > 0 and not mixk:
+                # ninp > 64 or nout2 > 24 (ptc.py:331-338 has ninp = 80): two plain library GEMMs + elementwise
+                out[:, nout1:] = torch.tanh(_linear(x, w11, b11)) * torch.tanh(_linear(x, w12, b12))
         ctx.csr, ctx.learnedge, ctx.nout2, ctx.has_cb = csr, learnedge, nout2, cb is not None
         ctx.save_for_backward(x, val, ea if learnedge else None, w1, w2, w3, w4, cw, w11, b11, w12, b12, out, ea_t)
         return out
@@ -440,8 +478,9 @@ class ML3LayerFunction(torch.autograd.Function):
             if not learnedge and fused_bwd_available(csr, S, Fin, nout1):
                 ea_t = csr.to_source_order(val, cache=True)              # raw supports: per-batch data
             want_cb = ctx.has_cb and need[7]
+            mixk = nout2 > 0 and node_mix_native(Fin, nout2)
             r = ml3_split_bwd(gy, out, nout1, x, w11, b11, w12, b12, need_dx=need[0], need_dcb=want_cb) \
-                if nout2 > 0 else ml3_split_bwd(gy, out, nout1, need_dcb=want_cb)
+                if mixk else ml3_split_bwd(gy, out, nout1, need_dcb=want_cb)
             if r is not None:
                 # one pass: relu mask, conv1.bias gradient, Hadamard branch (its dx written, conv adds to it)
                 G, dx0, g[7], g[8], g[9], g[10], g[11] = r
@@ -455,11 +494,8 @@ class ML3LayerFunction(torch.autograd.Function):
                 g[6] = dcw
                 if want_cb:
                     g[7] = G.sum(0)
-                if nout2 > 0:
+                if mixk:
                     nbytes = int(_lib.lib().gml_node_mix_bwd_workspace_bytes(N, Fin, nout2))
-                    if nbytes == 0:
-                        raise NotImplementedError('Hadamard branch backward: ninp=%d, nout2=%d outside the compiled '
-                                                  'kernel range' % (Fin, nout2))
                     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
                     g[8], g[9], g[10], g[11] = (torch.empty_like(w11), torch.empty_like(b11), torch.empty_like(w12),
                                                 torch.empty_like(b12))
@@ -467,6 +503,15 @@ class ML3LayerFunction(torch.autograd.Function):
                         _lib.call('gml_node_mix_bwd', _ptr(x), Fin, _ptr(w11), _ptr(b11), _ptr(w12), _ptr(b12),
                                   _off(gy, nout1), C, _ptr(dx) if need[0] else _ptr(None), Fin, _ptr(g[8]), _ptr(g[9]),
                                   _ptr(g[10]), _ptr(g[11]), N, Fin, nout2, _ptr(ws), ws.numel(), _stream(x.device))
+            if nout2 > 0 and not mixk:                              # wide Hadamard branch: library GEMMs (see forward)
+                ta, tb = torch.tanh(_linear(x, w11, b11)), torch.tanh(_linear(x, w12, b12))
+                g2 = gy[:, nout1:]
+                ga, gb = g2 * tb * (1 - ta * ta), g2 * ta * (1 - tb * tb)
+                g[8], g[10] = ga.t().mm(x), gb.t().mm(x)
+                g[9] = ga.sum(0) if b11 is not None else None
+                g[11] = gb.sum(0) if b12 is not None else None
+                if need[0]:
+                    dx = dx.addmm_(ga, w11).addmm_(gb, w12)
             g[0] = dx
             if learnedge:
                 if need_val:

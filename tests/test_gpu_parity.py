@@ -451,6 +451,41 @@ def test_ml3layer_golden(dev, golden):
             close(p.grad, c['grad/' + n], what=what + ' ' + n)
 
 
+@pytest.mark.parametrize('ne,neo,Fin,n1,n2', [(5, 3, 9, 24, 6), (3, 8, 9, 24, 6), (4, 12, 9, 24, 6),
+                                              (4, 4, 80, 64, 16), (3, 3, 21, 16, 40)])
+def test_ml3layer_wide_shapes(dev, ne, neo, Fin, n1, n2):
+    """Shapes off the fused kernels' main road, against the oracle in fp64: nedgeoutput != nedgeinput (allowed by
+    spect_conv.py:66-71, unused by the scripts), ninp = 80 (ptc.py:331-338) and a wide Hadamard branch."""
+    from gnn_matlang_amd import ML3Layer
+    from oracle.spect_conv_oracle import OracleML3Layer
+    from oracle.relu_margin import make_safe
+    torch.manual_seed(ne * 17 + neo)
+    N = 333
+    rng = np.random.default_rng(neo)
+    dst = np.repeat(np.arange(N), rng.integers(0, 6, N))
+    src = rng.integers(0, N, dst.size)
+    o = np.lexsort((dst, src))
+    ei = torch.from_numpy(np.stack([src[o], dst[o]]).astype(np.int64))
+    ref = OracleML3Layer(True, ne, neo, Fin, n1, n2).double()
+    m = ML3Layer(True, ne, neo, Fin, n1, n2).to(dev)
+    m.load_state_dict({n: p.detach().float() for n, p in ref.state_dict().items()})
+    x, ea, go = torch.randn(N, Fin), torch.randn(ei.size(1), ne) * 0.5, torch.randn(N, n1 + n2)
+    ea, mask = make_safe(x, ei, ea, ref.state_dict(), True)       # no relu argument within rounding of zero
+    go[:, :n1] *= mask.float()
+    xr, er = x.double().requires_grad_(True), ea.double().requires_grad_(True)
+    yr = ref(xr, ei, er)
+    (yr * go.double()).sum().backward()
+    xg, eg = x.to(dev).requires_grad_(True), ea.to(dev).requires_grad_(True)
+    y = m(xg, ei.to(dev), eg)
+    (y * go.to(dev)).sum().backward()
+    close(y, yr, what='out')
+    close(xg.grad, xr.grad, what='g_x')
+    close(eg.grad, er.grad, what='g_edge_attr')
+    gp = dict(m.named_parameters())
+    for n, p in ref.named_parameters():
+        close(gp[n].grad, p.grad, what=n)
+
+
 # ------------------------------------------------------------------------------------------ models (H1-H5)
 def _batch_from(g, dev):
     from gnn_matlang_amd.graph import Batch
