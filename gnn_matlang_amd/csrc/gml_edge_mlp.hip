@@ -3,11 +3,13 @@
 #include "gml_edge_chain_impl.h"
 #include <stdlib.h>
 
-// S <= 8 runs on the bf16 matrix cores (gml_edge_chain_impl.h); GML_EDGE_VALU=1 in the environment keeps the
-// one-edge-per-lane fp32 VALU kernels for every S (ablation / exact-fp32 arithmetic).
+// 2 <= S <= 8 runs on the bf16 matrix cores (gml_edge_chain_impl.h); GML_EDGE_VALU=1 in the environment keeps the
+// one-edge-per-lane fp32 VALU kernels for every S (ablation / exact-fp32 arithmetic).  S = 1 stays on the VALU
+// kernels: its contractions are single products, so the split's 2^-17 rounding is not averaged over a sum (measured
+// 5e-5 .. 1e-4 of the output scale against 1e-5 for S >= 2), and there is no arithmetic to save.
 static bool emlp_use_chain(int S) {
     static const bool valu = [] { const char* e = getenv("GML_EDGE_VALU"); return e && e[0] == '1'; }();
-    return S <= 8 && !valu;
+    return S >= 2 && S <= 8 && !valu;
 }
 #define GML_DECL_ECHAIN(SV)                                                                                  \
     template <> int gml_launch_edge_chain_fwd<SV>(const float*, const uint32_t*, const float*, const float*, \

@@ -20,7 +20,8 @@ template <int S>
 struct GmlFwd2Cfg {
     static constexpr int LDX = 36;                             // X window rows (floats, b128 aligned)
     static constexpr int W_HALF = S * 32 * 32;                 // bf16 elements of one (hi or lo) W image [s][o][f]
-    static constexpr int W_BYTES = 2 * W_HALF * 2;
+    static constexpr int TILE_BYTES = 8 * 16 * 36 * 4;         // stand-alone SpMM: one [16][36] output tile per wave
+    static constexpr int W_BYTES = 2 * W_HALF * 2 > TILE_BYTES ? 2 * W_HALF * 2 : TILE_BYTES;   // (shares the W area)
     static constexpr size_t lds_bytes() {
         return (size_t)W_BYTES + 136 * 4 + (size_t)GML_FWD2_ECAP * 4 + (size_t)GML_FWD2_ECAP * S * 4 +
                (size_t)GML_FWD2_XCAP * LDX * 4;

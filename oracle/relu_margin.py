@@ -9,7 +9,9 @@ whose relu arguments all keep a margin.  The three relus of the layer
 output relu(fc1_4 [...]) and the node output relu(conv1(...)).
 
 `margins()` returns, per relu, |argument| / sum|terms| evaluated in fp64 (the sum of absolute
-terms bounds the rounding error of any summation order); `make_safe()` re-draws the edge
+terms bounds the rounding error of any summation order; it is floored at 1e-2 of the largest such
+sum in the tensor, because fast tanh formulas are accurate to an ABSOLUTE 1e-7, so an argument
+built only from tiny terms is not resolved relative to itself); `make_safe()` re-draws the edge
 attribute rows whose edge-branch margins are too small and returns a 0/1 mask for the node
 outputs whose margin is too small (the test multiplies its output gradient by it).
 """
@@ -17,6 +19,12 @@ import torch
 import torch.nn.functional as F
 
 from .spect_conv_oracle import spectconv_forward
+
+
+def _ratio(arg, scale):
+    """|arg| / max(scale, 1e-2 max(scale)); 1 where every term is exactly zero (both sides compute an exact 0)."""
+    floor = 1e-2 * float(scale.max()) if scale.numel() else 0.0
+    return torch.where(scale > 0, arg.abs() / scale.clamp_min(max(floor, 1e-300)), torch.ones_like(scale))
 
 
 def _edge_parts(ea, p):
@@ -36,16 +44,28 @@ def margins(x, edge_index, edge_attr, p, learnedge):
     m_edge = None
     if learnedge:
         h1, s1, o, so = _edge_parts(ea, p)
-        r1 = torch.where(s1 > 0, h1.abs() / s1.clamp_min(1e-300), torch.ones_like(s1))
-        ro = torch.where(so > 0, o.abs() / so.clamp_min(1e-300), torch.ones_like(so))
+        r1, ro = _ratio(h1, s1), _ratio(o, so)
         m_edge = torch.minimum(r1.min(1).values, ro.min(1).values) if ea.size(0) else r1.new_zeros(0)
         ea = F.relu(o)
     cw = p['conv1.weight'].double()
     cb = p['conv1.bias'].double() if p.get('conv1.bias') is not None else None
     pre = spectconv_forward(x, edge_index, ea, cw, cb)
     sc = spectconv_forward(x.abs(), edge_index, ea.abs(), cw.abs(), cb.abs() if cb is not None else None)
-    m_node = torch.where(sc > 0, pre.abs() / sc.clamp_min(1e-300), torch.ones_like(sc))
-    return m_edge, m_node
+    return m_edge, _ratio(pre, sc)
+
+
+def make_safe_edges(edge_attr, w1, w2, w3, w4, margin=2e-4, scale=1.0, max_rounds=20, generator=None):
+    """edge_attr with the rows re-drawn whose two edge-branch relu arguments come within `margin` of zero."""
+    p = {'fc1_1.weight': w1, 'fc1_2.weight': w2, 'fc1_3.weight': w3, 'fc1_4.weight': w4}
+    ea = edge_attr.clone()
+    for _ in range(max_rounds):
+        h1, s1, o, so = _edge_parts(ea.double(), p)
+        r1, ro = _ratio(h1, s1), _ratio(o, so)
+        bad = (torch.minimum(r1.min(1).values, ro.min(1).values) < margin).nonzero().flatten()
+        if bad.numel() == 0:
+            return ea
+        ea[bad] = (torch.randn(bad.numel(), ea.size(1), generator=generator) * scale).to(ea.dtype)
+    raise RuntimeError('could not find relu-safe edge attributes')
 
 
 def make_safe(x, edge_index, edge_attr, p, learnedge, margin=2e-4, scale=0.5, max_rounds=20, generator=None):

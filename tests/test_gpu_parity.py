@@ -290,13 +290,14 @@ def test_spmm_sddmm_edge_mlp_node_mix_vs_oracle(dev):
     from gnn_matlang_amd import functional as Fn
     from gnn_matlang_amd.graph import GraphCSR
     from oracle import spect_conv_oracle as O
+    from oracle.relu_margin import make_safe_edges
     rng = np.random.default_rng(5)
     torch.manual_seed(5)
     N = 333
     ei = _random_graph(rng, N, 6)
     E = ei.shape[1]
     csr = GraphCSR.from_edge_index(T(ei).to(dev), N)
-    for S, fin in ((8, 32), (3, 7), (12, 70), (1, 130)):
+    for S, fin in ((8, 32), (3, 7), (12, 70), (1, 130), (4, 32), (4, 21), (8, 17)):
         ea, x = torch.randn(E, S), torch.randn(N, fin)
         val = csr.sort_values(ea.to(dev), cache=False)
         h = Fn.spmm(csr, val, x.to(dev), S, fin).view(N, S, fin)
@@ -306,10 +307,20 @@ def test_spmm_sddmm_edge_mlp_node_mix_vs_oracle(dev):
         dval = csr.unsort_values(Fn.sddmm(csr, x.to(dev), gw.to(dev).view(N, S * fin), S, fin))
         ref = torch.einsum('ef,esf->es', x[ei[0]], gw[ei[1]])
         close(dval, ref, what='sddmm S=%d' % S)
+    # one partly filled 128-row group, staged (E <= 1024): waves without rows finish first (LDS tile vs staging areas)
+    for N2, S, fin in ((7, 4, 32), (20, 4, 32), (20, 8, 32), (20, 4, 13), (100, 4, 32)):
+        dst = np.repeat(np.arange(N2), rng.integers(5, 1000 // N2, N2))
+        ei2 = np.stack([rng.integers(0, N2, dst.size), dst]).astype(np.int64)
+        csr2 = GraphCSR.from_edge_index(T(ei2).to(dev), N2)
+        ea, x = torch.randn(ei2.shape[1], S), torch.randn(N2, fin)
+        h = Fn.spmm(csr2, csr2.sort_values(ea.to(dev), cache=False), x.to(dev), S, fin).view(N2, S, fin)
+        href = torch.stack([O.propagate_add(x, T(ei2), ea[:, s]) for s in range(S)], 1)
+        close(h, href, what='spmm small N=%d S=%d' % (N2, S))
     for S in range(1, 17):
         E2 = 1000 + S
         ea = torch.randn(E2, S)
         ws = [torch.randn(2 * S, S) * 0.7 for _ in range(3)] + [torch.randn(S, 4 * S) * 0.5]
+        ea = make_safe_edges(ea, *ws)                      # no relu argument within rounding of zero
         eo = ea.clone().requires_grad_(True)
         wo = [w.clone().requires_grad_(True) for w in ws]
         yo = O.edge_mlp_forward(eo, *wo)
