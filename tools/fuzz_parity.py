@@ -118,16 +118,82 @@ def conv_sweep(a, dev):
     return fails
 
 
+def special_graph(rng, n):
+    """edge list [2,e] of one small graph: structured families with degenerate spectra among random ones."""
+    kind = rng.integers(0, 8)
+    idx = np.arange(n)
+    if kind == 0 or n == 1:                                   # edgeless
+        return np.zeros((2, 0), np.int64)
+    if kind == 1:                                             # ring
+        e = np.stack([idx, (idx + 1) % n])
+    elif kind == 2:                                           # star
+        e = np.stack([np.zeros(n - 1, np.int64), idx[1:]])
+    elif kind == 3:                                           # complete
+        a, b = np.meshgrid(idx, idx)
+        k = a != b
+        return np.stack([a[k], b[k]]).astype(np.int64)
+    elif kind == 4:                                           # two components, second one a path
+        h = max(1, n // 2)
+        e = np.concatenate([np.stack([idx[:h - 1], idx[1:h]]), np.stack([idx[h:-1], idx[h + 1:]])], 1)
+    elif kind == 5:                                           # circulant (regular, highly degenerate)
+        e = np.concatenate([np.stack([idx, (idx + k) % n]) for k in (1, 2, 5) if k < n], 1)
+    else:                                                     # sparse / dense random, duplicates and a self loop
+        m = int(rng.integers(1, n * (1 + int(kind == 7) * 4) + 1))
+        e = rng.integers(0, n, (2, m))
+        e = np.concatenate([e, e[:, :3], np.array([[0], [0]])], 1) if kind == 7 else e
+    return np.concatenate([e, e[::-1]], 1).astype(np.int64)   # symmetric
+
+
+def spectral_sweep(a, dev):
+    """device SpectralDesign (gml_spectral_count / gml_spectral_design) against the host path on random batches."""
+    from gnn_matlang_amd import SpectralDesign
+    rng = np.random.default_rng(a.seed + 177)
+    fails, worst = 0, 0.0
+    for k in range(a.cases):
+        kw = dict(recfield=int(rng.integers(0, 4)), dv=float(rng.choice([1, 2, 5, 20])), nfreq=int(rng.integers(1, 17)),
+                  adddegree=bool(rng.integers(0, 2)), laplacien=bool(rng.integers(0, 4) > 0), addadj=bool(rng.integers(0, 2)),
+                  vmax=None if rng.integers(0, 3) else 2.5)
+        B = int(rng.integers(1, 40))
+        nmax = int(rng.choice([1, 2, 5, 12, 30, 80]))
+        raw = []
+        for _ in range(B):
+            n = int(rng.integers(1, nmax + 1))
+            raw.append((rng.standard_normal((n, 2)).astype(np.float32), special_graph(rng, n), 0.0))
+        sd = SpectralDesign(**kw)
+        host = sd.design_many(raw)
+        sizes = np.array([x.shape[0] for x, _, _ in raw])
+        ptr = np.concatenate([[0], np.cumsum(sizes)])
+        X = np.concatenate([x for x, _, _ in raw])
+        EI = np.concatenate([np.asarray(ei, np.int64) + ptr[i] for i, (_, ei, _) in enumerate(raw)], 1)
+        d = sd.design_device(torch.from_numpy(X).to(dev), torch.from_numpy(EI).to(dev),
+                             torch.tensor(ptr, dtype=torch.int32, device=dev))
+        ei2 = np.concatenate([h['edge_index2'] + ptr[i] for i, h in enumerate(host)], 1)
+        ea2 = np.concatenate([h['edge_attr2'] for h in host])
+        tol = 5e-6 if kw['laplacien'] else 5e-5
+        ok = np.array_equal(d['edge_index2'].cpu().numpy(), ei2)
+        err = float(np.abs(d['edge_attr2'].cpu().numpy() - ea2).max()) if ok and ea2.size else 0.0
+        lerr = float(np.abs(d['lmax'].cpu().numpy() - np.array([h['lmax'] for h in host])).max())
+        xok = np.array_equal(d['x'].cpu().numpy(), np.concatenate([h['x'] for h in host]))
+        worst = max(worst, err / tol)
+        if not (ok and xok and err <= tol and lerr <= 1e-5):
+            fails += 1
+            print('FAIL', k, kw, 'B', B, 'nmax', nmax, 'mask ok', ok, 'x ok', xok, 'err %.1e lmax err %.1e' % (err, lerr), flush=True)
+    print(json.dumps({'sweep': 'spectral', 'cases': a.cases, 'seed': a.seed, 'worst_err_over_tol': worst, 'failures': fails}))
+    return fails
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--cases', type=int, default=80)
     ap.add_argument('--seed', type=int, default=0)
-    ap.add_argument('--sweep', choices=['ml3', 'conv'], default='ml3')
+    ap.add_argument('--sweep', choices=['ml3', 'conv', 'spectral'], default='ml3')
     ap.add_argument('--only', type=int, default=-1, help='ml3 sweep: run just this case of the sequence')
     ap.add_argument('--verbose', action='store_true')
     a = ap.parse_args()
     if a.sweep == 'conv':
         sys.exit(1 if conv_sweep(a, torch.device('cuda:0')) else 0)
+    if a.sweep == 'spectral':
+        sys.exit(1 if spectral_sweep(a, torch.device('cuda:0')) else 0)
     from gnn_matlang_amd import ML3Layer
     from oracle.spect_conv_oracle import OracleML3Layer
     from oracle.relu_margin import make_safe
