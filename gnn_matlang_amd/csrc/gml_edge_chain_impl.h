@@ -21,7 +21,6 @@
 #pragma once
 #include "gml_common.h"
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint32_t gml_pack2(float a, float b) {           // v_cvt_pk_bf16_f32 (RNE)
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2));

@@ -4,3 +4,5 @@ GML_DEFINE_FWD2(8, 2)
 GML_DEFINE_FWD2(8, 1)
 GML_DEFINE_FWD2(4, 2)
 GML_DEFINE_FWD2(4, 1)
+GML_DEFINE_SPMM2(8)
+GML_DEFINE_SPMM2(4)

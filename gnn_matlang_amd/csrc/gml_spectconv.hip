@@ -4,6 +4,7 @@
 
 #define GML_DECL_FWD2(S, B) template <> int gml_launch_fwd2<S, B>(const GmlFwdParams&, dim3, hipStream_t, bool, bool);
 GML_DECL_FWD2(8, 2) GML_DECL_FWD2(8, 1) GML_DECL_FWD2(4, 2) GML_DECL_FWD2(4, 1)
+GML_DECL_FWD2(8, 0) GML_DECL_FWD2(4, 0)            /* NOB = 0: the stand-alone SpMM instantiation */
 
 static bool fwd2_shape(int S, int Fin, int Fout, uint32_t flags) {
 #ifdef GML_NO_FWD2
@@ -232,8 +233,8 @@ extern "C" int gml_spmm_fwd(const int32_t* rowptr, const int32_t* col, const int
         int grid = p.ngroups < GML_NUM_CU ? p.ngroups : GML_NUM_CU;
         p.groups_per_wg = (int)gml_cdiv(p.ngroups, grid);
         grid = (int)gml_cdiv(p.ngroups, p.groups_per_wg);
-        if (S == 8) return gml_launch_fwd2<8, 1>(p, dim3(grid), st, xv, false);
-        if (S == 4) return gml_launch_fwd2<4, 1>(p, dim3(grid), st, xv, false);
+        if (S == 8) return gml_launch_fwd2<8, 0>(p, dim3(grid), st, xv, false);
+        if (S == 4) return gml_launch_fwd2<4, 0>(p, dim3(grid), st, xv, false);
     }
     int s0 = 0;
     while (s0 < S) {
