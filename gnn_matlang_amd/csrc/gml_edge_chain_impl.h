@@ -224,45 +224,94 @@ __global__ __launch_bounds__(256, 2) void gml_k_edge_chain_fwd(const float* __re
     GmlChainW<S> W;
     gml_chain_load_fwd_weights<S>(W, w1, w2, w3, w4, c16, g);
     const int q0 = 4 * (g & 1);
-    for (int64_t t = ((int64_t)blockIdx.x * 4 + wave) * 2; t < ntiles; t += (int64_t)gridDim.x * 8) {
+    const int64_t stride = (int64_t)gridDim.x * 8;
+    int64_t t = ((int64_t)blockIdx.x * 4 + wave) * 2;
+    // Stores go through buffer descriptors whose range check drops the lanes that have nothing to write (edges
+    // past E, q >= S): no predicate, so the compiler counts them and the wait for the NEXT tile pair's operands
+    // (prefetched below, before this pair's arithmetic) does not also wait for these stores to drain.
+    // `out`: descriptor based at the wave's tile pair (offsets stay tiny); `out_t`: one descriptor over the array
+    // (the dispatcher refuses the second order when E * S * 4 does not fit a 32-bit offset).
+    const auto rs_t = __builtin_amdgcn_make_buffer_rsrc(out_t != nullptr ? out_t : out, 0,
+                                                        out_t != nullptr ? (int)(uint32_t)(E * S * 4) : 0, 0x00020000);
+    const int32_t* tposb = out_t != nullptr ? tpos : reinterpret_cast<const int32_t*>(ea);   // always a readable array of >= E words
+    u32x4 b1n[2];
+    int32_t tpn[2] = {0, 0};
+    auto fetch = [&](int64_t tt) {                             // unconditional, clamped: the loads stay countable
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t e = min((tt + u) * 16 + c16, E - 1);
+            b1n[u] = *reinterpret_cast<const u32x4*>(es + e * 8 + 4 * (g & 1));
+            tpn[u] = tposb[e];
+        }
+    };
+    u32x4 b1[2];                                               // the current pair's operands: taken over from the prefetch
+    int32_t tp[2] = {0, 0};                                    // registers at the END of the previous trip, where the wait
+    if constexpr (PRE) {                                       // is an exact count (at the loop top it would merge with
+        fetch(t);                                              // the store-less entry path into vmcnt(0))
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            asm volatile("" : "+v"(b1n[u]), "+v"(tpn[u]));
+            b1[u] = b1n[u]; tp[u] = tpn[u];
+        }
+    }
+    for (; t < ntiles; t += stride) {
         GmlChainT T[2];
         int64_t eid[2];
         bool valid[2];
-        int32_t tp[2] = {0, 0};
-        u32x4 b1[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             eid[u] = (t + u) * 16 + c16;
             valid[u] = eid[u] < E;
             if constexpr (PRE) {
-                b1[u] = valid[u] ? *reinterpret_cast<const u32x4*>(es + eid[u] * 8 + 4 * (g & 1)) : u32x4{0u, 0u, 0u, 0u};
+                if (!valid[u]) b1[u] = u32x4{0u, 0u, 0u, 0u};
             } else {
                 gml_chain_load_e<S>(ea, eid[u], valid[u], T[u].e);
+                tp[u] = tposb[min(eid[u], E - 1)];
             }
-            if (out_t != nullptr && valid[u] && g >= 2) tp[u] = tpos[eid[u]];
+        }
+        if constexpr (PRE) {
+            fetch(t + stride);                                 // next pair in flight during this pair's chain
+            __builtin_amdgcn_sched_barrier(0);                 // (the scheduler would sink the loads to the loop's end)
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             if constexpr (PRE) gml_chain_forward<S, false>(W, T[u], __builtin_bit_cast(bf16x8, b1[u]), g);
             else gml_chain_forward<S, false>(W, T[u], gml_chain_b1(T[u].e, g), g);
         }
+        // lane groups 0,1 hold q = 0..3 / 4..7 and write `out`; groups 2,3 hold the same rows again and write the
+        // second (source-sorted) copy at tpos[e]
+        const int64_t tb = t * (16 * S * 4);                   // wave-uniform byte offset of the pair in `out`
+        const uint32_t tlo = __builtin_amdgcn_readfirstlane((uint32_t)tb), thi = __builtin_amdgcn_readfirstlane((uint32_t)(tb >> 32));
+        const int64_t left = E - t * 16;                       // edges from the pair's first one (wave-uniform)
+        const int nrec = __builtin_amdgcn_readfirstlane((int)(left < 32 ? left : 32)) * (S * 4);
+        const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<char*>(out) + (((uint64_t)thi << 32) | tlo), 0, nrec, 0x00020000);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            if (!valid[u]) continue;
-            // lane groups 0,1 hold q = 0..3 / 4..7 and write `out`; groups 2,3 hold the same rows again and
-            // write the second (source-sorted) copy at tpos[e], so one store instruction serves both orders
-            float* dst;
-            if (g < 2) dst = out + eid[u] * S + q0;
-            else if (out_t != nullptr) dst = out_t + (int64_t)tp[u] * S + q0;
-            else continue;
+            const int off_o = (g < 2) ? ((u * 16 + c16) * S + q0) * 4 : (int)0xffffff00;
+            const int off_t = (g >= 2 && valid[u]) ? (tp[u] * S + q0) * 4 : (int)0xffffff00;
             if constexpr (S % 4 == 0) {
-                if (q0 < S)
-                    *reinterpret_cast<f32x4*>(dst) = f32x4{fmaxf(T[u].out[0], 0.f), fmaxf(T[u].out[1], 0.f),
-                                                          fmaxf(T[u].out[2], 0.f), fmaxf(T[u].out[3], 0.f)};
+                const f32x4 v = f32x4{fmaxf(T[u].out[0], 0.f), fmaxf(T[u].out[1], 0.f), fmaxf(T[u].out[2], 0.f),
+                                      fmaxf(T[u].out[3], 0.f)};
+                const bool q_ok = q0 < S;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_o, q_ok ? off_o : (int)0xffffff00, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_t, q_ok ? off_t : (int)0xffffff00, 0, 0);
             } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (q0 + r < S) dst[r] = fmaxf(T[u].out[r], 0.f);
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t v = __float_as_uint(fmaxf(T[u].out[r], 0.f));
+                    const bool q_ok = q0 + r < S;
+                    __builtin_amdgcn_raw_buffer_store_b32(v, rs_o, q_ok ? off_o + 4 * r : (int)0xffffff00, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(v, rs_t, q_ok ? off_t + 4 * r : (int)0xffffff00, 0, 0);
+                }
+            }
+        }
+        if constexpr (PRE) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                asm volatile("" : "+v"(b1n[u]), "+v"(tpn[u]));    // the wait for the prefetch belongs HERE (exact count)
+                b1[u] = b1n[u]; tp[u] = tpn[u];
             }
         }
     }
@@ -380,38 +429,66 @@ __global__ __launch_bounds__(256, 3) void gml_k_edge_chain_bwd(
     // values of the [go | e] tile) and 4 values of the gout row
     float e_n[PRE ? 1 : 8], ye_n[4], g_n[4];
     u32x4 b1_n = u32x4{0u, 0u, 0u, 0u};
+    // PRE: unconditional loads with indices clamped into the arrays (the compiler can count them; a lane outside
+    // fetches a valid, unused element and is zeroed when the registers are taken over)
+    auto load_q_clamped = [&](const float* base, int64_t en, float (&v)[4]) {
+        if constexpr (S % 4 == 0) {
+            const f32x4 t4 = *reinterpret_cast<const f32x4*>(base + en * S + (q0 < S ? q0 : 0));
+            v[0] = t4.x; v[1] = t4.y; v[2] = t4.z; v[3] = t4.w;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = base[en * S + (q0 + r < S ? q0 + r : S - 1)];
+        }
+    };
     auto fetch = [&](int64_t tt) {
         const int64_t en = tt * 16 + c16;
-        const bool ok = tt < ntiles && en < E;
         if constexpr (PRE) {
-            b1_n = ok ? *reinterpret_cast<const u32x4*>(es + en * 8 + 4 * (g & 1)) : u32x4{0u, 0u, 0u, 0u};
-            gml_chain_load_q<S>(ea, en, ok, q0, ye_n);
+            const int64_t ec = en < E ? en : E - 1;
+            b1_n = *reinterpret_cast<const u32x4*>(es + ec * 8 + 4 * (g & 1));
+            load_q_clamped(ea, ec, ye_n);
+            load_q_clamped(gout, ec, g_n);
         } else {
+            const bool ok = tt < ntiles && en < E;
             gml_chain_load_e<S>(ea, en, ok, e_n);
+            gml_chain_load_q<S>(gout, en, ok, q0, g_n);
         }
-        gml_chain_load_q<S>(gout, en, ok, q0, g_n);
+    };
+    // the current tile's inputs; with PRE they are taken over from the prefetch registers at the END of the previous
+    // trip, where the wait is an exact count (at the loop top it would merge with the store-less entry path into
+    // vmcnt(0) and every tile would wait for the previous tile's gradient store to drain)
+    float gq[4], ye[4];
+    bf16x8 B1;
+    auto take = [&](int64_t tt) {
+        asm volatile("" : "+v"(b1_n));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(ye_n[r]), "+v"(g_n[r]));
+        const bool ok = tt * 16 + c16 < E;
+        const u32x4 bz = ok ? b1_n : u32x4{0u, 0u, 0u, 0u};
+        B1 = __builtin_bit_cast(bf16x8, bz);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool okq = ok && q0 + r < S;
+            ye[r] = okq ? ye_n[r] : 0.f;
+            gq[r] = okq ? g_n[r] : 0.f;
+        }
     };
     fetch(t);
+    if constexpr (PRE) take(t);
     for (; t < ntiles; t += stride) {
         GmlChainT T;
-        float gq[4], ye[4];
-        bf16x8 B1;
-        if constexpr (PRE) {
-            B1 = __builtin_bit_cast(bf16x8, b1_n);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ye[r] = ye_n[r];
-        } else {
+        if constexpr (!PRE) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) T.e[j] = e_n[j];
             B1 = gml_chain_b1(T.e, g);
 #pragma unroll
             for (int r = 0; r < 4; ++r) ye[r] = (g & 1) ? T.e[4 + r] : T.e[r];
-        }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) gq[r] = g_n[r];
+            for (int r = 0; r < 4; ++r) gq[r] = g_n[r];
+        }
         const int64_t eid = t * 16 + c16;
         const bool valid = eid < E;
         fetch(t + stride);                                     // next tile's rows are in flight while this one is computed
+        if constexpr (PRE) __builtin_amdgcn_sched_barrier(0);  // (the scheduler would sink the loads to the loop's end)
         gml_chain_forward<S, true>(W, T, B1, g);
         f32x4 go;
 #pragma unroll
@@ -440,15 +517,23 @@ __global__ __launch_bounds__(256, 3) void gml_k_edge_chain_bwd(
             de = GML_MFMA(WB.a5[2], L3y, de);
             de = GML_MFMA(WB.a5[0], H12, de);
             de = GML_MFMA(WB.a5[2], H3y, de);
-            if (valid && g < 2) {          // rows 4g + r = in-channel (rows 8..15 repeat 0..7)
-                float* dp = gin + eid * S + 4 * g;
-                if constexpr (S % 4 == 0) {
-                    if (4 * g < S) *reinterpret_cast<f32x4*>(dp) = de;
-                } else {
+            // rows 4g + r = in-channel (rows 8..15 repeat 0..7).  Store through a buffer descriptor based at the tile:
+            // its range check drops the edges past E, an out-of-range offset the lanes with nothing to write --
+            // no predicate, so the store is countable (see `take`)
+            const int64_t tb = t * (16 * S * 4);
+            const uint32_t tlo = __builtin_amdgcn_readfirstlane((uint32_t)tb), thi = __builtin_amdgcn_readfirstlane((uint32_t)(tb >> 32));
+            const int64_t left = E - t * 16;
+            const int nrec = __builtin_amdgcn_readfirstlane((int)(left < 16 ? left : 16)) * (S * 4);
+            const auto rs_g = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<char*>(gin) + (((uint64_t)thi << 32) | tlo), 0, nrec, 0x00020000);
+            const int off = (g < 2) ? (c16 * S + 4 * g) * 4 : (int)0xffffff00;
+            if constexpr (S % 4 == 0) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, de), rs_g, (4 * g < S) ? off : (int)0xffffff00, 0, 0);
+            } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (4 * g + r < S) dp[r] = de[r];
-                }
+                for (int r = 0; r < 4; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(de[r]), rs_g,
+                                                          (4 * g + r < S) ? off + 4 * r : (int)0xffffff00, 0, 0);
             }
         }
         // weight gradients of the 16 edges: k-slots (g, j < 4) = hi, (g, j >= 4) = lo of edge 4g + (j & 3);
@@ -464,6 +549,10 @@ __global__ __launch_bounds__(256, 3) void gml_k_edge_chain_bwd(
         for (int b = 0; b < 5; ++b) {
             acc[b] = GML_MFMA(XT[b], Bl0, acc[b]);
             acc[b] = GML_MFMA(XT[b], Bhh, acc[b]);
+        }
+        if constexpr (PRE) {
+            __builtin_amdgcn_sched_barrier(0);
+            take(t + stride);
         }
     }
 

@@ -114,6 +114,8 @@ extern "C" int gml_edge_mlp_fwd(const float* ea, const void* ea_split, const flo
     if (out_t && !tpos) return GML_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     if (emlp_use_chain(S)) {
+        // the second (source-order) copy is scattered through one buffer descriptor: 32-bit byte offsets
+        if (out_t && (uint64_t)num_edges * (uint64_t)S * 4u >= 0xffffff00ull) return GML_E_UNSUPPORTED;
 #define GML_CALL_CF(SV) \
     gml_launch_edge_chain_fwd<SV>(ea, (const uint32_t*)ea_split, w1, w2, w3, w4, out, tpos, out_t, num_edges, st)
         GML_ECHAIN_SWITCH(GML_CALL_CF)

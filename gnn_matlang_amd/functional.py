@@ -434,7 +434,8 @@ class ML3LayerFunction(torch.autograd.Function):
                 w1, w2, w3, w4 = (_f32c(w1, 'fc1_1.weight'), _f32c(w2, 'fc1_2.weight'), _f32c(w3, 'fc1_3.weight'),
                                   _f32c(w4, 'fc1_4.weight'))
                 # when the fused backward will run, the edge branch also emits its output in source order
-                dual = any(ctx.needs_input_grad) and fused_bwd_available(csr, S, Fin, nout1)
+                dual = (any(ctx.needs_input_grad) and fused_bwd_available(csr, S, Fin, nout1)
+                        and val.numel() * 4 < 0xffffff00)      # (32-bit scatter offsets of the second copy)
                 with _Timed('edge_mlp_fwd', 4 * val.numel() * (3 if dual else 2), 20 * val.size(0) * val.size(1) ** 2):
                     ea, ea_t = edge_mlp_fwd(val, w1, w2, w3, w4, csr.tpos if dual else None, csr.presplit(val))
             else:
