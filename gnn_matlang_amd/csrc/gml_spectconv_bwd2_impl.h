@@ -105,23 +105,28 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
 #ifdef GML_BWD2_TIMING
     unsigned long long tprev_ = __builtin_readcyclecounter();
 #endif
-    for (int g = g0; g < g1; ++g) {
+    // ---- staging registers.  A group's global loads are issued one phase early -- after the PREVIOUS group's dX
+    //      stores, before its dW phase (which touches no global memory and leaves the registers of the edge / dX phases
+    //      free) -- and committed to LDS at the top of the group, so the load latency runs under the dW arithmetic.
+    constexpr int NC = GML_BWD2_ECAP_MAX / 512, NE4 = (S % 4 == 0) ? GML_BWD2_ECAP_MAX * (S / 4) / 512 : 1;
+    constexpr int NG4 = (GML_BWD2_XCAP_MAX * 8 + 511) / 512;
+    int cv[NC], rpv = 0, row_n = 0;
+    uint32_t outrows_n = 0;
+    f32x4 ev4[NE4], gv4[NG4];
+    float xb[8];
+    auto vec_group = [&](const int4 gi) {
+        return (S % 4 == 0) && p.gvec && gi.y <= GML_BWD2_ECAP_MAX && gi.w <= GML_BWD2_XCAP_MAX;
+    };
+    auto issue = [&](int g) {
         const int64_t r0 = (int64_t)g * ROWS;
         const int nr = (int)min((int64_t)ROWS, p.nrows - r0);
         const int32_t* rec = p.ginfo + (int64_t)g * GML_GREC_INTS(ROWS);
         const int4 gi = *reinterpret_cast<const int4*>(rec);
         const int kb = gi.x, ne = gi.y, lo = gi.z, nwin = gi.w;
-        // degree-sorted row assignment: this lane's row, and the rows of its 4 dX output registers (one byte each)
-        const int row = reinterpret_cast<const unsigned char*>(rec + 4)[wave * 16 + r16];
-        const uint32_t out_rows = reinterpret_cast<const uint32_t*>(rec + 4)[wave * 4 + kq];
-        __syncthreads();                                     // previous group is done with every LDS region
-        GML_T(0);                                            // = previous group's dW phase + this barrier
-
-        // ---- stage: every global load of the group is in flight before the first LDS write
-        const bool rvalid = row < nr;
-        float xb[8];
+        // the lane's own x row (row_n: loaded a whole group earlier, see load_rows)
         {
-            const float* xr = p.x + (r0 + row) * p.ldx + 8 * kq;
+            const bool rvalid = row_n < nr;
+            const float* xr = p.x + (r0 + row_n) * p.ldx + 8 * kq;
             if (p.xvec) {
 #pragma unroll
                 for (int q4 = 0; q4 < 2; ++q4) {
@@ -134,27 +139,49 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
                 for (int t = 0; t < 8; ++t) xb[t] = (rvalid && 8 * kq + t < p.Fin) ? xr[t] : 0.f;
             }
         }
-        if (tid <= nr) rp_l[tid] = p.rowptr[r0 + tid];
-        if ((S % 4 == 0) && p.gvec && ne <= GML_BWD2_ECAP_MAX && nwin <= GML_BWD2_XCAP_MAX) {
-            constexpr int NC = GML_BWD2_ECAP_MAX / 512, NE4 = (S % 4 == 0) ? GML_BWD2_ECAP_MAX * (S / 4) / 512 : 1;
-            constexpr int NG4 = (GML_BWD2_XCAP_MAX * 8 + 511) / 512;
-            int cv[NC];
-            f32x4 ev4[NE4], gv4[NG4];
-            const f32x4* src = reinterpret_cast<const f32x4*>(p.val + (int64_t)kb * S);
+        rpv = p.rowptr[min(r0 + tid, p.nrows)];
+        // (every load under its own predicate, none under a common branch: a conditional DEFINITION of the staging
+        //  registers would keep their old values live through the whole trip)
+        const bool vg = vec_group(gi);
+        const f32x4* src = reinterpret_cast<const f32x4*>(p.val + (int64_t)kb * S);
 #pragma unroll
-            for (int t = 0; t < NC; ++t) { const int i = tid + 512 * t; cv[t] = (i < ne) ? p.col[kb + i] : 0; }
+        for (int t = 0; t < NC; ++t) { const int i = tid + 512 * t; cv[t] = (vg && i < ne) ? p.col[kb + i] : 0; }
 #pragma unroll
-            for (int t = 0; t < NE4; ++t) {
-                const int i = tid + 512 * t;
-                ev4[t] = (i < ne * (S / 4)) ? src[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+        for (int t = 0; t < NE4; ++t) {
+            const int i = tid + 512 * t;
+            ev4[t] = (vg && i < ne * (S / 4)) ? src[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
-            for (int t = 0; t < NG4; ++t) {
-                const int i = tid + 512 * t;
-                const int rr = i >> 3, o4 = (i & 7) * 4;
-                gv4[t] = (i < nwin * 8 && o4 < p.Fout) ? *reinterpret_cast<const f32x4*>(p.g + (int64_t)(lo + rr) * p.ldg + o4)
-                                                        : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+        for (int t = 0; t < NG4; ++t) {
+            const int i = tid + 512 * t;
+            const int rr = i >> 3, o4 = (i & 7) * 4;
+            gv4[t] = (vg && i < nwin * 8 && o4 < p.Fout) ? *reinterpret_cast<const f32x4*>(p.g + (int64_t)(lo + rr) * p.ldg + o4)
+                                                          : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    // degree-sorted row assignment: this lane's row, and the rows of its 4 dX output registers (one byte each)
+    auto load_rows = [&](int g) {
+        const int32_t* rec = p.ginfo + (int64_t)g * GML_GREC_INTS(ROWS);
+        row_n = reinterpret_cast<const unsigned char*>(rec + 4)[wave * 16 + r16];
+        outrows_n = reinterpret_cast<const uint32_t*>(rec + 4)[wave * 4 + kq];
+    };
+    if (g0 < g1) { load_rows(g0); issue(g0); }
+    for (int g = g0; g < g1; ++g) {
+        const int64_t r0 = (int64_t)g * ROWS;
+        const int nr = (int)min((int64_t)ROWS, p.nrows - r0);
+        const int32_t* rec = p.ginfo + (int64_t)g * GML_GREC_INTS(ROWS);
+        const int4 gi = *reinterpret_cast<const int4*>(rec);
+        const int kb = gi.x, ne = gi.y, lo = gi.z, nwin = gi.w;
+        const int row = row_n;
+        const uint32_t out_rows = outrows_n;
+        load_rows(min(g + 1, g1 - 1));                       // next group's rows: needed as addresses when its loads are issued
+        __syncthreads();                                     // previous group is done with every LDS region
+        GML_T(0);                                            // = previous group's dW phase + this barrier
+
+        // ---- stage: commit the registers loaded one phase ago
+        const bool rvalid = row < nr;
+        if (tid <= nr) rp_l[tid] = rpv;
+        if (vec_group(gi)) {
 #pragma unroll
             for (int t = 0; t < NC; ++t) { const int i = tid + 512 * t; if (i < ne) col_l[i] = cv[t] - lo; }
 #pragma unroll
@@ -311,6 +338,8 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
         }
 
         GML_T(5);
+        issue(min(g + 1, g1 - 1));                           // next group's loads fly during the dW phase (unconditional: a
+                                                             // conditional definition would keep the old values live all trip)
         // ---- dW += X^T P over the 128 rows of the group
         if (p.dw_partial) {
             // X^T / P^T tiles (bf16 hi, lo) [f or o][row] for the row contraction.  The 16 x 32 register tile of a wave
