@@ -110,6 +110,12 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
     //      free) -- and committed to LDS at the top of the group, so the load latency runs under the dW arithmetic.
     constexpr int NC = GML_BWD2_ECAP_MAX / 512, NE4 = (S % 4 == 0) ? GML_BWD2_ECAP_MAX * (S / 4) / 512 : 1;
     constexpr int NG4 = (GML_BWD2_XCAP_MAX * 8 + 511) / 512;
+    const int etot = p.rowptr[p.nrows];
+    const int* colb = etot > 0 ? p.col : p.ginfo;              // an edgeless graph reads the (always present) group records
+    const f32x4* valb = etot > 0 ? reinterpret_cast<const f32x4*>(p.val) : reinterpret_cast<const f32x4*>(p.ginfo);
+    const int emax = max(etot, 1) - 1;
+    const int64_t emax4 = (S % 4 == 0) ? max((int64_t)etot * (S / 4), (int64_t)1) - 1 : 0;
+    const int o4max = p.gvec ? ((p.Fout + 3) / 4 * 4 - 4) : 0;   // float4 rows of g only when gvec (else unused anyway)
     int cv[NC], rpv = 0, row_n = 0;
     uint32_t outrows_n = 0;
     f32x4 ev4[NE4], gv4[NG4];
@@ -117,11 +123,17 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
     auto vec_group = [&](const int4 gi) {
         return (S % 4 == 0) && p.gvec && gi.y <= GML_BWD2_ECAP_MAX && gi.w <= GML_BWD2_XCAP_MAX;
     };
+    // {kb, ne, lo, nwin} of the group whose loads are issued next (fetched with its row bytes a group ahead: it holds
+    // load ADDRESSES, and a record fetched right there would stall the issue for a full latency) and of the group
+    // being processed (wave-uniform: kept in scalar registers)
+    int4 gi_nv = int4{0, 0, 0, 0};
+    int4 gi_c = int4{0, 0, 0, 0};
     auto issue = [&](int g) {
         const int64_t r0 = (int64_t)g * ROWS;
         const int nr = (int)min((int64_t)ROWS, p.nrows - r0);
-        const int32_t* rec = p.ginfo + (int64_t)g * GML_GREC_INTS(ROWS);
-        const int4 gi = *reinterpret_cast<const int4*>(rec);
+        const int4 gi = int4{__builtin_amdgcn_readfirstlane(gi_nv.x), __builtin_amdgcn_readfirstlane(gi_nv.y),
+                             __builtin_amdgcn_readfirstlane(gi_nv.z), __builtin_amdgcn_readfirstlane(gi_nv.w)};
+        gi_c = gi;
         const int kb = gi.x, ne = gi.y, lo = gi.z, nwin = gi.w;
         // the lane's own x row (row_n: loaded a whole group earlier, see load_rows)
         {
@@ -140,28 +152,28 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
             }
         }
         rpv = p.rowptr[min(r0 + tid, p.nrows)];
-        // (every load under its own predicate, none under a common branch: a conditional DEFINITION of the staging
-        //  registers would keep their old values live through the whole trip)
-        const bool vg = vec_group(gi);
-        const f32x4* src = reinterpret_cast<const f32x4*>(p.val + (int64_t)kb * S);
+        // Unconditional loads, indices clamped into the arrays (lanes outside fetch a valid, unused element): the
+        // compiler can count them, so the dX phase's wait for the old dx values (issued just before these) is an
+        // exact vmcnt and does not cover them.  (A common branch around them would also keep the registers' old
+        // values live through the whole trip.)
+        // (clamped to the group's OWN last element, not the array's: the register batches cover the largest group
+        //  the path takes, and a lane beyond this group must not drag the following groups' data in)
+        const int ne1 = max(ne, 1) - 1, ne41 = max(ne * (S / 4), 1) - 1, nw1 = max(nwin, 1) - 1;
 #pragma unroll
-        for (int t = 0; t < NC; ++t) { const int i = tid + 512 * t; cv[t] = (vg && i < ne) ? p.col[kb + i] : 0; }
+        for (int t = 0; t < NC; ++t) cv[t] = colb[min(kb + min(tid + 512 * t, ne1), emax)];
 #pragma unroll
-        for (int t = 0; t < NE4; ++t) {
-            const int i = tid + 512 * t;
-            ev4[t] = (vg && i < ne * (S / 4)) ? src[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int t = 0; t < NE4; ++t) ev4[t] = valb[min((int64_t)kb * (S / 4) + min(tid + 512 * t, ne41), emax4)];
 #pragma unroll
         for (int t = 0; t < NG4; ++t) {
             const int i = tid + 512 * t;
-            const int rr = i >> 3, o4 = (i & 7) * 4;
-            gv4[t] = (vg && i < nwin * 8 && o4 < p.Fout) ? *reinterpret_cast<const f32x4*>(p.g + (int64_t)(lo + rr) * p.ldg + o4)
-                                                          : f32x4{0.f, 0.f, 0.f, 0.f};
+            const int64_t rr = min((int64_t)lo + min(i >> 3, nw1), p.nrows - 1);
+            gv4[t] = *reinterpret_cast<const f32x4*>(p.g + rr * p.ldg + min((i & 7) * 4, o4max));
         }
     };
     // degree-sorted row assignment: this lane's row, and the rows of its 4 dX output registers (one byte each)
     auto load_rows = [&](int g) {
         const int32_t* rec = p.ginfo + (int64_t)g * GML_GREC_INTS(ROWS);
+        gi_nv = *reinterpret_cast<const int4*>(rec);
         row_n = reinterpret_cast<const unsigned char*>(rec + 4)[wave * 16 + r16];
         outrows_n = reinterpret_cast<const uint32_t*>(rec + 4)[wave * 4 + kq];
     };
@@ -169,8 +181,7 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
     for (int g = g0; g < g1; ++g) {
         const int64_t r0 = (int64_t)g * ROWS;
         const int nr = (int)min((int64_t)ROWS, p.nrows - r0);
-        const int32_t* rec = p.ginfo + (int64_t)g * GML_GREC_INTS(ROWS);
-        const int4 gi = *reinterpret_cast<const int4*>(rec);
+        const int4 gi = gi_c;                                // latched when this group's loads were issued
         const int kb = gi.x, ne = gi.y, lo = gi.z, nwin = gi.w;
         const int row = row_n;
         const uint32_t out_rows = outrows_n;
@@ -192,7 +203,8 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
 #pragma unroll
             for (int t = 0; t < NG4; ++t) {
                 const int i = tid + 512 * t;
-                if (i < nwin * 8) *reinterpret_cast<f32x4*>(gs + (i >> 3) * LDG + (i & 7) * 4) = gv4[t];
+                if (i < nwin * 8)
+                    *reinterpret_cast<f32x4*>(gs + (i >> 3) * LDG + (i & 7) * 4) = ((i & 7) * 4 < p.Fout) ? gv4[t] : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         } else {
             for (int i = tid; i < ne; i += 512) col_l[i] = p.col[kb + i] - lo;
@@ -279,6 +291,25 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
         GML_T(3);
         __syncthreads();                                     // dval rows complete; G window no longer needed
         GML_T(4);
+        // The old dx values (accumulate mode) first, then the next group's loads: both BEFORE this group's dval / dX
+        // stores (memory operations complete in order: behind the stores the loads would first wait for those to
+        // drain), the latter in flight through the dX and dW phases.  All unconditional and clamped, so the dX
+        // chain's wait for the old values is an exact count that leaves the prefetch in flight.
+        f32x4 dxa[NFB];
+        {
+            const float* dxb = p.dx ? p.dx : p.x;            // (no dx wanted: any readable rows, the values are dropped)
+            const int64_t ldb = p.dx ? p.lddx : p.ldx;
+#pragma unroll
+            for (int fb = 0; fb < NFB; ++fb) {
+                const int f = fb * 16 + r16;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int lr = min((int)((out_rows >> (8 * reg)) & 255u), nr - 1);
+                    dxa[fb][reg] = dxb[(r0 + lr) * ldb + min(f, p.Fin - 1)];
+                }
+            }
+        }
+        issue(min(g + 1, g1 - 1));
 
         if (p.dval) {
             if constexpr (S % 4 == 0) {
@@ -298,19 +329,9 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
         }
         // ---- dX = P W^T: one K=32 step per support (k = o = 8*kq + i)
         if (p.dx) {
-            f32x4 dxa[NFB];
+            if (!(p.flags & GML_ACCUM)) {
 #pragma unroll
-            for (int fb = 0; fb < NFB; ++fb) dxa[fb] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (p.flags & GML_ACCUM) {                       // accumulate: the old values travel while the MFMAs run
-#pragma unroll
-                for (int fb = 0; fb < NFB; ++fb) {
-                    const int f = fb * 16 + r16;
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) {      // clamped, unconditional loads (lanes outside are never stored)
-                        const int lr = min((int)((out_rows >> (8 * reg)) & 255u), nr - 1);
-                        dxa[fb][reg] = p.dx[(r0 + lr) * p.lddx + min(f, p.Fin - 1)];
-                    }
-                }
+                for (int fb = 0; fb < NFB; ++fb) dxa[fb] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
             for (int s = 0; s < S; ++s) {
@@ -338,8 +359,6 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
         }
 
         GML_T(5);
-        issue(min(g + 1, g1 - 1));                           // next group's loads fly during the dW phase (unconditional: a
-                                                             // conditional definition would keep the old values live all trip)
         // ---- dW += X^T P over the 128 rows of the group
         if (p.dw_partial) {
             // X^T / P^T tiles (bf16 hi, lo) [f or o][row] for the row contraction.  The 16 x 32 register tile of a wave
