@@ -244,9 +244,9 @@ def main():
             if 'spectconv_fwd' in summ:
                 cands.append(roof('spectconv_fwd', 'gml_k_spectconv_fwd2 / gml_k_spectconv_fwd (fused SpectConv forward; the 8-wave kernel also carries the Hadamard branch)', pj_f, ed_f))
             # HBM bytes per launch from the PMC counters (collected offline with the same command under rocprofv3,
-            # separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied -- profiles/r01_h_hbm_traffic.md);
+            # separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied -- profiles/r01_j_hbm_traffic.md);
             # only valid for the workload it was measured on
-            tpath = os.path.join(ROOT, 'profiles', 'r01_h_hbm_traffic.json')
+            tpath = os.path.join(ROOT, 'profiles', 'r01_j_hbm_traffic.json')
             if os.path.exists(tpath) and data.num_graphs == 32768 and args.pool == 2048:
                 tk = json.load(open(tpath))['kernels']
                 for r in cands:
@@ -255,11 +255,34 @@ def main():
                     if hits:                                  # launch-weighted mean over the instantiations used
                         r['traffic'] = sum(h['hbm_bytes_per_launch'] * h.get('launches', 1) for h in hits) / \
                             sum(h.get('launches', 1) for h in hits)
-                        r['traffic_source'] = 'profiles/r01_h_hbm_traffic.json (rocprofv3 PMC, per launch)'
+                        r['traffic_source'] = 'profiles/r01_j_hbm_traffic.json (rocprofv3 PMC, per launch)'
             cands.sort(key=lambda r: -r['ms_per_step'])
             res['roofline'] = cands[0]                   # the kernel with the largest share of the step
             res['roofline_other'] = cands[1:]
             res['kernels_ms_per_step'] = {tag: round(v['ms'] * v['launches'] / args.steps, 4) for tag, v in summ.items()}
+        if world == 1 and not args.no_profile:
+            # the stand-alone multi-support SpMM of the same batch (gml_spmm_fwd: H = [A_s^T X]_s materialised), the
+            # bandwidth-bound piece BASELINE.json's metric names: algorithmic bytes / mean launch time (HIP events)
+            csr = data.csr('edge_index2')
+            S_, Fin_ = int(data.edge_attr2.size(1)), 32
+            xs = torch.randn(csr.N, Fin_, device=dev)
+            vals = csr.sort_values(data.edge_attr2)
+            for _ in range(3):
+                Fn.spmm(csr, vals, xs, S_, Fin_)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            nrep = 20
+            e0.record()
+            for _ in range(nrep):
+                Fn.spmm(csr, vals, xs, S_, Fin_)
+            e1.record()
+            torch.cuda.synchronize()
+            t_s = e0.elapsed_time(e1) / nrep * 1e-3
+            q_s = 4 * (csr.E * S_ + csr.N * Fin_ + csr.N * S_ * Fin_) + 4 * (csr.E + csr.N + 1)
+            res['spmm'] = {'kernel': 'gml_k_spectconv_fwd2<S, 0> via gml_spmm_fwd (8-wave SpMM, H written)', 'bound': 'hbm',
+                           'achieved': q_s / t_s / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': q_s / t_s / 1e9 / HBM_PEAK_GBS,
+                           'avg_launch_ms': t_s * 1e3, 'algorithmic_bytes_per_launch': q_s, 'S': S_, 'Fin': Fin_,
+                           'traffic_note': 'PMC: 1045 MB / launch (profiles/r01_j_spmm_hbm_traffic.md)'}
+            del xs, vals
         if world == 1 and args.ref_batch > 0:
             # the reference's own batch size: launch-latency bound, so the step is replayed from a HIP graph
             rb, _ = build_batch(args.ref_batch, args.ref_batch, seed=7, device=dev)
