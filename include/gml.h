@@ -145,7 +145,9 @@ int gml_sddmm(const int32_t* rowptr, const int32_t* col, const int32_t* epos,
  *   out = relu( W4 . [ relu(W1 . e) ; tanh(W2 . e) * tanh(W3 . e) ] )      per edge e in R^S
  * w1,w2,w3: [2S, S]; w4: [Sout, 4S]  (torch.nn.Linear layout, bias-free).  S = Sout <= 16.
  * If out_t != NULL the row of edge e is also written to out_t[tpos[e], :] (the same values in a second
- * edge order: the backward kernel walks the source-sorted order).
+ * edge order: the backward kernel walks the source-sorted order); on the matrix-core kernels (2 <= S <= 8) that
+ * scatter uses 32-bit byte offsets: num_edges * S * 4 must stay below 2^32 - 256, else GML_E_UNSUPPORTED (the
+ * caller then permutes `out` itself).
  * ea_split (optional, S <= 8): the rows of ea split once into bf16 hi[8] | lo[8] (32 bytes per edge, 16-byte aligned)
  * by gml_edge_presplit -- the raw supports are per-batch constants, so the matrix-core kernels load their first
  * operand ready-made instead of splitting it per layer and per step.  Must describe the same ea (same edge order). */
