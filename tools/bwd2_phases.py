@@ -20,7 +20,7 @@ for it in range(3):
     loss.backward()
     torch.cuda.synchronize()
     L.gml_debug_bwd2_prof(buf, 1)
-names = ['dW(prev)+issue+Z', 'barrier', 'commit+bar', 'edge', 'barrier', 'dval+dX', 'tail', '-']
+names = ['dW(prev)+barrier', 'commit staged regs', 'Z projection', 'edge phase', 'barrier', 'issue next + dval + dX', 'tail', '-']
 tot = float(sum(buf[:7]))
 for n, v in zip(names, buf):
     print('%-17s %12d  %5.1f%%' % (n, v, 100.0 * v / tot if tot else 0))
