@@ -132,6 +132,8 @@ extern "C" int gml_spectconv_bwd(const int32_t* rowptr, const int32_t* col, cons
     p.xvec = (Fin % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)x & 15) == 0);
     /* float4 groups up to roundup4(Fout) must exist in every row: true when ldg covers them (zero padded) */
     p.gvec = (ldg % 4 == 0) && ((Fout + 3) / 4 * 4 <= ldg) && (((uintptr_t)g & 15) == 0);
+    /* the 8-wave kernel prefetches the g window with float4 loads whether or not it will use them */
+    if (pl.rows == 128 && !p.gvec) return GML_E_BADARG;
     p.ngroups = (int)gml_cdiv(num_rows, pl.rows); p.groups_per_wg = pl.groups_per_wg; p.ecap = pl.ecap; p.xcap = pl.xcap;
     const int nfb = pl.nfb, nob = pl.nob;
     int rc = GML_E_UNSUPPORTED;

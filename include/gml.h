@@ -115,7 +115,9 @@ int gml_spectconv_fwd(const int32_t* rowptr, const int32_t* col, const int32_t* 
  * staging.  gml_spectconv_bwd_workspace_bytes returns 0 when the shape has no fused backward
  * (gml_spectconv_bwd then returns GML_E_UNSUPPORTED): the caller composes gml_spectconv_fwd on the
  * transposed view + gml_spmm_fwd + gml_sddmm instead.  flags: GML_ACCUM applies to dx; GML_F32_MFMA forces the
- * f32-input MFMA kernel (default: bf16x3 split on the bf16 matrix cores where the shape allows). */
+ * f32-input MFMA kernel (default: bf16x3 split on the bf16 matrix cores where the shape allows).
+ * With 128-row groups (see below) g must be float4-addressable: 16-byte aligned, ldg % 4 == 0 and
+ * ldg >= roundup4(Fout) with the padding columns zero (else GML_E_BADARG). */
 /* rows per staging group of the backward kernel this shape / flags selects: 128 (bf16x3 kernel), 64 (f32-MFMA
  * kernel) or 0 (no fused backward).  ginfo, max_group_edges and max_group_window passed to the two functions
  * below must be those of gml_csr_group_info(..., group_rows = this value). */
