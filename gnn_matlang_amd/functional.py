@@ -310,6 +310,12 @@ def fused_conv_bwd(csr, val_t, x, G, weight, need_x, need_val, need_w, dx_accum_
     S, Fin, Fout = weight.shape
     dev = x.device
     flags, ginfo, gmax, nbytes = _bwd_plan(csr, S, Fin, Fout)
+    ld4 = (Fout + 3) // 4 * 4
+    if G.stride(0) % 4 != 0 or G.stride(0) < ld4 or G.data_ptr() % 16 != 0:
+        # the 8-wave kernel reads the g window as float4: rows padded (with zeros) to a multiple of 4 floats
+        Gp = torch.zeros(csr.N, ld4, dtype=torch.float32, device=dev)
+        Gp[:, :Fout] = G
+        G = Gp[:, :Fout]
     ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=dev) if need_w else None
     if need_x and dx_accum_into is not None:                 # dx already holds another branch's contribution
         dx, flags = dx_accum_into, flags | _lib.GML_ACCUM
