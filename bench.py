@@ -261,6 +261,21 @@ def main():
             res['roofline_other'] = cands[1:]
             res['kernels_ms_per_step'] = {tag: round(v['ms'] * v['launches'] / args.steps, 4) for tag, v in summ.items()}
         if world == 1 and not args.no_profile:
+            # calibration: what torch's device-to-device copy reaches on THIS box (read + write bytes / time) -- a
+            # reference point, not a ceiling (MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy kernel); the
+            # rooflines are quoted against the 8 TB/s specification
+            ca = torch.empty(256 << 20, dtype=torch.float32, device=dev)          # 1 GiB
+            cb = torch.empty_like(ca)
+            for _ in range(2):
+                cb.copy_(ca)
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record()
+            for _ in range(10):
+                cb.copy_(ca)
+            c1.record()
+            torch.cuda.synchronize()
+            res['hbm_copy_GBps'] = 2 * ca.numel() * 4 * 10 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+            del ca, cb
             # the stand-alone multi-support SpMM of the same batch (gml_spmm_fwd: H = [A_s^T X]_s materialised), the
             # bandwidth-bound piece BASELINE.json's metric names: algorithmic bytes / mean launch time (HIP events)
             csr = data.csr('edge_index2')
@@ -281,6 +296,7 @@ def main():
             res['spmm'] = {'kernel': 'gml_k_spectconv_fwd2<S, 0> via gml_spmm_fwd (8-wave SpMM, H written)', 'bound': 'hbm',
                            'achieved': q_s / t_s / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': q_s / t_s / 1e9 / HBM_PEAK_GBS,
                            'avg_launch_ms': t_s * 1e3, 'algorithmic_bytes_per_launch': q_s, 'S': S_, 'Fin': Fin_,
+                           'frac_of_copy_rate': q_s / t_s / 1e9 / res['hbm_copy_GBps'],
                            'traffic_note': 'PMC: 1045 MB / launch (profiles/r01_j_spmm_hbm_traffic.md)'}
             del xs, vals
         if world == 1 and args.ref_batch > 0:
