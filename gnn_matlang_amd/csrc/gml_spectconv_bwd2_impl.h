@@ -21,8 +21,8 @@
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
 #define GML_BWD2_ROWS 128
-#define GML_BWD2_ECAP_MAX 2048     // register-batched staging bounds (per 128-row group)
-#define GML_BWD2_XCAP_MAX 320
+#define GML_BWD2_ECAP_MAX 1024     // register-batched staging bounds (per 128-row group)
+#define GML_BWD2_XCAP_MAX 224
 
 template <int S, int NFB>
 struct GmlBwd2Cfg {
