@@ -160,14 +160,15 @@ extern "C" int gml_spectconv_bwd(const int32_t* rowptr, const int32_t* col, cons
 
 #ifdef GML_BWD2_TIMING
 // debug build only: per-phase cycle sums of thread 0 of every workgroup
-// (0 dW of the previous group + barrier, 1 stage, 2 Z projection, 3 edge, 4 barrier, 5 dval + dX, 6 tail)
+// (0 dW of the previous group + barrier, 1 commit, 2 Z projection, 3 edge, 4 barrier, 5 dX chain + dx stores, 6 tail,
+//  8 old-dx loads + next group's loads issued, 9 dval stores, 10 P split)
 static unsigned long long* bwd2_prof_buf() {
-    static unsigned long long* b = [] { unsigned long long* q = nullptr; hipMalloc(&q, 64); hipMemset(q, 0, 64); return q; }();
+    static unsigned long long* b = [] { unsigned long long* q = nullptr; hipMalloc(&q, 128); hipMemset(q, 0, 128); return q; }();
     return b;
 }
 extern "C" int gml_debug_bwd2_prof(unsigned long long* out, int reset) {
-    hipError_t e = hipMemcpy(out, bwd2_prof_buf(), 64, hipMemcpyDeviceToHost);
-    if (e == hipSuccess && reset) e = hipMemset(bwd2_prof_buf(), 0, 64);
+    hipError_t e = hipMemcpy(out, bwd2_prof_buf(), 128, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && reset) e = hipMemset(bwd2_prof_buf(), 0, 128);
     return (int)e;
 }
 #endif

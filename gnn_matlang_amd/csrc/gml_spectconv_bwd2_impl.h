@@ -57,7 +57,8 @@ struct GmlBwd2Cfg {
 #define GML_T(i)
 #endif
 
-template <int S, int NFB>
+// XV: the X rows are float4-addressable (p.xvec); a template parameter so that each instantiation carries one load path
+template <int S, int NFB, bool XV>
 __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p) {
     using C = GmlBwd2Cfg<S, NFB>;
     constexpr int LDG = C::LDG;
@@ -128,29 +129,30 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
     // being processed (wave-uniform: kept in scalar registers)
     int4 gi_nv = int4{0, 0, 0, 0};
     int4 gi_c = int4{0, 0, 0, 0};
+    // latch(): the record fetched a group ahead -> scalar registers.  Called BEFORE the old-dx loads of the phase: its
+    // wait (the record's vector load, counted conservatively) must not sit behind loads issued just before it.
+    auto latch = [&]() {
+        gi_c = int4{__builtin_amdgcn_readfirstlane(gi_nv.x), __builtin_amdgcn_readfirstlane(gi_nv.y),
+                    __builtin_amdgcn_readfirstlane(gi_nv.z), __builtin_amdgcn_readfirstlane(gi_nv.w)};
+    };
     auto issue = [&](int g) {
         const int64_t r0 = (int64_t)g * ROWS;
         const int nr = (int)min((int64_t)ROWS, p.nrows - r0);
-        const int4 gi = int4{__builtin_amdgcn_readfirstlane(gi_nv.x), __builtin_amdgcn_readfirstlane(gi_nv.y),
-                             __builtin_amdgcn_readfirstlane(gi_nv.z), __builtin_amdgcn_readfirstlane(gi_nv.w)};
-        gi_c = gi;
+        const int4 gi = gi_c;
         const int kb = gi.x, ne = gi.y, lo = gi.z, nwin = gi.w;
-        // the lane's own x row (row_n: loaded a whole group earlier, see load_rows)
-        {
-            const bool rvalid = row_n < nr;
-            const float* xr = p.x + (r0 + row_n) * p.ldx + 8 * kq;
-            if (p.xvec) {
+        // the lane's own x row (row_n: loaded a whole group earlier, see load_rows): unconditional, clamped loads --
+        // a select on the loaded value here would wait for it on the spot; rows / features outside are zeroed when
+        // the registers are used (group top)
+        if constexpr (XV) {
+            const float* xr = p.x + min(r0 + row_n, p.nrows - 1) * p.ldx;
+            const int f4max = (p.Fin + 3) / 4 * 4 - 4;
 #pragma unroll
-                for (int q4 = 0; q4 < 2; ++q4) {
-                    f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (rvalid && 8 * kq + 4 * q4 < p.Fin) t = *reinterpret_cast<const f32x4*>(xr + 4 * q4);
-                    xb[4 * q4] = t.x; xb[4 * q4 + 1] = t.y; xb[4 * q4 + 2] = t.z; xb[4 * q4 + 3] = t.w;
-                }
-            } else {
-#pragma unroll
-                for (int t = 0; t < 8; ++t) xb[t] = (rvalid && 8 * kq + t < p.Fin) ? xr[t] : 0.f;
+            for (int q4 = 0; q4 < 2; ++q4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(xr + min(8 * kq + 4 * q4, f4max));
+                xb[4 * q4] = t.x; xb[4 * q4 + 1] = t.y; xb[4 * q4 + 2] = t.z; xb[4 * q4 + 3] = t.w;
             }
-        }
+        }                                                     // (rows that are not float4-addressable: loaded at the group top)
+        (void)nr;
         rpv = p.rowptr[min(r0 + tid, p.nrows)];
         // Unconditional loads, indices clamped into the arrays (lanes outside fetch a valid, unused element): the
         // compiler can count them, so the dX phase's wait for the old dx values (issued just before these) is an
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
         row_n = reinterpret_cast<const unsigned char*>(rec + 4)[wave * 16 + r16];
         outrows_n = reinterpret_cast<const uint32_t*>(rec + 4)[wave * 4 + kq];
     };
-    if (g0 < g1) { load_rows(g0); issue(g0); }
+    if (g0 < g1) { load_rows(g0); latch(); issue(g0); }
     for (int g = g0; g < g1; ++g) {
         const int64_t r0 = (int64_t)g * ROWS;
         const int nr = (int)min((int64_t)ROWS, p.nrows - r0);
@@ -191,6 +193,11 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
 
         // ---- stage: commit the registers loaded one phase ago
         const bool rvalid = row < nr;
+        if constexpr (!XV) {                                 // element-wise x row: issued here, used after the commit
+            const float* xr = p.x + (r0 + row) * p.ldx + 8 * kq;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) xb[t] = (rvalid && 8 * kq + t < p.Fin) ? xr[t] : 0.f;
+        }
         if (tid <= nr) rp_l[tid] = rpv;
         if (vec_group(gi)) {
 #pragma unroll
@@ -216,6 +223,21 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
         }
         __syncthreads();
         GML_T(1);
+        // old dx values (accumulate mode): loaded here, a whole Z + edge phase before the dX chain adds onto them
+        f32x4 dxa[NFB];
+        {
+            const float* dxb = p.dx ? p.dx : p.x;            // (no dx wanted: any readable rows, the values are dropped)
+            const int64_t ldb = p.dx ? p.lddx : p.ldx;
+#pragma unroll
+            for (int fb = 0; fb < NFB; ++fb) {
+                const int f = fb * 16 + r16;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int lr = min((int)((out_rows >> (8 * reg)) & 255u), nr - 1);
+                    dxa[fb][reg] = dxb[(r0 + lr) * ldb + min(f, p.Fin - 1)];
+                }
+            }
+        }
 
         const int kbeg = rvalid ? rp_l[row] - kb : 0;
         const int kend = rvalid ? rp_l[row + 1] - kb : 0;
@@ -223,6 +245,11 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
         // own X row (its load was issued ahead of the staging loads), features 8*kq .. 8*kq+7  ->  bf16 (hi, lo)
         // B fragment of Z^T, also the X^T tile of dW
         bf16x8 xh, xl;
+        if constexpr (XV) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (!(rvalid && 8 * kq + j < p.Fin)) xb[j] = 0.f;    // the prefetch loaded clamped addresses
+        }
         gml_split8(xb, xh, xl);
 
         // ---- Z^T = W^T X^T: MFMA row i of block ob carries o = 8*(i>>2) + 4*ob + (i&3), so lane kq receives
@@ -295,21 +322,9 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
         // stores (memory operations complete in order: behind the stores the loads would first wait for those to
         // drain), the latter in flight through the dX and dW phases.  All unconditional and clamped, so the dX
         // chain's wait for the old values is an exact count that leaves the prefetch in flight.
-        f32x4 dxa[NFB];
-        {
-            const float* dxb = p.dx ? p.dx : p.x;            // (no dx wanted: any readable rows, the values are dropped)
-            const int64_t ldb = p.dx ? p.lddx : p.ldx;
-#pragma unroll
-            for (int fb = 0; fb < NFB; ++fb) {
-                const int f = fb * 16 + r16;
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int lr = min((int)((out_rows >> (8 * reg)) & 255u), nr - 1);
-                    dxa[fb][reg] = dxb[(r0 + lr) * ldb + min(f, p.Fin - 1)];
-                }
-            }
-        }
+        latch();
         issue(min(g + 1, g1 - 1));
+        GML_T(8);
 
         if (p.dval) {
             if constexpr (S % 4 == 0) {
@@ -320,6 +335,7 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
             }
         }
 
+        GML_T(9);
         // P -> bf16 (hi, lo) once; the pairs are the A fragments of dX and the inputs of the dW transposes
         bf16x8 PH[S], PL[S];
 #pragma unroll
@@ -327,6 +343,7 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
             const float pv[8] = {P[s][0].x, P[s][0].y, P[s][1].x, P[s][1].y, P[s][2].x, P[s][2].y, P[s][3].x, P[s][3].y};
             gml_split8(pv, PH[s], PL[s]);
         }
+        GML_T(10);
         // ---- dX = P W^T: one K=32 step per support (k = o = 8*kq + i)
         if (p.dx) {
             if (!(p.flags & GML_ACCUM)) {
@@ -446,10 +463,15 @@ int gml_launch_bwd2(const GmlBwdParams& p, dim3 grid, size_t lds, hipStream_t st
     template <>                                                                                              \
     int gml_launch_bwd2<SV, NFBV>(const GmlBwdParams& p, dim3 grid, size_t lds, hipStream_t st) {            \
         static_assert(GmlBwd2Cfg<SV, NFBV>::OK, "S must be even");                                           \
-        static const hipError_t attr_rc = hipFuncSetAttribute(                                               \
-            reinterpret_cast<const void*>(&gml_k_spectconv_bwd2<SV, NFBV>),                                  \
+        static const hipError_t rc1 = hipFuncSetAttribute(                                                   \
+            reinterpret_cast<const void*>(&gml_k_spectconv_bwd2<SV, NFBV, true>),                            \
             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                         \
-        if (attr_rc != hipSuccess) return (int)attr_rc;                                                      \
-        hipLaunchKernelGGL((gml_k_spectconv_bwd2<SV, NFBV>), grid, dim3(512), lds, st, p);                   \
+        static const hipError_t rc0 = hipFuncSetAttribute(                                                   \
+            reinterpret_cast<const void*>(&gml_k_spectconv_bwd2<SV, NFBV, false>),                           \
+            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                         \
+        if (rc1 != hipSuccess) return (int)rc1;                                                              \
+        if (rc0 != hipSuccess) return (int)rc0;                                                              \
+        if (p.xvec) hipLaunchKernelGGL((gml_k_spectconv_bwd2<SV, NFBV, true>), grid, dim3(512), lds, st, p); \
+        else hipLaunchKernelGGL((gml_k_spectconv_bwd2<SV, NFBV, false>), grid, dim3(512), lds, st, p);       \
         return gml_launch_status();                                                                          \
     }

@@ -14,14 +14,15 @@ torch.manual_seed(0)
 model = models.zinc_gnnml3().to(dev)
 L = _lib.lib()
 L.gml_debug_bwd2_prof.restype = ctypes.c_int
-buf = (ctypes.c_ulonglong * 8)()
+buf = (ctypes.c_ulonglong * 16)()
 for it in range(3):
     loss = models.zinc_loss(model(data), data.y)
     loss.backward()
     torch.cuda.synchronize()
     L.gml_debug_bwd2_prof(buf, 1)
-names = ['dW(prev)+barrier', 'commit staged regs', 'Z projection', 'edge phase', 'barrier', 'issue next + dval + dX', 'tail', '-']
-tot = float(sum(buf[:7]))
+names = ['dW(prev)+barrier', 'commit staged regs', 'Z projection', 'edge phase', 'barrier', 'dX chain + dx stores', 'tail', '-',
+         'old dx + next loads issued', 'dval stores', 'P split', '-', '-', '-', '-', '-']
+tot = float(sum(buf))
 for n, v in zip(names, buf):
     print('%-17s %12d  %5.1f%%' % (n, v, 100.0 * v / tot if tot else 0))
 print('cycles per launch per workgroup: %.0f' % (tot / 4 / 256))
