@@ -244,9 +244,9 @@ def main():
             if 'spectconv_fwd' in summ:
                 cands.append(roof('spectconv_fwd', 'gml_k_spectconv_fwd2 / gml_k_spectconv_fwd (fused SpectConv forward; the 8-wave kernel also carries the Hadamard branch)', pj_f, ed_f))
             # HBM bytes per launch from the PMC counters (collected offline with the same command under rocprofv3,
-            # separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied -- profiles/r01_j_hbm_traffic.md);
+            # separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied -- profiles/r01_k_hbm_traffic.md);
             # only valid for the workload it was measured on
-            tpath = os.path.join(ROOT, 'profiles', 'r01_j_hbm_traffic.json')
+            tpath = os.path.join(ROOT, 'profiles', 'r01_k_hbm_traffic.json')
             if os.path.exists(tpath) and data.num_graphs == 32768 and args.pool == 2048:
                 tk = json.load(open(tpath))['kernels']
                 for r in cands:
@@ -255,7 +255,7 @@ def main():
                     if hits:                                  # launch-weighted mean over the instantiations used
                         r['traffic'] = sum(h['hbm_bytes_per_launch'] * h.get('launches', 1) for h in hits) / \
                             sum(h.get('launches', 1) for h in hits)
-                        r['traffic_source'] = 'profiles/r01_j_hbm_traffic.json (rocprofv3 PMC, per launch)'
+                        r['traffic_source'] = 'profiles/r01_k_hbm_traffic.json (rocprofv3 PMC, per launch)'
             cands.sort(key=lambda r: -r['ms_per_step'])
             res['roofline'] = cands[0]                   # the kernel with the largest share of the step
             res['roofline_other'] = cands[1:]
@@ -297,7 +297,7 @@ def main():
                            'achieved': q_s / t_s / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': q_s / t_s / 1e9 / HBM_PEAK_GBS,
                            'avg_launch_ms': t_s * 1e3, 'algorithmic_bytes_per_launch': q_s, 'S': S_, 'Fin': Fin_,
                            'frac_of_copy_rate': q_s / t_s / 1e9 / res['hbm_copy_GBps'],
-                           'traffic_note': 'PMC: 1045 MB / launch (profiles/r01_j_spmm_hbm_traffic.md)'}
+                           'traffic_note': 'PMC: 1045 MB / launch (profiles/r01_k_spmm_hbm_traffic.md)'}
             del xs, vals
         if world == 1 and args.ref_batch > 0:
             # the reference's own batch size: launch-latency bound, so the step is replayed from a HIP graph
