@@ -650,3 +650,18 @@ def test_full_size_properties(dev):
         o.square().sum().backward()
     for n, v in layer.named_parameters():
         close(v.grad, gfull[n], tol=5e-4, what='sharded grad ' + n)
+
+
+# ------------------------------------------------------------------------------------------ randomised sweeps (short)
+@pytest.mark.parametrize('sweep', ['ml3', 'conv', 'spectral'])
+def test_randomised_sweep_short(dev, sweep):
+    """A short run of tools/fuzz_parity.py (the long runs are in profiles/r01_i_fuzz_parity.jsonl): random shapes and
+    graphs through every kernel family against the oracle in fp64."""
+    import argparse
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tools'))
+    import fuzz_parity
+    a = argparse.Namespace(cases=24, seed=2026, only=-1, verbose=False, sweep=sweep)
+    fails = {'ml3': lambda: fuzz_parity.ml3_sweep(a), 'conv': lambda: fuzz_parity.conv_sweep(a, dev),
+             'spectral': lambda: fuzz_parity.spectral_sweep(a, dev)}[sweep]()
+    assert fails == 0

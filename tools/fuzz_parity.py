@@ -194,6 +194,11 @@ def main():
         sys.exit(1 if conv_sweep(a, torch.device('cuda:0')) else 0)
     if a.sweep == 'spectral':
         sys.exit(1 if spectral_sweep(a, torch.device('cuda:0')) else 0)
+    sys.exit(1 if ml3_sweep(a) else 0)
+
+
+def ml3_sweep(a):
+    """ML3Layer (all branches) on random graphs; returns the number of failures."""
     from gnn_matlang_amd import ML3Layer
     from oracle.spect_conv_oracle import OracleML3Layer
     from oracle.relu_margin import make_safe
@@ -267,7 +272,7 @@ def main():
             print('FAIL', json.dumps(tag), fails[-1][1], flush=True)
     print(json.dumps({'cases': a.cases, 'seed': a.seed, 'worst_rel_err': worst, 'failures': len(fails), 'unsupported': len(unsupported),
                       'tol': TOL}))
-    sys.exit(1 if fails else 0)
+    return len(fails)
 
 
 if __name__ == '__main__':
