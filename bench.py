@@ -94,7 +94,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=32768, help='graphs per GPU per step')
+    ap.add_argument('--batch', type=int, default=131072, help='graphs per GPU per step (SURVEY s8d: 65,536 .. 262,144 for the roofline run)')
     ap.add_argument('--pool', type=int, default=2048, help='distinct synthetic graphs (tiled to --batch)')
     ap.add_argument('--cpu-graphs', type=int, default=2048)
     ap.add_argument('--cpu-steps', type=int, default=3)
@@ -246,8 +246,10 @@ def main():
             # HBM bytes per launch from the PMC counters (collected offline with the same command under rocprofv3,
             # separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied -- profiles/r01_k_hbm_traffic.md);
             # only valid for the workload it was measured on
-            tpath = os.path.join(ROOT, 'profiles', 'r01_k_hbm_traffic.json')
-            if os.path.exists(tpath) and data.num_graphs == 32768 and args.pool == 2048:
+            tname = {32768: 'r01_k_hbm_traffic.json', 65536: 'r01_k_hbm_traffic_b65536.json',
+                     131072: 'r01_k_hbm_traffic_b131072.json'}.get(data.num_graphs, 'none')
+            tpath = os.path.join(ROOT, 'profiles', tname)
+            if os.path.exists(tpath) and args.pool == 2048:
                 tk = json.load(open(tpath))['kernels']
                 for r in cands:
                     pref = 'gml_k_spectconv_bwd' if 'backward' in r['kernel'] else 'gml_k_spectconv_fwd'
@@ -255,7 +257,7 @@ def main():
                     if hits:                                  # launch-weighted mean over the instantiations used
                         r['traffic'] = sum(h['hbm_bytes_per_launch'] * h.get('launches', 1) for h in hits) / \
                             sum(h.get('launches', 1) for h in hits)
-                        r['traffic_source'] = 'profiles/r01_k_hbm_traffic.json (rocprofv3 PMC, per launch)'
+                        r['traffic_source'] = 'profiles/%s (rocprofv3 PMC, per launch)' % tname
             cands.sort(key=lambda r: -r['ms_per_step'])
             res['roofline'] = cands[0]                   # the kernel with the largest share of the step
             res['roofline_other'] = cands[1:]
@@ -297,7 +299,7 @@ def main():
                            'achieved': q_s / t_s / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': q_s / t_s / 1e9 / HBM_PEAK_GBS,
                            'avg_launch_ms': t_s * 1e3, 'algorithmic_bytes_per_launch': q_s, 'S': S_, 'Fin': Fin_,
                            'frac_of_copy_rate': q_s / t_s / 1e9 / res['hbm_copy_GBps'],
-                           'traffic_note': 'PMC: 1045 MB / launch (profiles/r01_k_spmm_hbm_traffic.md)'}
+                           'traffic_note': 'PMC at 32,768 graphs: 1045 MB / launch = 1.01x algorithmic (profiles/r01_k_spmm_hbm_traffic.md)'}
             del xs, vals
         if world == 1 and args.ref_batch > 0:
             # the reference's own batch size: launch-latency bound, so the step is replayed from a HIP graph

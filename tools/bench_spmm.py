@@ -9,7 +9,7 @@ import bench
 from gnn_matlang_amd import functional as Fn, _lib
 
 dev = torch.device('cuda:0')
-data, _ = bench.build_batch(32768, 2048, seed=1000, device=dev)
+data, _ = bench.build_batch(int(os.environ.get('GML_SPMM_BATCH', '32768')), 2048, seed=1000, device=dev)
 csr = data.csr('edge_index2')
 N, E, S, Fin, Fout = csr.N, csr.E, 8, 32, 30
 val = csr.sort_values(data.edge_attr2)
