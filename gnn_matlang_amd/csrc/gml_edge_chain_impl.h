@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void gml_k_edge_chain_fwd(const float* __re
                 const f32x4 v = f32x4{fmaxf(T[u].out[0], 0.f), fmaxf(T[u].out[1], 0.f), fmaxf(T[u].out[2], 0.f),
                                       fmaxf(T[u].out[3], 0.f)};
                 const bool q_ok = q0 < S;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_o, q_ok ? off_o : (int)0xffffff00, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_o, q_ok ? off_o : (int)0xffffff00, 0, /*nt: written once, read by the next kernel from HBM anyway*/ 2);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_t, q_ok ? off_t : (int)0xffffff00, 0, 0);
             } else {
 #pragma unroll
