@@ -1,5 +1,5 @@
 """HBM rate of the stand-alone multi-support SpMM (gml_spmm_fwd: H[r, s, :] = sum_k val[k, s] x[col[k], :], H materialised)
-beside the fused forward that never writes H.  python tools/bench_spmm.py"""
+beside the fused forward that never writes H.  python tools/bench_spmm.py   (GML_SPMM_BATCH=<graphs>, default 32768)"""
 import json
 import os
 import sys
