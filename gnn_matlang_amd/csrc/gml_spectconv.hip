@@ -5,13 +5,14 @@
 #define GML_DECL_FWD2(S, B) template <> int gml_launch_fwd2<S, B>(const GmlFwdParams&, dim3, hipStream_t, bool, bool);
 GML_DECL_FWD2(8, 2) GML_DECL_FWD2(8, 1) GML_DECL_FWD2(4, 2) GML_DECL_FWD2(4, 1)
 GML_DECL_FWD2(8, 0) GML_DECL_FWD2(4, 0)            /* NOB = 0: the stand-alone SpMM instantiation */
+GML_DECL_FWD2(12, 2) GML_DECL_FWD2(12, 1) GML_DECL_FWD2(12, 0)  /* counting.py's 12 supports */
 
 static bool fwd2_shape(int S, int Fin, int Fout, uint32_t flags) {
 #ifdef GML_NO_FWD2
     return false;
 #endif
     // S % 4 == 0: the register-staged value rows are float4 (other S keep the 64-row kernel, which stages any S)
-    return (flags & GML_F32_MFMA) == 0 && (S == 4 || S == 8) && Fin <= 32 && Fout <= 32;
+    return (flags & GML_F32_MFMA) == 0 && (S == 4 || S == 8 || S == 12) && Fin <= 32 && Fout <= 32;
 }
 
 extern "C" int32_t gml_spectconv_fwd_group_rows(int32_t S, int32_t Fin, int32_t Fout, uint32_t flags) {
@@ -61,7 +62,7 @@ static int launch_fwd2(const int32_t* rowptr, const int32_t* col, const int32_t*
     const int nob = Fout > 16 ? 2 : 1;
     const bool mix = F2 > 0;
 #define GML_FWD2_GO(SV, B) if (S == SV && nob == B) return gml_launch_fwd2<SV, B>(p, dim3(grid), st, xv, mix);
-    GML_FWD2_GO(8, 2) GML_FWD2_GO(8, 1) GML_FWD2_GO(4, 2) GML_FWD2_GO(4, 1)
+    GML_FWD2_GO(8, 2) GML_FWD2_GO(8, 1) GML_FWD2_GO(4, 2) GML_FWD2_GO(4, 1) GML_FWD2_GO(12, 2) GML_FWD2_GO(12, 1)
     return GML_E_UNSUPPORTED;
 }
 
@@ -235,6 +236,7 @@ extern "C" int gml_spmm_fwd(const int32_t* rowptr, const int32_t* col, const int
         grid = (int)gml_cdiv(p.ngroups, p.groups_per_wg);
         if (S == 8) return gml_launch_fwd2<8, 0>(p, dim3(grid), st, xv, false);
         if (S == 4) return gml_launch_fwd2<4, 0>(p, dim3(grid), st, xv, false);
+        if (S == 12) return gml_launch_fwd2<12, 0>(p, dim3(grid), st, xv, false);
     }
     int s0 = 0;
     while (s0 < S) {
