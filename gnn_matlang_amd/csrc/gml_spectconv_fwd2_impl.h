@@ -1,4 +1,4 @@
-// Fused forward, 128-row / 8-wave geometry (bf16x3 projection; Fin <= 32, Fout <= 32, S in {4, 8}): same function as
+// Fused forward, 128-row / 8-wave geometry (bf16x3 projection; Fin <= 32, Fout <= 32, S in {4, 8, 12}): same function as
 // gml_k_spectconv_fwd (gml_spectconv_impl.h)
 //
 //   out[r, :] = act( sum_s (sum_{k in row r} val[k, s] x[col[k], :]) W_s + b )

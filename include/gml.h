@@ -133,7 +133,7 @@ int gml_spectconv_bwd(const int32_t* rowptr, const int32_t* col, const int32_t* 
 
 /* H[r, s, :] = sum_{k in row r} val[pos(k), s] * x[col[k], :]     H is [N, S, Fin] contiguous.
  * ginfo128 (optional): 128-row group records of this CSR -> staged, degree-ranked aggregation of the 8-wave kernel
- * (S in {4, 8}, Fin <= 32, epos NULL); NULL: one-row-per-lane-group kernel for any shape. */
+ * (S in {4, 8, 12}, Fin <= 32, epos NULL); NULL: one-row-per-lane-group kernel for any shape. */
 int gml_spmm_fwd(const int32_t* rowptr, const int32_t* col, const int32_t* ginfo128, const int32_t* epos,
                  const float* val, const float* x, int64_t ldx, float* h,
                  int64_t num_rows, int32_t S, int32_t Fin, gml_stream_t stream);
