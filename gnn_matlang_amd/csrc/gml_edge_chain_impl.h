@@ -603,7 +603,7 @@ static inline int64_t gml_edge_chain_bwd_groups(int64_t E, int wgs_per_cu = 4) {
                                       float* out_t, int64_t E, hipStream_t st) {                                \
         const int64_t ntiles = gml_cdiv(E, 16);                                                                 \
         int64_t grid = gml_cdiv(ntiles, 8);                                                                     \
-        if (grid > 8 * GML_NUM_CU) grid = 8 * GML_NUM_CU;                                                       \
+        if (grid > 6 * GML_NUM_CU) grid = 6 * GML_NUM_CU;   /* all resident at 70 VGPRs; 4..8 measured within 2 % */   \
         if (es != nullptr)                                                                                      \
             hipLaunchKernelGGL((gml_k_edge_chain_fwd<SV, true>), dim3((unsigned)grid), dim3(256), 0, st, ea,    \
                                es, w1, w2, w3, w4, out, tpos, out_t, E, ntiles);                                \
