@@ -6,7 +6,8 @@ import ctypes
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, 'libgml_hip.so')
+# GML_LIB: another build of the same library (A/B and instrumented builds of tools/build_variant.py)
+LIB_PATH = os.environ.get('GML_LIB') or os.path.join(_PKG, 'libgml_hip.so')
 
 _i32, _i64, _u32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32
 _p, _sz = ctypes.c_void_p, ctypes.c_size_t

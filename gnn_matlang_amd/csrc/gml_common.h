@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "gml.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -18,11 +19,41 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define GML_NUM_CU 256
 #define GML_NUM_XCD 8
 
-// return code of the last launch on this thread (no sync)
+// XOR key of the 16-byte chunks of a 64-byte-row bf16 image ([32 rows][32 k], hi or lo) whose MFMA fragments are read
+// with ds_read_b128: lane (r16, kq) reads chunk kq ^ key(row) of row 16*blk + r16 (or of the permuted rows of the
+// backward's Z projection).  ds_read_b128 is served in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... (not
+// in contiguous 16-lane groups), so the key must separate rows r and r + 4 of DIFFERENT kq: key = -(row >> 2) mod 4 is
+// conflict-free for both row orders (tools/lds_sim.py; the round-1 keys (row >> 2) / (row >> 3) were 2-way).
+__host__ __device__ __forceinline__ int gml_wkey(int row) { return (-(row >> 2)) & 3; }
+
+// return code of the last launch on this thread (no sync).  Peek, not Get: the runtime's sticky error state is left
+// for whoever else checks it (torch), an unrelated earlier error is neither swallowed nor cleared here.
 static inline int gml_launch_status() {
-    hipError_t e = hipGetLastError();
+    hipError_t e = hipPeekAtLastError();
     return e == hipSuccess ? GML_OK : (int)e;
 }
+
+// Opt a kernel into more than 64 KiB of dynamic LDS.  The attribute belongs to the (kernel, device) pair, so it is set
+// once per device the calling process launches on (bit d of a per-call-site mask = done on device d), not once per
+// process: a process that drives several devices gets it on each.
+static inline hipError_t gml_allow_big_lds_impl(std::atomic<uint64_t>& done, const void* kernel, int nbytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, nbytes);
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
+}
+// declares `const hipError_t rcvar`; one mask per expansion (and per template instantiation it expands in)
+#define GML_ALLOW_BIG_LDS(rcvar, kernel_ptr, nbytes)                                                   \
+    hipError_t rcvar##_v = hipSuccess;                                                                 \
+    {                                                                                                  \
+        static std::atomic<uint64_t> done_{0};                                                         \
+        rcvar##_v = gml_allow_big_lds_impl(done_, reinterpret_cast<const void*>(kernel_ptr), (nbytes)); \
+    }                                                                                                  \
+    const hipError_t rcvar = rcvar##_v;
 
 static inline int64_t gml_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -226,8 +226,7 @@ static int node_mix_launch(int FINP, dim3 grid, size_t lds, hipStream_t st, cons
                            int F2, int ntiles) {
 #define NM_GO(FP)                                                                                             \
     if (FINP == FP) {                                                                                         \
-        static const hipError_t arc = hipFuncSetAttribute(reinterpret_cast<const void*>(&gml_k_node_mix<FP, BWD>), \
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        GML_ALLOW_BIG_LDS(arc, (&gml_k_node_mix<FP, BWD>), 160 * 1024) \
         if (arc != hipSuccess) return (int)arc;                                                               \
         hipLaunchKernelGGL((gml_k_node_mix<FP, BWD>), grid, dim3(256), lds, st, x, ldx, w11, b11, w12, b12, gout, ldg, \
                            out, ldo, dx, lddx, partial, nrows, Fin, F2, ntiles);                              \

@@ -355,9 +355,7 @@ extern "C" int gml_ml3_split_bwd(const float* gy, int64_t ldgy, const float* y, 
     const int vx = (F2 == 0 || (((ldx | (dx ? lddx : 0)) & 3) == 0 && (((uintptr_t)x | (uintptr_t)dx) & 15) == 0)) ? 4 : 1;
 #define SB_GO(FP, VA, VXX)                                                                                       \
     if (FINP == FP && va == VA && vx == VXX) {                                                                   \
-        static const hipError_t arc = hipFuncSetAttribute(                                                       \
-            reinterpret_cast<const void*>(&gml_k_ml3_split_bwd<FP, VA, VXX>),                                    \
-            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                             \
+        GML_ALLOW_BIG_LDS(arc, (&gml_k_ml3_split_bwd<FP, VA, VXX>), 160 * 1024) \
         if (arc != hipSuccess) return (int)arc;                                                                  \
         hipLaunchKernelGGL((gml_k_ml3_split_bwd<FP, VA, VXX>), dim3(grid), dim3(SB_ROWS), lds, st, p);           \
     }
@@ -491,8 +489,7 @@ extern "C" int gml_xty(const float* A, int64_t lda, const float* B, int64_t ldb,
     size_t lds = sizeof(float) * (size_t)XTY_ROWS * (xty_ld(a) + xty_ld(b));
     const size_t fold = sizeof(float) * (size_t)4 * ((a + 15) / 16) * ((b + 15) / 16) * 4 * 64;
     if (fold > lds) lds = fold;
-    static const hipError_t arc = hipFuncSetAttribute(reinterpret_cast<const void*>(&gml_k_xty),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    GML_ALLOW_BIG_LDS(arc, (&gml_k_xty), 160 * 1024)
     if (arc != hipSuccess) return (int)arc;
     hipLaunchKernelGGL(gml_k_xty, dim3(grid), dim3(256), lds, st, A, lda, B, ldb, (float*)ws, n, a, b,
                        (int)gml_cdiv(n, XTY_ROWS));

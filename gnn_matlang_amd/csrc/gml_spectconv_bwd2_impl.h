@@ -32,8 +32,9 @@ struct GmlBwd2Cfg {
     static constexpr int W_BYTES = 4 * W_HALF * 2;           // fo-hi, fo-lo, of-hi, of-lo
     static constexpr int SE = 2;                             // supports per dW slab (8 blocks -> 8 waves when NFB=2)
     static constexpr int NSLAB = S / SE;
-    static constexpr int LDT = GML_BWD2_ROWS + 8;           // row stride (bf16) of the transposed tiles: +16 B spreads
-                                                             // the 16 rows a fragment read touches over all 64 LDS banks
+    static constexpr int LDT = GML_BWD2_ROWS + 16;          // row stride (bf16) of the transposed tiles; with the 16-byte
+                                                             // chunks of every 64-byte K step XOR-ed by (channel >> 2) & 3
+                                                             // the fragment reads are conflict-free (tools/lds_sim.py)
     static constexpr int XT_BYTES = 2 * 32 * LDT * 2;                  // X^T hi, lo  [f][row]
     static constexpr int PT_BYTES = 2 * SE * 32 * LDT * 2;             // P^T hi, lo  [se][o][row]
     static constexpr bool OK = (S % SE == 0);
@@ -91,10 +92,10 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
         const float v = (f < p.Fin && o < p.Fout) ? p.w[((int64_t)s * p.Fin + f) * p.Fout + o] : 0.f;
         const __bf16 h = (__bf16)v;
         const __bf16 l = (__bf16)(v - (float)h);
-        // 16-byte chunks of a 64-byte row are XOR-swizzled so that the 16 rows one fragment read touches
-        // (stride 64 B = 4-way conflict) land on distinct banks: key (f>>2)&3 for [s][f][o], (o>>3)&3 for [s][o][f]
-        const int ifo = (s * 32 + f) * 32 + ((((o >> 3) ^ (f >> 2)) & 3) << 3) + (o & 7);
-        const int iof = (s * 32 + o) * 32 + ((((f >> 3) ^ (o >> 3)) & 3) << 3) + (f & 7);
+        // 16-byte chunks of a 64-byte row are XOR-swizzled (gml_wkey) so that the rows one ds_read_b128 lane group
+        // touches land on distinct banks
+        const int ifo = (s * 32 + f) * 32 + ((((o >> 3) ^ gml_wkey(f)) & 3) << 3) + (o & 7);
+        const int iof = (s * 32 + o) * 32 + ((((f >> 3) ^ gml_wkey(o)) & 3) << 3) + (f & 7);
         Wfo_h[ifo] = h; Wfo_l[ifo] = l;
         Wof_h[iof] = h; Wof_l[iof] = l;
     }
@@ -257,23 +258,42 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
         f32x2 Z[S][4], P[S][4];                              // pair h of block ob: o = 8*kq + 4*ob + 2*h + {0,1}
         {
             const int oa0 = 8 * (r16 >> 2) + (r16 & 3);      // A-fragment row -> output column (block 0); +4 for block 1
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
+            // The W fragments of support s + 1 are requested before the MFMAs of support s are issued, and the two output
+            // blocks' chains are interleaved: as first written (read, wait, three dependent MFMAs, per block) every
+            // step exposed a full LDS round trip and the MFMA latency (r02a: Z = 3.6 k cycles for 1.5 k of matrix work).
+            bf16x8 wh[2][2], wl[2][2];                       // [stage][ob]
+            auto frag = [&](int s, int st) {
 #pragma unroll
                 for (int ob = 0; ob < 2; ++ob) {
                     const int oa = oa0 + 4 * ob;
-                    const int off = (s * 32 + oa) * 32 + (((kq ^ (oa >> 3)) & 3) << 3);
-                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(Wof_h + off);
-                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(Wof_l + off);
-                    f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
-                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, xh, d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xl, d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xh, d, 0, 0, 0);
-                    Z[s][2 * ob] = f32x2{d[0], d[1]};
-                    Z[s][2 * ob + 1] = f32x2{d[2], d[3]};
-                    P[s][2 * ob] = f32x2{0.f, 0.f};
-                    P[s][2 * ob + 1] = f32x2{0.f, 0.f};
+                    const int off = (s * 32 + oa) * 32 + (((kq ^ gml_wkey(oa)) & 3) << 3);
+                    wh[st][ob] = *reinterpret_cast<const bf16x8*>(Wof_h + off);
+                    wl[st][ob] = *reinterpret_cast<const bf16x8*>(Wof_l + off);
                 }
+            };
+            frag(0, 0);
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int st = s & 1;
+                if (s + 1 < S) frag(s + 1, st ^ 1);
+                f32x4 d0 = f32x4{0.f, 0.f, 0.f, 0.f}, d1 = f32x4{0.f, 0.f, 0.f, 0.f};
+                d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[st][0], xh, d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[st][1], xh, d1, 0, 0, 0);
+                d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[st][0], xl, d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[st][1], xl, d1, 0, 0, 0);
+                d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[st][0], xh, d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[st][1], xh, d1, 0, 0, 0);
+                Z[s][0] = f32x2{d0[0], d0[1]}; Z[s][1] = f32x2{d0[2], d0[3]};
+                Z[s][2] = f32x2{d1[0], d1[1]}; Z[s][3] = f32x2{d1[2], d1[3]};
+#pragma unroll
+                for (int h = 0; h < 4; ++h) P[s][h] = f32x2{0.f, 0.f};
+            }
+            // pin the order the scheduler would otherwise undo: 4 reads, then per support (4 reads of the next, 6 MFMAs)
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                if (s + 1 < S) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
             }
         }
 
@@ -350,19 +370,35 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
 #pragma unroll
                 for (int fb = 0; fb < NFB; ++fb) dxa[fb] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const bf16x8 ph = PH[s], pl = PL[s];
+            // fragments of support s + 1 in flight while the MFMAs of support s run (see the Z projection)
+            bf16x8 vh[2][NFB], vl[2][NFB];
+            auto fragx = [&](int s, int st) {
 #pragma unroll
                 for (int fb = 0; fb < NFB; ++fb) {
                     const int ff = fb * 16 + r16;                              // B[k = o][j = f]: 8 consecutive o of row f
-                    const int off = (s * 32 + ff) * 32 + (((kq ^ (ff >> 2)) & 3) << 3);
-                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(Wfo_h + off);
-                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Wfo_l + off);
-                    dxa[fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, bh, dxa[fb], 0, 0, 0);
-                    dxa[fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, bl, dxa[fb], 0, 0, 0);
-                    dxa[fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, bh, dxa[fb], 0, 0, 0);
+                    const int off = (s * 32 + ff) * 32 + (((kq ^ gml_wkey(ff)) & 3) << 3);
+                    vh[st][fb] = *reinterpret_cast<const bf16x8*>(Wfo_h + off);
+                    vl[st][fb] = *reinterpret_cast<const bf16x8*>(Wfo_l + off);
                 }
+            };
+            fragx(0, 0);
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int st = s & 1;
+                if (s + 1 < S) fragx(s + 1, st ^ 1);
+                const bf16x8 ph = PH[s], pl = PL[s];
+#pragma unroll
+                for (int fb = 0; fb < NFB; ++fb) dxa[fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, vh[st][fb], dxa[fb], 0, 0, 0);
+#pragma unroll
+                for (int fb = 0; fb < NFB; ++fb) dxa[fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vl[st][fb], dxa[fb], 0, 0, 0);
+#pragma unroll
+                for (int fb = 0; fb < NFB; ++fb) dxa[fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vh[st][fb], dxa[fb], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * NFB, 1);
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                if (s + 1 < S) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NFB, 1);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3 * NFB, 1);
             }
 #pragma unroll
             for (int fb = 0; fb < NFB; ++fb) {
@@ -401,7 +437,10 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
                     const bf16x2 p01 = __builtin_convertvector(f32x2{t[0], t[1]}, bf16x2);
                     const bf16x2 p23 = __builtin_convertvector(f32x2{t[2], t[3]}, bf16x2);
                     uint32_t w2[2] = {__builtin_bit_cast(uint32_t, p01), __builtin_bit_cast(uint32_t, p23)};
-                    *reinterpret_cast<uint2*>(dst_row0 + (16 * blk + r16) * LDT + wave * 16 + 4 * kq) = uint2{w2[0], w2[1]};
+                    // rows wave*16 + 4*kq .. +3 of channel ch: K step wave >> 1, 16-byte chunk 2*(wave & 1) + (kq >> 1)
+                    const int ch = 16 * blk + r16;
+                    const int c16 = (2 * (wave & 1) + (kq >> 1)) ^ ((ch >> 2) & 3);
+                    *reinterpret_cast<uint2*>(dst_row0 + ch * LDT + 32 * (wave >> 1) + 8 * c16 + 4 * (kq & 1)) = uint2{w2[0], w2[1]};
                 }
             };
             put_t(xh, xT_h);
@@ -419,19 +458,35 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_bwd2(const GmlBwdParams p
                 __syncthreads();
                 if (wave < C::SE * NFB * 2) {
                     const int ob = wave & 1, fb = (wave >> 1) % NFB, se = (wave >> 1) / NFB;
-                    f32x4 d = dwacc[sl];
+                    // two independent accumulator chains (hi.lo + lo.hi, hi.hi) and the next K step's fragments in
+                    // flight: the single chain of 12 dependent MFMAs behind 16 serial reads was latency, not work
+                    f32x4 d = dwacc[sl], d2 = f32x4{0.f, 0.f, 0.f, 0.f};
+                    bf16x8 fa[2][2], fbv[2][2];                // [stage][hi, lo]
+                    auto fragw = [&](int st, int sg) {
+                        const int kx = kq ^ (((fb * 16 + r16) >> 2) & 3), kp = kq ^ (((ob * 16 + r16) >> 2) & 3);
+                        const int xo = (fb * 16 + r16) * LDT + 32 * st + 8 * kx;                 // A[i = f][k = row]
+                        const int po = (se * 32 + ob * 16 + r16) * LDT + 32 * st + 8 * kp;       // B[k = row][j = o]
+                        fa[sg][0] = *reinterpret_cast<const bf16x8*>(xT_h + xo);
+                        fa[sg][1] = *reinterpret_cast<const bf16x8*>(xT_l + xo);
+                        fbv[sg][0] = *reinterpret_cast<const bf16x8*>(pT_h + po);
+                        fbv[sg][1] = *reinterpret_cast<const bf16x8*>(pT_l + po);
+                    };
+                    fragw(0, 0);
 #pragma unroll
                     for (int st = 0; st < ROWS / 32; ++st) {
-                        const int xo = (fb * 16 + r16) * LDT + 32 * st + 8 * kq;                 // A[i = f][k = row]
-                        const int po = (se * 32 + ob * 16 + r16) * LDT + 32 * st + 8 * kq;       // B[k = row][j = o]
-                        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(xT_h + xo);
-                        const bf16x8 al = *reinterpret_cast<const bf16x8*>(xT_l + xo);
-                        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(pT_h + po);
-                        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(pT_l + po);
-                        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, d, 0, 0, 0);
-                        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, d, 0, 0, 0);
-                        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, d, 0, 0, 0);
+                        const int sg = st & 1;
+                        if (st + 1 < ROWS / 32) fragw(st + 1, sg ^ 1);
+                        d2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[sg][1], fbv[sg][0], d2, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[sg][0], fbv[sg][0], d, 0, 0, 0);
+                        d2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[sg][0], fbv[sg][1], d2, 0, 0, 0);
                     }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 2);
+#pragma unroll
+                    for (int st = 0; st < ROWS / 32; ++st) {
+                        if (st + 1 < ROWS / 32) __builtin_amdgcn_sched_group_barrier(0x100, 4, 2);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 3, 2);
+                    }
+                    d += d2;
                     dwacc[sl] = d;
                 }
             }
@@ -463,12 +518,8 @@ int gml_launch_bwd2(const GmlBwdParams& p, dim3 grid, size_t lds, hipStream_t st
     template <>                                                                                              \
     int gml_launch_bwd2<SV, NFBV>(const GmlBwdParams& p, dim3 grid, size_t lds, hipStream_t st) {            \
         static_assert(GmlBwd2Cfg<SV, NFBV>::OK, "S must be even");                                           \
-        static const hipError_t rc1 = hipFuncSetAttribute(                                                   \
-            reinterpret_cast<const void*>(&gml_k_spectconv_bwd2<SV, NFBV, true>),                            \
-            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                         \
-        static const hipError_t rc0 = hipFuncSetAttribute(                                                   \
-            reinterpret_cast<const void*>(&gml_k_spectconv_bwd2<SV, NFBV, false>),                           \
-            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                         \
+        GML_ALLOW_BIG_LDS(rc1, (&gml_k_spectconv_bwd2<SV, NFBV, true>), 160 * 1024) \
+        GML_ALLOW_BIG_LDS(rc0, (&gml_k_spectconv_bwd2<SV, NFBV, false>), 160 * 1024) \
         if (rc1 != hipSuccess) return (int)rc1;                                                              \
         if (rc0 != hipSuccess) return (int)rc0;                                                              \
         if (p.xvec) hipLaunchKernelGGL((gml_k_spectconv_bwd2<SV, NFBV, true>), grid, dim3(512), lds, st, p); \

@@ -406,9 +406,7 @@ int gml_launch_bwd(const GmlBwdParams& p, dim3 grid, size_t lds, hipStream_t st)
     template <>                                                                                              \
     int gml_launch_bwd<SV, NFBV, NOBV>(const GmlBwdParams& p, dim3 grid, size_t lds, hipStream_t st) {       \
         static_assert(GmlBwdCfg<SV, NFBV, NOBV>::OK, "no slab size for this shape");                         \
-        static const hipError_t attr_rc = hipFuncSetAttribute(                                               \
-            reinterpret_cast<const void*>(&gml_k_spectconv_bwd<SV, NFBV, NOBV>),                             \
-            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                         \
+        GML_ALLOW_BIG_LDS(attr_rc, (&gml_k_spectconv_bwd<SV, NFBV, NOBV>), 160 * 1024) \
         if (attr_rc != hipSuccess) return (int)attr_rc;                                                      \
         hipLaunchKernelGGL((gml_k_spectconv_bwd<SV, NFBV, NOBV>), grid, dim3(256), lds, st, p);              \
         return gml_launch_status();                                                                          \

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p
     constexpr int LDX = C::LDX, ROWS = GML_FWD2_ROWS;
     constexpr int VAL_ALIGN = (S % 4 == 0) ? 4 : ((S % 2 == 0) ? 2 : 1);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    __bf16* Wof_h = reinterpret_cast<__bf16*>(lds_raw);       // [s][o][f], 16-byte chunks XOR-swizzled by (o >> 3) & 3
+    __bf16* Wof_h = reinterpret_cast<__bf16*>(lds_raw);       // [s][o][f], 16-byte chunks XOR-swizzled by gml_wkey(o)
     __bf16* Wof_l = Wof_h + C::W_HALF;
     int* rp_l = reinterpret_cast<int*>(lds_raw + C::W_BYTES);
     int* col_l = rp_l + 136;
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p
         const float v = (f < p.Fin && o < p.Fout) ? p.w[(int64_t)(p.s0 + s) * p.w_ss + (int64_t)f * p.w_si + (int64_t)o * p.w_so] : 0.f;
         const __bf16 h = (__bf16)v;
         const __bf16 l = (__bf16)(v - (float)h);
-        const int iof = (s * 32 + o) * 32 + ((((f >> 3) ^ (o >> 3)) & 3) << 3) + (f & 7);
+        const int iof = (s * 32 + o) * 32 + ((((f >> 3) ^ gml_wkey(o)) & 3) << 3) + (f & 7);
         Wof_h[iof] = h;
         Wof_l[iof] = l;
     }
@@ -329,20 +329,39 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p
                     oacc[ob][reg] = p.out[(r0 + lr) * p.ldo + min(ob * 16 + r16, p.Fout - 1)];
                 }
         }
+        {
+            // W fragments of support s + 1 are requested before the MFMAs of support s (the projection as first written --
+            // read, wait, dependent MFMA triple, per block -- exposed one LDS round trip per block)
+            bf16x8 wh[2][NOBA], wl[2][NOBA];
+            auto frag = [&](int s, int st) {
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
-            const float av[8] = {acc[s][0].x, acc[s][0].y, acc[s][1].x, acc[s][1].y, acc[s][2].x, acc[s][2].y, acc[s][3].x, acc[s][3].y};
-            bf16x8 ah, al;
-            gml_split8(av, ah, al);
+                for (int ob = 0; ob < NOB; ++ob) {
+                    const int o = ob * 16 + r16;               // B[k = f][n = o]: 8 consecutive f of column o
+                    const int off = (s * 32 + o) * 32 + (((kq ^ gml_wkey(o)) & 3) << 3);
+                    wh[st][ob] = *reinterpret_cast<const bf16x8*>(Wof_h + off);
+                    wl[st][ob] = *reinterpret_cast<const bf16x8*>(Wof_l + off);
+                }
+            };
+            frag(0, 0);
 #pragma unroll
-            for (int ob = 0; ob < NOB; ++ob) {
-                const int o = ob * 16 + r16;                   // B[k = f][n = o]: 8 consecutive f of column o
-                const int off = (s * 32 + o) * 32 + (((kq ^ (o >> 3)) & 3) << 3);
-                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(Wof_h + off);
-                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Wof_l + off);
-                oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, oacc[ob], 0, 0, 0);
-                oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, oacc[ob], 0, 0, 0);
-                oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, oacc[ob], 0, 0, 0);
+            for (int s = 0; s < S; ++s) {
+                const int st = s & 1;
+                if (s + 1 < S) frag(s + 1, st ^ 1);
+                const float av[8] = {acc[s][0].x, acc[s][0].y, acc[s][1].x, acc[s][1].y, acc[s][2].x, acc[s][2].y, acc[s][3].x, acc[s][3].y};
+                bf16x8 ah, al;
+                gml_split8(av, ah, al);
+#pragma unroll
+                for (int ob = 0; ob < NOB; ++ob) oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wh[st][ob], oacc[ob], 0, 0, 0);
+#pragma unroll
+                for (int ob = 0; ob < NOB; ++ob) oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wl[st][ob], oacc[ob], 0, 0, 0);
+#pragma unroll
+                for (int ob = 0; ob < NOB; ++ob) oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wh[st][ob], oacc[ob], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * NOB, 0);
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                if (s + 1 < S) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NOB, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3 * NOB, 0);
             }
         }
         // output stores through a buffer descriptor based at this group's first row: lanes outside (row >= nr,
@@ -395,9 +414,7 @@ int gml_launch_fwd2(const GmlFwdParams& p, dim3 grid, hipStream_t st, bool xvec,
 
 #define GML_FWD2_LAUNCH(SV, NOBV, XV, MX)                                                                    \
     {                                                                                                        \
-        static const hipError_t rc_ = hipFuncSetAttribute(                                                   \
-            reinterpret_cast<const void*>(&gml_k_spectconv_fwd2<SV, NOBV, XV, MX>),                          \
-            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                         \
+        GML_ALLOW_BIG_LDS(rc_, (&gml_k_spectconv_fwd2<SV, NOBV, XV, MX>), 160 * 1024) \
         if (rc_ != hipSuccess) return (int)rc_;                                                              \
         hipLaunchKernelGGL((gml_k_spectconv_fwd2<SV, NOBV, XV, MX>), grid, dim3(512),                        \
                            GmlFwd2Cfg<SV>::lds_bytes(), st, p);                                              \

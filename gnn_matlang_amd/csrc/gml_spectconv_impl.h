@@ -473,9 +473,7 @@ int gml_launch_fwd_family(const GmlFwdParams& p, int NB, bool xvec, bool bf, dim
 
 #define GML_FWD_GO(NBV, XV, BFV)                                                                      \
     {                                                                                                 \
-        static const hipError_t attr_rc = hipFuncSetAttribute(                                        \
-            reinterpret_cast<const void*>(&gml_k_spectconv_fwd<SC, FPL, NBV, XV, BFV>),               \
-            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                  \
+        GML_ALLOW_BIG_LDS(attr_rc, (&gml_k_spectconv_fwd<SC, FPL, NBV, XV, BFV>), 160 * 1024) \
         if (attr_rc != hipSuccess) return (int)attr_rc;                                               \
         hipLaunchKernelGGL((gml_k_spectconv_fwd<SC, FPL, NBV, XV, BFV>), grid, dim3(256), lds, st, p); \
         return gml_launch_status();                                                                   \

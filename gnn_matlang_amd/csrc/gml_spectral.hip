@@ -301,8 +301,7 @@ extern "C" int gml_spectral_design(const int32_t* node_ptr, const int32_t* edge_
     p.recfield = recfield; p.nfreq = nfreq; p.addadj = addadj; p.laplacien = laplacien; p.has_vmax = has_vmax;
     p.dv = dv; p.vmax = vmax; p.out_ptr = out_ptr; p.edge_index2 = edge_index2; p.edge_attr2 = edge_attr2;
     p.lmax = lmax; p.m_total = m_total;
-    static const hipError_t arc = hipFuncSetAttribute(reinterpret_cast<const void*>(&gml_k_spectral_design),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    GML_ALLOW_BIG_LDS(arc, (&gml_k_spectral_design), 156 * 1024)
     if (arc != hipSuccess) return (int)arc;
     hipLaunchKernelGGL(gml_k_spectral_design, dim3((unsigned)num_graphs), dim3(SPD_THREADS),
                        spd_lds_bytes(max_nodes, nfreq, true), (hipStream_t)stream, p);
