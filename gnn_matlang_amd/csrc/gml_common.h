@@ -15,7 +15,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // group record of gml_csr_group_info: {first edge, #edges, first column, window width}; 128-row groups (bf16x3 backward)
 // append one byte per lane position = the row of the group handled by that position (rows sorted by degree so a
 // 16-row tile has near-equal trip counts)
-#define GML_GREC_INTS(group_rows) ((group_rows) == 128 ? 4 + 128 / 4 : 4)
+#define GML_GREC_INTS(group_rows) ((group_rows) == 128 ? 4 + 128 / 4 : ((group_rows) == GML_GROUPS64_RANKED ? 4 + 64 / 4 : 4))
 #define GML_NUM_CU 256
 #define GML_NUM_XCD 8
 

@@ -184,7 +184,8 @@ extern "C" int gml_csr_link_transpose(const int32_t* perm_fwd, const int32_t* pe
 //   Which row a lane serves does not change any row's result (each row keeps its own edge order).
 __global__ __launch_bounds__(128) void gml_k_group_info(const int32_t* __restrict__ rowptr,
                                                        const int32_t* __restrict__ col, int64_t nrows,
-                                                       int32_t group_rows, int32_t* __restrict__ ginfo) {
+                                                       int32_t group_kind, int32_t* __restrict__ ginfo) {
+    const int group_rows = group_kind == GML_GROUPS64_RANKED ? 64 : group_kind;
     __shared__ int deg[128];
     __shared__ int red[4];
     __shared__ unsigned char row_of_rank[128];
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(128) void gml_k_group_info(const int32_t* __restric
     if ((t & 63) == 0) { red[2 * (t >> 6)] = mn; red[2 * (t >> 6) + 1] = mx; }
     if (t < group_rows) deg[t] = (r0 + t < nrows) ? rowptr[r0 + t + 1] - rowptr[r0 + t] : -1;   // rows past the end rank last
     __syncthreads();
-    int32_t* rec = ginfo + g * GML_GREC_INTS(group_rows);
+    int32_t* rec = ginfo + g * GML_GREC_INTS(group_kind);
     if (t == 0) {
         mn = min(red[0], red[2]);
         mx = max(red[1], red[3]);
@@ -228,20 +229,23 @@ __global__ __launch_bounds__(128) void gml_k_group_info(const int32_t* __restric
             const int a = ((wave & 3) + (int)g) & 3;
             const int blk = (wave < 4) ? a : 7 - a;
             reinterpret_cast<unsigned char*>(rec + 4)[t] = row_of_rank[blk * 16 + i];
+        } else if (group_kind == GML_GROUPS64_RANKED) {      // 4 waves, one per SIMD: rank blocks rotate with the group
+            reinterpret_cast<unsigned char*>(rec + 4)[t] = row_of_rank[(((wave + (int)g) & 3)) * 16 + i];
         }
     }
 }
 
 extern "C" int32_t gml_csr_group_record_ints(int32_t group_rows) {
-    return (group_rows == 64 || group_rows == 128) ? GML_GREC_INTS(group_rows) : 0;
+    return (group_rows == 64 || group_rows == 128 || group_rows == GML_GROUPS64_RANKED) ? GML_GREC_INTS(group_rows) : 0;
 }
 
 extern "C" int gml_csr_group_info(const int32_t* rowptr, const int32_t* col, int64_t num_rows, int32_t group_rows,
                                   int32_t* ginfo, gml_stream_t stream) {
-    if (num_rows < 0 || (group_rows != 64 && group_rows != 128)) return GML_E_BADARG;
+    if (num_rows < 0 || (group_rows != 64 && group_rows != 128 && group_rows != GML_GROUPS64_RANKED)) return GML_E_BADARG;
+    const int rows = group_rows == GML_GROUPS64_RANKED ? 64 : group_rows;
     if (num_rows == 0) return GML_OK;
     if (!rowptr || !ginfo) return GML_E_BADARG;
-    hipLaunchKernelGGL(gml_k_group_info, dim3((unsigned)gml_cdiv(num_rows, group_rows)), dim3(128), 0,
+    hipLaunchKernelGGL(gml_k_group_info, dim3((unsigned)gml_cdiv(num_rows, rows)), dim3(128), 0,
                        (hipStream_t)stream, rowptr, col, num_rows, group_rows, ginfo);
     return gml_launch_status();
 }

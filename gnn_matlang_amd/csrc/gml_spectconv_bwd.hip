@@ -1,5 +1,7 @@
 // C-ABI dispatch of the fused backward kernel + the deterministic partial fold.
 #include "gml_spectconv_bwd2_impl.h"
+#include "gml_spectconv_bwd3_impl.h"
+#include <stdlib.h>
 
 __global__ __launch_bounds__(256) void gml_k_reduce_rows(const float* __restrict__ partial, int64_t nparts, int64_t n,
                                                         float* __restrict__ out) {
@@ -32,10 +34,21 @@ static unsigned long long* bwd2_prof_buf();
 GML_DECL_BWD2(8, 2) GML_DECL_BWD2(8, 1) GML_DECL_BWD2(6, 2) GML_DECL_BWD2(6, 1)
 GML_DECL_BWD2(4, 2) GML_DECL_BWD2(4, 1) GML_DECL_BWD2(2, 2) GML_DECL_BWD2(2, 1)
 
+#define GML_DECL_BWD3(S, A, W) template <> int gml_launch_bwd3<S, A, W>(const GmlBwdParams&, dim3, size_t, hipStream_t);
+GML_DECL_BWD3(8, 2, 8) GML_DECL_BWD3(8, 1, 8) GML_DECL_BWD3(6, 2, 8) GML_DECL_BWD3(6, 1, 8)
+GML_DECL_BWD3(4, 2, 8) GML_DECL_BWD3(4, 1, 8) GML_DECL_BWD3(2, 2, 8) GML_DECL_BWD3(2, 1, 8)
+GML_DECL_BWD3(8, 2, 4) GML_DECL_BWD3(8, 1, 4)
+
 struct BwdPlan {
-    int ok, S, nfb, nob, grid, groups_per_wg, ecap, xcap, rows;   /* rows: 64 (f32 MFMA kernel) or 128 (bf16x3 kernel) */
+    int ok, S, nfb, nob, grid, groups_per_wg, ecap, xcap, rows;   /* rows: 64 (f32 MFMA kernel) or 128 / 64 (bf16x3 kernels) */
+    int layout, nw;                                                /* bf16x3: layout 2 (bwd2) or 3 (bwd3), waves per workgroup */
     size_t lds;
 };
+
+/* bf16x3 kernel selection (experiments: GML_BWD_LAYOUT = 2 | 3, GML_BWD_NW = 4 | 8), read once */
+static int bwd_layout_env() { static const int v = [] { const char* e = getenv("GML_BWD_LAYOUT"); return e ? atoi(e) : 3; }(); return v; }
+static int bwd_nw_env() { static const int v = [] { const char* e = getenv("GML_BWD_NW"); return e ? atoi(e) : 8; }(); return v; }
+static int bwd3_nw(int S) { return (bwd_nw_env() == 4 && S == 8) ? 4 : 8; }
 
 #define GML_BWD_TRY(SV, A, B)                                                              \
     if (S == SV && nfb == A && nob == B) {                                                 \
@@ -50,15 +63,32 @@ static bool bwd2_shape(int S, int Fin, int Fout, uint32_t flags) {
 
 static BwdPlan plan_bwd(int64_t num_rows, int S, int Fin, int Fout, int max_edges, int max_window, uint32_t flags) {
     BwdPlan pl;
-    pl.ok = 0; pl.S = S; pl.rows = 64;
+    pl.ok = 0; pl.S = S; pl.rows = 64; pl.layout = 0; pl.nw = 4;
     const int nfb = (Fin + 15) / 16, nob = (Fout + 15) / 16;
     pl.nfb = nfb; pl.nob = nob;
     pl.ecap = (max_edges + 15) / 16 * 16;
     if (pl.ecap < 64) pl.ecap = 64;
     pl.xcap = (max_window + 15) / 16 * 16;
     if (pl.xcap < 64) pl.xcap = 64;
-    if (bwd2_shape(S, Fin, Fout, flags)) {                 /* bf16x3 kernel: 128-row groups, one 8-wave workgroup per CU */
-        pl.rows = 128;
+    if (bwd2_shape(S, Fin, Fout, flags) && bwd_layout_env() != 2) {   /* bf16x3 kernel, third layout */
+        pl.layout = 3; pl.nw = bwd3_nw(S); pl.rows = 16 * pl.nw;
+        pl.nfb = (Fin + 15) / 16;
+        const int ng = (int)gml_cdiv(num_rows, pl.rows);
+        const int wgs = GML_NUM_CU * (pl.nw == 4 ? 2 : 1);
+        int grid3 = ng < wgs ? ng : wgs;
+        if (grid3 < 1) grid3 = 1;
+        pl.groups_per_wg = (int)gml_cdiv(ng, grid3);
+        pl.grid = pl.groups_per_wg > 0 ? (int)gml_cdiv(ng, pl.groups_per_wg) : 1;
+#define GML_BWD3_LDS(SV, A, W) if (S == SV && pl.nfb == A && pl.nw == W) pl.lds = GmlBwd3Cfg<SV, A, W>::lds_bytes(pl.ecap, pl.xcap);
+        pl.lds = 0;
+        GML_BWD3_LDS(8, 2, 8) GML_BWD3_LDS(8, 1, 8) GML_BWD3_LDS(6, 2, 8) GML_BWD3_LDS(6, 1, 8)
+        GML_BWD3_LDS(4, 2, 8) GML_BWD3_LDS(4, 1, 8) GML_BWD3_LDS(2, 2, 8) GML_BWD3_LDS(2, 1, 8)
+        GML_BWD3_LDS(8, 2, 4) GML_BWD3_LDS(8, 1, 4)
+        /* (a group too large for the LDS: not ok -- the caller then asks for the f32-MFMA kernel with ITS group records) */
+        pl.ok = pl.lds > 0 && pl.lds <= (pl.nw == 4 ? 80 : 160) * 1024;
+        return pl;
+    } else if (bwd2_shape(S, Fin, Fout, flags)) {          /* bf16x3 kernel: 128-row groups, one 8-wave workgroup per CU */
+        pl.rows = 128; pl.layout = 2; pl.nw = 8;
         pl.nfb = (Fin + 15) / 16;
         if (pl.ecap < 512) pl.ecap = 512;                  /* the value rows' region later holds the P^T slab */
         const int ng = (int)gml_cdiv(num_rows, 128);
@@ -89,7 +119,7 @@ static BwdPlan plan_bwd(int64_t num_rows, int S, int Fin, int Fout, int max_edge
 
 extern "C" int gml_spectconv_bwd_group_rows(int32_t S, int32_t Fin, int32_t Fout, uint32_t flags) {
     if (S <= 0 || Fin <= 0 || Fout <= 0) return 0;
-    if (bwd2_shape(S, Fin, Fout, flags)) return 128;
+    if (bwd2_shape(S, Fin, Fout, flags)) return (bwd_layout_env() != 2 && bwd3_nw(S) == 4) ? GML_GROUPS64_RANKED : 128;
     const BwdPlan pl = plan_bwd(64, S, Fin, Fout, 64, 64, flags | GML_F32_MFMA);
     return pl.ok ? 64 : 0;
 }
@@ -130,14 +160,20 @@ extern "C" int gml_spectconv_bwd(const int32_t* rowptr, const int32_t* col, cons
     p.prof = bwd2_prof_buf();
 #endif
     p.xvec = (Fin % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)x & 15) == 0);
+    p.dxvec = dx && (Fin % 4 == 0) && (lddx % 4 == 0) && (((uintptr_t)dx & 15) == 0);
     /* float4 groups up to roundup4(Fout) must exist in every row: true when ldg covers them (zero padded) */
     p.gvec = (ldg % 4 == 0) && ((Fout + 3) / 4 * 4 <= ldg) && (((uintptr_t)g & 15) == 0);
     /* the 8-wave kernel prefetches the g window with float4 loads whether or not it will use them */
-    if (pl.rows == 128 && !p.gvec) return GML_E_BADARG;
+    if (pl.layout >= 2 && !p.gvec) return GML_E_BADARG;
     p.ngroups = (int)gml_cdiv(num_rows, pl.rows); p.groups_per_wg = pl.groups_per_wg; p.ecap = pl.ecap; p.xcap = pl.xcap;
     const int nfb = pl.nfb, nob = pl.nob;
     int rc = GML_E_UNSUPPORTED;
-    if (pl.rows == 128) {
+    if (pl.layout == 3) {
+#define GML_BWD3_GO(SV, A, W) if (S == SV && nfb == A && pl.nw == W) rc = gml_launch_bwd3<SV, A, W>(p, dim3(pl.grid), pl.lds, st);
+        GML_BWD3_GO(8, 2, 8) GML_BWD3_GO(8, 1, 8) GML_BWD3_GO(6, 2, 8) GML_BWD3_GO(6, 1, 8)
+        GML_BWD3_GO(4, 2, 8) GML_BWD3_GO(4, 1, 8) GML_BWD3_GO(2, 2, 8) GML_BWD3_GO(2, 1, 8)
+        GML_BWD3_GO(8, 2, 4) GML_BWD3_GO(8, 1, 4)
+    } else if (pl.layout == 2) {
 #define GML_BWD2_GO(SV, A) if (S == SV && nfb == A) rc = gml_launch_bwd2<SV, A>(p, dim3(pl.grid), pl.lds, st);
         GML_BWD2_GO(8, 2) GML_BWD2_GO(8, 1) GML_BWD2_GO(6, 2) GML_BWD2_GO(6, 1)
         GML_BWD2_GO(4, 2) GML_BWD2_GO(4, 1) GML_BWD2_GO(2, 2) GML_BWD2_GO(2, 1)

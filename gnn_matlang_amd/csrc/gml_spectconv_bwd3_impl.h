@@ -1,0 +1,554 @@
+// Fused backward, bf16x3, third layout (default for S in {2,4,6,8}, Fin <= 32, 16 < Fout <= 32): same outputs as
+// gml_k_spectconv_bwd / gml_k_spectconv_bwd2
+//
+//   dX = sum_s A_s (G W_s^T),   dval[e,s] = < X[src] W_s, G[dst] >,   dW_s = X^T (A_s G)
+//
+// What changed against bwd2 (profiles/r02a_*: VALU 43 %, LDS 52 % busy -- half of it bank conflicts --, matrix pipe 20 %,
+// waves parked 39 % of their cycles):
+//   * ONE bf16 (hi, lo) image of W in LDS, [s][o][f], serves both projections: Z^T = W^T X^T reads its A fragments with
+//     ds_read_b128 (f contiguous), dX^T = W P^T reads the transposed fragments with ds_read_b64_tr_b16 (the hardware
+//     transposes 4 x 16 blocks) -- 32 KB instead of 64;
+//   * dX is computed transposed (D[i = f][j = row]): a lane ends up with 4 consecutive features of ITS OWN row, so the old
+//     dx values and the results move as one 16-byte access per 16-wide feature block instead of 8 dword accesses to 4 rows;
+//   * the row contraction of dW takes its operands from row-major bf16 images of X and P ([position][32 channels], written
+//     with one ds_write_b128 per lane and image) through ds_read_b64_tr_b16: the 36 matrix-core transposes, their 72
+//     conversions and 8-byte stores per tile are gone, four supports per slab (two barriers per slab, S/4 slabs);
+//   * NW = 8 waves / 128-row groups (one workgroup per CU) or NW = 4 waves / 64-row groups (78 KB of LDS: two
+//     independent workgroups per CU, whose matrix / LDS phases overlap each other's VALU edge phases).
+// All XOR keys of the LDS images are chosen with tools/lds_sim.py (conflict-free for every access kind that touches them).
+#pragma once
+#include "gml_common.h"
+#include "gml_spectconv_bwd_impl.h"
+
+typedef short gml_s16x4 __attribute__((ext_vector_type(4)));
+typedef short gml_s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) gml_s16x4 gml_lds_s16x4;
+
+// one MFMA operand (8 k-slots) from two transposing reads: lane (t, g) of a 16-lane group receives, for j = 0..3, element
+// (t & 3) of the 8-byte chunk whose address lane 4 j + (t >> 2) of the same group passed (probed: tools/probes/probe_tr.hip)
+__device__ __forceinline__ bf16x8 gml_tr_frag(const unsigned char* p0, const unsigned char* p1) {
+    const gml_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((gml_lds_s16x4*)(p0));
+    const gml_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((gml_lds_s16x4*)(p1));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+// XOR key (16-byte chunks of a 64-byte row) of the W image [s][o][f]: b128 fragment reads of the natural and of the Z
+// projection's permuted rows and the transposing reads of dX are all conflict-free with it
+__host__ __device__ __forceinline__ int gml_wkey3(int o) { return ((o >> 3) & 1) << 1; }
+// XOR key of the row-major X / P images [position][32 channels]: conflict-free ds_write_b128 (lane = (position, chunk))
+// and conflict-free transposing reads of 8 consecutive positions per lane group
+__host__ __device__ __forceinline__ int gml_tkey3(int pos) { return ((pos >> 2) & 1) | ((((pos >> 1) ^ (pos >> 2) ^ (pos >> 3)) & 1) << 1); }
+
+template <int S, int NFB, int NW>
+struct GmlBwd3Cfg {
+    static constexpr int ROWS = 16 * NW, NT = 64 * NW;
+    static constexpr int ECAP_MAX = 8 * ROWS;               // register-batched staging bounds (per group)
+    static constexpr int XCAP_MAX = NW == 8 ? 224 : 160;
+    static constexpr int LDG = 36;                           // G window rows (floats, b128 aligned)
+    static constexpr int W_HALF = S * 32 * 32;               // bf16 elements of one (hi or lo) W image
+    static constexpr int W_BYTES = 2 * W_HALF * 2;
+    static constexpr int SS = (S % 4 == 0) ? 4 : ((S % 3 == 0) ? 3 : S);   // supports per dW slab
+    static constexpr int NSLAB = S / SS;
+    static constexpr int NBLK = SS * NFB * 2;                // 16 x 16 output blocks of a slab: (se, fb, ob)
+    static constexpr int BPW = (NBLK + NW - 1) / NW;         // blocks per wave
+    static constexpr int XT_BYTES = 2 * ROWS * 64;           // X hi, lo   [position][32 f]
+    static constexpr int PT_BYTES = 2 * SS * ROWS * 64;      // P hi, lo   [se][position][32 o]
+    static constexpr int GREC = 4 + ROWS / 4;                // ints per group record (ranked)
+    static constexpr bool OK = (S % SS == 0) && (NFB == 1 || NFB == 2) && (NW == 4 || NW == 8);
+    __host__ __device__ static size_t stage_bytes(int ecap, int xcap) { return (size_t)ecap * S * 4 + (size_t)xcap * LDG * 4; }
+    __host__ __device__ static size_t r_bytes(int ecap, int xcap) {          // staged values + G window, later the P slab
+        const size_t a = stage_bytes(ecap, xcap);
+        return a > (size_t)PT_BYTES ? a : (size_t)PT_BYTES;
+    }
+    __host__ __device__ static size_t lds_bytes(int ecap, int xcap) {
+        return (size_t)W_BYTES + (ROWS + 8) * 4 + (size_t)ecap * 4 + r_bytes(ecap, xcap) + XT_BYTES;
+    }
+};
+
+// ablation builds (tools/build_variant.py abl -DGML_ABL=<bits>): results are WRONG, the timing says what a phase costs
+//   1 = every group loads the workgroup's first group (cache-hot loads), 2 = no dW phase, 4 = no edge loop,
+//   8 = no dval / dx stores, 16 = no Z projection, 32 = no dX projection
+#ifndef GML_ABL
+#define GML_ABL 0
+#endif
+
+// timing build: every wave sums its phase durations in scalar registers (s_memtime, no memory traffic inside the loop)
+// and adds them to p.prof once at the end -- the round-1 form (one global atomic per phase) shifted the waits it measured
+#ifdef GML_BWD2_TIMING
+#define GML_T3(i) do { const unsigned t_ = (unsigned)__builtin_readcyclecounter(); tacc_[i] += t_ - tprev_; tprev_ = t_; } while (0)
+#else
+#define GML_T3(i)
+#endif
+
+template <int S, int NFB, int NW, bool XV>
+__global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdParams p) {
+    using C = GmlBwd3Cfg<S, NFB, NW>;
+    constexpr int LDG = C::LDG, ROWS = C::ROWS, NT = C::NT, SS = C::SS, BPW = C::BPW;
+    constexpr int VAL_ALIGN = (S % 4 == 0) ? 4 : ((S % 2 == 0) ? 2 : 1);
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __bf16* W_h = reinterpret_cast<__bf16*>(lds_raw);        // [s][o][f], chunks XOR gml_wkey3(o)
+    __bf16* W_l = W_h + C::W_HALF;
+    int* rp_l = reinterpret_cast<int*>(lds_raw + C::W_BYTES);
+    int* col_l = rp_l + ROWS + 8;
+    unsigned char* rreg = reinterpret_cast<unsigned char*>(col_l + p.ecap);
+    float* ea_l = reinterpret_cast<float*>(rreg);
+    float* gs = ea_l + (size_t)p.ecap * S;
+    unsigned char* pT = rreg;                                // [hi, lo][se][position] 64-byte rows (after the dval rows left)
+    unsigned char* xT = rreg + C::r_bytes(p.ecap, p.xcap);   // [hi, lo][position]     64-byte rows (own region)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int wg = gml_xcd_remap(blockIdx.x, gridDim.x);
+    const int g0 = wg * p.groups_per_wg;
+    const int g1 = min(g0 + p.groups_per_wg, p.ngroups);
+
+    // W -> bf16 (hi, lo) image, zero padded to 32 x 32
+    for (int e = tid; e < S * 32 * 32; e += NT) {
+        const int f = e & 31, o = (e >> 5) & 31, s = e >> 10;
+        const float v = (f < p.Fin && o < p.Fout) ? p.w[((int64_t)s * p.Fin + f) * p.Fout + o] : 0.f;
+        const __bf16 h = (__bf16)v;
+        const __bf16 l = (__bf16)(v - (float)h);
+        const int i = (s * 32 + o) * 32 + ((((f >> 3) ^ gml_wkey3(o)) & 3) << 3) + (f & 7);
+        W_h[i] = h; W_l[i] = l;
+    }
+
+    f32x4 dwacc[C::NSLAB][BPW];
+#pragma unroll
+    for (int i = 0; i < C::NSLAB; ++i)
+#pragma unroll
+        for (int j = 0; j < BPW; ++j) dwacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#ifdef GML_BWD2_TIMING
+    unsigned tacc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned tprev_ = (unsigned)__builtin_readcyclecounter();
+#endif
+    // ---- staging registers: a group's global loads are issued one phase early (after the previous group's edge phase,
+    //      before its stores) and committed to LDS at the top of the group; all unconditional with clamped indices so that
+    //      the compiler can count them (see gml_spectconv_bwd2_impl.h)
+    constexpr int NC = C::ECAP_MAX / NT, NE4 = (S % 4 == 0) ? C::ECAP_MAX * (S / 4) / NT : 1;
+    constexpr int NG4 = (C::XCAP_MAX * 8 + NT - 1) / NT;
+    const int etot = p.rowptr[p.nrows];
+    const int* colb = etot > 0 ? p.col : p.ginfo;
+    const f32x4* valb = etot > 0 ? reinterpret_cast<const f32x4*>(p.val) : reinterpret_cast<const f32x4*>(p.ginfo);
+    const int emax = max(etot, 1) - 1;
+    const int64_t emax4 = (S % 4 == 0) ? max((int64_t)etot * (S / 4), (int64_t)1) - 1 : 0;
+    const int o4max = p.gvec ? ((p.Fout + 3) / 4 * 4 - 4) : 0;
+    int cv[NC], rpv = 0, row_n = 0;
+    f32x4 ev4[NE4], gv4[NG4];
+    float xb[8];
+    auto vec_group = [&](const int4 gi) {
+        return (S % 4 == 0) && p.gvec && gi.y <= C::ECAP_MAX && gi.w <= C::XCAP_MAX;
+    };
+    int4 gi_nv = int4{0, 0, 0, 0};
+    int4 gi_c = int4{0, 0, 0, 0};
+    auto latch = [&]() {
+        gi_c = int4{__builtin_amdgcn_readfirstlane(gi_nv.x), __builtin_amdgcn_readfirstlane(gi_nv.y),
+                    __builtin_amdgcn_readfirstlane(gi_nv.z), __builtin_amdgcn_readfirstlane(gi_nv.w)};
+    };
+    auto issue = [&](int g) {
+        const int64_t r0 = (int64_t)g * ROWS;
+        const int4 gi = gi_c;
+        const int kb = gi.x, ne = gi.y, lo = gi.z, nwin = gi.w;
+        if constexpr (XV) {
+            const float* xr = p.x + min(r0 + row_n, p.nrows - 1) * p.ldx;
+            const int f4max = (p.Fin + 3) / 4 * 4 - 4;
+#pragma unroll
+            for (int q4 = 0; q4 < 2; ++q4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(xr + min(8 * kq + 4 * q4, f4max));
+                xb[4 * q4] = t.x; xb[4 * q4 + 1] = t.y; xb[4 * q4 + 2] = t.z; xb[4 * q4 + 3] = t.w;
+            }
+        }
+        rpv = p.rowptr[min(r0 + tid, p.nrows)];
+        const int ne1 = max(ne, 1) - 1, ne41 = max(ne * (S / 4), 1) - 1, nw1 = max(nwin, 1) - 1;
+#pragma unroll
+        for (int t = 0; t < NC; ++t) cv[t] = colb[min(kb + min(tid + NT * t, ne1), emax)];
+#pragma unroll
+        for (int t = 0; t < NE4; ++t) ev4[t] = valb[min((int64_t)kb * (S / 4) + min(tid + NT * t, ne41), emax4)];
+#pragma unroll
+        for (int t = 0; t < NG4; ++t) {
+            const int i = tid + NT * t;
+            const int64_t rr = min((int64_t)lo + min(i >> 3, nw1), p.nrows - 1);
+            gv4[t] = *reinterpret_cast<const f32x4*>(p.g + rr * p.ldg + min((i & 7) * 4, o4max));
+        }
+    };
+    auto load_rows = [&](int g) {                            // ranked record: {kb, ne, lo, nwin}, then the row of every position
+        const int32_t* rec = p.ginfo + (int64_t)g * C::GREC;
+        gi_nv = *reinterpret_cast<const int4*>(rec);
+        row_n = reinterpret_cast<const unsigned char*>(rec + 4)[wave * 16 + r16];
+    };
+    if (g0 < g1) { load_rows(g0); latch(); issue(g0); }
+    for (int g = g0; g < g1; ++g) {
+        const int64_t r0 = (int64_t)g * ROWS;
+        const int nr = (int)min((int64_t)ROWS, p.nrows - r0);
+        const int4 gi = gi_c;
+        const int kb = gi.x, ne = gi.y, lo = gi.z, nwin = gi.w;
+        const int row = row_n;
+        load_rows((GML_ABL & 1) ? g0 : min(g + 1, g1 - 1));
+        __syncthreads();                                     // previous group is done with every LDS region
+        GML_T3(0);
+
+        // ---- stage: commit the registers loaded one phase ago
+        const bool rvalid = row < nr;
+        if constexpr (!XV) {
+            const float* xr = p.x + (r0 + row) * p.ldx + 8 * kq;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) xb[t] = (rvalid && 8 * kq + t < p.Fin) ? xr[t] : 0.f;
+        }
+        if (tid <= nr) rp_l[tid] = rpv;
+        if (vec_group(gi)) {
+#pragma unroll
+            for (int t = 0; t < NC; ++t) { const int i = tid + NT * t; if (i < ne) col_l[i] = cv[t] - lo; }
+#pragma unroll
+            for (int t = 0; t < NE4; ++t) {
+                const int i = tid + NT * t;
+                if (i < ne * (S / 4)) reinterpret_cast<f32x4*>(ea_l)[i] = ev4[t];
+            }
+#pragma unroll
+            for (int t = 0; t < NG4; ++t) {
+                const int i = tid + NT * t;
+                if (i < nwin * 8)
+                    *reinterpret_cast<f32x4*>(gs + (i >> 3) * LDG + (i & 7) * 4) = ((i & 7) * 4 < p.Fout) ? gv4[t] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        } else {
+            for (int i = tid; i < ne; i += NT) col_l[i] = p.col[kb + i] - lo;
+            for (int i = tid; i < ne * S; i += NT) ea_l[i] = p.val[(int64_t)kb * S + i];
+            for (int i = tid; i < nwin * 32; i += NT) {
+                const int rr = i >> 5, o = i & 31;
+                gs[rr * LDG + o] = (o < p.Fout) ? p.g[(int64_t)(lo + rr) * p.ldg + o] : 0.f;
+            }
+        }
+        __syncthreads();
+        GML_T3(1);
+        // old dx values (accumulate mode): the lane's own row, features 16 fb + 4 kq .. + 3 (D rows of dX^T)
+        f32x4 dxa[NFB];
+        const bool dxv = p.dx && p.dxvec;                    // dx rows float4-addressable (Fin % 4 == 0, aligned rows)
+        {
+            const float* dxb = p.dx ? p.dx : p.x;            // (no dx wanted: any readable rows, the values are dropped)
+            const int64_t ldb = p.dx ? p.lddx : p.ldx;
+            const float* dr = dxb + min(r0 + row, p.nrows - 1) * ldb;
+            if (dxv) {
+                const int f4max = (p.Fin + 3) / 4 * 4 - 4;
+#pragma unroll
+                for (int fb = 0; fb < NFB; ++fb) dxa[fb] = *reinterpret_cast<const f32x4*>(dr + min(16 * fb + 4 * kq, f4max));
+            } else {
+#pragma unroll
+                for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) dxa[fb][reg] = dr[min(16 * fb + 4 * kq + reg, p.Fin - 1)];
+            }
+        }
+
+        const int kbeg = rvalid ? rp_l[row] - kb : 0;
+        const int kend = rvalid ? rp_l[row + 1] - kb : 0;
+
+        bf16x8 xh, xl;                                       // own X row, features 8*kq .. 8*kq+7: B fragment of Z^T, row of the X image
+        if constexpr (XV) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (!(rvalid && 8 * kq + j < p.Fin)) xb[j] = 0.f;
+        }
+        gml_split8(xb, xh, xl);
+
+        // ---- Z^T = W^T X^T: MFMA row i of block ob carries o = 8*(i>>2) + 4*ob + (i&3), so lane kq receives its 8
+        //      consecutive outputs o = 8*kq + 4*ob + reg.  Fragments of support s + 1 are requested before the MFMAs of s.
+        f32x2 Z[S][4], P[S][4];
+        {
+            const int oa0 = 8 * (r16 >> 2) + (r16 & 3);
+            bf16x8 wh[2][2], wl[2][2];
+            auto frag = [&](int s, int st) {
+#pragma unroll
+                for (int ob = 0; ob < 2; ++ob) {
+                    const int oa = oa0 + 4 * ob;
+                    const int off = (s * 32 + oa) * 32 + (((kq ^ gml_wkey3(oa)) & 3) << 3);
+                    wh[st][ob] = *reinterpret_cast<const bf16x8*>(W_h + off);
+                    wl[st][ob] = *reinterpret_cast<const bf16x8*>(W_l + off);
+                }
+            };
+            if (!(GML_ABL & 16)) frag(0, 0);
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int st = s & 1;
+                if (GML_ABL & 16) {
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) { Z[s][h] = f32x2{xb[h], xb[h + 4]}; P[s][h] = f32x2{0.f, 0.f}; }
+                    continue;
+                }
+                if (s + 1 < S) frag(s + 1, st ^ 1);
+                f32x4 d0 = f32x4{0.f, 0.f, 0.f, 0.f}, d1 = f32x4{0.f, 0.f, 0.f, 0.f};
+                d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[st][0], xh, d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[st][1], xh, d1, 0, 0, 0);
+                d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[st][0], xl, d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[st][1], xl, d1, 0, 0, 0);
+                d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[st][0], xh, d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[st][1], xh, d1, 0, 0, 0);
+                Z[s][0] = f32x2{d0[0], d0[1]}; Z[s][1] = f32x2{d0[2], d0[3]};
+                Z[s][2] = f32x2{d1[0], d1[1]}; Z[s][3] = f32x2{d1[2], d1[3]};
+#pragma unroll
+                for (int h = 0; h < 4; ++h) P[s][h] = f32x2{0.f, 0.f};
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                if (s + 1 < S) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+            }
+        }
+
+        GML_T3(2);
+        // ---- edge phase (fp32 VALU, packed): P += val * G[dst],  d[s] = <Z[s], G[dst]>
+        // (tried and measured slower, r02: requesting edge k + 1's value row / G row and edge k + 2's column before the
+        //  arithmetic of edge k -- the rotation costs ~20 moves and two clamps per trip and pushes 16 registers into spills)
+        for (int k = kbeg; k < ((GML_ABL & 4) ? kbeg : kend); ++k) {
+            const int dstl = col_l[k];
+            float ev[S];
+            gml_load_row<S, VAL_ALIGN>(ea_l + k * S, ev);
+            f32x2 gv[4];
+            {
+                const f32x4 t0 = *reinterpret_cast<const f32x4*>(gs + dstl * LDG + 8 * kq);
+                const f32x4 t1 = *reinterpret_cast<const f32x4*>(gs + dstl * LDG + 8 * kq + 4);
+                gv[0] = f32x2{t0.x, t0.y}; gv[1] = f32x2{t0.z, t0.w};
+                gv[2] = f32x2{t1.x, t1.y}; gv[3] = f32x2{t1.z, t1.w};
+            }
+            float d[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                f32x2 a2 = f32x2{0.f, 0.f};
+                const f32x2 e2 = f32x2{ev[s], ev[s]};
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    P[s][h] = e2 * gv[h] + P[s][h];
+                    a2 = Z[s][h] * gv[h] + a2;
+                }
+                d[s] = a2.x + a2.y;
+            }
+#pragma unroll
+            for (int c = 0; c < (S + 3) / 4; ++c) {
+                const float v0 = d[4 * c], v1 = (4 * c + 1 < S) ? d[4 * c + 1] : 0.f;
+                const float v2 = (4 * c + 2 < S) ? d[4 * c + 2] : 0.f, v3 = (4 * c + 3 < S) ? d[4 * c + 3] : 0.f;
+                const auto a01 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v0), __float_as_uint(v1), false, false);
+                const auto a23 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v2), __float_as_uint(v3), false, false);
+                const float c01 = __uint_as_float(a01[0]) + __uint_as_float(a01[1]);
+                const float c23 = __uint_as_float(a23[0]) + __uint_as_float(a23[1]);
+                const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(c01), __float_as_uint(c23), false, false);
+                const float tot = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+                if (4 * c + kq < S) ea_l[k * S + 4 * c + kq] = tot;
+            }
+        }
+        GML_T3(3);
+        __syncthreads();                                     // dval rows complete; G window no longer needed
+        GML_T3(4);
+        // Lane-only address terms of the phases below are recomputed per group from an opaque copy of the thread id: left
+        // visible, they are hoisted out of the group loop, spilled, and every reload waits (vmcnt(0)) for the whole
+        // prefetch that was just issued -- measured as 16 % of the kernel in front of the dval stores.
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));
+        const int r16o = tid_o & 15, kqo = (tid_o >> 4) & 3, waveo = __builtin_amdgcn_readfirstlane(tid_o >> 6);
+        // P -> bf16 (hi, lo) once: B fragments of dX^T (k = o = 8*kq + j) and the rows of the P image.  Before the next
+        // group's loads are issued: P and its split are both live here, the prefetch registers are not yet.
+        bf16x8 PH[S], PL[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const float pv[8] = {P[s][0].x, P[s][0].y, P[s][1].x, P[s][1].y, P[s][2].x, P[s][2].y, P[s][3].x, P[s][3].y};
+            gml_split8(pv, PH[s], PL[s]);
+        }
+        GML_T3(10);
+        latch();
+        issue((GML_ABL & 1) ? g0 : min(g + 1, g1 - 1));
+        GML_T3(8);
+
+        if (p.dval && !(GML_ABL & 8)) {
+            if constexpr (S % 4 == 0) {
+                f32x4* dst = reinterpret_cast<f32x4*>(p.dval + (int64_t)kb * S);
+                for (int i = tid_o; i < ne * (S / 4); i += NT) dst[i] = reinterpret_cast<const f32x4*>(ea_l)[i];
+            } else {
+                for (int i = tid_o; i < ne * S; i += NT) p.dval[(int64_t)kb * S + i] = ea_l[i];
+            }
+        }
+
+        GML_T3(9);
+        // ---- dX^T = W P^T: A[i = f][k = o] = W_s[f][o] comes transposed out of the [s][o][f] image: lane (t, kq) passes the
+        //      address of row o = 8 kq + 4 h + (t >> 2), 8-byte chunk 4 fb + (t & 3), and receives W[8 kq + 4 h + j][16 fb + t]
+        if (p.dx && !(GML_ABL & 32)) {
+            if (!(p.flags & GML_ACCUM)) {
+#pragma unroll
+                for (int fb = 0; fb < NFB; ++fb) dxa[fb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            const int tj = r16o >> 2, tc = r16o & 3;
+            int aoff[2][NFB];                                // byte offsets inside one support's image
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int fb = 0; fb < NFB; ++fb) {
+                    const int o = 8 * kqo + 4 * h + tj, cidx = 4 * fb + tc;
+                    aoff[h][fb] = o * 64 + ((((cidx >> 1) ^ gml_wkey3(o)) & 3) << 4) + ((cidx & 1) << 3);
+                }
+            const unsigned char* Wh8 = reinterpret_cast<const unsigned char*>(W_h);
+            const unsigned char* Wl8 = reinterpret_cast<const unsigned char*>(W_l);
+            bf16x8 vh[2][NFB], vl[2][NFB];
+            auto fragx = [&](int s, int st) {
+#pragma unroll
+                for (int fb = 0; fb < NFB; ++fb) {
+                    vh[st][fb] = gml_tr_frag(Wh8 + s * 2048 + aoff[0][fb], Wh8 + s * 2048 + aoff[1][fb]);
+                    vl[st][fb] = gml_tr_frag(Wl8 + s * 2048 + aoff[0][fb], Wl8 + s * 2048 + aoff[1][fb]);
+                }
+            };
+            fragx(0, 0);
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int st = s & 1;
+                if (s + 1 < S) fragx(s + 1, st ^ 1);
+                const bf16x8 ph = PH[s], pl = PL[s];
+#pragma unroll
+                for (int fb = 0; fb < NFB; ++fb) dxa[fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl[st][fb], ph, dxa[fb], 0, 0, 0);
+#pragma unroll
+                for (int fb = 0; fb < NFB; ++fb) dxa[fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh[st][fb], pl, dxa[fb], 0, 0, 0);
+#pragma unroll
+                for (int fb = 0; fb < NFB; ++fb) dxa[fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh[st][fb], ph, dxa[fb], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 4 * NFB, 1);
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                if (s + 1 < S) __builtin_amdgcn_sched_group_barrier(0x100, 4 * NFB, 1);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3 * NFB, 1);
+            }
+            float* dr = p.dx + (r0 + row) * p.lddx + 4 * kqo;
+            if (GML_ABL & 8) {
+#pragma unroll
+                for (int fb = 0; fb < NFB; ++fb) asm volatile("" :: "v"(dxa[fb]));
+            } else if (dxv) {
+#pragma unroll
+                for (int fb = 0; fb < NFB; ++fb)
+                    if (rvalid && 16 * fb + 4 * kqo < p.Fin) *reinterpret_cast<f32x4*>(dr + 16 * fb) = dxa[fb];
+            } else {
+#pragma unroll
+                for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg)
+                        if (rvalid && 16 * fb + 4 * kqo + reg < p.Fin) dr[16 * fb + reg] = dxa[fb][reg];
+            }
+        }
+
+        GML_T3(5);
+        // ---- dW += X^T P over the rows of the group.  Row-major bf16 images [position = wave*16 + r16][32 channels]
+        //      (a lane's 8 channels = one 16-byte chunk, XOR gml_tkey3(position)); the contraction reads them transposed.
+        if (p.dw_partial && !(GML_ABL & 2)) {
+            const int pos = waveo * 16 + r16o;
+            const int woff = pos * 64 + (((kqo ^ gml_tkey3(pos)) & 3) << 4);
+            *reinterpret_cast<bf16x8*>(xT + woff) = xh;
+            *reinterpret_cast<bf16x8*>(xT + ROWS * 64 + woff) = xl;
+            // transposing-read offsets of K step 0: lane (t, kq): position 8 kq + 4 h + (t >> 2), chunk 4 blk + (t & 3)
+            const int tj = r16o >> 2, tc = r16o & 3;
+            int roff[2][2];                                  // [h][16-wide channel block]
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) {
+                    const int ps = 8 * kqo + 4 * h + tj, cidx = 4 * blk + tc;
+                    roff[h][blk] = ps * 64 + ((((cidx >> 1) ^ gml_tkey3(ps)) & 3) << 4) + ((cidx & 1) << 3);
+                }
+#pragma unroll
+            for (int sl = 0; sl < C::NSLAB; ++sl) {
+                __syncthreads();                             // slab region free: the dval copy-out (sl == 0) or the
+                                                             // previous slab's fragment reads are done in every wave
+#pragma unroll
+                for (int se = 0; se < SS; ++se) {
+                    const int s = sl * SS + se;
+                    *reinterpret_cast<bf16x8*>(pT + se * ROWS * 64 + woff) = PH[s];
+                    *reinterpret_cast<bf16x8*>(pT + (SS + se) * ROWS * 64 + woff) = PL[s];
+                }
+                __syncthreads();
+                GML_T3(11);
+                // wave's blocks b = wave + NW i: ob = b & 1, fb = (b >> 1) % NFB (the same for every i), se = (b >> 1) / NFB.
+                // The fragments of K step st + 1 are requested before the MFMAs of step st, and the blocks' accumulator
+                // chains are interleaved (one chain of dependent MFMAs behind its own reads is pure latency).
+                const int ob = wave & 1, fb = (wave >> 1) % NFB;
+                constexpr int NB_ = (C::NBLK >= NW) ? BPW : 1;     // (fewer blocks than waves: one block on the first waves)
+                if (wave < C::NBLK) {
+                    bf16x8 fah[2], fal[2], fbh[2][NB_], fbl[2][NB_];
+                    auto fragw = [&](int st, int sg) {
+                        const unsigned char* xa = xT + st * 2048;
+                        fah[sg] = gml_tr_frag(xa + roff[0][fb], xa + roff[1][fb]);
+                        fal[sg] = gml_tr_frag(xa + ROWS * 64 + roff[0][fb], xa + ROWS * 64 + roff[1][fb]);
+#pragma unroll
+                        for (int i = 0; i < NB_; ++i) {
+                            const int b = min(wave + NW * i, C::NBLK - 1);       // (a wave without an i-th block re-reads its last one)
+                            const int se = (b >> 1) / NFB;
+                            const unsigned char* pa = pT + se * ROWS * 64 + st * 2048;
+                            fbh[sg][i] = gml_tr_frag(pa + roff[0][ob], pa + roff[1][ob]);
+                            fbl[sg][i] = gml_tr_frag(pa + SS * ROWS * 64 + roff[0][ob], pa + SS * ROWS * 64 + roff[1][ob]);
+                        }
+                    };
+                    f32x4 d[NB_];
+#pragma unroll
+                    for (int i = 0; i < NB_; ++i) d[i] = dwacc[sl][i];
+                    fragw(0, 0);
+#pragma unroll
+                    for (int st = 0; st < ROWS / 32; ++st) {
+                        const int sg = st & 1;
+                        if (st + 1 < ROWS / 32) fragw(st + 1, sg ^ 1);
+#pragma unroll
+                        for (int i = 0; i < NB_; ++i) d[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fal[sg], fbh[sg][i], d[i], 0, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < NB_; ++i) d[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[sg], fbl[sg][i], d[i], 0, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < NB_; ++i) d[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[sg], fbh[sg][i], d[i], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4 + 4 * NB_, 2);
+#pragma unroll
+                    for (int st = 0; st < ROWS / 32; ++st) {
+                        if (st + 1 < ROWS / 32) __builtin_amdgcn_sched_group_barrier(0x100, 4 + 4 * NB_, 2);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 3 * NB_, 2);
+                    }
+#pragma unroll
+                    for (int i = 0; i < NB_; ++i)
+                        if (wave + NW * i < C::NBLK) dwacc[sl][i] = d[i];
+                }
+                GML_T3(7);
+            }
+        }
+    }
+
+    GML_T3(6);
+#ifdef GML_BWD2_TIMING
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) atomicAdd(&p.prof[i], (unsigned long long)tacc_[i]);
+    }
+#endif
+    // ---- one dW partial per workgroup: block b of slab sl: D[i = f][j = o], lane (o = r16, kq): f = 16 fb + 4 kq + reg
+    if (p.dw_partial && g0 < g1) {
+        float* out = p.dw_partial + (int64_t)wg * S * p.Fin * p.Fout;
+#pragma unroll
+        for (int sl = 0; sl < C::NSLAB; ++sl)
+#pragma unroll
+            for (int i = 0; i < BPW; ++i) {
+                const int b = wave + NW * i;
+                if (b < C::NBLK) {
+                    const int ob = b & 1, fb = (b >> 1) % NFB, s = sl * SS + (b >> 1) / NFB;
+                    const int o = ob * 16 + r16;
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int f = fb * 16 + 4 * kq + reg;
+                        if (f < p.Fin && o < p.Fout) out[((int64_t)s * p.Fin + f) * p.Fout + o] = dwacc[sl][i][reg];
+                    }
+                }
+            }
+    }
+}
+
+template <int S, int NFB, int NW>
+int gml_launch_bwd3(const GmlBwdParams& p, dim3 grid, size_t lds, hipStream_t st);
+
+#define GML_DEFINE_BWD3(SV, NFBV, NWV)                                                                       \
+    template <>                                                                                              \
+    int gml_launch_bwd3<SV, NFBV, NWV>(const GmlBwdParams& p, dim3 grid, size_t lds, hipStream_t st) {       \
+        static_assert(GmlBwd3Cfg<SV, NFBV, NWV>::OK, "unsupported shape");                                   \
+        GML_ALLOW_BIG_LDS(rc1, (&gml_k_spectconv_bwd3<SV, NFBV, NWV, true>), 160 * 1024)                     \
+        GML_ALLOW_BIG_LDS(rc0, (&gml_k_spectconv_bwd3<SV, NFBV, NWV, false>), 160 * 1024)                    \
+        if (rc1 != hipSuccess) return (int)rc1;                                                              \
+        if (rc0 != hipSuccess) return (int)rc0;                                                              \
+        if (p.xvec) hipLaunchKernelGGL((gml_k_spectconv_bwd3<SV, NFBV, NWV, true>), grid, dim3(64 * NWV), lds, st, p);  \
+        else hipLaunchKernelGGL((gml_k_spectconv_bwd3<SV, NFBV, NWV, false>), grid, dim3(64 * NWV), lds, st, p);        \
+        return gml_launch_status();                                                                          \
+    }

@@ -43,6 +43,7 @@ struct GmlBwdParams {
     int32_t ngroups, groups_per_wg;
     int32_t ecap, xcap;      // LDS capacities (edges per group, G-window rows), multiples of 4
     int32_t xvec, gvec;      // x / g rows may be read as aligned float4
+    int32_t dxvec;           // dx rows may be read / written as aligned float4 (bwd3)
 #ifdef GML_BWD2_TIMING
     unsigned long long* prof;    // debug build: per-phase cycle sums
 #endif

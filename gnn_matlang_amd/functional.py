@@ -104,6 +104,8 @@ def fwd_groups(csr, x, S, Fin, Fout):
     """(group records, extra flags) the forward kernel wants for this shape: the 8-wave kernel on 128-row records when
     the shape is compiled for it, else the 64-row kernel."""
     flags = _lib.GML_F32_MFMA if F32_MFMA else 0
+    if _os.environ.get('GML_FWD64'):                         # experiments: force the 4-wave / 64-row kernel family
+        return csr.ginfo, 0
     if int(_lib.lib().gml_spectconv_fwd_group_rows(int(S), int(Fin), int(Fout), flags)) == 128:
         return csr.ginfo128, _lib.GML_GROUPS128
     return csr.ginfo, 0
@@ -294,7 +296,12 @@ def _bwd_plan(csr, S, Fin, Fout):
         rows = int(L.gml_spectconv_bwd_group_rows(int(S), int(Fin), int(Fout), flags))
         if rows == 0:
             continue
-        ginfo, gmax = (csr.ginfo_t128, csr.gmax_t128) if rows == 128 else (csr.ginfo_t, csr.gmax_t)
+        if rows == 128:
+            ginfo, gmax = csr.ginfo_t128, csr.gmax_t128
+        elif rows == _lib.GML_GROUPS64_RANKED:
+            ginfo, gmax = csr.ranked64_t()
+        else:
+            ginfo, gmax = csr.ginfo_t, csr.gmax_t
         nbytes = int(L.gml_spectconv_bwd_workspace_bytes(csr.N, int(S), int(Fin), int(Fout), gmax[0], gmax[1], flags))
         if nbytes > 0:
             return flags, ginfo, gmax, nbytes

@@ -36,11 +36,13 @@ def _require_cuda(t, name):
 
 class GraphCSR(object):
     __slots__ = ('N', 'E', 'device', 'rowptr', 'col', 'perm', 'rowptr_t', 'col_t', 'pos_t', 'perm_t',
-                 'ginfo', 'ginfo_t', 'gmax', 'gmax_t', 'ginfo_t128', 'gmax_t128', 'ginfo128', 'tpos', '_val_cache', '_keep')
+                 'ginfo', 'ginfo_t', 'gmax', 'gmax_t', 'ginfo_t128', 'gmax_t128', 'ginfo128', 'tpos', '_val_cache', '_keep',
+                 '_r64t')
 
     def __init__(self):
         self._val_cache = OrderedDict()
         self._keep = None
+        self._r64t = None
 
     @staticmethod
     def from_edge_index(edge_index, num_nodes):
@@ -87,6 +89,19 @@ class GraphCSR(object):
                               g.ginfo_t[:, 3].max(), g.ginfo_t128[:, 1].max(), g.ginfo_t128[:, 3].max()]).tolist()
             g.gmax, g.gmax_t, g.gmax_t128 = (int(mx[0]), int(mx[1])), (int(mx[2]), int(mx[3])), (int(mx[4]), int(mx[5]))
         return g
+
+    def ranked64_t(self):
+        """(records, (max edges, max window)) of the source view in ranked 64-row groups: the staging schedule of the
+        4-wave backward kernel (two workgroups per CU); built on first use."""
+        if self._r64t is None:
+            with torch.cuda.device(self.device):
+                rec = int(_lib.lib().gml_csr_group_record_ints(_lib.GML_GROUPS64_RANKED))
+                gi = torch.zeros(max((self.N + 63) // 64, 1), rec, dtype=torch.int32, device=self.device)
+                _lib.call('gml_csr_group_info', _ptr(self.rowptr_t), _ptr(self.col_t), self.N, _lib.GML_GROUPS64_RANKED,
+                          _ptr(gi), _stream(self.device))
+                mx = torch.stack([gi[:, 1].max(), gi[:, 3].max()]).tolist()
+                self._r64t = (gi, (int(mx[0]), int(mx[1])))
+        return self._r64t
 
     # values [E, S] in input-edge order -> target-sorted order (cached: raw supports are per-batch data)
     def sort_values(self, edge_attr, cache=True):

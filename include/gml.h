@@ -76,8 +76,11 @@ int gml_csr_link_transpose(const int32_t* perm_fwd, const int32_t* perm_t, int64
  *   {first edge, #edges, smallest column id, column-window width},
  *   128-row groups: then 128 bytes, the local row each lane position of the backward kernel works on -- rows ranked
  *   by degree so that the 16 rows of a tile run near-equal edge loops, rank blocks dealt to the waves so the SIMDs
- *   stay balanced (which lane serves a row never changes the row's result).
+ *   stay balanced (which lane serves a row never changes the row's result);
+ *   group_rows = GML_GROUPS64_RANKED (1064): 64-row groups that carry the same rank bytes (64 of them) -- the staging
+ *   schedule of the 4-wave backward kernel that runs two workgroups per CU.
  * Callers size LDS with the maxima of ints 1 and 3 over the records.  gml_csr_group_record_ints = int32 per record. */
+#define GML_GROUPS64_RANKED 1064
 int32_t gml_csr_group_record_ints(int32_t group_rows);
 int gml_csr_group_info(const int32_t* rowptr, const int32_t* col, int64_t num_rows, int32_t group_rows,
                        int32_t* ginfo, gml_stream_t stream);
@@ -118,9 +121,10 @@ int gml_spectconv_fwd(const int32_t* rowptr, const int32_t* col, const int32_t* 
  * f32-input MFMA kernel (default: bf16x3 split on the bf16 matrix cores where the shape allows).
  * With 128-row groups (see below) g must be float4-addressable: 16-byte aligned, ldg % 4 == 0 and
  * ldg >= roundup4(Fout) with the padding columns zero (else GML_E_BADARG). */
-/* rows per staging group of the backward kernel this shape / flags selects: 128 (bf16x3 kernel), 64 (f32-MFMA
- * kernel) or 0 (no fused backward).  ginfo, max_group_edges and max_group_window passed to the two functions
- * below must be those of gml_csr_group_info(..., group_rows = this value). */
+/* group kind of the backward kernel this shape / flags selects: 128 (bf16x3 kernel, 8 waves), GML_GROUPS64_RANKED
+ * (bf16x3 kernel, 4 waves, two workgroups per CU), 64 (f32-MFMA kernel) or 0 (no fused backward).  ginfo,
+ * max_group_edges and max_group_window passed to the two functions below must be those of
+ * gml_csr_group_info(..., group_rows = this value). */
 int gml_spectconv_bwd_group_rows(int32_t S, int32_t Fin, int32_t Fout, uint32_t flags);
 size_t gml_spectconv_bwd_workspace_bytes(int64_t num_rows, int32_t S, int32_t Fin, int32_t Fout,
                                          int32_t max_group_edges, int32_t max_group_window, uint32_t flags);

@@ -20,9 +20,10 @@ for it in range(3):
     loss.backward()
     torch.cuda.synchronize()
     L.gml_debug_bwd2_prof(buf, 1)
-names = ['dW(prev)+barrier', 'commit staged regs', 'Z projection', 'edge phase', 'barrier', 'dX chain + dx stores', 'tail', '-',
-         'old dx + next loads issued', 'dval stores', 'P split', '-', '-', '-', '-', '-']
+names = ['top barrier (bwd2: + dW of the previous group)', 'commit staged regs + barrier', 'Z projection', 'edge phase', 'barrier', 'dX chain + dx stores', 'tail', 'dW contraction (bwd3)',
+         'next loads issued', 'dval stores', 'P split', 'dW images + slab barriers (bwd3)', '-', '-', '-', '-']
 tot = float(sum(buf))
 for n, v in zip(names, buf):
-    print('%-17s %12d  %5.1f%%' % (n, v, 100.0 * v / tot if tot else 0))
+    if v:
+        print('%-52s %12d  %5.1f%%' % (n, v, 100.0 * v / tot if tot else 0))
 print('cycles per launch per workgroup: %.0f' % (tot / 4 / 256))
