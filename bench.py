@@ -1,35 +1,79 @@
 #!/usr/bin/env python3
 """bench.py -- GNNML3 training-step throughput on ZINC-12k-shaped synthetic graphs (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--batch GRAPHS_PER_GPU]
+    python bench.py --gpus N --steps K --warmup W [--batch GRAPHS_PER_GPU | --global-batch GRAPHS]
 
 A step = forward + L1-sum loss + backward + (N>1: one flat SUM all-reduce of the gradients) + Adam,
 of the reference's ZINC GNNML3 (Zinc12k.py:310-371: 4 x ML3Layer 30+2, S = 8 supports, 25 input
 features, add-pool, fc 32 -> 1, lr 1e-3) over one batch of synthetic ZINC-like graphs per GPU (weak
-scaling: graphs per GPU fixed).  Inputs are resident in HBM before the timed region.  fp32.
-Rank 0 prints ONE JSON line; ``roofline`` is for the dominant kernel (the fused SpectConv backward; the
-fused forward is under ``roofline_other``), timed live with HIP events inside the timed region; ``cpu_baseline`` is the CPU oracle (a port of the
-reference algorithm, op for op) timed on this box's host cores on a bounded sample (N = 1 only).
+scaling: graphs per GPU fixed; --global-batch: strong scaling).  Inputs are resident in HBM before the
+timed region.  Storage and accumulation are fp32; the projections run as bf16 hi/lo splits on the matrix
+cores (``value_exact_fp32`` is the same step with exact fp32 products).
+
+With --gpus N > 1 and no WORLD_SIZE in the environment bench.py starts the N ranks itself
+(python -m torch.distributed.run ...) before touching the GPU and relays rank 0's line.
+
+Rank 0 prints ONE JSON line.  Besides the contract's fields:
+  roofline        the dominant kernel (fused SpectConv backward), timed live with HIP events on the launch stream
+  fresh_batch     the same step when every step receives a NEW batch: CSR, group records, bf16 pre-split and the
+                  source-order copy are rebuilt inside the timed region (the reference reshuffles every epoch)
+  epoch_bs64      one shuffled epoch over 10,000 distinct graphs at the reference's batch size 64, batches assembled
+                  on the device (gnn_matlang_amd.dataset), index build included, end to end
+  ref_batch       one batch-64 step replayed from a HIP graph (launch-latency floor of that batch size)
+  cpu_baseline    the CPU oracle (a port of the reference algorithm, op for op) on this box's host cores (N = 1 only)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 import numpy as np
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 measured achievable
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32-in MFMA (= fp32 vector) peak
+DTYPE = 'f32 storage/accumulate, bf16x3-split products'
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=131072, help='graphs per GPU per step (SURVEY s8d: 65,536 .. 262,144 for the roofline run)')
+    ap.add_argument('--global-batch', type=int, default=0, help='strong scaling: total graphs per step, split over the ranks')
+    ap.add_argument('--pool', type=int, default=2048, help='distinct synthetic graphs (tiled to --batch)')
+    ap.add_argument('--min-seconds', type=float, default=3.0, help='repeat the K-step block until this much GPU time; the median block is reported')
+    ap.add_argument('--cpu-graphs', type=int, default=2048)
+    ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--no-profile', action='store_true', help='skip the live per-kernel HIP-event timing and the extra measurements')
+    ap.add_argument('--no-extras', action='store_true', help='skip fresh_batch / epoch_bs64 / value_exact_fp32')
+    ap.add_argument('--ref-batch', type=int, default=64, help='also time the reference batch size (Zinc12k.py:20) as a '
+                    'HIP-graph-captured step; 0 = skip')
+    return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """--gpus N from a bare shell: start N fresh rank processes (never re-exec a process that touched the GPU)."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, env=env)
+    sys.exit(r.returncode)
 
 
 def build_batch(graphs_per_gpu, pool, seed, device):
     """pool distinct ZINC-like graphs -> supports -> tiled on the device to graphs_per_gpu graphs."""
+    import torch
     from gnn_matlang_amd import SpectralDesign, collate, synthetic
     from gnn_matlang_amd.graph import Batch
     pool = min(pool, graphs_per_gpu)
@@ -52,8 +96,19 @@ def build_batch(graphs_per_gpu, pool, seed, device):
     return full, base
 
 
-def cpu_baseline(host_batch, nsteps, warm, threads):
-    """the oracle (port of the reference CPU algorithm) on the host cores: graphs / s"""
+def cpu_model_name():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_oracle_rate(host_batch, nsteps, warm, threads):
+    """the oracle (port of the reference CPU algorithm) on the host cores: median step time of fwd + bwd + Adam"""
+    import torch
     from oracle import models_oracle as MO
     torch.set_num_threads(threads)
     b = host_batch
@@ -75,10 +130,47 @@ def cpu_baseline(host_batch, nsteps, warm, threads):
         step()
         t.append(time.perf_counter() - t0)
     med = float(np.median(t))
-    return dict(value=B / med, unit='graphs/s', cores=torch.get_num_threads(), kind='port',
-                sample='%d ZINC-like graphs/step (N=%d, E=%d), %d timed steps after %d warm-up, median; fwd+bwd+Adam, '
-                       'torch CPU fp32' % (B, b.x.size(0), b.edge_index2.size(1), nsteps, warm),
+    return dict(value=B / med, unit='graphs/s', threads=torch.get_num_threads(), graphs_per_step=B,
+                nodes=int(b.x.size(0)), support_edges=int(b.edge_index2.size(1)), warmup=warm, timed_steps=nsteps,
                 ms_per_step=med * 1e3)
+
+
+def cpu_baseline(cpu_graphs, log):
+    """the oracle at the reference batch size (64) and at a large batch, >= 5 warm-up + >= 20 timed steps,
+    median; the thread count is chosen by a short ladder up to os.cpu_count() (ATen's intra-op threading of these
+    small index ops stops scaling long before this box's core count)."""
+    import torch
+    from gnn_matlang_amd import SpectralDesign, collate, synthetic
+    raw = synthetic.make_graphs('zinc', cpu_graphs, seed=1000)
+    ds = SpectralDesign(recfield=2, dv=2, nfreq=7).design_many(raw)
+    host, host64 = collate(ds), collate(ds[:64])
+    ncpu = os.cpu_count() or 1
+    default_threads = torch.get_num_threads()
+    ladder, best, worse = [], None, 0
+    for th in [t for t in (8, 16, 32, 64, 128, 256) if t <= ncpu] or [ncpu]:
+        r = cpu_oracle_rate(host, 2, 1, th)
+        ladder.append(dict(threads=th, value=r['value']))
+        log('cpu baseline ladder: %d graphs on %d threads -> %.0f graphs/s' % (host.num_graphs, th, r['value']))
+        if best is None or r['value'] > best[1]:
+            best, worse = (th, r['value']), 0
+        else:
+            worse += 1
+            if worse >= 2:
+                break
+    th = best[0]
+    large = cpu_oracle_rate(host, 20, 5, th)
+    log('cpu baseline large: %.0f graphs/s (%d threads)' % (large['value'], th))
+    bs64 = max((cpu_oracle_rate(host64, 20, 5, t) for t in sorted({min(8, ncpu), min(th, 16)})), key=lambda r: r['value'])
+    log('cpu baseline bs64: %.0f graphs/s (%d threads)' % (bs64['value'], bs64['threads']))
+    return dict(value=large['value'], unit='graphs/s', cores=large['threads'], kind='port',
+                sample='%d ZINC-like graphs/step (N=%d, E=%d), %d timed steps after %d warm-up, median; fwd+bwd+Adam of '
+                       'the oracle (op-for-op port of the reference CPU algorithm), torch CPU fp32'
+                       % (large['graphs_per_step'], large['nodes'], large['support_edges'], large['timed_steps'], large['warmup']),
+                ms_per_step=large['ms_per_step'], large=large, bs64=bs64, thread_ladder=ladder,
+                host_cores=ncpu, cpu_model=cpu_model_name(), torch_threads_default=default_threads)
+
+
+_T0 = time.perf_counter()
 
 
 def log(*a):
@@ -86,31 +178,18 @@ def log(*a):
         print('[bench %7.1fs]' % (time.perf_counter() - _T0), *a, file=sys.stderr, flush=True)
 
 
-_T0 = time.perf_counter()
-
-
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=131072, help='graphs per GPU per step (SURVEY s8d: 65,536 .. 262,144 for the roofline run)')
-    ap.add_argument('--pool', type=int, default=2048, help='distinct synthetic graphs (tiled to --batch)')
-    ap.add_argument('--cpu-graphs', type=int, default=2048)
-    ap.add_argument('--cpu-steps', type=int, default=3)
-    ap.add_argument('--no-cpu', action='store_true')
-    ap.add_argument('--no-profile', action='store_true', help='skip the live per-kernel HIP-event timing')
-    ap.add_argument('--graph', action='store_true', help='capture the whole step in a HIP graph (launch-bound small batches)')
-    ap.add_argument('--ref-batch', type=int, default=64, help='also time the reference batch size (Zinc12k.py:20) as a '
-                    'HIP-graph-captured step; 0 = skip')
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        spawn_ranks(args)                                  # (before any GPU call)
 
+    import torch
+    import torch.distributed as dist
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d'
-                         % (args.gpus, world, args.gpus))
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     assert torch.cuda.is_available(), 'bench.py needs the MI355X (no CPU fallback)'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
@@ -120,44 +199,32 @@ def main():
 
     from gnn_matlang_amd import functional as Fn, models
     from gnn_matlang_amd.dist import FlatGradSync, broadcast_parameters
+    from gnn_matlang_amd.graph import Batch
 
+    per_gpu = args.batch
+    scaling = 'weak'
+    if args.global_batch:
+        scaling = 'strong'
+        lo = rank * args.global_batch // world
+        per_gpu = (rank + 1) * args.global_batch // world - lo
     log('building data')
-    data, base = build_batch(args.batch, args.pool, seed=1000 + rank, device=dev)
+    data, base = build_batch(per_gpu, args.pool, seed=1000 + rank, device=dev)
     log('data ready: %d graphs, %d nodes, %d support edges' % (data.num_graphs, data.x.size(0), data.edge_index2.size(1)))
-    data.csr('edge_index2')                            # built once per batch (data loading, not the step)
+    data.csr('edge_index2')                            # built once per batch (data loading, not the step); see fresh_batch
     torch.manual_seed(0)
     model = models.zinc_gnnml3().to(dev)
     broadcast_parameters(model)
     sync = FlatGradSync(model.parameters())
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)    # same update rule (Zinc12k.py:349), one multi-tensor kernel
 
-    def step():
+    def step(d=None):
+        d = data if d is None else d
         sync.zero()
-        loss = models.zinc_loss(model(data), data.y)
+        loss = models.zinc_loss(model(d), d.y)
         loss.backward()
         sync.sync()
         opt.step()
         return loss
-
-    def make_graph_step(mdl, dat, lr=1e-3):
-        """whole train step (fwd + loss + bwd + Adam) captured once in a HIP graph, replayed per step."""
-        o = torch.optim.Adam(mdl.parameters(), lr=lr, capturable=True, fused=True)
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                      # warm-up on a side stream (allocator, lazy init)
-            for _ in range(3):
-                o.zero_grad(set_to_none=True)
-                models.zinc_loss(mdl(dat), dat.y).backward()
-                o.step()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        g_ = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g_):
-            o.zero_grad(set_to_none=True)               # gradients are handed over, not accumulated
-            l_ = models.zinc_loss(mdl(dat), dat.y)
-            l_.backward()
-            o.step()
-        return g_, l_
 
     def fence():
         torch.cuda.synchronize()
@@ -165,24 +232,45 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed_block(fn, nsteps):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            out = fn()
+        fence()
+        return time.perf_counter() - t0, out
+
     for _ in range(args.warmup):
         step()
     fence()
     log('warm-up done')
-    if not args.no_profile:
-        Fn.PROFILE = {}
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    fence()
-    dt = time.perf_counter() - t0
-    log('timed region: %.3f s for %d steps' % (dt, args.steps))
+    # EXACTLY K steps per block, bracketed by barrier + synchronize; the block is repeated until min-seconds of GPU time
+    # have passed (so that a sampler sees the GPU busy) and the MEDIAN block is reported.  Kernel events: last block.
+    # (all ranks take the same number of blocks: the decision is made on rank 0's clock and broadcast)
+    blocks, total = [], 0.0
+    while True:
+        last = total + (blocks[-1] if blocks else 0) >= args.min_seconds or len(blocks) >= 63
+        if world > 1:
+            flag = torch.tensor([1 if last else 0], device=dev)
+            dist.broadcast(flag, 0)
+            last = bool(flag.item())
+        if last and not args.no_profile:
+            Fn.PROFILE = {}
+        dt, loss = timed_block(step, args.steps)
+        blocks.append(dt)
+        total += dt
+        if last:
+            break
     prof, Fn.PROFILE = Fn.PROFILE, None
+    dt = float(np.median(blocks))
+    log('timed region: %d blocks of %d steps, median %.3f s (min %.3f, max %.3f)' % (len(blocks), args.steps, dt, min(blocks), max(blocks)))
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    gcount = torch.tensor([data.num_graphs], dtype=torch.int64, device=dev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(gcount, op=dist.ReduceOp.SUM)
     dt = float(tt.item())
-    graphs = data.num_graphs * world
+    graphs = int(gcount.item())
     lossv = float(loss.item())
     assert np.isfinite(lossv) or os.environ.get('GML_BENCH_NOCHECK'), 'loss diverged'   # (NOCHECK: ablation builds)
 
@@ -190,16 +278,17 @@ def main():
         ms = dt / args.steps * 1e3
         res = dict(metric='GNNML3 training graphs/sec on ZINC-12k', value=graphs * args.steps / dt, unit='graphs/s',
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms, higher_is_better=True,
-                   scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+                   scaling=scaling, vs_baseline=None, dtype=DTYPE, data='synthetic',
                    config=dict(workload='Zinc12k.py GNNML3 regression train step (4x ML3Layer 30+2, S=8 supports, '
                                         'learnedge, add-pool, L1-sum, Adam 1e-3), ZINC-like synthetic graphs',
                                graphs_per_gpu=data.num_graphs, global_batch=graphs, nodes_per_gpu=int(data.x.size(0)),
                                support_edges_per_gpu=int(data.edge_index2.size(1)), supports=8,
                                parallelism='dp%d' % world, params=sum(p.numel() for p in model.parameters())),
-                   final_loss=lossv)
+                   final_loss=lossv, blocks=len(blocks), block_seconds=[round(b, 4) for b in blocks],
+                   n_ranks_seen=dist.get_world_size() if world > 1 else 1,
+                   rccl_version='.'.join(str(v) for v in torch.cuda.nccl.version()) if world > 1 else None)
         if prof:
             summ = Fn.profile_summary(prof)
-
             bf16x3 = not Fn.F32_MFMA
             BF16_PEAK_TFLOPS = 2500.0                       # dense bf16 MFMA (MI355X_MICROARCH.md)
 
@@ -240,24 +329,23 @@ def main():
             ed_b = sum(4 * E_ * 8 * 30 for f in fins) * args.steps              # P update + Z.g dot
             cands = []
             if 'spectconv_bwd' in summ:
-                cands.append(roof('spectconv_bwd', 'gml_k_spectconv_bwd2 / gml_k_spectconv_bwd (fused SpectConv backward: dX, dval, dW)', pj_b, ed_b))
+                cands.append(roof('spectconv_bwd', 'gml_k_spectconv_bwd3 (fused SpectConv backward: dX, dval, dW)', pj_b, ed_b))
             if 'spectconv_fwd' in summ:
-                cands.append(roof('spectconv_fwd', 'gml_k_spectconv_fwd2 / gml_k_spectconv_fwd (fused SpectConv forward; the 8-wave kernel also carries the Hadamard branch)', pj_f, ed_f))
-            # HBM bytes per launch from the PMC counters (collected offline with the same command under rocprofv3,
-            # separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied -- profiles/r01_k_hbm_traffic.md);
-            # only valid for the workload it was measured on
-            tname = {32768: 'r01_k_hbm_traffic.json', 65536: 'r01_k_hbm_traffic_b65536.json',
-                     131072: 'r01_k_hbm_traffic_b131072.json'}.get(data.num_graphs, 'none')
-            tpath = os.path.join(ROOT, 'profiles', tname)
+                cands.append(roof('spectconv_fwd', 'gml_k_spectconv_fwd2 (fused SpectConv forward; the 8-wave kernel also carries the Hadamard branch)', pj_f, ed_f))
+            # HBM bytes per launch from the PMC counters: collected OFFLINE with the same command under rocprofv3
+            # (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied); valid for the code state and
+            # workload the profile names -- the file records the commit it was taken at
+            tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic_b%d.json' % data.num_graphs)
             if os.path.exists(tpath) and args.pool == 2048:
-                tk = json.load(open(tpath))['kernels']
+                tj = json.load(open(tpath))
                 for r in cands:
                     pref = 'gml_k_spectconv_bwd' if 'backward' in r['kernel'] else 'gml_k_spectconv_fwd'
-                    hits = [v for kname, v in tk.items() if kname.startswith(pref)]
+                    hits = [v for kname, v in tj['kernels'].items() if kname.startswith(pref)]
                     if hits:                                  # launch-weighted mean over the instantiations used
                         r['traffic'] = sum(h['hbm_bytes_per_launch'] * h.get('launches', 1) for h in hits) / \
                             sum(h.get('launches', 1) for h in hits)
-                        r['traffic_source'] = 'profiles/%s (rocprofv3 PMC, per launch)' % tname
+                        r['traffic_source'] = 'profiles/%s: rocprofv3 PMC, per launch, measured OFFLINE at commit %s' % (
+                            os.path.basename(tpath), tj.get('commit', '?'))
             cands.sort(key=lambda r: -r['ms_per_step'])
             res['roofline'] = cands[0]                   # the kernel with the largest share of the step
             res['roofline_other'] = cands[1:]
@@ -298,16 +386,54 @@ def main():
             res['spmm'] = {'kernel': 'gml_k_spectconv_fwd2<S, 0> via gml_spmm_fwd (8-wave SpMM, H written)', 'bound': 'hbm',
                            'achieved': q_s / t_s / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': q_s / t_s / 1e9 / HBM_PEAK_GBS,
                            'avg_launch_ms': t_s * 1e3, 'algorithmic_bytes_per_launch': q_s, 'S': S_, 'Fin': Fin_,
-                           'frac_of_copy_rate': q_s / t_s / 1e9 / res['hbm_copy_GBps'],
-                           'traffic_note': 'PMC at 32,768 graphs: 1045 MB / launch = 1.01x algorithmic (profiles/r01_k_spmm_hbm_traffic.md)'}
+                           'frac_of_copy_rate': q_s / t_s / 1e9 / res['hbm_copy_GBps']}
             del xs, vals
+        if world == 1 and not args.no_profile and not args.no_extras:
+            # ---- the same step with exact fp32 products (f32-input MFMA; bit-identical to an fmaf chain)
+            Fn.F32_MFMA = True
+            for _ in range(2):
+                step()
+            dtx, _ = timed_block(step, args.steps)
+            Fn.F32_MFMA = False
+            res['value_exact_fp32'] = dict(value=data.num_graphs * args.steps / dtx, unit='graphs/s', ms_per_step=dtx / args.steps * 1e3,
+                                           arithmetic='f32-input MFMA (GML_F32_MFMA=1): every product exact fp32')
+            log('exact fp32: %.3f ms/step' % (dtx / args.steps * 1e3))
+            # ---- a NEW batch every step: the per-batch index work inside the timed region
+            fields = {k: v for k, v in data.__dict__.items() if not k.startswith('_')}
+
+            def fresh_step():
+                return step(Batch(**fields))               # new Batch: CSR, group records, pre-split, source order rebuilt
+            for _ in range(2):
+                fresh_step()
+            nfr = max(5, args.steps // 2)
+            dtf, _ = timed_block(fresh_step, nfr)
+            res['fresh_batch'] = dict(value=data.num_graphs * nfr / dtf, unit='graphs/s', ms_per_step=dtf / nfr * 1e3, steps=nfr,
+                                      index_build_ms_per_batch=dtf / nfr * 1e3 - ms,
+                                      note='every step builds CSR (both views), group records, the bf16 pre-split and the '
+                                           'source-order copy of the supports for its batch inside the timed region')
+            log('fresh batch: %.3f ms/step' % (dtf / nfr * 1e3))
         if world == 1 and args.ref_batch > 0:
             # the reference's own batch size: launch-latency bound, so the step is replayed from a HIP graph
             rb, _ = build_batch(args.ref_batch, args.ref_batch, seed=7, device=dev)
             rb.csr('edge_index2')
             torch.manual_seed(0)
             rm = models.zinc_gnnml3().to(dev)
-            gr, gl = make_graph_step(rm, rb)
+            o = torch.optim.Adam(rm.parameters(), lr=1e-3, capturable=True, fused=True)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                      # warm-up on a side stream (allocator, lazy init)
+                for _ in range(3):
+                    o.zero_grad(set_to_none=True)
+                    models.zinc_loss(rm(rb), rb.y).backward()
+                    o.step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                o.zero_grad(set_to_none=True)               # gradients are handed over, not accumulated
+                gl = models.zinc_loss(rm(rb), rb.y)
+                gl.backward()
+                o.step()
             for _ in range(20):
                 gr.replay()
             torch.cuda.synchronize()
@@ -318,24 +444,47 @@ def main():
             torch.cuda.synchronize()
             dt1 = (time.perf_counter() - t1) / nrep
             res['ref_batch'] = dict(graphs_per_step=rb.num_graphs, ms_per_step=dt1 * 1e3, value=rb.num_graphs / dt1,
-                                    unit='graphs/s', mode='whole step replayed from one HIP graph',
+                                    unit='graphs/s', mode='ONE batch, whole step replayed from one HIP graph (launch-latency '
+                                    'floor of this batch size; see epoch_bs64 for distinct batches)',
                                     final_loss=float(gl.item()))
             log('reference batch %d: %.3f ms/step (HIP graph)' % (rb.num_graphs, dt1 * 1e3))
+            if not args.no_extras:
+                # ---- one epoch of Zinc12k.py:354-371 over 10,000 distinct synthetic graphs: shuffled, batch 64, every
+                #      batch assembled on the device and indexed inside the loop (eager launches, no graph replay)
+                from gnn_matlang_amd import SpectralDesign, synthetic
+                from gnn_matlang_amd.dataset import DeviceDataset
+                raw = synthetic.make_graphs('zinc', 10000, seed=4242)
+                dsd = DeviceDataset.from_graphs(SpectralDesign(recfield=2, dv=2, nfreq=7).design_many(raw), dev)
+                torch.manual_seed(0)
+                em = models.zinc_gnnml3().to(dev)
+                eo = torch.optim.Adam(em.parameters(), lr=1e-3, fused=True)
+                gen = torch.Generator().manual_seed(1)
+
+                def epoch():
+                    tot = torch.zeros((), device=dev)
+                    nb = 0
+                    for b in dsd.epoch(args.ref_batch, generator=gen):
+                        eo.zero_grad(set_to_none=True)
+                        l = models.zinc_loss(em(b), b.y)
+                        l.backward()
+                        eo.step()
+                        tot += l.detach()                      # (no .item() per step: the reference syncs at Zinc12k.py:369)
+                        nb += 1
+                    return tot, nb
+                epoch()
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                tot, nb = epoch()
+                torch.cuda.synchronize()
+                dt2 = time.perf_counter() - t2
+                res['epoch_bs64'] = dict(graphs=len(dsd), batches=nb, batch_size=args.ref_batch, seconds=dt2, value=len(dsd) / dt2,
+                                         unit='graphs/s', ms_per_step=dt2 / nb * 1e3, mean_loss=float(tot.item()) / len(dsd),
+                                         mode='eager: per batch device-side assembly from the HBM-resident data set '
+                                              '(one host read for the sizes), CSR + group records + pre-split built, '
+                                              'fwd + loss + bwd + fused Adam; distinct shuffled batches')
+                log('epoch at batch %d: %.3f s for %d graphs (%.3f ms/step)' % (args.ref_batch, dt2, len(dsd), dt2 / nb * 1e3))
         if world == 1 and not args.no_cpu:
-            from gnn_matlang_amd import SpectralDesign, collate, synthetic
-            raw = synthetic.make_graphs('zinc', args.cpu_graphs, seed=1000)
-            host = collate(SpectralDesign(recfield=2, dv=2, nfreq=7).design_many(raw))
-            # ATen intra-op threading of these small index ops stops scaling long before this box's core
-            # count; time a short ladder of thread counts and report the best one (cores = threads used)
-            best = None
-            for th in [t for t in (8, 16, 32, 64) if t <= (os.cpu_count() or 1)] or [os.cpu_count() or 1]:
-                log('cpu baseline: %d graphs on %d threads' % (host.num_graphs, th))
-                r = cpu_baseline(host, args.cpu_steps, 1, th)
-                log('   -> %.0f graphs/s' % r['value'])
-                if best is None or r['value'] > best['value']:
-                    best = r
-            best['host_cores'] = os.cpu_count()
-            res['cpu_baseline'] = best
+            res['cpu_baseline'] = cpu_baseline(args.cpu_graphs, log)
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

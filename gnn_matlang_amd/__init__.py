@@ -9,7 +9,8 @@ include/gml.h), loaded lazily with ctypes on the first forward.  No CPU fallback
 """
 from .spect_conv import SpectConv, SpectConCatConv, ML3Layer, glorot, zeros
 from .spectral_design import SpectralDesign
-from .graph import GraphCSR, Batch, collate, csr_for, shard_graphs
+from .graph import GraphCSR, Batch, collate, csr_for, shard_graphs, shard_graphs_balanced
+from .dataset import DeviceDataset
 
 __all__ = ['SpectConv', 'SpectConCatConv', 'ML3Layer', 'SpectralDesign', 'GraphCSR', 'Batch', 'collate',
-           'csr_for', 'shard_graphs', 'glorot', 'zeros']
+           'csr_for', 'shard_graphs', 'shard_graphs_balanced', 'DeviceDataset', 'glorot', 'zeros']

@@ -11,9 +11,20 @@
 #define SCAN_ITEMS 4
 #define SCAN_TILE (SCAN_BLOCK * SCAN_ITEMS)
 
-__global__ void gml_k_hist(const int64_t* __restrict__ key, int64_t E, int32_t* __restrict__ counts1) {
+// A key outside [0, N) is clamped (so nothing is written outside the arrays) and reported through *bad: the caller
+// raises after its next host read -- the reference's scatter raises an index error for the same input.
+__device__ __forceinline__ int64_t gml_checked_key(int64_t k, int64_t N, int32_t* __restrict__ bad) {
+    if ((uint64_t)k >= (uint64_t)N) {
+        atomicOr(bad, 1);
+        return k < 0 ? 0 : N - 1;
+    }
+    return k;
+}
+
+__global__ void gml_k_hist(const int64_t* __restrict__ key, int64_t E, int64_t N, int32_t* __restrict__ counts1,
+                           int32_t* __restrict__ bad) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < E) atomicAdd(&counts1[key[e] + 1], 1);
+    if (e < E) atomicAdd(&counts1[gml_checked_key(key[e], N, bad) + 1], 1);
 }
 
 // in-place inclusive scan of tiles; tile totals -> sums[b]
@@ -83,10 +94,10 @@ __global__ __launch_bounds__(SCAN_BLOCK) void gml_k_scan_add(int32_t* __restrict
         if (base + i < n) a[base + i] += off;
 }
 
-__global__ void gml_k_slot(const int64_t* __restrict__ key, int64_t E, int32_t* __restrict__ cursor,
-                           int32_t* __restrict__ perm) {
+__global__ void gml_k_slot(const int64_t* __restrict__ key, int64_t E, int64_t N, int32_t* __restrict__ cursor,
+                           int32_t* __restrict__ perm, int32_t* __restrict__ bad) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < E) perm[atomicAdd(&cursor[key[e]], 1)] = (int32_t)e;
+    if (e < E) perm[atomicAdd(&cursor[gml_checked_key(key[e], N, bad)], 1)] = (int32_t)e;
 }
 
 // one lane per row: insertion sort of the row's edge ids (rows are short and nearly sorted)
@@ -102,17 +113,17 @@ __global__ void gml_k_sort_rows(const int32_t* __restrict__ rowptr, int64_t N, i
     }
 }
 
-__global__ void gml_k_take_i64(const int64_t* __restrict__ in, const int32_t* __restrict__ perm, int64_t E,
-                               int32_t* __restrict__ out) {
+__global__ void gml_k_take_i64(const int64_t* __restrict__ in, const int32_t* __restrict__ perm, int64_t E, int64_t N,
+                               int32_t* __restrict__ out, int32_t* __restrict__ bad) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < E) out[k] = (int32_t)in[perm[k]];
+    if (k < E) out[k] = (int32_t)gml_checked_key(in[perm[k]], N, bad);
 }
 
 extern "C" size_t gml_csr_workspace_bytes(int64_t num_nodes, int64_t num_edges) {
     (void)num_edges;
     if (num_nodes < 0) return 0;
     const int64_t nb = gml_cdiv(num_nodes + 1, SCAN_TILE);
-    return (size_t)(nb + 1 + num_nodes + 1) * sizeof(int32_t);
+    return (size_t)(nb + 1 + num_nodes + 1 + 1) * sizeof(int32_t);     /* scan sums, cursors, the bad-id flag (last int32) */
 }
 
 extern "C" int gml_csr_from_coo(const int64_t* key, const int64_t* other_in, int64_t num_nodes, int64_t num_edges,
@@ -131,18 +142,19 @@ extern "C" int gml_csr_from_coo(const int64_t* key, const int64_t* other_in, int
     const int64_t nb = gml_cdiv(n1, SCAN_TILE);
     int32_t* sums = (int32_t*)ws;
     int32_t* cursor = sums + nb + 1;
+    int32_t* bad = cursor + n1;                                /* OR-ed, never cleared here: the caller zeroes it */
     const unsigned eg = (unsigned)gml_cdiv(num_edges, 256);
 
-    hipLaunchKernelGGL(gml_k_hist, dim3(eg), dim3(256), 0, st, key, num_edges, rowptr);
+    hipLaunchKernelGGL(gml_k_hist, dim3(eg), dim3(256), 0, st, key, num_edges, num_nodes, rowptr, bad);
     hipLaunchKernelGGL(gml_k_scan_tiles, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, rowptr, n1, sums);
     hipLaunchKernelGGL(gml_k_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, st, sums, nb);
     hipLaunchKernelGGL(gml_k_scan_add, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, rowptr, n1, sums);
     he = hipMemcpyAsync(cursor, rowptr, sizeof(int32_t) * n1, hipMemcpyDeviceToDevice, st);
     if (he != hipSuccess) return (int)he;
-    hipLaunchKernelGGL(gml_k_slot, dim3(eg), dim3(256), 0, st, key, num_edges, cursor, perm);
+    hipLaunchKernelGGL(gml_k_slot, dim3(eg), dim3(256), 0, st, key, num_edges, num_nodes, cursor, perm, bad);
     hipLaunchKernelGGL(gml_k_sort_rows, dim3((unsigned)gml_cdiv(num_nodes, 256)), dim3(256), 0, st, rowptr,
                        num_nodes, perm);
-    hipLaunchKernelGGL(gml_k_take_i64, dim3(eg), dim3(256), 0, st, other_in, perm, num_edges, other);
+    hipLaunchKernelGGL(gml_k_take_i64, dim3(eg), dim3(256), 0, st, other_in, perm, num_edges, num_nodes, other, bad);
     return gml_launch_status();
 }
 

@@ -271,8 +271,18 @@ def tall_linear(x, lin):
     return TallLinearFunction.apply(x, lin.weight, lin.bias)
 
 
+def _ptr32(ptr):
+    """segment pointers as the kernels read them: int32, contiguous (a PyG-style int64 ``ptr`` is converted)."""
+    if ptr.dtype != torch.int32:
+        if ptr.dtype not in (torch.int64, torch.int16, torch.uint8):
+            raise TypeError('ptr must be an integer tensor, got %s' % ptr.dtype)
+        ptr = ptr.to(torch.int32)
+    return ptr.contiguous()
+
+
 def segment_bcast(g, ptr, nrows, mean=False):
     """gradient of segment_sum: row r of segment s receives g[s] (divided by the segment length for the mean)."""
+    ptr = _ptr32(ptr)
     B, F = int(ptr.numel() - 1), int(g.size(1))
     out = torch.empty(nrows, F, dtype=torch.float32, device=g.device)
     _lib.call('gml_segment_bcast', _ptr(g), int(g.stride(0)), _ptr(ptr), _ptr(out), F, B, F, 1 if mean else 0,
@@ -282,6 +292,7 @@ def segment_bcast(g, ptr, nrows, mean=False):
 
 def segment_sum(x, ptr, mean=False):
     """global_add_pool / global_mean_pool over a batch whose nodes are grouped per graph (ptr [B+1] int32)."""
+    ptr = _ptr32(ptr)
     B, F = int(ptr.numel() - 1), int(x.size(1))
     out = torch.empty(B, F, dtype=torch.float32, device=x.device)
     _lib.call('gml_segment_sum', _ptr(x), int(x.stride(0)), _ptr(ptr), _ptr(out), F, B, F, 1 if mean else 0,
@@ -490,7 +501,7 @@ class ML3LayerFunction(torch.autograd.Function):
         with torch.cuda.device(x.device):
             need_val = need[1] or (learnedge and any(need[2:6]))
             if not learnedge and fused_bwd_available(csr, S, Fin, nout1):
-                ea_t = csr.to_source_order(val, cache=True)              # raw supports: per-batch data
+                ea_t = csr.to_source_order(val, cache=not val.requires_grad)   # raw supports: per-batch data (trained ones change)
             want_cb = ctx.has_cb and need[7]
             mixk = nout2 > 0 and node_mix_native(Fin, nout2)
             r = ml3_split_bwd(gy, out, nout1, x, w11, b11, w12, b12, need_dx=need[0], need_dcb=want_cb) \
@@ -530,7 +541,7 @@ class ML3LayerFunction(torch.autograd.Function):
             if learnedge:
                 if need_val:
                     # the edge MLP is per-edge, so it can run in whichever order dea arrived in
-                    val_in = csr.to_source_order(val, cache=True) if dea_src else val
+                    val_in = csr.to_source_order(val, cache=not val.requires_grad) if dea_src else val
                     with _Timed('edge_mlp_bwd', 4 * val.numel() * 2, 60 * val.size(0) * val.size(1) ** 2):
                         gin, g[2], g[3], g[4], g[5] = edge_mlp_bwd(val_in, w1, w2, w3, w4, dea, need[1],
                                                                    csr.presplit(val_in))

@@ -58,7 +58,10 @@ class GraphCSR(object):
         with torch.cuda.device(dev):
             st = _stream(dev)
             L = _lib.lib()
-            ws = torch.empty(max(int(L.gml_csr_workspace_bytes(N, E)), 4), dtype=torch.uint8, device=dev)
+            nws = max(int(L.gml_csr_workspace_bytes(N, E)), 4)
+            ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+            bad = ws[nws - 4:].view(torch.int32)               # OR-ed by the index kernels when a node id is out of range
+            bad.zero_()
             src, dst = ei[0], ei[1]
             g.rowptr, g.col, g.perm = torch.empty(N + 1, **i32), torch.empty(E, **i32), torch.empty(E, **i32)
             _lib.call('gml_csr_from_coo', _ptr(dst), _ptr(src), N, E, _ptr(g.rowptr), _ptr(g.col), _ptr(g.perm),
@@ -85,9 +88,13 @@ class GraphCSR(object):
             _lib.call('gml_csr_group_info', _ptr(g.rowptr), _ptr(g.col), N, 128, _ptr(g.ginfo128), st)
             # per-batch maxima (edges per 64-row group, column window): they size the LDS staging of the fused
             # backward kernel.  One device->host read per batch, at index-build time (not in the step).
+            # The same read carries the bad-id flag of the index kernels (ids outside [0, num_nodes) were clamped there, so
+            # nothing was written out of bounds): raise like the reference's scatter does for such an edge_index.
             mx = torch.stack([g.ginfo[:, 1].max(), g.ginfo[:, 3].max(), g.ginfo_t[:, 1].max(),
-                              g.ginfo_t[:, 3].max(), g.ginfo_t128[:, 1].max(), g.ginfo_t128[:, 3].max()]).tolist()
+                              g.ginfo_t[:, 3].max(), g.ginfo_t128[:, 1].max(), g.ginfo_t128[:, 3].max(), bad[0]]).tolist()
             g.gmax, g.gmax_t, g.gmax_t128 = (int(mx[0]), int(mx[1])), (int(mx[2]), int(mx[3])), (int(mx[4]), int(mx[5]))
+            if mx[6]:
+                raise IndexError('edge_index holds node ids outside [0, %d)' % N)
         return g
 
     def ranked64_t(self):
@@ -251,3 +258,22 @@ def shard_graphs(num_graphs, rank, world_size):
     base, rem = divmod(num_graphs, world_size)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_graphs_balanced(work, rank, world_size):
+    """Contiguous split of the graphs [0, len(work)) over ranks with near-equal TOTAL work instead of equal counts
+    (balance by the sum of nnz when graph sizes vary, e.g. proteins' 4 .. 620 nodes): rank r takes the graphs
+    whose cumulative work lies in (r, r + 1] x total / world_size.  ``work``: per-graph cost (support edges).
+    Every rank computes the same cut points, and their ranges tile [0, G) without gaps or overlap."""
+    w = np.asarray(work, dtype=np.float64)
+    G = int(w.size)
+    if G == 0:
+        return 0, 0
+    cum = np.cumsum(w)
+    total = float(cum[-1])
+    if total <= 0:
+        return shard_graphs(G, rank, world_size)
+    mid = cum - 0.5 * w                                       # a graph belongs to the rank its mid-point falls into
+    cuts = np.searchsorted(mid, total * np.arange(1, world_size) / world_size, side='left')
+    cuts = np.concatenate([[0], cuts, [G]])
+    return int(cuts[rank]), int(cuts[rank + 1])

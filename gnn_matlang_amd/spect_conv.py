@@ -44,11 +44,15 @@ def _check_mp_kwargs(kwargs):
     return aggr, flow, node_dim
 
 
-def _sorted_values(csr, edge_index, edge_attr):
-    """supports in target-sorted order, differentiable w.r.t. edge_attr."""
+def _sorted_values(csr, edge_index, edge_attr, ncols=None):
+    """supports in target-sorted order, differentiable w.r.t. edge_attr.  ncols: the layer reads only the first ncols
+    columns (the reference indexes edge_attr[:, i] for i < K, libs/spect_conv.py:77, so a wider input is legal); the
+    narrowing happens here, outside the autograd Function, so the gradient keeps the caller's shape."""
     _require_cuda(edge_attr, 'edge_attr')
     if edge_attr.dim() == 1:
         edge_attr = edge_attr.view(-1, 1)
+    if ncols is not None and edge_attr.size(1) > ncols:
+        edge_attr = edge_attr[:, :ncols]
     if edge_attr.size(0) != csr.E:
         raise ValueError('edge_attr has %d rows, edge_index has %d edges' % (edge_attr.size(0), csr.E))
     if edge_attr.dtype != torch.float32:
@@ -119,7 +123,7 @@ class SpectConv(torch.nn.Module):
         _require_cuda(x, 'x')
         csr = csr_for(edge_index, x.size(0))
         w, wself = self._effective()
-        val = _sorted_values(csr, edge_index, edge_attr)
+        val = _sorted_values(csr, edge_index, edge_attr, w.size(0))
         out = SpectConvFunction.apply(x, val, w.contiguous(), None if wself is not None else self.bias, csr, False)
         if wself is not None:
             out = torch.addmm(self.bias, x, wself) + out if self.bias is not None else torch.mm(x, wself) + out
@@ -158,7 +162,7 @@ class SpectConCatConv(torch.nn.Module):
         csr = csr_for(edge_index, x.size(0))
         Kp, Fin, Fout = self.weight.shape
         S = Kp - 1 if self.selfconn else Kp
-        val = _sorted_values(csr, edge_index, edge_attr)
+        val = _sorted_values(csr, edge_index, edge_attr, S)
         # block-structured weights: support i only feeds output columns [i*Fout, (i+1)*Fout)
         off = 1 if self.selfconn else 0
         wbig = x.new_zeros(S, Fin, Kp * Fout)
@@ -200,8 +204,10 @@ class ML3Layer(torch.nn.Module):
     def forward(self, x, edge_index, edge_attr):
         _require_cuda(x, 'x')
         csr = csr_for(edge_index, x.size(0))
-        val = _sorted_values(csr, edge_index, edge_attr)
         le, n2 = self.learnedge, self.nout2
+        # learnedge: fc1_1..3 are Linear(nedgeinput, .) -- the width must match, as in the reference; otherwise conv1
+        # reads the first K columns only
+        val = _sorted_values(csr, edge_index, edge_attr, None if le else self.conv1.weight.size(0))
         return ML3LayerFunction.apply(
             x, val,
             self.fc1_1.weight if le else None, self.fc1_2.weight if le else None,

@@ -61,7 +61,10 @@ const char* gml_error_string(int code);
 /* ---------------------------------------------------------------- CSR build (integer-exact)
  * Stable sort of the COO edge list by `key` (key = dst for the forward view, key = src for the
  * transposed view): rowptr[N+1], other[E] = the non-key endpoint of each sorted edge, perm[E] =
- * input edge id of each sorted edge (ascending inside a row).  ws: gml_csr_workspace_bytes(). */
+ * input edge id of each sorted edge (ascending inside a row).  ws: gml_csr_workspace_bytes().
+ * Node ids outside [0, num_nodes) are clamped (no out-of-bounds access) and reported: the LAST int32 of the workspace
+ * (byte offset gml_csr_workspace_bytes() - 4) is OR-ed with 1.  The caller zeroes that word before the call(s) that share
+ * the workspace and raises when it reads non-zero (the reference's scatter raises an index error for such input). */
 size_t gml_csr_workspace_bytes(int64_t num_nodes, int64_t num_edges);
 int gml_csr_from_coo(const int64_t* key, const int64_t* other_in, int64_t num_nodes, int64_t num_edges,
                      int32_t* rowptr, int32_t* other, int32_t* perm,

@@ -665,3 +665,42 @@ def test_randomised_sweep_short(dev, sweep):
     fails = {'ml3': lambda: fuzz_parity.ml3_sweep(a), 'conv': lambda: fuzz_parity.conv_sweep(a, dev),
              'spectral': lambda: fuzz_parity.spectral_sweep(a, dev)}[sweep]()
     assert fails == 0
+
+
+# ------------------------------------------------------------------------------------------ drop-in behaviour (round 2)
+def test_bad_node_ids_raise_like_the_reference(dev):
+    """an edge_index entry outside [0, num_nodes) is an error (the reference's scatter raises an index error)"""
+    from gnn_matlang_amd.graph import GraphCSR
+    ei = torch.tensor([[0, 1, 2], [1, 2, 7]], device=dev)
+    with pytest.raises(IndexError):
+        GraphCSR.from_edge_index(ei, 4)
+    GraphCSR.from_edge_index(torch.tensor([[0, 1, 2], [1, 2, 3]], device=dev), 4)
+
+
+def test_wider_edge_attr_and_int64_ptr(dev):
+    """the reference reads edge_attr[:, i] for i < K only (libs/spect_conv.py:77): wider inputs are legal and their
+    gradient keeps the input's shape; PyG-style int64 segment pointers pool correctly"""
+    from gnn_matlang_amd import SpectConv, ML3Layer
+    from gnn_matlang_amd.functional import segment_sum
+    from oracle import spect_conv_oracle as O
+    rng = np.random.default_rng(5)
+    N, E, K = 40, 160, 3
+    ei = cu(rng.integers(0, N, size=(2, E)), dev)
+    x = cu(rng.standard_normal((N, 6)).astype(np.float32), dev)
+    ea = cu(rng.standard_normal((E, K + 2)).astype(np.float32), dev).requires_grad_(True)
+    conv = SpectConv(6, 5, K, selfconn=False).to(dev)
+    out = conv(x, ei, ea)
+    out.square().sum().backward()
+    assert ea.grad.shape == ea.shape and float(ea.grad[:, K:].abs().max()) == 0.0
+    ref = O.OracleSpectConv(6, 5, K, selfconn=False)
+    ref.load_state_dict({k: v.detach().cpu() for k, v in conv.state_dict().items()})
+    ea_c = ea.detach().cpu().requires_grad_(True)
+    out_r = ref(x.cpu(), ei.cpu(), ea_c)
+    out_r.square().sum().backward()
+    close(out, out_r, what='out')
+    close(ea.grad, ea_c.grad, what='d edge_attr')
+    lay = ML3Layer(False, K, K, 6, 8, 4).to(dev)                       # learnedge=False: conv1 reads the first K columns
+    assert lay(x, ei, ea.detach()).shape == (N, 12)
+    ptr64 = torch.tensor([0, 10, 25, 40], dtype=torch.int64, device=dev)
+    pooled = segment_sum(x.contiguous(), ptr64)
+    close(pooled, torch.stack([x[0:10].sum(0), x[10:25].sum(0), x[25:40].sum(0)]).cpu(), what='int64 ptr pooling')

@@ -154,3 +154,37 @@ def test_synthetic_generators_are_seeded_and_shaped():
     assert y == pytest.approx(np.trace(A @ A @ A) / 6)            # libs/utils.py:395-397
     x, ei, y = synthetic.make_graphs('mnist75', 1, seed=2)[0]
     assert x.shape == (75, 2)
+
+
+# ------------------------------------------------------------------------------------------ batch plumbing (round 2)
+def test_shard_graphs_balanced_tiles_and_balances():
+    from gnn_matlang_amd.graph import shard_graphs_balanced
+    rng = np.random.default_rng(0)
+    for G, W in ((37, 1), (37, 2), (37, 8), (5, 8), (1000, 8), (0, 4)):
+        w = rng.integers(1, 100, size=G)
+        cuts = [shard_graphs_balanced(w, r, W) for r in range(W)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == G
+        assert all(cuts[r][1] == cuts[r + 1][0] for r in range(W - 1))         # tile [0, G): no gap, no overlap
+        if G >= 100:                                                            # near-equal total work, unlike equal counts
+            tot = np.array([w[a:b].sum() for a, b in cuts], dtype=np.float64)
+            assert tot.max() - tot.min() <= 2 * w.max()
+    assert shard_graphs_balanced(np.zeros(10), 1, 2) == (5, 10)                 # no work information: equal counts
+
+
+def test_device_dataset_batches_equal_host_collate():
+    """dataset.DeviceDataset (torch ops only: also runs on CPU tensors) assembles the same block-diagonal batch as
+    graph.collate, for any selection and order of graphs."""
+    import torch
+    from gnn_matlang_amd import SpectralDesign, collate, synthetic
+    from gnn_matlang_amd.dataset import DeviceDataset
+    raw = synthetic.make_graphs('zinc', 12, seed=3)
+    ds = SpectralDesign(recfield=2, dv=2, nfreq=3).design_many(raw)
+    dd = DeviceDataset.from_graphs(ds, torch.device('cpu'))
+    assert len(dd) == 12
+    ids = [7, 0, 11, 3]
+    got, ref = dd.batch(torch.tensor(ids)), collate([ds[i] for i in ids])
+    for k in ('x', 'edge_index', 'edge_index2', 'edge_attr2', 'batch', 'ptr', 'y'):
+        a, b = getattr(got, k), getattr(ref, k)
+        assert a.shape == b.shape and torch.equal(a.to(b.dtype), b), k
+    seen = torch.cat([b.y for b in dd.epoch(5, generator=torch.Generator().manual_seed(0))])
+    assert seen.numel() == 12 and torch.equal(torch.sort(seen)[0], torch.sort(dd.y)[0])   # one epoch = every graph once
