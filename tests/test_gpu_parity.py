@@ -23,6 +23,17 @@ def dev():
     return torch.device('cuda:0')
 
 
+@pytest.fixture(params=['bf16x3', 'f32'])
+def arith(request):
+    """projection arithmetic of the fused kernels: the default bf16 hi/lo split on the matrix cores (three products per
+    fp32 product, ~2^-17 operand residual) and the exact f32-input MFMA (GML_F32_MFMA).  The golden suites run in both."""
+    from gnn_matlang_amd import functional as Fn
+    old = Fn.F32_MFMA
+    Fn.F32_MFMA = request.param == 'f32'
+    yield request.param
+    Fn.F32_MFMA = old
+
+
 def cu(a, dev):
     return T(a).to(dev)
 
@@ -94,7 +105,7 @@ def test_csr_large_is_stable_sort(dev):
 
 
 # ------------------------------------------------------------------------------------------ SpectConv
-def test_spectconv_golden(dev, golden):
+def test_spectconv_golden(dev, golden, arith):
     from gnn_matlang_amd import SpectConv
     g = golden('spectconv.npz')
     for k in range(int(g['ncases'])):
@@ -122,7 +133,7 @@ def test_spectconv_golden(dev, golden):
             close(m.DSweight.grad, c['g_DSweight'], what=what + ' g_DSweight')
 
 
-def test_spectconcat_golden(dev, golden):
+def test_spectconcat_golden(dev, golden, arith):
     from gnn_matlang_amd import SpectConCatConv
     g = golden('spectconv.npz')
     for k in range(int(g['nconcat'])):
@@ -442,7 +453,7 @@ def test_spectral_design_on_device(dev, golden):
 
 
 # ------------------------------------------------------------------------------------------ ML3Layer
-def test_ml3layer_golden(dev, golden):
+def test_ml3layer_golden(dev, golden, arith):
     from gnn_matlang_amd import ML3Layer
     g = golden('ml3layer.npz')
     for k in range(int(g['ncases'])):
@@ -512,7 +523,12 @@ def _batch_from(g, dev):
     ('model_mutag_gnnml3.npz', 'mutag_gnnml3', 'mutag_loss'),
     ('model_mutag_gnnml1.npz', 'GNNML1Mutag', 'mutag_loss'),
 ])
-def test_model_step_golden(dev, golden, fname, ctor, loss):
+def test_model_step_golden(dev, golden, fname, ctor, loss, arith):
+    """logits, loss, every parameter gradient and the 5-step Adam loss trajectory against the reference's own outputs.
+    Bar: 1e-4 of the tensor's scale in BOTH arithmetics.  One documented exception (profiles/r02_parity_report.jsonl):
+    mutag GNNML3 in the default bf16x3 arithmetic -- conv1.conv1.weight 1.6e-4, conv1.conv1.bias 1.3e-4: three
+    BatchNorm layers sit behind that first layer, and the BatchNorm backward (differences of near-equal batch statistics)
+    amplifies the ~1e-5 relative error of the split products; the exact arithmetic gives 2e-5 on the same tensors."""
     from gnn_matlang_amd import models
     g = golden(fname)
     data = _batch_from(g, dev)
@@ -525,8 +541,9 @@ def test_model_step_golden(dev, golden, fname, ctor, loss):
     l.backward()
     close(pre, g['logits'], what='logits')
     assert abs(l.item() - float(g['loss'])) <= TOL * abs(float(g['loss']))
+    gtol = 2e-4 if (arith == 'bf16x3' and fname == 'model_mutag_gnnml3.npz') else TOL
     for n, p in m.named_parameters():
-        close(p.grad, g['grad/' + n], tol=2e-4, what='grad ' + n)
+        close(p.grad, g['grad/' + n], tol=gtol, what='grad ' + n)
     opt = torch.optim.Adam(m.parameters(), lr=1e-3)
     traj = []
     for _ in range(5):
@@ -535,10 +552,10 @@ def test_model_step_golden(dev, golden, fname, ctor, loss):
         l.backward()
         opt.step()
         traj.append(l.item())
-    np.testing.assert_allclose(traj, g['loss_traj'], rtol=2e-4)
+    np.testing.assert_allclose(traj, g['loss_traj'], rtol=TOL)
 
 
-def test_sr25_isomorphism_golden(dev, golden):
+def test_sr25_isomorphism_golden(dev, golden, arith):
     """sr25.py:282-300 -- forward only, untrained nets, pairs never separated across seeds."""
     from gnn_matlang_amd import models
     g = golden('model_sr25_gnnml3.npz')
@@ -555,7 +572,7 @@ def test_sr25_isomorphism_golden(dev, golden):
         assert int(((Mcnt == 0).sum() - 15) / 2) == int(g['seed%d/similar' % seed])
 
 
-def test_mnist75_gnnml3_vs_oracle(dev):
+def test_mnist75_gnnml3_vs_oracle(dev, arith):
     """config 4 (TF DSGCNN: S=6 near-dense supports of 75-node graphs, widths 2->64->128->128, mean readout + BN):
     the TF reference cannot run here, so this config is checked against the CPU oracle only (parity unpinned by
     reference outputs); it exercises the wide-feature paths (multi-chunk forward, unfused backward)."""
@@ -580,7 +597,7 @@ def test_mnist75_gnnml3_vs_oracle(dev):
     assert abs(l.item() - l_ref.item()) <= TOL * abs(l_ref.item())
     rp = dict(ref.named_parameters())
     for n, p in m.named_parameters():
-        close(p.grad, rp[n].grad, tol=3e-4, what='mnist grad ' + n)
+        close(p.grad, rp[n].grad, tol=TOL, what='mnist grad ' + n)
     # dense-block evaluation (batched library GEMMs over [B, S*75, 75] support blocks): same parameters, same values
     md = models.mnist_gnnml3(dense_n=75)
     md.load_state_dict(ref.state_dict())
@@ -590,7 +607,7 @@ def test_mnist75_gnnml3_vs_oracle(dev):
     ld.backward()
     close(pre_d, pre_ref, what='mnist logits (dense blocks)')
     for n, p in md.named_parameters():
-        close(p.grad, rp[n].grad, tol=3e-4, what='mnist dense grad ' + n)
+        close(p.grad, rp[n].grad, tol=TOL, what='mnist dense grad ' + n)
 
 
 # ------------------------------------------------------------------------------------------ full size
@@ -605,8 +622,9 @@ def _big_zinc_batch(dev, ngraph_pool=512, reps=64):
 def test_full_size_properties(dev):
     """BASELINE-size ZINC-like batch (32768 graphs, ~0.75M nodes, ~4.9M support edges): properties that
     need no oracle -- bitwise run-to-run determinism (no atomics on the value path), linearity in x,
-    fused forward == unfused SpMM + GEMM, d/dx matches a directional finite difference in fp64 of the
-    same fp32 function within tolerance, and agreement with the oracle on a slice of whole graphs."""
+    fused forward == unfused SpMM + GEMM, the adjoint identity <A^T g, v> == <g, A v> between the backward's d/dx and the
+    forward (SpectConv is linear in x: exact up to round-off, no finite-difference truncation), and agreement with the
+    oracle on a slice of whole graphs."""
     from gnn_matlang_amd import ML3Layer, SpectConv, functional as Fn
     from oracle import spect_conv_oracle as O
     torch.manual_seed(0)
@@ -625,6 +643,13 @@ def test_full_size_properties(dev):
     h = Fn.spmm(csr, val, data.x, 8, 25)
     yu = torch.addmm(conv.bias, h, conv.weight.view(8 * 25, 30))
     close(y1, yu, what='fused vs unfused')
+    # adjoint identity: x.grad of sum(y * g) is A^T g; against a random direction v it must equal <g, A v>
+    xg = data.x.clone().requires_grad_(True)
+    gout, v = torch.randn_like(y1), torch.randn_like(data.x)
+    (conv(xg, csr, data.edge_attr2) * gout).sum().backward()
+    av = (conv(v, csr, data.edge_attr2) - conv.bias).double()
+    lhs, rhs = (xg.grad.double() * v.double()).sum().detach(), (gout.double() * av).sum().detach()
+    assert abs(float(lhs - rhs)) <= TOL * float((gout.double().norm() * av.norm()).detach()), ('adjoint identity', float(lhs), float(rhs))
     # oracle on the first 40 graphs (whole graphs: block-diagonal => independent of the rest)
     ng = 40
     n0 = int(data.ptr[ng])
@@ -649,7 +674,7 @@ def test_full_size_properties(dev):
         o = layer(data.x[lo:hi].contiguous(), GraphCSR.from_edge_index(ei_s, hi - lo), data.edge_attr2[m].contiguous())
         o.square().sum().backward()
     for n, v in layer.named_parameters():
-        close(v.grad, gfull[n], tol=5e-4, what='sharded grad ' + n)
+        close(v.grad, gfull[n], tol=TOL, what='sharded grad ' + n)
 
 
 # ------------------------------------------------------------------------------------------ randomised sweeps (short)
