@@ -323,6 +323,7 @@ struct GmlChainWB {
     bf16x8 a3[2];             // W4^T blocks (h1 part, h23 part): k = q, groups 0,1 hi / 2,3 lo, slots [q | q]
     bf16x8 a5[GIN ? 4 : 1];   // [W1|W2|W3]^T operands for d e: [H1|H2], [L1|L2], [H3|0], [L3|0]
     bf16x8 bIh, bIl;          // [I ; 0] and [0 ; I]: transposes of the hi / the lo image of a split tile
+    bf16x8 aE;                // rows 8..15 <- hi + lo of the pre-split supports (e rows of the [go | e] tile, exact)
 };
 
 #define GML_CHAIN_NW(S) (6 * (S) * (S) + 4 * (S) * (S))
@@ -405,6 +406,12 @@ __global__ __launch_bounds__(256, 3) void gml_k_edge_chain_bwd(
         }
         WB.bIh = gml_wop(vh, false);
         WB.bIl = gml_wop(vl, false);
+        // e = hi + lo on the matrix pipe: lane groups 2, 3 pass (hi[4q..], lo[4q..]) of their edge as k-slots; row 8 + c of D
+        // picks both slots of channel c.  The fp32 support rows are then never read (r01 profile: 1.5x the 64 B / edge)
+        float ve[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ve[j] = (g >= 2 && c16 == 4 * g + (j & 3)) ? 1.f : 0.f;
+        WB.aE = gml_wop(ve, false);
     }
     const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 acc[5];
@@ -427,8 +434,9 @@ __global__ __launch_bounds__(256, 3) void gml_k_edge_chain_bwd(
     int64_t t = (int64_t)blockIdx.x * 4 + wave;
     // prefetched inputs of the next tile: fp32 row (or, with the presplit buffer, the ready layer-1 operand + the 4 raw
     // values of the [go | e] tile) and 4 values of the gout row
-    float e_n[PRE ? 1 : 8], ye_n[4], g_n[4];
+    float e_n[PRE ? 1 : 8], g_n[4];
     u32x4 b1_n = u32x4{0u, 0u, 0u, 0u};
+    uint2 eh_n = uint2{0u, 0u}, el_n = uint2{0u, 0u};         // PRE: bf16 hi / lo of channels 4 (g & 1) .. + 3 of the edge's supports
     // PRE: unconditional loads with indices clamped into the arrays (the compiler can count them; a lane outside
     // fetches a valid, unused element and is zeroed when the registers are taken over)
     auto load_q_clamped = [&](const float* base, int64_t en, float (&v)[4]) {
@@ -445,7 +453,8 @@ __global__ __launch_bounds__(256, 3) void gml_k_edge_chain_bwd(
         if constexpr (PRE) {
             const int64_t ec = en < E ? en : E - 1;
             b1_n = *reinterpret_cast<const u32x4*>(es + ec * 8 + 4 * (g & 1));
-            load_q_clamped(ea, ec, ye_n);
+            eh_n = *reinterpret_cast<const uint2*>(es + ec * 8 + 2 * (g & 1));        // same 32-byte row: no extra HBM traffic
+            el_n = *reinterpret_cast<const uint2*>(es + ec * 8 + 4 + 2 * (g & 1));
             load_q_clamped(gout, ec, g_n);
         } else {
             const bool ok = tt < ntiles && en < E;
@@ -457,18 +466,19 @@ __global__ __launch_bounds__(256, 3) void gml_k_edge_chain_bwd(
     // trip, where the wait is an exact count (at the loop top it would merge with the store-less entry path into
     // vmcnt(0) and every tile would wait for the previous tile's gradient store to drain)
     float gq[4], ye[4];
-    bf16x8 B1;
+    bf16x8 B1, BE;
     auto take = [&](int64_t tt) {
-        asm volatile("" : "+v"(b1_n));
+        asm volatile("" : "+v"(b1_n), "+v"(eh_n), "+v"(el_n));
 #pragma unroll
-        for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(ye_n[r]), "+v"(g_n[r]));
+        for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(g_n[r]));
         const bool ok = tt * 16 + c16 < E;
         const u32x4 bz = ok ? b1_n : u32x4{0u, 0u, 0u, 0u};
         B1 = __builtin_bit_cast(bf16x8, bz);
+        // (channels >= S of the pre-split rows are zero, edges past E are zeroed here)
+        BE = __builtin_bit_cast(bf16x8, ok ? u32x4{eh_n.x, eh_n.y, el_n.x, el_n.y} : u32x4{0u, 0u, 0u, 0u});
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const bool okq = ok && q0 + r < S;
-            ye[r] = okq ? ye_n[r] : 0.f;
             gq[r] = okq ? g_n[r] : 0.f;
         }
     };
@@ -490,6 +500,11 @@ __global__ __launch_bounds__(256, 3) void gml_k_edge_chain_bwd(
         fetch(t + stride);                                     // next tile's rows are in flight while this one is computed
         if constexpr (PRE) __builtin_amdgcn_sched_barrier(0);  // (the scheduler would sink the loads to the loop's end)
         gml_chain_forward<S, true>(W, T, B1, g);
+        if constexpr (PRE) {
+            const f32x4 ef = GML_MFMA(WB.aE, BE, zero);        // rows 8..15 (lane groups 2, 3): e = hi + lo, exact
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ye[r] = ef[r];
+        }
         f32x4 go;
 #pragma unroll
         for (int r = 0; r < 4; ++r) go[r] = (T.out[r] > 0.f) ? gq[r] : 0.f;

@@ -417,6 +417,110 @@ def gen_models(mutag, mutag_tr, sr25):
     print('model_sr25_gnnml3.npz similar:', [int(out['seed%d/similar' % s]) for s in range(3)])
 
 
+# ------------------------------------------------------------------ H4: MNIST-75 GNNML3 of the TF pipeline
+def gen_mnist_tf():
+    """Config 4 exists only as TensorFlow-1.15 code (libs/models_tf.py:223-268 DSGCNN, libs/layers_tf.py:193-245
+    GraphConvolutionBatch, :323-351 ReadoutLayer, :85-135 Dense, libs/metrics_tf.py:17-20) and TensorFlow is not
+    installed, so the fixture restates that GRAPH -- dense-batched, exactly as the TF code writes it -- in float32 torch:
+
+        per layer   out = relu( add_n_i tensordot( matmul(support[:, i], x), W_i ) + bias )       layers_tf.py:231-241
+        readout     batch_normalization( reduce_sum(x, 1) / ND )   (training=True, epsilon 1e-3)  layers_tf.py:343-349
+        head        relu(x W + b) ; x W + b                                                        layers_tf.py:117-128
+        loss        reduce_mean( softmax_cross_entropy_with_logits )                               metrics_tf.py:17-20
+        optimiser   tf.train.AdamOptimizer(0.01): lr_t = lr sqrt(1-b2^t)/(1-b1^t); p -= lr_t m / (sqrt(v) + 1e-8)
+
+    The supports [B, 6, 75, 75] are laid out as prepareMnist_gnnml3_tf.py:33-66 does (5 Gaussians with dv = 10 on the
+    (A+I)^4 > 0 mask + identity) from the output of the reference's own SpectralDesign (same formulas, libs/utils.py:
+    546-610, run unmodified).  This formulation shares nothing with the sparse gather / scatter one of the oracle and the
+    kernels except the inputs.  dropout: the placeholder's default 0."""
+    raw = synthetic.make_graphs('mnist75', 6, seed=9)
+    gs = design_all(raw, **SD_CFG['mnist'])
+    b = collate(gs)
+    B, n, S = len(gs), 75, 6
+    SP = np.zeros((B, S, n, n), dtype=np.float32)
+    for i, d in enumerate(gs):
+        e0, e1 = d['edge_index2']
+        SP[i, :, e0, e1] = d['edge_attr2']                          # SP[:, E0, E1] = edge_attr2^T   (utils.py:608-610)
+    X = torch.tensor(b['x'].reshape(B, n, 2))
+    Y = torch.nn.functional.one_hot(torch.tensor(b['y'].astype(np.int64)), 10).float()
+    SPt = torch.tensor(SP)
+    ND = torch.full((B, 1), 75.0)
+    torch.manual_seed(5)
+    dims = [(2, 64), (64, 128), (128, 128)]
+
+    def glorot(shape):                                                # inits_tf.py:12-16
+        r = float(np.sqrt(6.0 / (shape[0] + shape[1])))
+        return torch.nn.Parameter((torch.rand(shape) * 2 - 1) * r)
+    Wc = [[glorot(d) for _ in range(S)] for d in dims]
+    bc = [torch.nn.Parameter(torch.randn(d[1]) * 0.05) for d in dims]   # (zeros in the reference; non-zero exercises the path)
+    gamma, beta = torch.nn.Parameter(torch.ones(128) + 0.1 * torch.randn(128)), torch.nn.Parameter(0.1 * torch.randn(128))
+    W1, b1 = glorot((128, 32)), torch.nn.Parameter(torch.randn(32) * 0.05)
+    W2, b2 = glorot((32, 10)), torch.nn.Parameter(torch.randn(10) * 0.05)
+    params = [w for ws in Wc for w in ws] + bc + [gamma, beta, W1, b1, W2, b2]
+
+    def forward():
+        x = X
+        for l in range(3):
+            outs = [torch.tensordot(torch.matmul(SPt[:, i], x), Wc[l][i], dims=([2], [0])) for i in range(S)]
+            x = torch.relu(sum(outs) + bc[l])
+        o = x.sum(1) / ND
+        mean, var = o.mean(0), o.var(0, unbiased=False)
+        o = (o - mean) / torch.sqrt(var + 1e-3) * gamma + beta
+        o = torch.relu(o @ W1 + b1)
+        return o @ W2 + b2
+
+    def loss_of(logits):
+        return (-(Y * torch.log_softmax(logits, 1)).sum(1)).mean()
+
+    def state():                                                      # under the names of gnn_matlang_amd.models.mnist_gnnml3
+        sd = {}
+        for l in range(3):
+            sd['conv%d.conv1.weight' % (l + 1)] = torch.stack([w.detach() for w in Wc[l]]).numpy().copy()
+            sd['conv%d.conv1.bias' % (l + 1)] = bc[l].detach().numpy().copy()
+        sd['bnr.weight'], sd['bnr.bias'] = gamma.detach().numpy().copy(), beta.detach().numpy().copy()
+        sd['fc1.weight'], sd['fc1.bias'] = W1.detach().t().numpy().copy(), b1.detach().numpy().copy()
+        sd['fc2.weight'], sd['fc2.bias'] = W2.detach().t().numpy().copy(), b2.detach().numpy().copy()
+        return sd
+
+    def grads():
+        g = {}
+        for l in range(3):
+            g['conv%d.conv1.weight' % (l + 1)] = torch.stack([w.grad for w in Wc[l]]).numpy().copy()
+            g['conv%d.conv1.bias' % (l + 1)] = bc[l].grad.numpy().copy()
+        g['bnr.weight'], g['bnr.bias'] = gamma.grad.numpy().copy(), beta.grad.numpy().copy()
+        g['fc1.weight'], g['fc1.bias'] = W1.grad.t().numpy().copy(), b1.grad.numpy().copy()
+        g['fc2.weight'], g['fc2.bias'] = W2.grad.t().numpy().copy(), b2.grad.numpy().copy()
+        return g
+    out = {('batch/' + k): b[k] for k in ('x', 'edge_index', 'edge_index2', 'edge_attr2', 'batch')}
+    out['batch/y'] = b['y'].astype(np.int64)
+    for k, v in state().items():
+        out['param/' + k] = v
+    logits = forward()
+    loss = loss_of(logits)
+    loss.backward()
+    out['logits'], out['loss'] = logits.detach().numpy(), np.float32(loss.item())
+    for k, v in grads().items():
+        out['grad/' + k] = v
+    m = [torch.zeros_like(p) for p in params]
+    v = [torch.zeros_like(p) for p in params]
+    traj, lr, b1_, b2_ = [], 0.01, 0.9, 0.999
+    for t in range(1, 6):                                             # tf.train.AdamOptimizer's update rule
+        for p_ in params:
+            p_.grad = None
+        l = loss_of(forward())
+        l.backward()
+        traj.append(l.item())
+        lr_t = lr * np.sqrt(1 - b2_ ** t) / (1 - b1_ ** t)
+        with torch.no_grad():
+            for i, p_ in enumerate(params):
+                m[i] = b1_ * m[i] + (1 - b1_) * p_.grad
+                v[i] = b2_ * v[i] + (1 - b2_) * p_.grad * p_.grad
+                p_ -= lr_t * m[i] / (torch.sqrt(v[i]) + 1e-8)
+    out['loss_traj'] = np.asarray(traj, dtype=np.float32)
+    np.savez_compressed(os.path.join(OUT, 'model_mnist_gnnml3_tf.npz'), **out)
+    print('model_mnist_gnnml3_tf.npz loss', out['loss'], 'traj', traj)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)          # deterministic summation order inside matmul
@@ -430,6 +534,7 @@ def main():
     gen_spectconv()
     gen_ml3layer()
     gen_models(mutag, tr, sr25)
+    gen_mnist_tf()
 
 
 if __name__ == '__main__':

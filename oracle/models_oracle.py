@@ -50,7 +50,8 @@ class OracleGNNML3(torch.nn.Module):
                 setattr(self, 'bn%d' % (i + 1), torch.nn.BatchNorm1d(fin))
         nin = fin
         if readout_bn:                       # TF ReadoutLayer: batch_normalization of the pooled vector
-            self.bnr = torch.nn.BatchNorm1d(nin)
+            # tf.layers.batch_normalization defaults (libs/layers_tf.py:349): epsilon 1e-3, momentum 0.99 (= 0.01 in torch's convention)
+            self.bnr = torch.nn.BatchNorm1d(nin, eps=1e-3, momentum=0.01)
         if head == 'mlp32':
             self.fc1 = torch.nn.Linear(nin, 32)
             self.fc2 = torch.nn.Linear(32, nclass)
