@@ -364,6 +364,66 @@ extern "C" int gml_segment_bcast(const float* g, int64_t ldg, const int32_t* ptr
     return gml_launch_status();
 }
 
+// global_max_pool (torch_geometric.nn, /root/reference/enzymes.py:384): per segment and column the maximum over the
+// segment's rows and the row that holds it (the FIRST one on ties: ascending scan with a strict compare); an empty
+// segment gives 0 and argmax -1 (PyG's scatter-max fills empty outputs with 0).
+__global__ void gml_k_segment_max(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ ptr,
+                                  float* __restrict__ out, int64_t ldo, int32_t* __restrict__ arg, int64_t nseg, int F) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nseg * F) return;
+    const int64_t g = i / F;
+    const int c = (int)(i % F);
+    const int r0 = ptr[g], r1 = ptr[g + 1];
+    float best = 0.f;
+    int where = -1;
+    for (int r = r0; r < r1; r += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = x[(int64_t)min(r + u, r1 - 1) * ldx + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (r + u < r1 && (where < 0 || v[u] > best)) { best = v[u]; where = r + u; }
+    }
+    out[g * ldo + c] = best;
+    if (arg) arg[g * F + c] = where;
+}
+
+extern "C" int gml_segment_max(const float* x, int64_t ldx, const int32_t* ptr, float* out, int64_t ldo, int32_t* argmax,
+                               int64_t num_segments, int32_t F, gml_stream_t stream) {
+    if (num_segments < 0 || F <= 0 || ldx < F || ldo < F) return GML_E_BADARG;
+    if (num_segments == 0) return GML_OK;
+    if (!x || !ptr || !out) return GML_E_BADARG;
+    hipLaunchKernelGGL(gml_k_segment_max, dim3((unsigned)gml_cdiv(num_segments * F, 256)), dim3(256), 0,
+                       (hipStream_t)stream, x, ldx, ptr, out, ldo, argmax, num_segments, F);
+    return gml_launch_status();
+}
+
+// its gradient: dx[r, c] = g[seg, c] where r = argmax[seg, c], 0 elsewhere.  One wave per segment writes the segment's
+// whole block (rows are owned by exactly one segment: no atomics, no separate zero fill).
+__global__ void gml_k_segment_max_bwd(const float* __restrict__ g, int64_t ldg, const int32_t* __restrict__ ptr,
+                                      const int32_t* __restrict__ arg, float* __restrict__ out, int64_t ldo, int64_t nseg, int F) {
+    const int64_t seg = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (seg >= nseg) return;
+    const int lane = threadIdx.x & 63;
+    const int r0 = ptr[seg], r1 = ptr[seg + 1];
+    const int64_t n = (int64_t)(r1 - r0) * F;
+    for (int64_t i = lane; i < n; i += 64) {
+        const int64_t r = i / F;
+        const int c = (int)(i - r * F);
+        out[(r0 + r) * ldo + c] = (arg[seg * F + c] == r0 + (int)r) ? g[seg * ldg + c] : 0.f;
+    }
+}
+
+extern "C" int gml_segment_max_bwd(const float* g, int64_t ldg, const int32_t* ptr, const int32_t* argmax, float* out,
+                                   int64_t ldo, int64_t num_segments, int32_t F, gml_stream_t stream) {
+    if (num_segments < 0 || F <= 0 || ldg < F || ldo < F) return GML_E_BADARG;
+    if (num_segments == 0) return GML_OK;
+    if (!g || !ptr || !argmax || !out) return GML_E_BADARG;
+    hipLaunchKernelGGL(gml_k_segment_max_bwd, dim3((unsigned)gml_cdiv(num_segments, 4)), dim3(256), 0,
+                       (hipStream_t)stream, g, ldg, ptr, argmax, out, ldo, num_segments, F);
+    return gml_launch_status();
+}
+
 // ---------------------------------------------------------------------------------------------
 template <bool SCATTER>
 __global__ void gml_k_perm_rows(const float* __restrict__ in, const int32_t* __restrict__ perm,

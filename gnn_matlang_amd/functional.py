@@ -28,6 +28,25 @@ _linear = torch.nn.functional.linear
 F32_MFMA = _os.environ.get('GML_F32_MFMA', '0') not in ('0', '')
 
 
+# GML_VERBOSE=1: count which kernel family every layer call takes (shapes off the compiled set degrade in SPEED, never in
+# results -- this is how a caller sees it).  PATHS maps e.g. 'conv_bwd: fused bf16x3 (S=8 Fin=32 Fout=30)' -> calls;
+# printed at exit, read by tools/bench_configs.py to assert "no unfused fallback on any BASELINE config".
+VERBOSE = _os.environ.get('GML_VERBOSE', '0') not in ('0', '')
+PATHS = {}
+
+
+def _path(kind, what, S=None, Fin=None, Fout=None):
+    if VERBOSE:
+        key = '%s: %s' % (kind, what) + ((' (S=%s Fin=%s Fout=%s)' % (S, Fin, Fout)) if S is not None else '')
+        PATHS[key] = PATHS.get(key, 0) + 1
+
+
+if VERBOSE:
+    import atexit as _atexit
+    import sys as _sys
+    _atexit.register(lambda: [print('[gml path] %5d x %s' % (n, k), file=_sys.stderr) for k, n in sorted(PATHS.items())])
+
+
 class _Timed(object):
     __slots__ = ('tag', 'q', 'f', 'e0')
 
@@ -107,7 +126,9 @@ def fwd_groups(csr, x, S, Fin, Fout):
     if _os.environ.get('GML_FWD64'):                         # experiments: force the 4-wave / 64-row kernel family
         return csr.ginfo, 0
     if int(_lib.lib().gml_spectconv_fwd_group_rows(int(S), int(Fin), int(Fout), flags)) == 128:
+        _path('conv_fwd', 'fused 8-wave bf16x3', S, Fin, Fout)
         return csr.ginfo128, _lib.GML_GROUPS128
+    _path('conv_fwd', 'fused 4-wave (%s)' % ('f32 MFMA' if (F32_MFMA or Fin > 32 or Fout > 32) else 'generic'), S, Fin, Fout)
     return csr.ginfo, 0
 
 
@@ -300,6 +321,24 @@ def segment_sum(x, ptr, mean=False):
     return out
 
 
+def segment_max(x, ptr):
+    """global_max_pool over a batch whose nodes are grouped per graph: (max [B, F], argmax rows [B, F] int32)."""
+    ptr = _ptr32(ptr)
+    B, F = int(ptr.numel() - 1), int(x.size(1))
+    out = torch.empty(B, F, dtype=torch.float32, device=x.device)
+    arg = torch.empty(B, F, dtype=torch.int32, device=x.device)
+    _lib.call('gml_segment_max', _ptr(x), int(x.stride(0)), _ptr(ptr), _ptr(out), F, _ptr(arg), B, F, _stream(x.device))
+    return out, arg
+
+
+def segment_max_bwd(g, ptr, arg, nrows):
+    ptr = _ptr32(ptr)
+    B, F = int(ptr.numel() - 1), int(g.size(1))
+    out = torch.empty(nrows, F, dtype=torch.float32, device=g.device)
+    _lib.call('gml_segment_max_bwd', _ptr(g), int(g.stride(0)), _ptr(ptr), _ptr(arg), _ptr(out), F, B, F, _stream(g.device))
+    return out
+
+
 def _bwd_plan(csr, S, Fin, Fout):
     """(flags, ginfo, (max_edges, max_window), workspace bytes) of the fused backward for this shape, or None."""
     L = _lib.lib()
@@ -315,7 +354,7 @@ def _bwd_plan(csr, S, Fin, Fout):
             ginfo, gmax = csr.ginfo_t, csr.gmax_t
         nbytes = int(L.gml_spectconv_bwd_workspace_bytes(csr.N, int(S), int(Fin), int(Fout), gmax[0], gmax[1], flags))
         if nbytes > 0:
-            return flags, ginfo, gmax, nbytes
+            return flags, ginfo, gmax, nbytes, rows
     return None
 
 
@@ -327,7 +366,7 @@ def fused_conv_bwd(csr, val_t, x, G, weight, need_x, need_val, need_w, dx_accum_
     """one launch: dX, dval (source order), dW.  val_t: supports in source order."""
     S, Fin, Fout = weight.shape
     dev = x.device
-    flags, ginfo, gmax, nbytes = _bwd_plan(csr, S, Fin, Fout)
+    flags, ginfo, gmax, nbytes, _ = _bwd_plan(csr, S, Fin, Fout)
     ld4 = (Fout + 3) // 4 * 4
     if G.stride(0) % 4 != 0 or G.stride(0) < ld4 or G.data_ptr() % 16 != 0:
         # the 8-wave kernel reads the g window as float4: rows padded (with zeros) to a multiple of 4 floats
@@ -362,6 +401,7 @@ def _conv_backward(csr, x, val, weight, G, need_x, need_val, need_w, val_t=None,
     if G.stride(1) != 1:
         G = G.contiguous()
     if fused_bwd_available(csr, S, Fin, Fout):
+        _path('conv_bwd', 'fused (group kind %d)' % _bwd_plan(csr, S, Fin, Fout)[4], S, Fin, Fout)
         if val_t is None:
             with _Timed('val_to_source_order'):
                 val_t = csr.to_source_order(val)
@@ -370,6 +410,7 @@ def _conv_backward(csr, x, val, weight, G, need_x, need_val, need_w, val_t=None,
             with _Timed('dval_from_source_order'):
                 dval_t = csr.from_source_order(dval_t)
         return dx, dval_t, dw, (want_source_order and need_val)
+    _path('conv_bwd', 'UNFUSED composition (transposed forward + SpMM + SDDMM + GEMMs)', S, Fin, Fout)
     if not G.is_contiguous():
         G = G.contiguous()
     if need_x:
@@ -460,6 +501,7 @@ class ML3LayerFunction(torch.autograd.Function):
                 # when the fused backward will run, the edge branch also emits its output in source order
                 dual = (any(ctx.needs_input_grad) and fused_bwd_available(csr, S, Fin, nout1)
                         and val.numel() * 4 < 0xffffff00)      # (32-bit scatter offsets of the second copy)
+                _path('edge', 'matrix-core chain' if max(val.size(1), w4.size(0)) <= 8 else 'VALU kernels (S > 8)', val.size(1), '-', w4.size(0))
                 with _Timed('edge_mlp_fwd', 4 * val.numel() * (3 if dual else 2), 20 * val.size(0) * val.size(1) ** 2):
                     ea, ea_t = edge_mlp_fwd(val, w1, w2, w3, w4, csr.tpos if dual else None, csr.presplit(val))
             else:
@@ -474,6 +516,8 @@ class ML3LayerFunction(torch.autograd.Function):
                                       _f32c(b12, 'fc12.bias'))
             q, f = conv_cost(N, int(ea.size(0)), S, Fin, nout1) if PROFILE is not None else (0, 0)
             mixk = nout2 > 0 and node_mix_native(Fin, nout2)
+            if nout2 > 0:
+                _path('hadamard', 'fused kernels' if mixk else 'library GEMMs (ninp > 64 or nout2 > 24)', '-', Fin, nout2)
             with _Timed('spectconv_fwd', q, f):                    # conv (+ Hadamard branch of the same rows)
                 _lib.call('gml_ml3_fwd', _ptr(csr.rowptr), _ptr(csr.col), _ptr(gi), _ptr(ea), _ptr(x), Fin, _ptr(cw),
                           Fin * nout1, nout1, 1, _ptr(cb_), _ptr(w11 if mixk else None),

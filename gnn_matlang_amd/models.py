@@ -9,7 +9,7 @@ edge_index2, edge_attr2, batch, ptr, y).
 import torch
 import torch.nn.functional as F
 
-from .functional import segment_bcast, segment_sum, tall_linear
+from .functional import segment_bcast, segment_max, segment_max_bwd, segment_sum, tall_linear
 from .spect_conv import ML3Layer, SpectConv
 
 
@@ -26,6 +26,26 @@ class _SegmentPool(torch.autograd.Function):
     def backward(ctx, g):
         ptr, batch = ctx.saved_tensors
         return segment_bcast(g.contiguous(), ptr, batch.numel(), ctx.mean), None, None, None
+
+
+class _SegmentMax(torch.autograd.Function):
+    """global_max_pool (torch_geometric.nn, used at /root/reference/enzymes.py:384): the gradient goes to the arg-max row."""
+
+    @staticmethod
+    def forward(ctx, x, ptr):
+        out, arg = segment_max(x.contiguous(), ptr)
+        ctx.save_for_backward(ptr, arg)
+        ctx.nrows = x.size(0)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ptr, arg = ctx.saved_tensors
+        return segment_max_bwd(g.contiguous(), ptr, arg, ctx.nrows), None
+
+
+def global_max_pool(x, data):
+    return _SegmentMax.apply(x, data.ptr)
 
 
 def global_add_pool(x, data):
@@ -83,7 +103,7 @@ class GNNML3(torch.nn.Module):
                 x = layer(x, csr, data.edge_attr2)
             if self.bn:
                 x = getattr(self, 'bn%d' % (i + 1))(x)
-        x = global_add_pool(x, data) if self.pool == 'add' else global_mean_pool(x, data)
+        x = {'add': global_add_pool, 'mean': global_mean_pool, 'max': global_max_pool}[self.pool](x, data)
         if self.readout_bn:
             x = self.bnr(x)
         if self.head == 'mlp32':
@@ -117,6 +137,54 @@ class GNNML1Mutag(torch.nn.Module):
             x = g('bn%d')(x)
         x = global_mean_pool(x, data)
         return tall_linear(F.relu(tall_linear(x, self.fc1)), self.fc2)
+
+
+class GNNML1(torch.nn.Module):
+    """GNNML1 as sr25.py:192-246 / graph8c.py:205-246 / mnist75.py:262-326 write it: three blocks of
+         concat=False:  x <- act( fc_i1(x) + conv_i1(x) + fc_i2(x) * fc_i3(x) )            (the scripts' setting)
+         concat=True :  x <- cat[ act(fc_i1 x), act(conv_i1 x), act(fc_i2 x * fc_i3 x) ]
+    with conv_i1 = SpectConv(K=1, selfconn=False) over the RAW adjacency with unit edge values, then pooling and
+    head 'lin10' (sr25 / graph8c: fc1: nin -> 10) or 'bn_mlp' (mnist75: bn1, relu(fc1: nin -> 32), log_softmax(fc2: 32 -> 10)).
+    Same attribute names as the reference, so its state_dict loads.  (mutag.py's variant -- relu on the factors, BatchNorm
+    per block -- is GNNML1Mutag.)"""
+
+    def __init__(self, ninp, nout=64, concat=False, act='tanh', pool='add', head='lin10', nclass=10):
+        super().__init__()
+        self.concat, self.pool, self.head = concat, pool, head
+        self.act = {'tanh': torch.tanh, 'relu': F.relu}[act]
+        nin = 3 * nout if concat else nout
+        for i, fin in enumerate([ninp, nin, nin], start=1):
+            setattr(self, 'conv%d1' % i, SpectConv(fin, nout, selfconn=False))
+            for j in (1, 2, 3):
+                setattr(self, 'fc%d%d' % (i, j), torch.nn.Linear(fin, nout))
+        if head == 'lin10':
+            self.fc1 = torch.nn.Linear(nin, nclass)
+        else:
+            self.bn1 = torch.nn.BatchNorm1d(nin)
+            self.fc1 = torch.nn.Linear(nin, 32)
+            self.fc2 = torch.nn.Linear(32, nclass)
+
+    def forward(self, data):
+        x = data.x
+        csr = data.csr('edge_index')
+        ones = torch.ones(csr.E, 1, dtype=x.dtype, device=x.device)      # sr25.py:231
+        for i in (1, 2, 3):
+            g = lambda n: getattr(self, n % i)
+            a, c, h = g('fc%d1')(x), g('conv%d1')(x, csr, ones), g('fc%d2')(x) * g('fc%d3')(x)
+            x = torch.cat([self.act(a), self.act(c), self.act(h)], 1) if self.concat else self.act(a + c + h)
+        x = {'add': global_add_pool, 'mean': global_mean_pool, 'max': global_max_pool}[self.pool](x, data)
+        if self.head == 'lin10':
+            return tall_linear(x, self.fc1)
+        x = F.relu(tall_linear(self.bn1(x), self.fc1))
+        return F.log_softmax(tall_linear(x, self.fc2), dim=1)
+
+
+def sr25_gnnml1(ninp=2):                   # sr25.py:192-246 (nout = 64, sum form, tanh, add-pool, fc1 -> 10)
+    return GNNML1(ninp, 64, concat=False, act='tanh', pool='add', head='lin10')
+
+
+def mnist75_gnnml1(ninp=3):                # mnist75.py:262-326 (relu, mean-pool, bn1, 32 -> 10; dropout p = 0.1 omitted: eval)
+    return GNNML1(ninp, 64, concat=False, act='relu', pool='mean', head='bn_mlp')
 
 
 def zinc_gnnml3(ninp=25, ne=8):            # Zinc12k.py:316-329

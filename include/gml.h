@@ -225,6 +225,13 @@ int gml_segment_sum(const float* x, int64_t ldx, const int32_t* ptr, float* out,
 /* its gradient: out[r, :] = g[seg(r), :] (/ segment length when mean != 0) for r in [ptr[seg], ptr[seg+1]) */
 int gml_segment_bcast(const float* g, int64_t ldg, const int32_t* ptr, float* out, int64_t ldo,
                       int64_t num_segments, int32_t F, int32_t mean, gml_stream_t stream);
+/* out[g, c] = max_{r in [ptr[g], ptr[g+1])} x[r, c]  (global_max_pool, /root/reference/enzymes.py:384); argmax[g, c]
+ * (int32 [num_segments, F], may be NULL) = the first row that attains it; an empty segment gives 0 / -1 */
+int gml_segment_max(const float* x, int64_t ldx, const int32_t* ptr, float* out, int64_t ldo, int32_t* argmax,
+                    int64_t num_segments, int32_t F, gml_stream_t stream);
+/* its gradient: out[r, c] = (r == argmax[seg(r), c]) ? g[seg(r), c] : 0 -- every row of every segment is written */
+int gml_segment_max_bwd(const float* g, int64_t ldg, const int32_t* ptr, const int32_t* argmax, float* out, int64_t ldo,
+                        int64_t num_segments, int32_t F, gml_stream_t stream);
 
 /* ---------------------------------------------------------------- support precompute on the device (adjacent step, P1)
  * SpectralDesign.__call__ (libs/utils.py:546-610) for a batch of graphs with at most 80 nodes each (larger: host

@@ -415,6 +415,27 @@ def gen_models(mutag, mutag_tr, sr25):
         out['seed%d/similar' % seed] = np.int64(((Mcnt == 0).sum() - Mcnt.shape[0]) / 2)          # sr25.py:299
     np.savez_compressed(os.path.join(OUT, 'model_sr25_gnnml3.npz'), **out)
     print('model_sr25_gnnml3.npz similar:', [int(out['seed%d/similar' % s]) for s in range(3)])
+    gen_sr25_gnnml1(sb)
+
+
+def gen_sr25_gnnml1(sb):
+    """sr25.py:192-246,282-300 with model = GNNML1() (the sum form, tanh): embeddings of the 15 graphs and the running
+    count of never-separated pairs for seeds 0..2; the reference SpectConv class is injected for conv_i1."""
+    out = {('batch/' + k): sb[k] for k in ('x', 'edge_index', 'edge_index2', 'edge_attr2', 'batch', 'y')}
+    Mcnt = 0
+    for seed in range(3):
+        torch.manual_seed(seed)
+        m = MO.OracleGNNML1Sum(ninp=2, conv_cls=RefSpectConv)
+        m.eval()
+        with torch.no_grad():
+            E = m(T(sb['x']), T(sb['edge_index']), T(sb['batch']), 15).numpy()
+        for n, p in m.state_dict().items():
+            out['seed%d/param/%s' % (seed, n)] = p.numpy().copy()
+        out['seed%d/emb' % seed] = E
+        Mcnt = Mcnt + 1 * ((np.abs(np.expand_dims(E, 1) - np.expand_dims(E, 0))).sum(2) > 0.001)   # sr25.py:298
+        out['seed%d/similar' % seed] = np.int64(((Mcnt == 0).sum() - Mcnt.shape[0]) / 2)          # sr25.py:299
+    np.savez_compressed(os.path.join(OUT, 'model_sr25_gnnml1.npz'), **out)
+    print('model_sr25_gnnml1.npz similar:', [int(out['seed%d/similar' % s]) for s in range(3)])
 
 
 # ------------------------------------------------------------------ H4: MNIST-75 GNNML3 of the TF pipeline

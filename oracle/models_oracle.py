@@ -101,6 +101,26 @@ class OracleGNNML1Mutag(torch.nn.Module):
         return self.fc2(F.relu(self.fc1(x)))
 
 
+class OracleGNNML1Sum(torch.nn.Module):
+    """sr25.py:192-246 (graph8c.py:205-246 alike): x <- tanh(fc_i1 x + conv_i1 x + fc_i2 x * fc_i3 x), three blocks,
+    conv_i1 = SpectConv(K=1, selfconn=False) with unit edge values, add-pool, fc1: nout -> 10."""
+
+    def __init__(self, ninp, nout=64, conv_cls=OracleSpectConv):
+        super().__init__()
+        for i, fin in enumerate([ninp, nout, nout], start=1):
+            setattr(self, 'conv%d1' % i, conv_cls(fin, nout, selfconn=False))
+            for j in (1, 2, 3):
+                setattr(self, 'fc%d%d' % (i, j), torch.nn.Linear(fin, nout))
+        self.fc1 = torch.nn.Linear(nout, 10)
+
+    def forward(self, x, edge_index, batch, num_graphs):
+        ones = torch.ones(edge_index.shape[1], 1, dtype=x.dtype, device=x.device)
+        for i in (1, 2, 3):
+            g = lambda n: getattr(self, n % i)
+            x = torch.tanh(g('fc%d1')(x) + g('conv%d1')(x, edge_index, ones) + g('fc%d2')(x) * g('fc%d3')(x))
+        return self.fc1(global_add_pool(x, batch, num_graphs))
+
+
 # ---- per-config constructors (shapes cited above) --------------------------
 def zinc_gnnml3(ninp=25, ne=8, **kw):
     return OracleGNNML3(ninp, ne, 30, 2, 4, **kw)

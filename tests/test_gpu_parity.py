@@ -575,6 +575,47 @@ def test_sr25_isomorphism_golden(dev, golden, arith):
         assert int(((Mcnt == 0).sum() - 15) / 2) == int(g['seed%d/similar' % seed])
 
 
+def test_sr25_gnnml1_sum_variant_golden(dev, golden):
+    """sr25.py:192-246 with model = GNNML1() (sum form): embeddings and the `similar` count against the reference's"""
+    from gnn_matlang_amd import models
+    g = golden('model_sr25_gnnml1.npz')
+    data = _batch_from(g, dev)
+    Mcnt = 0
+    for seed in range(3):
+        m = models.sr25_gnnml1(2)
+        m.load_state_dict({k: T(v) for k, v in g.sub('seed%d/param/' % seed).items()})
+        m = m.to(dev).eval()
+        with torch.no_grad():
+            E = m(data).cpu().numpy()
+        close(E, g['seed%d/emb' % seed], what='GNNML1 embeddings seed %d' % seed)
+        Mcnt = Mcnt + 1 * (np.abs(E[:, None] - E[None]).sum(2) > 0.001)
+        assert int(((Mcnt == 0).sum() - 15) / 2) == int(g['seed%d/similar' % seed])
+    # the other assembly of the class (mnist75.py:262-326: relu, mean-pool, bn1, 32 -> 10) runs and trains
+    m2 = models.mnist75_gnnml1(2).to(dev).train()
+    out = m2(data)
+    assert out.shape == (15, 10) and torch.isfinite(out).all()
+    out[:, 0].sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m2.parameters())
+
+
+def test_global_max_pool(dev):
+    """gml_segment_max / _bwd (global_max_pool, enzymes.py:384) against torch: values, arg-max gradient routing, empty segment"""
+    from gnn_matlang_amd import models
+    from gnn_matlang_amd.graph import Batch
+    rng = np.random.default_rng(11)
+    sizes = [5, 1, 0, 17, 64, 3]
+    ptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    x = torch.tensor(rng.standard_normal((ptr[-1], 13)).astype(np.float32), device=dev, requires_grad=True)
+    data = Batch(x=x, ptr=T(ptr).to(dev), batch=T(np.repeat(np.arange(len(sizes)), sizes)).to(dev))
+    out = models.global_max_pool(x, data)
+    gout = torch.randn_like(out)
+    (out * gout).sum().backward()
+    xr = x.detach().clone().requires_grad_(True)
+    ref = torch.stack([xr[ptr[i]:ptr[i + 1]].max(0)[0] if sizes[i] else torch.zeros(13, device=dev) for i in range(len(sizes))])
+    (ref * gout).sum().backward()
+    assert torch.equal(out, ref) and torch.equal(x.grad, xr.grad)
+
+
 def test_mnist75_gnnml3_vs_oracle(dev, arith):
     """config 4 (TF DSGCNN: S=6 near-dense supports of 75-node graphs, widths 2->64->128->128, mean readout + BN):
     the TF reference cannot run here, so this config is checked against the CPU oracle only (parity unpinned by

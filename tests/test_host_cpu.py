@@ -13,6 +13,7 @@ import torch
 import gnn_matlang_amd as G
 from gnn_matlang_amd import _lib, models, synthetic
 from gnn_matlang_amd.graph import collate, shard_graphs
+from conftest import GOLDEN
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 T = lambda a: torch.tensor(np.asarray(a))
@@ -188,3 +189,21 @@ def test_device_dataset_batches_equal_host_collate():
         assert a.shape == b.shape and torch.equal(a.to(b.dtype), b), k
     seen = torch.cat([b.y for b in dd.epoch(5, generator=torch.Generator().manual_seed(0))])
     assert seen.numel() == 12 and torch.equal(torch.sort(seen)[0], torch.sort(dd.y)[0])   # one epoch = every graph once
+
+
+def test_raw_readers_reproduce_the_reference_datasets():
+    """readers.py (numpy only) on the raw files the reference ships (tests/golden/raw: mutag.mat 22 KB, sr251256.g6 780 B)
+    against the arrays the golden generator extracted with scipy / networkx through the reference's own ``process``
+    bodies (libs/utils.py:192-209, 506-513)."""
+    from gnn_matlang_amd import readers
+    raw = os.path.join(GOLDEN, 'raw')
+    for fname, loader, gold in (('mutag.mat', readers.load_mutag, 'data_mutag.npz'),
+                                ('sr251256.g6', readers.load_sr, 'data_sr25.npz')):
+        graphs = loader(os.path.join(raw, fname))
+        z = np.load(os.path.join(GOLDEN, gold))
+        nptr, eptr = z['node_ptr'], z['edge_ptr']
+        assert len(graphs) == len(nptr) - 1
+        for i, (x, ei, y) in enumerate(graphs):
+            assert np.array_equal(x, z['x'][nptr[i]:nptr[i + 1]]) and x.dtype == np.float32, (fname, i)
+            assert np.array_equal(ei, z['edge_index'][:, eptr[i]:eptr[i + 1]]) and ei.dtype == np.int64, (fname, i)
+            assert float(y) == float(z['y'][i])

@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gnn_matlang_amd import SpectralDesign, collate, models, synthetic, functional as Fn
 
 dev = torch.device('cuda:0')
+Fn.VERBOSE = True            # record the kernel family of every layer call (functional.PATHS)
 CFG = [('counting', 'counting', 256, 64, dict(recfield=1, dv=1, nfreq=10, addadj=True), lambda: models.counting_gnnml3(1, 12), models.counting_loss, 1),
        ('sr25', 'regular', 64, 32, dict(recfield=1, dv=1, nfreq=5), lambda: models.sr25_gnnml3(1, 6), None, 1),
        ('mutag_gnnml3', 'zinc', 512, 32, dict(recfield=1, dv=1, nfreq=3), lambda: models.mutag_gnnml3(21, 4), models.mutag_loss, 21)]
@@ -33,7 +34,10 @@ for name, kind, pool_n, reps, kw, ctor, loss, fdim in CFG:
         l = loss(pre, data.y) if loss is not None else pre.square().sum()
         l.backward()
         opt.step()
-    for _ in range(3):
+    Fn.PATHS.clear()
+    step()
+    paths = dict(Fn.PATHS)
+    for _ in range(2):
         step()
     torch.cuda.synchronize()
     Fn.PROFILE = {}
@@ -47,4 +51,6 @@ for name, kind, pool_n, reps, kw, ctor, loss, fdim in CFG:
     Fn.PROFILE = None
     print(json.dumps(dict(config=name, graphs=B, nodes=int(data.x.size(0)), support_edges=int(data.edge_index2.size(1)),
                           S=int(data.edge_attr2.size(1)), ms_per_step=round(dt * 1e3, 3), graphs_per_s=round(B / dt),
-                          kernels_ms_per_step={k: round(v['ms'] * v['launches'] / n, 3) for k, v in summ.items()})))
+                          kernels_ms_per_step={k: round(v['ms'] * v['launches'] / n, 3) for k, v in summ.items()},
+                          kernel_paths_per_step=paths,
+                          slow_paths=sorted(k for k in paths if 'UNFUSED' in k or 'library GEMMs' in k or 'VALU kernels' in k))))
