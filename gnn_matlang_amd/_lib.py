@@ -18,10 +18,12 @@ SIGNATURES = {
     'gml_error_string': (ctypes.c_char_p, [ctypes.c_int]),
     'gml_csr_workspace_bytes': (_sz, [_i64, _i64]),
     'gml_csr_from_coo': (ctypes.c_int, [_p, _p, _i64, _i64, _p, _p, _p, _p, _sz, _p]),
+    'gml_csr_from_sorted_coo': (ctypes.c_int, [_p, _p, _i64, _i64, _p, _p, _p, _p, _sz, _p]),
     'gml_csr_link_transpose': (ctypes.c_int, [_p, _p, _i64, _p, _p, _p]),
     'gml_csr_group_record_ints': (ctypes.c_int32, [_i32]),
     'gml_csr_group_info': (ctypes.c_int, [_p, _p, _i64, _i32, _p, _p]),
     'gml_gather_rows': (ctypes.c_int, [_p, _p, _p, _i64, _i32, _p]),
+    'gml_gather_rows_presplit': (ctypes.c_int, [_p, _p, _p, _p, _i64, _i32, _p]),
     'gml_scatter_rows': (ctypes.c_int, [_p, _p, _p, _i64, _i32, _p]),
     'gml_spectconv_fwd_group_rows': (ctypes.c_int32, [_i32, _i32, _i32, ctypes.c_uint32]),
     'gml_spectconv_fwd': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _p, _p, _i64,

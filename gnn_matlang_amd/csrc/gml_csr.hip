@@ -158,6 +158,45 @@ extern "C" int gml_csr_from_coo(const int64_t* key, const int64_t* other_in, int
     return gml_launch_status();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Keys that are ALREADY non-decreasing (the reference's transform emits edge_index2 in row-major np.where order,
+// libs/utils.py:608-609: sorted by source): the view keyed by them needs no sort at all -- rowptr from the run
+// boundaries, perm = identity.  A decreasing pair sets bit 1 of *bad (the caller then builds this view the general way).
+__global__ void gml_k_sorted_view(const int64_t* __restrict__ key, const int64_t* __restrict__ other_in, int64_t E, int64_t N,
+                                  int32_t* __restrict__ rowptr, int32_t* __restrict__ other, int32_t* __restrict__ perm,
+                                  int32_t* __restrict__ bad) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e > E) return;
+    if (e < E) {
+        other[e] = (int32_t)gml_checked_key(other_in[e], N, bad);
+        perm[e] = (int32_t)e;
+    }
+    const int64_t kprev = e == 0 ? -1 : gml_checked_key(key[e - 1], N, bad);
+    const int64_t kcur = e == E ? N : gml_checked_key(key[e], N, bad);
+    // Not sorted: flagged.  rowptr was zero-filled and only ever receives values <= E, perm is the identity and other is
+    // range-checked, so whatever the caller launches on these arrays before it reads the flag stays inside them.
+    if (kcur < kprev) { atomicOr(bad, 2); return; }
+    for (int64_t r = kprev + 1; r <= kcur; ++r) rowptr[r] = (int32_t)e;      // rows (kprev, kcur] start at e (empty rows included)
+}
+
+extern "C" int gml_csr_from_sorted_coo(const int64_t* key, const int64_t* other_in, int64_t num_nodes, int64_t num_edges,
+                                       int32_t* rowptr, int32_t* other, int32_t* perm, void* ws, size_t ws_bytes,
+                                       gml_stream_t stream) {
+    if (num_nodes < 0 || num_edges < 0) return GML_E_BADARG;
+    if (num_nodes >= INT32_MAX || num_edges >= INT32_MAX) return GML_E_UNSUPPORTED;
+    if (!rowptr) return GML_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t he = hipMemsetAsync(rowptr, 0, sizeof(int32_t) * (num_nodes + 1), st);
+    if (he != hipSuccess) return (int)he;
+    if (num_edges == 0 || num_nodes == 0) return GML_OK;
+    if (!key || !other_in || !other || !perm || !ws) return GML_E_BADARG;
+    if (ws_bytes < gml_csr_workspace_bytes(num_nodes, num_edges)) return GML_E_WORKSPACE;
+    int32_t* bad = (int32_t*)((char*)ws + gml_csr_workspace_bytes(num_nodes, num_edges) - sizeof(int32_t));
+    hipLaunchKernelGGL(gml_k_sorted_view, dim3((unsigned)gml_cdiv(num_edges + 1, 256)), dim3(256), 0, st, key, other_in,
+                       num_edges, num_nodes, rowptr, other, perm, bad);
+    return gml_launch_status();
+}
+
 __global__ void gml_k_invert(const int32_t* __restrict__ perm, int64_t E, int32_t* __restrict__ inv) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k < E) inv[perm[k]] = (int32_t)k;

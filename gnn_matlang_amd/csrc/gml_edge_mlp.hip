@@ -90,6 +90,52 @@ __global__ __launch_bounds__(256) void gml_k_edge_presplit(const float* __restri
     o[1] = u32x4{lo[0], lo[1], lo[2], lo[3]};
 }
 
+// the same with the row gather of the value sort in front: out[k] = in[perm[k]] and its pre-split in ONE pass (a fresh
+// batch otherwise reads and writes the supports twice: gml_gather_rows, then gml_edge_presplit)
+__global__ __launch_bounds__(256) void gml_k_gather_presplit(const float* __restrict__ in, const int32_t* __restrict__ perm,
+                                                            float* __restrict__ out, uint32_t* __restrict__ es,
+                                                            int64_t E, int S) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    const float* src = in + (int64_t)perm[e] * S;
+    float x[8];
+    if (S == 8) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(src)[0], b = reinterpret_cast<const f32x4*>(src)[1];
+        x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+        reinterpret_cast<f32x4*>(out + e * 8)[0] = a;
+        reinterpret_cast<f32x4*>(out + e * 8)[1] = b;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            x[j] = (j < S) ? src[j] : 0.f;
+            if (j < S) out[e * S + j] = x[j];
+        }
+    }
+    uint32_t hi[4], lo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float t0 = __uint_as_float(__float_as_uint(x[2 * j]) & 0xffff0000u);
+        const float t1 = __uint_as_float(__float_as_uint(x[2 * j + 1]) & 0xffff0000u);
+        hi[j] = gml_pack2(t0, t1);
+        lo[j] = gml_pack2(x[2 * j] - t0, x[2 * j + 1] - t1);
+    }
+    u32x4* o = reinterpret_cast<u32x4*>(es + e * 8);
+    o[0] = u32x4{hi[0], hi[1], hi[2], hi[3]};
+    o[1] = u32x4{lo[0], lo[1], lo[2], lo[3]};
+}
+
+extern "C" int gml_gather_rows_presplit(const float* in, const int32_t* perm, float* out, void* out_split, int64_t rows,
+                                        int32_t S, gml_stream_t stream) {
+    if (rows < 0 || S <= 0) return GML_E_BADARG;
+    if (S > 8) return GML_E_UNSUPPORTED;
+    if (rows == 0) return GML_OK;
+    if (!in || !perm || !out || !out_split) return GML_E_BADARG;
+    if ((((uintptr_t)out_split) & 15) != 0 || (S == 8 && ((((uintptr_t)in) | ((uintptr_t)out)) & 15) != 0)) return GML_E_BADARG;
+    hipLaunchKernelGGL(gml_k_gather_presplit, dim3((unsigned)gml_cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream, in, perm,
+                       out, (uint32_t*)out_split, rows, S);
+    return gml_launch_status();
+}
+
 extern "C" int gml_edge_presplit(const float* ea, void* ea_split, int64_t num_edges, int32_t S, gml_stream_t stream) {
     if (num_edges < 0 || S <= 0) return GML_E_BADARG;
     if (S > 8) return GML_E_UNSUPPORTED;

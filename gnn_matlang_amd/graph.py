@@ -35,17 +35,21 @@ def _require_cuda(t, name):
 
 
 class GraphCSR(object):
-    __slots__ = ('N', 'E', 'device', 'rowptr', 'col', 'perm', 'rowptr_t', 'col_t', 'pos_t', 'perm_t',
-                 'ginfo', 'ginfo_t', 'gmax', 'gmax_t', 'ginfo_t128', 'gmax_t128', 'ginfo128', 'tpos', '_val_cache', '_keep',
+    __slots__ = ('N', 'E', 'device', 'rowptr', 'col', 'perm', 'rowptr_t', 'col_t', 'pos_t', 'perm_t', 'src_sorted',
+                 '_ginfo', '_ginfo_t', '_gmax', '_gmax_t', 'ginfo_t128', 'gmax_t128', 'ginfo128', 'tpos', '_val_cache', '_keep',
                  '_r64t')
 
     def __init__(self):
         self._val_cache = OrderedDict()
         self._keep = None
         self._r64t = None
+        self._ginfo = self._ginfo_t = self._gmax = self._gmax_t = None
 
     @staticmethod
-    def from_edge_index(edge_index, num_nodes):
+    def from_edge_index(edge_index, num_nodes, assume_source_sorted=True):
+        """assume_source_sorted: try the no-sort construction of the source view first (edge_index2 as SpectralDesign
+        emits it is sorted by source, libs/utils.py:608-609); the kernel checks, and an unsorted input is rebuilt the
+        general way after the one host read this function does anyway."""
         _require_cuda(edge_index, 'edge_index')
         if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.size(0) != 2:
             raise ValueError('edge_index must be int64 [2, E], got %s %s' % (edge_index.dtype, tuple(edge_index.shape)))
@@ -60,42 +64,59 @@ class GraphCSR(object):
             L = _lib.lib()
             nws = max(int(L.gml_csr_workspace_bytes(N, E)), 4)
             ws = torch.empty(nws, dtype=torch.uint8, device=dev)
-            bad = ws[nws - 4:].view(torch.int32)               # OR-ed by the index kernels when a node id is out of range
+            bad = ws[nws - 4:].view(torch.int32)               # bit 0: a node id out of range; bit 1: source keys not sorted
             bad.zero_()
             src, dst = ei[0], ei[1]
             g.rowptr, g.col, g.perm = torch.empty(N + 1, **i32), torch.empty(E, **i32), torch.empty(E, **i32)
             _lib.call('gml_csr_from_coo', _ptr(dst), _ptr(src), N, E, _ptr(g.rowptr), _ptr(g.col), _ptr(g.perm),
                       _ptr(ws), ws.numel(), st)
             g.rowptr_t, g.col_t, g.perm_t = torch.empty(N + 1, **i32), torch.empty(E, **i32), torch.empty(E, **i32)
-            _lib.call('gml_csr_from_coo', _ptr(src), _ptr(dst), N, E, _ptr(g.rowptr_t), _ptr(g.col_t), _ptr(g.perm_t),
-                      _ptr(ws), ws.numel(), st)
+            _lib.call('gml_csr_from_sorted_coo' if assume_source_sorted else 'gml_csr_from_coo', _ptr(src), _ptr(dst), N, E,
+                      _ptr(g.rowptr_t), _ptr(g.col_t), _ptr(g.perm_t), _ptr(ws), ws.numel(), st)
             inv = torch.empty(E, **i32)
             g.pos_t = torch.empty(E, **i32)
             _lib.call('gml_csr_link_transpose', _ptr(g.perm), _ptr(g.perm_t), E, _ptr(inv), _ptr(g.pos_t), st)
             # tpos = inverse of pos_t: source-sorted position of every target-sorted edge
             g.tpos = torch.empty(E, **i32)
             _lib.call('gml_csr_link_transpose', _ptr(g.pos_t), _ptr(g.pos_t), E, _ptr(g.tpos), _ptr(inv), st)
-            ng = max((N + 63) // 64, 1)
-            rec64 = int(_lib.lib().gml_csr_group_record_ints(64))    # int32 per group record
-            rec128 = int(_lib.lib().gml_csr_group_record_ints(128))
-            g.ginfo, g.ginfo_t = torch.zeros(ng, rec64, **i32), torch.zeros(ng, rec64, **i32)
+            # 128-row group records of both views (the 8-wave kernels); the 64-row ones are built on first use
             ng2 = max((N + 127) // 128, 1)
+            rec128 = int(_lib.lib().gml_csr_group_record_ints(128))
             g.ginfo_t128 = torch.zeros(ng2, rec128, **i32)
             g.ginfo128 = torch.zeros(ng2, rec128, **i32)
-            _lib.call('gml_csr_group_info', _ptr(g.rowptr), _ptr(g.col), N, 64, _ptr(g.ginfo), st)
-            _lib.call('gml_csr_group_info', _ptr(g.rowptr_t), _ptr(g.col_t), N, 64, _ptr(g.ginfo_t), st)
             _lib.call('gml_csr_group_info', _ptr(g.rowptr_t), _ptr(g.col_t), N, 128, _ptr(g.ginfo_t128), st)
             _lib.call('gml_csr_group_info', _ptr(g.rowptr), _ptr(g.col), N, 128, _ptr(g.ginfo128), st)
-            # per-batch maxima (edges per 64-row group, column window): they size the LDS staging of the fused
-            # backward kernel.  One device->host read per batch, at index-build time (not in the step).
-            # The same read carries the bad-id flag of the index kernels (ids outside [0, num_nodes) were clamped there, so
-            # nothing was written out of bounds): raise like the reference's scatter does for such an edge_index.
-            mx = torch.stack([g.ginfo[:, 1].max(), g.ginfo[:, 3].max(), g.ginfo_t[:, 1].max(),
-                              g.ginfo_t[:, 3].max(), g.ginfo_t128[:, 1].max(), g.ginfo_t128[:, 3].max(), bad[0]]).tolist()
-            g.gmax, g.gmax_t, g.gmax_t128 = (int(mx[0]), int(mx[1])), (int(mx[2]), int(mx[3])), (int(mx[4]), int(mx[5]))
-            if mx[6]:
+            # ONE device->host read per batch, at index-build time (not in the step): the per-batch maxima that size the LDS
+            # staging of the fused backward, and the flag word of the index kernels (ids outside [0, num_nodes) were
+            # clamped there, so nothing was written out of bounds: raise like the reference's scatter does)
+            mx = torch.stack([g.ginfo_t128[:, 1].max(), g.ginfo_t128[:, 3].max(), bad[0]]).tolist()
+            g.gmax_t128 = (int(mx[0]), int(mx[1]))
+            if mx[2] & 1:
                 raise IndexError('edge_index holds node ids outside [0, %d)' % N)
+            if mx[2] & 2:                                      # source keys were not sorted: general construction
+                return GraphCSR.from_edge_index(edge_index, num_nodes, assume_source_sorted=False)
+            g.src_sorted = bool(assume_source_sorted)
         return g
+
+    def _need64(self):
+        """64-row group records of both views (the 4-wave kernel families: shapes off the 8-wave kernels' set) + maxima"""
+        if self._ginfo is None:
+            with torch.cuda.device(self.device):
+                st = _stream(self.device)
+                i32 = dict(dtype=torch.int32, device=self.device)
+                ng = max((self.N + 63) // 64, 1)
+                rec64 = int(_lib.lib().gml_csr_group_record_ints(64))
+                gi, git = torch.zeros(ng, rec64, **i32), torch.zeros(ng, rec64, **i32)
+                _lib.call('gml_csr_group_info', _ptr(self.rowptr), _ptr(self.col), self.N, 64, _ptr(gi), st)
+                _lib.call('gml_csr_group_info', _ptr(self.rowptr_t), _ptr(self.col_t), self.N, 64, _ptr(git), st)
+                mx = torch.stack([gi[:, 1].max(), gi[:, 3].max(), git[:, 1].max(), git[:, 3].max()]).tolist()
+                self._gmax, self._gmax_t = (int(mx[0]), int(mx[1])), (int(mx[2]), int(mx[3]))
+                self._ginfo, self._ginfo_t = gi, git
+
+    ginfo = property(lambda self: (self._need64(), self._ginfo)[1])
+    ginfo_t = property(lambda self: (self._need64(), self._ginfo_t)[1])
+    gmax = property(lambda self: (self._need64(), self._gmax)[1])
+    gmax_t = property(lambda self: (self._need64(), self._gmax_t)[1])
 
     def ranked64_t(self):
         """(records, (max edges, max window)) of the source view in ranked 64-row groups: the staging schedule of the
@@ -117,10 +138,20 @@ class GraphCSR(object):
             return self._val_cache[key][1]
         ea = edge_attr.contiguous()
         out = torch.empty_like(ea)
-        _lib.call('gml_gather_rows', _ptr(ea), _ptr(self.perm), _ptr(out), self.E, int(ea.size(1)), _stream(ea.device))
+        S = int(ea.size(1))
+        if cache and S <= 8 and self.E > 0 and (S != 8 or (ea.data_ptr() | out.data_ptr()) % 16 == 0):
+            # per-batch data: the sorted rows and their bf16 pre-split (the matrix-core edge kernels' operand) in one pass
+            es = torch.empty(self.E, 8, dtype=torch.int32, device=ea.device)
+            _lib.call('gml_gather_rows_presplit', _ptr(ea), _ptr(self.perm), _ptr(out), _ptr(es), self.E, S, _stream(ea.device))
+            self._val_cache[('p', out.data_ptr(), out._version, tuple(out.shape))] = (out, es)
+        else:
+            _lib.call('gml_gather_rows', _ptr(ea), _ptr(self.perm), _ptr(out), self.E, S, _stream(ea.device))
         if cache:
             self._val_cache[key] = (edge_attr, out)        # keep the source alive: its address is the key
-            while len(self._val_cache) > 8:
+            if self.src_sorted and ea is edge_attr:
+                # input order IS source order: the source-order copy of these values is the input itself
+                self._val_cache[('t', out.data_ptr(), out._version, tuple(out.shape))] = (out, ea)
+            while len(self._val_cache) > 12:
                 self._val_cache.popitem(last=False)
         return out
 
@@ -135,7 +166,7 @@ class GraphCSR(object):
                   _stream(val_sorted.device))
         if cache:
             self._val_cache[key] = (val_sorted, out)
-            while len(self._val_cache) > 8:
+            while len(self._val_cache) > 12:
                 self._val_cache.popitem(last=False)
         return out
 
@@ -154,7 +185,7 @@ class GraphCSR(object):
         out = edge_presplit(val)
         if out is not None:
             self._val_cache[key] = (val, out)
-            while len(self._val_cache) > 8:
+            while len(self._val_cache) > 12:
                 self._val_cache.popitem(last=False)
         return out
 

@@ -69,6 +69,13 @@ size_t gml_csr_workspace_bytes(int64_t num_nodes, int64_t num_edges);
 int gml_csr_from_coo(const int64_t* key, const int64_t* other_in, int64_t num_nodes, int64_t num_edges,
                      int32_t* rowptr, int32_t* other, int32_t* perm,
                      void* ws, size_t ws_bytes, gml_stream_t stream);
+/* The same for keys that are ALREADY non-decreasing (edge_index2 as the reference's transform emits it is sorted by
+ * source, libs/utils.py:608-609): no sort -- rowptr from the run boundaries, perm = identity, one pass.  If a key is
+ * smaller than its predecessor, bit 1 (value 2) of the workspace's flag word is set and the outputs are unspecified: the
+ * caller must then use gml_csr_from_coo for this view. */
+int gml_csr_from_sorted_coo(const int64_t* key, const int64_t* other_in, int64_t num_nodes, int64_t num_edges,
+                            int32_t* rowptr, int32_t* other, int32_t* perm,
+                            void* ws, size_t ws_bytes, gml_stream_t stream);
 /* pos_t[j] = inverse(perm_fwd)[perm_t[j]]: where, in forward (target-sorted) order, the j-th
  * source-sorted edge keeps its values.  inv_scratch: E int32. */
 int gml_csr_link_transpose(const int32_t* perm_fwd, const int32_t* perm_t, int64_t num_edges,
@@ -90,6 +97,9 @@ int gml_csr_group_info(const int32_t* rowptr, const int32_t* col, int64_t num_ro
 /* out[k, :] = in[perm[k], :]   (rows of `width` floats) */
 int gml_gather_rows(const float* in, const int32_t* perm, float* out, int64_t rows, int32_t width,
                     gml_stream_t stream);
+/* out[k, :] = in[perm[k], :] and, in the same pass, its bf16 pre-split (gml_edge_presplit of out); S <= 8 */
+int gml_gather_rows_presplit(const float* in, const int32_t* perm, float* out, void* out_split, int64_t rows,
+                             int32_t S, gml_stream_t stream);
 /* out[perm[k], :] = in[k, :] */
 int gml_scatter_rows(const float* in, const int32_t* perm, float* out, int64_t rows, int32_t width,
                      gml_stream_t stream);
