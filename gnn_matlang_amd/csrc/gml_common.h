@@ -57,6 +57,27 @@ static inline hipError_t gml_allow_big_lds_impl(std::atomic<uint64_t>& done, con
 
 static inline int64_t gml_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Zero fill / copy as KERNELS, not hipMemsetAsync / hipMemcpyAsync: on this ROCm the runtime calls issued while a stream
+// is being captured into a HIP graph ran at capture time only -- a replayed index build then accumulated its row
+// histogram on top of the previous replay's row pointers and the slot kernel wrote out of bounds (r02, bench.py's captured
+// epoch).  A kernel launch is captured like every other launch of the library.
+static __global__ void gml_k_fill_zero_u32(uint32_t* __restrict__ p, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+static __global__ void gml_k_copy_u32(const uint32_t* __restrict__ a, uint32_t* __restrict__ b, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) b[i] = a[i];
+}
+static inline void gml_zero_async(void* p, size_t nbytes, hipStream_t st) {        // nbytes: a multiple of 4
+    const int64_t n = (int64_t)(nbytes / 4);
+    if (n > 0) hipLaunchKernelGGL(gml_k_fill_zero_u32, dim3((unsigned)gml_cdiv(n, 256)), dim3(256), 0, st, (uint32_t*)p, n);
+}
+static inline void gml_copy_async(void* dst, const void* src, size_t nbytes, hipStream_t st) {
+    const int64_t n = (int64_t)(nbytes / 4);
+    if (n > 0) hipLaunchKernelGGL(gml_k_copy_u32, dim3((unsigned)gml_cdiv(n, 256)), dim3(256), 0, st, (const uint32_t*)src, (uint32_t*)dst, n);
+}
+
 // Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, observed, speed only).
 // Give each XCD one contiguous range of work items so neighbouring row tiles (which gather the
 // same X rows and value lines) share an L2.  Bijective for any grid size.

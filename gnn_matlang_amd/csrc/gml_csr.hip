@@ -134,8 +134,7 @@ extern "C" int gml_csr_from_coo(const int64_t* key, const int64_t* other_in, int
     if (!rowptr) return GML_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     const int64_t n1 = num_nodes + 1;
-    hipError_t he = hipMemsetAsync(rowptr, 0, sizeof(int32_t) * n1, st);
-    if (he != hipSuccess) return (int)he;
+    gml_zero_async(rowptr, sizeof(int32_t) * n1, st);
     if (num_edges == 0 || num_nodes == 0) return GML_OK;
     if (!key || !other_in || !other || !perm || !ws) return GML_E_BADARG;
     if (ws_bytes < gml_csr_workspace_bytes(num_nodes, num_edges)) return GML_E_WORKSPACE;
@@ -149,8 +148,7 @@ extern "C" int gml_csr_from_coo(const int64_t* key, const int64_t* other_in, int
     hipLaunchKernelGGL(gml_k_scan_tiles, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, rowptr, n1, sums);
     hipLaunchKernelGGL(gml_k_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, st, sums, nb);
     hipLaunchKernelGGL(gml_k_scan_add, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, rowptr, n1, sums);
-    he = hipMemcpyAsync(cursor, rowptr, sizeof(int32_t) * n1, hipMemcpyDeviceToDevice, st);
-    if (he != hipSuccess) return (int)he;
+    gml_copy_async(cursor, rowptr, sizeof(int32_t) * n1, st);
     hipLaunchKernelGGL(gml_k_slot, dim3(eg), dim3(256), 0, st, key, num_edges, num_nodes, cursor, perm, bad);
     hipLaunchKernelGGL(gml_k_sort_rows, dim3((unsigned)gml_cdiv(num_nodes, 256)), dim3(256), 0, st, rowptr,
                        num_nodes, perm);
@@ -186,8 +184,7 @@ extern "C" int gml_csr_from_sorted_coo(const int64_t* key, const int64_t* other_
     if (num_nodes >= INT32_MAX || num_edges >= INT32_MAX) return GML_E_UNSUPPORTED;
     if (!rowptr) return GML_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t he = hipMemsetAsync(rowptr, 0, sizeof(int32_t) * (num_nodes + 1), st);
-    if (he != hipSuccess) return (int)he;
+    gml_zero_async(rowptr, sizeof(int32_t) * (num_nodes + 1), st);
     if (num_edges == 0 || num_nodes == 0) return GML_OK;
     if (!key || !other_in || !other || !perm || !ws) return GML_E_BADARG;
     if (ws_bytes < gml_csr_workspace_bytes(num_nodes, num_edges)) return GML_E_WORKSPACE;

@@ -194,10 +194,10 @@ extern "C" int gml_edge_mlp_bwd(const float* ea, const void* ea_split, const flo
     if (S != Sout) return GML_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     if (num_edges == 0) {
-        hipMemsetAsync(dw1, 0, sizeof(float) * 2 * S * S, st);
-        hipMemsetAsync(dw2, 0, sizeof(float) * 2 * S * S, st);
-        hipMemsetAsync(dw3, 0, sizeof(float) * 2 * S * S, st);
-        hipMemsetAsync(dw4, 0, sizeof(float) * 4 * S * Sout, st);
+        gml_zero_async(dw1, sizeof(float) * 2 * S * S, st);
+        gml_zero_async(dw2, sizeof(float) * 2 * S * S, st);
+        gml_zero_async(dw3, sizeof(float) * 2 * S * S, st);
+        gml_zero_async(dw4, sizeof(float) * 4 * S * Sout, st);
         return gml_launch_status();
     }
     if (!ea || !gout || !ws) return GML_E_BADARG;

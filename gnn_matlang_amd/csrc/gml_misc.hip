@@ -261,10 +261,10 @@ extern "C" int gml_node_mix_bwd(const float* x, int64_t ldx, const float* w11, c
     if (!w11 || !w12 || !dw11 || !dw12) return GML_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     if (num_rows == 0) {
-        hipMemsetAsync(dw11, 0, sizeof(float) * F2 * Fin, st);
-        hipMemsetAsync(dw12, 0, sizeof(float) * F2 * Fin, st);
-        if (db11) hipMemsetAsync(db11, 0, sizeof(float) * F2, st);
-        if (db12) hipMemsetAsync(db12, 0, sizeof(float) * F2, st);
+        gml_zero_async(dw11, sizeof(float) * F2 * Fin, st);
+        gml_zero_async(dw12, sizeof(float) * F2 * Fin, st);
+        if (db11) gml_zero_async(db11, sizeof(float) * F2, st);
+        if (db12) gml_zero_async(db12, sizeof(float) * F2, st);
         return gml_launch_status();
     }
     if (!x || !gout) return GML_E_BADARG;

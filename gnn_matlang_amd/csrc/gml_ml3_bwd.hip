@@ -329,12 +329,12 @@ extern "C" int gml_ml3_split_bwd(const float* gy, int64_t ldgy, const float* y, 
     hipStream_t st = (hipStream_t)stream;
     if (F2 == 0) Fin = 0;
     if (num_rows == 0) {
-        if (dcb) hipMemsetAsync(dcb, 0, sizeof(float) * nout1, st);
+        if (dcb) gml_zero_async(dcb, sizeof(float) * nout1, st);
         if (F2 > 0) {
-            hipMemsetAsync(dw11, 0, sizeof(float) * F2 * Fin, st);
-            hipMemsetAsync(dw12, 0, sizeof(float) * F2 * Fin, st);
-            if (db11) hipMemsetAsync(db11, 0, sizeof(float) * F2, st);
-            if (db12) hipMemsetAsync(db12, 0, sizeof(float) * F2, st);
+            gml_zero_async(dw11, sizeof(float) * F2 * Fin, st);
+            gml_zero_async(dw12, sizeof(float) * F2 * Fin, st);
+            if (db11) gml_zero_async(db11, sizeof(float) * F2, st);
+            if (db12) gml_zero_async(db12, sizeof(float) * F2, st);
         }
         return gml_launch_status();
     }
@@ -480,7 +480,7 @@ extern "C" int gml_xty(const float* A, int64_t lda, const float* B, int64_t ldb,
     if (a > 64 || b > 64) return GML_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) {
-        hipMemsetAsync(out, 0, sizeof(float) * a * b, st);
+        gml_zero_async(out, sizeof(float) * a * b, st);
         return gml_launch_status();
     }
     if (!A || !B) return GML_E_BADARG;

@@ -142,7 +142,7 @@ extern "C" int gml_spectconv_bwd(const int32_t* rowptr, const int32_t* col, cons
     if (dx && lddx < Fin) return GML_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     if (num_rows == 0) {
-        if (dw) hipMemsetAsync(dw, 0, sizeof(float) * S * Fin * Fout, st);
+        if (dw) gml_zero_async(dw, sizeof(float) * S * Fin * Fout, st);
         return gml_launch_status();
     }
     if (!rowptr || !ginfo || !x || !g || !w) return GML_E_BADARG;

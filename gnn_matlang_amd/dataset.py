@@ -73,6 +73,60 @@ class DeviceDataset(object):
             out['edge_attr2'] = self.edge_attr2[epos2]
         return Batch(**out)
 
+    # ------------------------------------------------------------------ static shapes: one captured step for every batch
+    def bounds(self, batch_size):
+        """dict(n_pad, e2_pad, dmax, caps) that hold for EVERY batch of batch_size graphs of this data set -- what a
+        HIP-graph-captured step is sized with (one host read per data set, not per batch).  caps = (edges, column window)
+        per 128 source rows; n_pad leaves room for e2_pad / dmax padding nodes, so that the padding edges can be dealt dmax
+        per node and the caps also hold on the padding."""
+        n = (self.node_ptr[1:] - self.node_ptr[:-1])
+        e = (self.edge_ptr2[1:] - self.edge_ptr2[:-1])
+        gid = torch.repeat_interleave(torch.arange(len(self), device=n.device), e)
+        deg = torch.bincount(self.edge_index2[0] + self.node_ptr[gid], minlength=int(self.x.size(0)))
+        nmax, n_top, e_top, dmax = [int(v) for v in torch.stack([
+            n.max(), torch.topk(n, min(batch_size, n.numel()))[0].sum(), torch.topk(e, min(batch_size, e.numel()))[0].sum(),
+            deg.max()]).tolist()]
+        dmax = max(dmax, 1)
+        e2_pad = (e_top + 63) // 64 * 64
+        n_pad = (n_top + (e2_pad + dmax - 1) // dmax + 127) // 128 * 128
+        return dict(n_pad=n_pad, e2_pad=e2_pad, dmax=dmax, caps=(128 * dmax, 128 + 2 * nmax))
+
+    def batch_padded(self, ids, bounds):
+        """The batch of graphs ``ids`` (entries equal to len(self) = no graph) padded to bounds['n_pad'] nodes and
+        bounds['e2_pad'] support edges with torch ops of STATIC shapes only (no host read): padding nodes carry zero
+        features and form one extra graph (index B) at the end; padding edges are zero-valued self loops dealt dmax per
+        padding node (sorted by source like the rest; a zero support stays zero through the bias-free edge MLP and moves
+        no gradient).  Returns a Batch with ptr [B + 2], y [B + 1] and ``graph_valid`` [B] (0 for absent graphs)."""
+        n_pad, e2_pad, dmax = bounds['n_pad'], bounds['e2_pad'], bounds['dmax']
+        dev = ids.device
+        B = int(ids.numel())
+        G = len(self)
+        has = ids < G
+        idc = ids.clamp(max=G - 1)
+
+        def layout(ptr, total_pad):
+            lo = ptr[idc]
+            cnt = torch.where(has, ptr[idc + 1] - lo, torch.zeros_like(lo))
+            new = torch.zeros(B + 1, dtype=torch.int64, device=dev)
+            new[1:] = torch.cumsum(cnt, 0)
+            j = torch.arange(total_pad, device=dev)
+            seg = torch.searchsorted(new[1:].contiguous(), j, right=True)      # = B at and beyond the real total
+            ok = seg < B
+            sc = seg.clamp(max=B - 1)
+            return torch.where(ok, j - new[sc] + lo[sc], torch.zeros_like(j)), new, seg, ok, sc, j
+        npos, nptr, nseg, nok, _, _ = layout(self.node_ptr, n_pad)
+        epos, eptr, _, eok, esc, k = layout(self.edge_ptr2, e2_pad)
+        x = self.x[npos] * nok.unsqueeze(1).to(self.x.dtype)
+        pad_node = (nptr[-1] + (k - eptr[-1]).clamp(min=0) // dmax).clamp(max=n_pad - 1)
+        ei2 = torch.where(eok.unsqueeze(0), self.edge_index2[:, epos] + nptr[esc].unsqueeze(0), pad_node.unsqueeze(0))
+        ea2 = self.edge_attr2[epos] * eok.unsqueeze(1).to(self.edge_attr2.dtype)
+        ptr = torch.cat([nptr, torch.full((1,), n_pad, dtype=torch.int64, device=dev)]).int()
+        y = torch.cat([torch.where(has, self.y[idc], torch.zeros_like(self.y[idc])), torch.zeros(1, dtype=self.y.dtype, device=dev)])
+        b = Batch(x=x, edge_index=ei2, edge_index2=ei2, edge_attr2=ea2, batch=nseg, ptr=ptr, y=y,
+                  graph_valid=has.to(self.x.dtype))
+        b.static_caps = bounds['caps']
+        return b
+
     def epoch(self, batch_size, generator=None, shuffle=True):
         """yields one shuffled epoch of batches (the DataLoader(shuffle=True) loop of Zinc12k.py:20,359)."""
         G = len(self)

@@ -46,10 +46,14 @@ class GraphCSR(object):
         self._ginfo = self._ginfo_t = self._gmax = self._gmax_t = None
 
     @staticmethod
-    def from_edge_index(edge_index, num_nodes, assume_source_sorted=True):
+    def from_edge_index(edge_index, num_nodes, assume_source_sorted=True, static_caps=None):
         """assume_source_sorted: try the no-sort construction of the source view first (edge_index2 as SpectralDesign
         emits it is sorted by source, libs/utils.py:608-609); the kernel checks, and an unsorted input is rebuilt the
-        general way after the one host read this function does anyway."""
+        general way after the one host read this function does anyway.
+        static_caps = (max edges, max column window) per 128 source rows, known to the caller (dataset.DeviceDataset
+        bounds them for a whole data set): NO host read happens -- the build is then a fixed sequence of launches that a HIP
+        graph can capture and replay on new data of the same (padded) shape.  The caller vouches for sorted sources and
+        ids in range; the kernels still clamp, so a violation cannot write out of bounds."""
         _require_cuda(edge_index, 'edge_index')
         if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.size(0) != 2:
             raise ValueError('edge_index must be int64 [2, E], got %s %s' % (edge_index.dtype, tuple(edge_index.shape)))
@@ -89,6 +93,10 @@ class GraphCSR(object):
             # ONE device->host read per batch, at index-build time (not in the step): the per-batch maxima that size the LDS
             # staging of the fused backward, and the flag word of the index kernels (ids outside [0, num_nodes) were
             # clamped there, so nothing was written out of bounds: raise like the reference's scatter does)
+            if static_caps is not None:
+                g.gmax_t128 = (int(static_caps[0]), int(static_caps[1]))
+                g.src_sorted = bool(assume_source_sorted)
+                return g
             mx = torch.stack([g.ginfo_t128[:, 1].max(), g.ginfo_t128[:, 3].max(), bad[0]]).tolist()
             g.gmax_t128 = (int(mx[0]), int(mx[1]))
             if mx[2] & 1:
@@ -254,7 +262,8 @@ class Batch(object):
     def csr(self, which='edge_index2'):
         """GraphCSR of ``edge_index2`` (spectral supports) or ``edge_index`` (raw adjacency), built once."""
         if which not in self._csr:
-            self._csr[which] = GraphCSR.from_edge_index(getattr(self, which), int(self.x.size(0)))
+            caps = getattr(self, 'static_caps', None) if which == 'edge_index2' else None
+            self._csr[which] = GraphCSR.from_edge_index(getattr(self, which), int(self.x.size(0)), static_caps=caps)
         return self._csr[which]
 
 

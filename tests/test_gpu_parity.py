@@ -805,3 +805,28 @@ def test_wider_edge_attr_and_int64_ptr(dev):
     ptr64 = torch.tensor([0, 10, 25, 40], dtype=torch.int64, device=dev)
     pooled = segment_sum(x.contiguous(), ptr64)
     close(pooled, torch.stack([x[0:10].sum(0), x[10:25].sum(0), x[25:40].sum(0)]).cpu(), what='int64 ptr pooling')
+
+
+def test_padded_static_batch_equals_plain_batch(dev):
+    """dataset.DeviceDataset.batch_padded (static shapes, index build without a host read: what the captured epoch of
+    bench.py replays) gives the same loss and parameter gradients as the plain batch of the same graphs."""
+    from gnn_matlang_amd import SpectralDesign, models, synthetic
+    from gnn_matlang_amd.dataset import DeviceDataset
+    raw = synthetic.make_graphs('zinc', 40, seed=8)
+    dsd = DeviceDataset.from_graphs(SpectralDesign(recfield=2, dv=2, nfreq=7).design_many(raw), dev)
+    bd = dsd.bounds(8)
+    ids = torch.tensor([5, 33, 0, 17, 21, 40, 40, 40], device=dev)              # 5 graphs + 3 absent slots
+    torch.manual_seed(1)
+    m = models.zinc_gnnml3().to(dev)
+    bp = dsd.batch_padded(ids, bd)
+    pre = m(bp)
+    lp = ((pre[:8, 0] - bp.y[:8]).abs() * bp.graph_valid).sum()
+    lp.backward()
+    gp = {n: p.grad.clone() for n, p in m.named_parameters()}
+    m.zero_grad()
+    b = dsd.batch(ids[:5])
+    l = models.zinc_loss(m(b), b.y)
+    l.backward()
+    assert abs(lp.item() - l.item()) <= 1e-5 * abs(l.item())
+    for n, p in m.named_parameters():
+        close(gp[n], p.grad, tol=2e-5, what='padded vs plain grad ' + n)
