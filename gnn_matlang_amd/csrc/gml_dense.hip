@@ -1,0 +1,214 @@
+// Dense-block SpectConv for batches of equal-size graphs with near-dense masks (MNIST-75: the TF reference formulates the
+// layer exactly this way, /root/reference/libs/layers_tf.py:231-236:  s0 = matmul(support[:, i], x);  out += s0 . W_i).
+//
+// One kernel, both directions -- the batched support product
+//
+//      out[b n + r][s so + f]  (=, or summed over s)   sum_k  D[b][s][r][k] . act[b n + k][s sa + f]
+//
+//   forward :  D = support blocks as stored (row = target node), act = X (sa = 0: the same tile for every support),
+//              out = Hcat [B n, S Fin] (so = Fin), whose product with the stacked weights is one tall GEMM;
+//   backward:  D = the transposed blocks, act = d Hcat (sa = Fin), the S products summed in registers -> d X.
+//
+// Machine mapping: one workgroup per graph, one wave per 16 support rows (n = 75 -> 5 waves).  The supports are per
+// data set constants, kept in HBM as bf16 (hi, lo) images [B][S][2][n][KP] (gml_dense_pack: x = hi + lo to 2^-17, rows
+// padded to KP = 32 ceil(n / 32) with zeros): a lane's MFMA operand (its row, 8 consecutive k) is ONE 16-byte load straight
+// from HBM, no LDS, nothing shared between waves, every support byte read once.  The activation tile goes through LDS
+// once per graph (forward) or once per support (backward): fp32 -> (hi, lo) row-major bf16 images [k][f], read back
+// transposed by ds_read_b64_tr_b16 as the other operand.  The product is computed transposed (D[i = f][j = row]): a lane
+// ends up with 4 consecutive features of its own row = one 16-byte store.  bf16x3: hi.hi + lo.hi + hi.lo in fp32
+// accumulators (relative error ~2^-16 per product; the tolerance of the parity tests is 1e-4).
+#include "gml_common.h"
+
+typedef short dn_s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) dn_s16x4 dn_lds_s16x4;
+
+struct GmlDenseParams {
+    const uint16_t* dimg;
+    const float* act;
+    float* out;
+    int64_t lda, ldo;
+    int32_t sa, so, B, S, n, KP, F, vec_in, vec_out;
+};
+
+__device__ __forceinline__ uint32_t dn_pack2(float a, float b) {             // v_cvt_pk_bf16_f32 (RNE)
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
+// one MFMA operand (8 k-slots) from two transposing reads (lane semantics probed by tools/probes/probe_tr.hip)
+__device__ __forceinline__ bf16x8 dn_tr_frag(const unsigned char* p0, const unsigned char* p1) {
+    const dn_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((dn_lds_s16x4*)(p0));
+    const dn_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((dn_lds_s16x4*)(p1));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+#define DN_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+// image row pitch in bytes: 32 bytes per 16-feature tile + 16 (tools/lds_sim.py: the transposing reads of 8 rows x 32 bytes
+// then fall on distinct banks; a single tile needs no pad)
+__host__ __device__ constexpr int dn_pitch(int nft) { return 32 * nft + (nft == 1 ? 0 : 16); }
+
+template <int NFT, bool ACC>
+__global__ __launch_bounds__(384) void gml_k_dense_support_mm(GmlDenseParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dn_lds[];
+    constexpr int PA = dn_pitch(NFT);
+    constexpr int NCH = 4 * NFT;                             // 8-byte chunks (4 features) per image row
+    constexpr int KSMAX = 3;                                 // KP <= 96
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
+    const int t16 = lane & 15, kq = lane >> 4;
+    const int b = blockIdx.x, n = p.n, KP = p.KP, KS = KP >> 5, F = p.F;
+    unsigned char* img_h = dn_lds;
+    unsigned char* img_l = dn_lds + KP * PA;
+    const int row = wave * 16 + t16;                         // this lane's support row (the column of the transposed product)
+    const int rowc = row < n ? row : n - 1;
+    const float* actb = p.act + (int64_t)b * n * p.lda;
+    float* outr = p.out + ((int64_t)b * n + rowc) * p.ldo;
+
+    auto stage = [&](int s) {                                // act[:, s sa : s sa + F] of this graph -> (hi, lo) images [k][f]
+        const float* a = actb + s * p.sa;
+        for (int idx = tid; idx < KP * NCH; idx += nthr) {
+            const int k = idx / NCH, ch = idx % NCH;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (k < n && 4 * ch < F) {
+                const float* q = a + (int64_t)k * p.lda + 4 * ch;
+                if (p.vec_in) v = *reinterpret_cast<const f32x4*>(q);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (4 * ch + j < F) v[j] = q[j];
+                }
+            }
+            const uint32_t h0 = dn_pack2(v[0], v[1]), h1 = dn_pack2(v[2], v[3]);
+            const uint32_t l0 = dn_pack2(v[0] - __uint_as_float(h0 << 16), v[1] - __uint_as_float(h0 & 0xffff0000u));
+            const uint32_t l1 = dn_pack2(v[2] - __uint_as_float(h1 << 16), v[3] - __uint_as_float(h1 & 0xffff0000u));
+            *reinterpret_cast<uint2*>(img_h + k * PA + 8 * ch) = uint2{h0, h1};
+            *reinterpret_cast<uint2*>(img_l + k * PA + 8 * ch) = uint2{l0, l1};
+        }
+    };
+    // support operand of this lane for support s: row rowc, k = 32 ks + 8 kq .. + 7 of the hi and the lo image
+    u32x4 bh[KSMAX], bl[KSMAX];
+    auto load_rows = [&](int s) {
+        const uint16_t* base = p.dimg + ((int64_t)(b * p.S + s) * 2 * n + rowc) * KP + 8 * kq;
+#pragma unroll
+        for (int ks = 0; ks < KSMAX; ++ks) {
+            const int kc = ks < KS ? ks : KS - 1;            // (clamped: the loads stay unconditional, the product skips ks >= KS)
+            bh[ks] = *reinterpret_cast<const u32x4*>(base + 32 * kc);
+            bl[ks] = *reinterpret_cast<const u32x4*>(base + (int64_t)n * KP + 32 * kc);
+        }
+    };
+    // transposing-read addresses: lane (t, kq) passes row 8 kq + (t >> 2) (+ 4 for the second read), 8-byte chunk (t & 3)
+    const int aoff = (8 * kq + (t16 >> 2)) * PA + 8 * (t16 & 3);
+
+    f32x4 acc[NFT];
+#pragma unroll
+    for (int ft = 0; ft < NFT; ++ft) acc[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto store = [&](int s) {
+        if (row >= n) return;
+        float* o = outr + s * p.so + 4 * kq;
+#pragma unroll
+        for (int ft = 0; ft < NFT; ++ft) {
+            const int f0 = 16 * ft + 4 * kq;
+            if (f0 >= F) continue;
+            if (p.vec_out) *reinterpret_cast<f32x4*>(o + 16 * ft) = acc[ft];
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (f0 + j < F) o[16 * ft + j] = acc[ft][j];
+            }
+        }
+    };
+
+    load_rows(0);
+    for (int s = 0; s < p.S; ++s) {
+        if (s == 0 || p.sa != 0) {
+            if (s > 0) __syncthreads();                      // every wave is done with the previous tile
+            stage(s);
+            __syncthreads();
+        }
+        u32x4 ch[KSMAX], cl[KSMAX];
+#pragma unroll
+        for (int ks = 0; ks < KSMAX; ++ks) { ch[ks] = bh[ks]; cl[ks] = bl[ks]; }
+        if (s + 1 < p.S) load_rows(s + 1);                   // next support's rows in flight during this product
+#pragma unroll
+        for (int ks = 0; ks < KSMAX; ++ks) {
+            if (ks < KS) {
+                const bf16x8 Bh = __builtin_bit_cast(bf16x8, ch[ks]), Bl = __builtin_bit_cast(bf16x8, cl[ks]);
+                const unsigned char* ah = img_h + 32 * ks * PA + aoff;
+                const unsigned char* al = img_l + 32 * ks * PA + aoff;
+#pragma unroll
+                for (int ft = 0; ft < NFT; ++ft) {
+                    const bf16x8 Ah = dn_tr_frag(ah + 32 * ft, ah + 32 * ft + 4 * PA);
+                    const bf16x8 Al = dn_tr_frag(al + 32 * ft, al + 32 * ft + 4 * PA);
+                    acc[ft] = DN_MFMA(Al, Bh, acc[ft]);
+                    acc[ft] = DN_MFMA(Ah, Bl, acc[ft]);
+                    acc[ft] = DN_MFMA(Ah, Bh, acc[ft]);
+                }
+            }
+        }
+        if constexpr (!ACC) {
+            store(s);
+#pragma unroll
+            for (int ft = 0; ft < NFT; ++ft) acc[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    if constexpr (ACC) store(0);
+}
+
+// fp32 blocks [B][S][n][n] (row-major; transpose = 1 takes block^T) -> bf16 (hi, lo) images [B][S][2][n][KP]
+__global__ __launch_bounds__(256) void gml_k_dense_pack(const float* __restrict__ blocks, uint16_t* __restrict__ img,
+                                                        int64_t nblocks, int n, int KP, int transpose) {
+    const int64_t total = nblocks * n * KP;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int k = (int)(i % KP);
+        const int r = (int)((i / KP) % n);
+        const int64_t blk = i / ((int64_t)KP * n);
+        float v = 0.f;
+        if (k < n) v = blocks[blk * n * n + (transpose ? (int64_t)k * n + r : (int64_t)r * n + k)];
+        const uint32_t h = dn_pack2(v, 0.f) & 0xffffu;
+        const float res = v - __uint_as_float(h << 16);
+        const uint32_t l = dn_pack2(res, 0.f) & 0xffffu;
+        img[(blk * 2) * n * KP + (int64_t)r * KP + k] = (uint16_t)h;
+        img[(blk * 2 + 1) * n * KP + (int64_t)r * KP + k] = (uint16_t)l;
+    }
+}
+
+extern "C" int gml_dense_pack(const float* blocks, uint16_t* img, int64_t nblocks, int32_t n, int32_t KP, int32_t transpose,
+                              void* stream) {
+    if (blocks == nullptr || img == nullptr) return GML_E_BADARG;
+    if (n < 1 || n > 96 || KP % 32 != 0 || KP < n || KP > 96 || nblocks < 0) return GML_E_UNSUPPORTED;
+    if (nblocks == 0) return GML_OK;
+    const int64_t total = nblocks * n * KP;
+    int64_t grid = gml_cdiv(total, 256);
+    if (grid > 64 * GML_NUM_CU) grid = 64 * GML_NUM_CU;
+    hipLaunchKernelGGL(gml_k_dense_pack, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, blocks, img, nblocks, n, KP,
+                       transpose);
+    return gml_launch_status();
+}
+
+template <int NFT, bool ACC>
+static int dn_launch(const GmlDenseParams& p, hipStream_t st) {
+    const size_t lds = (size_t)2 * p.KP * dn_pitch(NFT);
+    GML_ALLOW_BIG_LDS(rc, (gml_k_dense_support_mm<NFT, ACC>), lds);
+    if (rc != hipSuccess) return (int)rc;
+    const int nwaves = (p.n + 15) / 16;
+    hipLaunchKernelGGL((gml_k_dense_support_mm<NFT, ACC>), dim3((unsigned)p.B), dim3(64 * nwaves), lds, st, p);
+    return gml_launch_status();
+}
+
+// out[(b n + r) ldo + s so + f] (=, or += over s when sum_s) sum_k D[b][s][r][k] act[(b n + k) lda + s sa + f],  f < F <= 128
+extern "C" int gml_dense_support_mm(const uint16_t* dimg, const float* act, int64_t lda, int32_t sa, float* out, int64_t ldo,
+                                    int32_t so, int32_t sum_s, int32_t B, int32_t S, int32_t n, int32_t KP, int32_t F,
+                                    void* stream) {
+    if (dimg == nullptr || act == nullptr || out == nullptr || lda < F || ldo < F) return GML_E_BADARG;
+    if (n < 1 || n > 96 || KP % 32 != 0 || KP < n || KP > 96 || F < 1 || F > 128 || S < 1 || B < 0) return GML_E_UNSUPPORTED;
+    if (B == 0) return GML_OK;
+    GmlDenseParams p;
+    p.dimg = dimg; p.act = act; p.out = out; p.lda = lda; p.ldo = ldo; p.sa = sa; p.so = so;
+    p.B = B; p.S = S; p.n = n; p.KP = KP; p.F = F;
+    p.vec_in = (F % 4 == 0 && lda % 4 == 0 && sa % 4 == 0 && ((uintptr_t)act & 15) == 0) ? 1 : 0;
+    p.vec_out = (F % 4 == 0 && ldo % 4 == 0 && so % 4 == 0 && ((uintptr_t)out & 15) == 0) ? 1 : 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int nft = (F + 15) / 16;
+#define DN_CASE(NFT)                                                              \
+    return sum_s ? dn_launch<NFT, true>(p, st) : dn_launch<NFT, false>(p, st)
+    if (nft <= 1) { DN_CASE(1); }
+    if (nft <= 2) { DN_CASE(2); }
+    if (nft <= 4) { DN_CASE(4); }
+    DN_CASE(8);
+#undef DN_CASE
+}

@@ -190,8 +190,12 @@ __device__ __forceinline__ void gml_chain_forward(const GmlChainW<S>& W, GmlChai
     f32x4 h1, h23;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {                            // z2, z3 arrive pre-scaled by 2 log2(e)
+#if defined(GML_EABL) && (GML_EABL & 4)
+        T.t2[r] = z2[r]; T.t3[r] = z3[r];
+#else
         T.t2[r] = fmaf(-2.f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(z2[r]) + 1.f), 1.f);
         T.t3[r] = fmaf(-2.f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(z3[r]) + 1.f), 1.f);
+#endif
         h1[r] = fmaxf(T.z1[r], 0.f);
         h23[r] = T.t2[r] * T.t3[r];
     }
@@ -553,6 +557,15 @@ __global__ __launch_bounds__(256, 3) void gml_k_edge_chain_bwd(
         }
         // weight gradients of the 16 edges: k-slots (g, j < 4) = hi, (g, j >= 4) = lo of edge 4g + (j & 3);
         //   X.[Yh | Yh] = Xh Yh + Xl Yh ,  X.[Yl | 0] = Xh Yl
+#ifndef GML_EABL
+#define GML_EABL 0
+#endif
+#if GML_EABL & 2
+        asm volatile("" :: "v"(T.hh), "v"(T.hl), "v"(g12h), "v"(g12l), "v"(g3yh), "v"(g3yl));
+        if (false) {
+#else
+        {
+#endif
         bf16x8 XT[5], YTb;
         transpose_pair(T.hh, T.hl, XT[0], XT[1]);            // h1, h23
         transpose_pair(g12h, g12l, XT[2], XT[3]);            // gz1, gz2
@@ -560,10 +573,16 @@ __global__ __launch_bounds__(256, 3) void gml_k_edge_chain_bwd(
         const u32x4 YT = __builtin_bit_cast(u32x4, YTb);
         const bf16x8 Bhh = gml_op(YT.x, YT.y, YT.x, YT.y);
         const bf16x8 Bl0 = gml_op(YT.z, YT.w, 0u, 0u);
+#if GML_EABL & 1
+#pragma unroll
+        for (int b = 0; b < 5; ++b) asm volatile("" :: "v"(XT[b]), "v"(Bl0), "v"(Bhh));
+#else
 #pragma unroll
         for (int b = 0; b < 5; ++b) {
             acc[b] = GML_MFMA(XT[b], Bl0, acc[b]);
             acc[b] = GML_MFMA(XT[b], Bhh, acc[b]);
+        }
+#endif
         }
         if constexpr (PRE) {
             __builtin_amdgcn_sched_barrier(0);
@@ -603,8 +622,12 @@ __global__ void gml_k_reduce_partials(const float* __restrict__ partial, int64_t
                                       float* __restrict__ d0, int n0, float* __restrict__ d1, int n1,
                                       float* __restrict__ d2, int n2, float* __restrict__ d3, int n3);
 
-// persistent workgroups per CU: the register footprint (130..162) allows 3 waves per SIMD
-static inline int64_t gml_edge_chain_bwd_groups(int64_t E, int wgs_per_cu = 4) {
+// persistent workgroups per CU (GML_EDGE_BWD_WGS, 1..8); the workspace is sized for the maximum
+static inline int gml_edge_chain_bwd_wgs() {
+    static const int v = [] { const char* e = getenv("GML_EDGE_BWD_WGS"); const int n = e ? atoi(e) : 3; return n < 1 ? 1 : (n > 8 ? 8 : n); }();
+    return v;
+}
+static inline int64_t gml_edge_chain_bwd_groups(int64_t E, int wgs_per_cu = 8) {
     const int64_t ntiles = gml_cdiv(E, 16);
     int64_t grid = gml_cdiv(ntiles, 4);
     if (grid > wgs_per_cu * GML_NUM_CU) grid = wgs_per_cu * GML_NUM_CU;
@@ -618,7 +641,8 @@ static inline int64_t gml_edge_chain_bwd_groups(int64_t E, int wgs_per_cu = 4) {
                                       float* out_t, int64_t E, hipStream_t st) {                                \
         const int64_t ntiles = gml_cdiv(E, 16);                                                                 \
         int64_t grid = gml_cdiv(ntiles, 8);                                                                     \
-        if (grid > 6 * GML_NUM_CU) grid = 6 * GML_NUM_CU;   /* all resident at 70 VGPRs; 4..8 measured within 2 % */   \
+        static const int fw = [] { const char* e = getenv("GML_EDGE_FWD_WGS"); const int n = e ? atoi(e) : 6; return n < 1 ? 1 : n; }();  \
+        if (grid > fw * GML_NUM_CU) grid = fw * GML_NUM_CU;   /* all resident at 70 VGPRs; 4..8 measured within 2 % */   \
         if (es != nullptr)                                                                                      \
             hipLaunchKernelGGL((gml_k_edge_chain_fwd<SV, true>), dim3((unsigned)grid), dim3(256), 0, st, ea,    \
                                es, w1, w2, w3, w4, out, tpos, out_t, E, ntiles);                                \
@@ -633,7 +657,7 @@ static inline int64_t gml_edge_chain_bwd_groups(int64_t E, int wgs_per_cu = 4) {
                                       float* dw1, float* dw2, float* dw3, float* dw4, int64_t E, void* ws,      \
                                       size_t ws_bytes, hipStream_t st) {                                        \
         const int64_t ntiles = gml_cdiv(E, 16);                                                                 \
-        const int64_t grid = gml_edge_chain_bwd_groups(E, 3);                                                   \
+        const int64_t grid = gml_edge_chain_bwd_groups(E, gml_edge_chain_bwd_wgs());                                                  \
         constexpr int NW = GML_CHAIN_NW(SV);                                                                    \
         if (ws_bytes < (size_t)grid * NW * sizeof(float)) return GML_E_WORKSPACE;                               \
         const dim3 gd((unsigned)grid), bd(256);                                                                 \

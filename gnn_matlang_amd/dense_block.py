@@ -2,36 +2,142 @@
 MNIST-75, recfield >= 3 -- the 4-hop mask of a 75-node superpixel graph is ~80 % full, so block-CSR degenerates to dense
 blocks; the TF reference formulates the layer exactly this way, libs/layers_tf.py:231-236).
 
-    H[b, s] = A[b, s]^T X[b]            one batched GEMM  [B, S n, n] x [B, n, Fin]
-    out     = [H[b, 0] | ... | H[b, S-1]] W + bias      one GEMM  [B n, S Fin] x [S Fin, Fout]
+    Hcat[b n + j, s Fin + f] = sum_i D[b, s][j, i] X[b n + i, f]        gml_dense_support_mm  (csrc/gml_dense.hip)
+    out                      = Hcat Wcat + bias                         one tall GEMM  [B n, S Fin] x [S Fin, Fout]
 
-Both are plain library GEMMs (rocBLAS through torch.bmm / torch.mm): nothing here needs a hand-written kernel, the
-supports are read once per layer at full HBM rate and autograd provides the backward as three more GEMMs.  Same
-parameters and values as ``SpectConv`` on the sparse path (tests/test_gpu_parity.py compares the two and the oracle).
+The batched support product is the hand-written part (one workgroup per graph, the supports streamed once from bf16
+(hi, lo) images, bf16x3 on the matrix cores); its adjoint d X = sum_s D_s^T d Hcat_s is the same kernel on the transposed
+images.  The tall GEMM and its two gradient GEMMs contract over S Fin = 384 .. 768 or over all nodes of the batch -- plain
+library GEMM shapes, left to rocBLAS through torch.  ``GML_DENSE_LIB=1`` (or the exact-product mode GML_F32_MFMA=1, which
+this kernel does not have) evaluates the support product with torch.bmm instead: the round-1 path, kept as the A/B
+baseline of tools/bench_mnist.py.  Same parameters and values as ``SpectConv`` on the sparse path
+(tests/test_gpu_parity.py compares both with the oracle and with the TF-graph fixture).
 """
+import os
+
 import torch
+
+from . import _lib
+from . import functional as Fn
+from .graph import _ptr, _stream
+
+USE_LIBRARY = os.environ.get('GML_DENSE_LIB', '0') not in ('0', '')
+
+
+class DenseSupports(object):
+    """Per-batch (in practice per-data-set: the supports are constants) dense support blocks of B graphs of n nodes.
+
+    blocks [B, S, n, n] fp32 (row = target node j, column = source node i; only kept for the library path);
+    fwd / bwd: bf16 (hi, lo) images [B, S, 2, n, KP] of the blocks / of their transposes (gml_dense_pack)."""
+
+    def __init__(self, blocks, keep_blocks):
+        B, S, n, _ = blocks.shape
+        self.B, self.S, self.n = int(B), int(S), int(n)
+        self.KP = (self.n + 31) // 32 * 32
+        self.blocks = blocks if keep_blocks else None
+        self.fwd = self.bwd = None
+        if not keep_blocks:
+            self.fwd, self.bwd = self._pack(blocks, 0), self._pack(blocks, 1)
+
+    def _pack(self, blocks, transpose):
+        img = torch.empty(self.B, self.S, 2, self.n, self.KP, dtype=torch.int16, device=blocks.device)
+        _lib.call('gml_dense_pack', _ptr(blocks), _ptr(img), self.B * self.S, self.n, self.KP, transpose, _stream(blocks.device))
+        return img
+
+
+def _library():
+    return USE_LIBRARY or Fn.F32_MFMA
 
 
 def dense_supports(edge_index2, edge_attr2, ptr, n):
-    """[B, S*n, n] stack of A_s^T blocks: row s*n + j, column i = value of edge i -> j of support s.
-    Every graph of the batch must have exactly n nodes (ptr [B+1])."""
+    """DenseSupports of a batch whose graphs all have exactly n nodes (ptr [B+1]): block[b, s][j, i] = value of edge
+    i -> j of support s (the mask lists every (i, j) once)."""
     B = int(ptr.numel() - 1)
     S = int(edge_attr2.size(1))
     if B * n != int(ptr[-1]):
         raise ValueError('dense blocks need equal-size graphs: %d graphs, %d nodes, n=%d' % (B, int(ptr[-1]), n))
+    if n > 96:
+        raise ValueError('dense blocks are built for n <= 96 nodes per graph, got %d' % n)
     src, dst = edge_index2[0], edge_index2[1]
     b = torch.div(src, n, rounding_mode='floor')
     i, j = src - b * n, dst - b * n
-    out = torch.zeros(B, S, n, n, dtype=edge_attr2.dtype, device=edge_attr2.device)
-    out[b, :, j, i] = edge_attr2                      # duplicates do not occur: the mask lists every (i, j) once
-    return out.view(B, S * n, n)
+    blocks = torch.zeros(B, S, n, n, dtype=torch.float32, device=edge_attr2.device)
+    blocks[b, :, j, i] = edge_attr2.float()
+    return DenseSupports(blocks, keep_blocks=_library())
 
 
-def spectconv_dense(x, spT, weight, bias, n):
-    """x [B*n, Fin], spT from dense_supports, weight [S, Fin, Fout] -> [B*n, Fout] = sum_s (A_s^T x) W_s + bias."""
+def support_mm(img, act, sup, F, sa, so, sum_s):
+    """gml_dense_support_mm on packed images: act [B n, >= F (+ s sa)] -> [B n, F] (sum_s) or [B n, S so]."""
+    act = act.contiguous()
+    out = torch.empty(sup.B * sup.n, F if sum_s else sup.S * so, dtype=torch.float32, device=act.device)
+    _lib.call('gml_dense_support_mm', _ptr(img), _ptr(act), int(act.stride(0)), int(sa), _ptr(out), int(out.stride(0)), int(so),
+              int(bool(sum_s)), sup.B, sup.S, sup.n, sup.KP, int(F), _stream(act.device))
+    return out
+
+
+class _SupportProduct(torch.autograd.Function):
+    """Hcat = [D_0 X | ... | D_{S-1} X] per graph; gradient d X = sum_s D_s^T d Hcat_s (the supports are constants)."""
+
+    @staticmethod
+    def forward(ctx, x, sup):
+        ctx.sup, ctx.Fin = sup, int(x.size(1))
+        Fn._path('dense', 'support product fwd (bf16x3 HIP)', sup.S, ctx.Fin, ctx.Fin)
+        return support_mm(sup.fwd, x, sup, ctx.Fin, 0, ctx.Fin, False)
+
+    @staticmethod
+    def backward(ctx, g):
+        if not ctx.needs_input_grad[0]:
+            return None, None
+        Fn._path('dense', 'support product bwd (bf16x3 HIP)', ctx.sup.S, ctx.Fin, ctx.Fin)
+        return support_mm(ctx.sup.bwd, g, ctx.sup, ctx.Fin, ctx.Fin, 0, True), None
+
+
+def _splits(rows, lo=1024):
+    """number of row slabs of the weight-gradient GEMM: the largest divisor of rows <= 64 that leaves slabs of >= lo rows"""
+    for p in range(64, 1, -1):
+        if rows % p == 0 and rows // p >= lo:
+            return p
+    return 1
+
+
+class _TallGemm(torch.autograd.Function):
+    """out = h w + bias for h [B n, S Fin] (hundreds of thousands of rows), w [S Fin, Fout].  Forward and d h are library
+    GEMMs as they are; d w = h^T g contracts over ALL rows into a 768 x 128 result, which rocBLAS tiles into ~24
+    workgroups (352 us at 76,800 rows, profiles/r02_mnist75_*): it is evaluated as a batched GEMM over row slabs
+    (every CU busy) followed by a fixed-order sum of the slab results."""
+
+    @staticmethod
+    def forward(ctx, h, w, bias):
+        ctx.save_for_backward(h, w)
+        ctx.has_bias = bias is not None
+        return h.mm(w) if bias is None else torch.addmm(bias, h, w)
+
+    @staticmethod
+    def backward(ctx, g):
+        h, w = ctx.saved_tensors
+        g = g.contiguous()
+        dh = g.mm(w.t()) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            rows = int(h.size(0))
+            P = _splits(rows)
+            dw = torch.bmm(h.view(P, rows // P, h.size(1)).transpose(1, 2), g.view(P, rows // P, g.size(1))).sum(0) if P > 1 else h.t().mm(g)
+        db = g.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dh, dw, db
+
+
+def spectconv_dense(x, sup, weight, bias, n):
+    """x [B*n, Fin], sup from dense_supports, weight [S, Fin, Fout] -> [B*n, Fout] = sum_s (D_s x) W_s + bias."""
     S, Fin, Fout = weight.shape
-    B = spT.size(0)
-    h = torch.bmm(spT, x.view(B, n, Fin))             # [B, S*n, Fin]
-    h = h.view(B, S, n, Fin).permute(0, 2, 1, 3).reshape(B * n, S * Fin)
-    out = h.mm(weight.reshape(S * Fin, Fout))
-    return out if bias is None else out + bias
+    if sup.n != n or sup.S != S or x.size(0) != sup.B * n:
+        raise ValueError('supports [%d graphs, S=%d, n=%d] do not match x %s / weight %s' %
+                         (sup.B, sup.S, sup.n, tuple(x.shape), tuple(weight.shape)))
+    if sup.blocks is not None:                         # library path (GML_DENSE_LIB=1 / GML_F32_MFMA=1)
+        Fn._path('dense', 'support product (torch.bmm fp32)', S, Fin, Fout)
+        h = torch.bmm(sup.blocks.view(sup.B, S * n, n), x.view(sup.B, n, Fin))
+        h = h.view(sup.B, S, n, Fin).permute(0, 2, 1, 3).reshape(sup.B * n, S * Fin)
+    else:
+        if Fin > 128:
+            raise ValueError('the dense-block kernel covers Fin <= 128, got %d' % Fin)
+        h = _SupportProduct.apply(x, sup)
+    return _TallGemm.apply(h, weight.reshape(S * Fin, Fout), bias)

@@ -63,7 +63,7 @@ class GNNML3(torch.nn.Module):
                  nclass=1, readout_bn=False, dense_n=0):
         super().__init__()
         # dense_n > 0: equal-size graphs of dense_n nodes with near-dense masks (MNIST-75) are evaluated as dense
-        # blocks with batched library GEMMs (dense_block.py); same parameters, same values
+        # blocks (dense_block.py: HIP batched support product + one tall GEMM per layer); same parameters, same values
         if dense_n and (learnedge or nout2):
             raise ValueError('the dense-block path covers plain SpectConv stacks (learnedge=False, nout2=0)')
         self.dense_n = int(dense_n)
@@ -90,8 +90,9 @@ class GNNML3(torch.nn.Module):
     def forward(self, data):
         x = data.x
         if self.dense_n:
-            from .dense_block import dense_supports, spectconv_dense
-            if getattr(data, '_spT', None) is None:             # per-batch data, like the CSR
+            from .dense_block import dense_supports, spectconv_dense, _library
+            sp = getattr(data, '_spT', None)                    # per-batch data, like the CSR
+            if sp is None or (sp.blocks is not None) != bool(_library()):
                 data._spT = dense_supports(data.edge_index2, data.edge_attr2, data.ptr, self.dense_n)
         else:
             csr = data.csr('edge_index2')

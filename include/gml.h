@@ -243,6 +243,22 @@ int gml_segment_max(const float* x, int64_t ldx, const int32_t* ptr, float* out,
 int gml_segment_max_bwd(const float* g, int64_t ldg, const int32_t* ptr, const int32_t* argmax, float* out, int64_t ldo,
                         int64_t num_segments, int32_t F, gml_stream_t stream);
 
+/* ---------------------------------------------------------------- dense-block SpectConv (equal-size graphs, near-dense masks)
+ * The TF formulation of the layer, /root/reference/libs/layers_tf.py:231-236 (s0 = matmul(support[:, i], x); out += s0 . W_i),
+ * for batches of B graphs of exactly n <= 96 nodes (MNIST-75: n = 75, S = 6).
+ *   gml_dense_pack       : fp32 blocks [nblocks][n][n] (row-major; transpose != 0 takes block^T) -> bf16 (hi, lo) images
+ *                          img [nblocks][2][n][KP] (uint16; block = hi + lo to 2^-17 relative; KP = 32 ceil(n / 32), columns
+ *                          >= n zero).  Done once per data set: the supports are constants.
+ *   gml_dense_support_mm : out[(b n + r) ldo + s so + f]  =  sum_k D[b][s][r][k] . act[(b n + k) lda + s sa + f]   (f < F <= 128),
+ *                          summed over s into out[(b n + r) ldo + f] when sum_s != 0.  Forward: D = the packed supports,
+ *                          act = X (sa = 0), out = Hcat [B n, S Fin] (so = Fin); backward: D = the packed transposes,
+ *                          act = d Hcat (sa = Fin), sum_s = 1 -> d X.  bf16x3 products, fp32 accumulate. */
+int gml_dense_pack(const float* blocks, uint16_t* img, int64_t nblocks, int32_t n, int32_t KP, int32_t transpose,
+                   gml_stream_t stream);
+int gml_dense_support_mm(const uint16_t* dimg, const float* act, int64_t lda, int32_t sa, float* out, int64_t ldo,
+                         int32_t so, int32_t sum_s, int32_t B, int32_t S, int32_t n, int32_t KP, int32_t F,
+                         gml_stream_t stream);
+
 /* ---------------------------------------------------------------- support precompute on the device (adjacent step, P1)
  * SpectralDesign.__call__ (libs/utils.py:546-610) for a batch of graphs with at most 80 nodes each (larger: host
  * implementation).  node_ptr [B+1], edge_ptr [B+1]: graph b owns nodes [node_ptr[b], node_ptr[b+1]) and the edges

@@ -830,3 +830,29 @@ def test_padded_static_batch_equals_plain_batch(dev):
     assert abs(lp.item() - l.item()) <= 1e-5 * abs(l.item())
     for n, p in m.named_parameters():
         close(gp[n], p.grad, tol=2e-5, what='padded vs plain grad ' + n)
+
+
+# ------------------------------------------------------------------------------------------ dense-block support product
+@pytest.mark.parametrize('n,S,F', [(75, 6, 2), (75, 6, 64), (75, 6, 128), (16, 1, 30), (33, 3, 7), (96, 2, 20), (5, 4, 48)])
+def test_dense_support_mm_vs_fp64(dev, n, S, F):
+    """gml_dense_support_mm (csrc/gml_dense.hip; libs/layers_tf.py:231 `matmul(support[:, i], x)` for every support of
+    every graph) and its adjoint against fp64 einsum: ragged n (not a multiple of 16 / 32), F off the 4-alignment."""
+    from gnn_matlang_amd import dense_block as DB
+    g = torch.Generator().manual_seed(100 * n + F)
+    B = 5
+    blocks = (torch.randn(B, S, n, n, generator=g) * (torch.rand(B, S, n, n, generator=g) < 0.8)).to(dev)
+    x = torch.randn(B * n, F, generator=g).to(dev).requires_grad_(True)
+    sup = DB.DenseSupports(blocks, keep_blocks=False)
+    h = DB._SupportProduct.apply(x, sup)
+    ref = torch.einsum('bsji,bif->bjsf', blocks.double(), x.detach().double().view(B, n, F)).reshape(B * n, S * F)
+    close(h, ref.float(), what='Hcat n=%d S=%d F=%d' % (n, S, F))
+    gh = torch.randn(B * n, S * F, generator=g).to(dev)
+    h.backward(gh)
+    gref = torch.einsum('bsji,bjsf->bif', blocks.double(), gh.double().view(B, n, S, F)).reshape(B * n, F)
+    close(x.grad, gref.float(), what='dX n=%d S=%d F=%d' % (n, S, F))
+    # the packed images: hi + lo reproduces the block to 2^-16 relative, padding columns are zero
+    img = sup.fwd.view(torch.bfloat16).float()
+    rec = img[:, :, 0] + img[:, :, 1]
+    assert float((rec[..., :n] - blocks).abs().max()) <= 2.0 ** -16 * float(blocks.abs().max())
+    assert float(rec[..., n:].abs().max() if sup.KP > n else 0.0) == 0.0
+    assert torch.equal(sup.bwd.view(torch.bfloat16)[..., :n], sup.fwd.view(torch.bfloat16)[..., :n].transpose(-1, -2))

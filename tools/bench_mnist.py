@@ -1,4 +1,5 @@
-"""MNIST-75 GNNML3 (config 4) train step: sparse (block-CSR HIP kernels) vs dense-block (batched library GEMMs) path.
+"""MNIST-75 GNNML3 (config 4) train step: sparse (block-CSR HIP kernels) vs dense-block with torch.bmm ('dense_lib', the
+round-1 path) vs dense-block with the HIP batched support product ('dense', csrc/gml_dense.hip).
 python tools/bench_mnist.py [graphs]"""
 import json
 import os
@@ -7,7 +8,7 @@ import time
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from gnn_matlang_amd import SpectralDesign, collate, models, synthetic
+from gnn_matlang_amd import SpectralDesign, collate, models, synthetic, dense_block
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 dev = torch.device('cuda:0')
@@ -16,7 +17,8 @@ pool = SpectralDesign(recfield=3, dv=10, nfreq=5).design_many(raw)
 data = collate([pool[i % 64] for i in range(B)]).to(dev)
 data.y = torch.randint(0, 10, (B,), device=dev)
 out = {}
-for name, dn in (('sparse', 0), ('dense', 75)):
+for name, dn in (('sparse', 0), ('dense_lib', 75), ('dense', 75)):
+    dense_block.USE_LIBRARY = name == 'dense_lib'
     torch.manual_seed(0)
     m = models.mnist_gnnml3(dense_n=dn).to(dev).train()
     opt = torch.optim.Adam(m.parameters(), lr=1e-3, fused=True)
