@@ -27,6 +27,18 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // conflict-free for both row orders (tools/lds_sim.py; the round-1 keys (row >> 2) / (row >> 3) were 2-way).
 __host__ __device__ __forceinline__ int gml_wkey(int row) { return (-(row >> 2)) & 3; }
 
+typedef short gml_s16x4 __attribute__((ext_vector_type(4)));
+typedef short gml_s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) gml_s16x4 gml_lds_s16x4;
+
+// one MFMA operand (8 k-slots) from two transposing reads: lane (t, g) of a 16-lane group receives, for j = 0..3, element
+// (t & 3) of the 8-byte chunk whose address lane 4 j + (t >> 2) of the same group passed (probed: tools/probes/probe_tr.hip)
+__device__ __forceinline__ bf16x8 gml_tr_frag(const unsigned char* p0, const unsigned char* p1) {
+    const gml_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((gml_lds_s16x4*)(p0));
+    const gml_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((gml_lds_s16x4*)(p1));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
 // return code of the last launch on this thread (no sync).  Peek, not Get: the runtime's sticky error state is left
 // for whoever else checks it (torch), an unrelated earlier error is neither swallowed nor cleared here.
 static inline int gml_launch_status() {

@@ -358,10 +358,20 @@ __global__ __launch_bounds__(256, 3) void gml_k_edge_chain_bwd(
     const float* __restrict__ w3, const float* __restrict__ w4, const float* __restrict__ gout,
     float* __restrict__ gin, float* __restrict__ partial, int64_t E, int64_t ntiles) {
     constexpr int H2 = 2 * S, H4 = 4 * S;
-    __shared__ float red[4][20][64];
+    // 4 waves x 12 row-major bf16 tile images [edge][16 channels] (the transposition scratch of the weight-gradient
+    // operands); the same bytes hold the workgroup's partial sums at the end
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 12 * 512];
+    float (*red)[20][64] = reinterpret_cast<float (*)[20][64]>(smem);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c16 = lane & 15, g = lane >> 4;
     const int q0 = 4 * (g & 1);
+    unsigned char* trw = smem + wave * (12 * 512);
+    // chunk (edge e, channels 4cc..4cc+3) lives at cc * 128 + (e ^ 8 (cc >> 1)) * 8: the 16 lanes of a write group (one cc)
+    // cover 128 contiguous bytes, the 32 lanes of a read half (8 edges x 4 cc) 4 distinct 64-byte bank segments
+    // (tools/lds_sim.py; the plain [edge][channel] rows made every ds_write_b64 a 4-way bank conflict: 66 % of the LDS
+    // cycles in gpurun_out/e6_pmcC)
+    const int tr_wo = g * 128 + ((c16 ^ ((g >> 1) << 3)) << 3);                                   // lane (edge c16, cc = g)
+    const int tr_ro = (c16 & 3) * 128 + (((4 * g + (c16 >> 2)) ^ (((c16 & 3) >> 1) << 3)) << 3);  // gml_tr_frag: lane (channel c16, edges 4g..)
     GmlChainW<S> W;
     gml_chain_load_fwd_weights<S>(W, w1, w2, w3, w4, c16, g);
     GmlChainWB<S, GIN> WB;
@@ -476,10 +486,10 @@ __global__ __launch_bounds__(256, 3) void gml_k_edge_chain_bwd(
 #pragma unroll
         for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(g_n[r]));
         const bool ok = tt * 16 + c16 < E;
-        const u32x4 bz = ok ? b1_n : u32x4{0u, 0u, 0u, 0u};
-        B1 = __builtin_bit_cast(bf16x8, bz);
-        // (channels >= S of the pre-split rows are zero, edges past E are zeroed here)
-        BE = __builtin_bit_cast(bf16x8, ok ? u32x4{eh_n.x, eh_n.y, el_n.x, el_n.y} : u32x4{0u, 0u, 0u, 0u});
+        // (channels >= S of the pre-split rows are zero.  Lanes past E keep the clamped edge's finite values: their
+        //  gout is zeroed below, so go = 0 and with it every gradient term of the lane)
+        B1 = __builtin_bit_cast(bf16x8, b1_n);
+        BE = __builtin_bit_cast(bf16x8, u32x4{eh_n.x, eh_n.y, el_n.x, el_n.y});
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const bool okq = ok && q0 + r < S;
@@ -567,9 +577,32 @@ __global__ __launch_bounds__(256, 3) void gml_k_edge_chain_bwd(
         {
 #endif
         bf16x8 XT[5], YTb;
+#ifdef GML_EDGE_MFMA_TRANSPOSE
         transpose_pair(T.hh, T.hl, XT[0], XT[1]);            // h1, h23
         transpose_pair(g12h, g12l, XT[2], XT[3]);            // gz1, gz2
         transpose_pair(g3yh, g3yl, XT[4], YTb);              // gz3, [go | e]
+#else
+        // The split tiles are bf16 pairs already (lane (edge, g): channels 4g..4g+3 = 8 bytes per image): written as
+        // [edge][channel] images (swizzled, see tr_wo) to the wave's LDS scratch and read back with ds_read_b64_tr_b16, lane (channel, g) receives
+        // edges 4g..4g+3 -- the same operands as the matrix-core transposes, without their 12 MFMAs and 24 conversions
+        // (an MFMA holds the VALU issue port for 8 cycles, tools/probes/probe_overlap.hip: this kernel is issue-bound).
+        // One wave, in-order LDS queue: no barrier.
+        {
+            const u32x4 im[6] = {T.hh, T.hl, g12h, g12l, g3yh, g3yl};
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {                    // pair tuple i: tiles 2i (x, y) and 2i + 1 (z, w); hi then lo
+                *reinterpret_cast<uint2*>(trw + (4 * i + 0) * 512 + tr_wo) = uint2{im[2 * i].x, im[2 * i].y};
+                *reinterpret_cast<uint2*>(trw + (4 * i + 1) * 512 + tr_wo) = uint2{im[2 * i + 1].x, im[2 * i + 1].y};
+                *reinterpret_cast<uint2*>(trw + (4 * i + 2) * 512 + tr_wo) = uint2{im[2 * i].z, im[2 * i].w};
+                *reinterpret_cast<uint2*>(trw + (4 * i + 3) * 512 + tr_wo) = uint2{im[2 * i + 1].z, im[2 * i + 1].w};
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int b = 0; b < 5; ++b) XT[b] = gml_tr_frag(trw + (2 * b) * 512 + tr_ro, trw + (2 * b + 1) * 512 + tr_ro);
+            YTb = gml_tr_frag(trw + 10 * 512 + tr_ro, trw + 11 * 512 + tr_ro);
+            __builtin_amdgcn_wave_barrier();
+        }
+#endif
         const u32x4 YT = __builtin_bit_cast(u32x4, YTb);
         const bf16x8 Bhh = gml_op(YT.x, YT.y, YT.x, YT.y);
         const bf16x8 Bl0 = gml_op(YT.z, YT.w, 0u, 0u);
@@ -591,6 +624,7 @@ __global__ __launch_bounds__(256, 3) void gml_k_edge_chain_bwd(
     }
 
     // one partial per workgroup: fixed-order sum of the 4 waves, then [dw1 (2S*S) | dw2 | dw3 | dw4 (S*4S)]
+    __syncthreads();                                          // (the scratch of slower waves is still in use)
 #pragma unroll
     for (int b = 0; b < 5; ++b)
 #pragma unroll
@@ -622,9 +656,9 @@ __global__ void gml_k_reduce_partials(const float* __restrict__ partial, int64_t
                                       float* __restrict__ d0, int n0, float* __restrict__ d1, int n1,
                                       float* __restrict__ d2, int n2, float* __restrict__ d3, int n3);
 
-// persistent workgroups per CU (GML_EDGE_BWD_WGS, 1..8); the workspace is sized for the maximum
+// persistent workgroups per CU (GML_EDGE_BWD_WGS, 1..6: 24.5 KB of LDS each); the workspace is sized for the maximum
 static inline int gml_edge_chain_bwd_wgs() {
-    static const int v = [] { const char* e = getenv("GML_EDGE_BWD_WGS"); const int n = e ? atoi(e) : 3; return n < 1 ? 1 : (n > 8 ? 8 : n); }();
+    static const int v = [] { const char* e = getenv("GML_EDGE_BWD_WGS"); const int n = e ? atoi(e) : 6; return n < 1 ? 1 : (n > 6 ? 6 : n); }();
     return v;
 }
 static inline int64_t gml_edge_chain_bwd_groups(int64_t E, int wgs_per_cu = 8) {

@@ -20,18 +20,6 @@
 #include "gml_common.h"
 #include "gml_spectconv_bwd_impl.h"
 
-typedef short gml_s16x4 __attribute__((ext_vector_type(4)));
-typedef short gml_s16x8 __attribute__((ext_vector_type(8)));
-typedef __attribute__((address_space(3))) gml_s16x4 gml_lds_s16x4;
-
-// one MFMA operand (8 k-slots) from two transposing reads: lane (t, g) of a 16-lane group receives, for j = 0..3, element
-// (t & 3) of the 8-byte chunk whose address lane 4 j + (t >> 2) of the same group passed (probed: tools/probes/probe_tr.hip)
-__device__ __forceinline__ bf16x8 gml_tr_frag(const unsigned char* p0, const unsigned char* p1) {
-    const gml_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((gml_lds_s16x4*)(p0));
-    const gml_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((gml_lds_s16x4*)(p1));
-    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
-}
-
 // XOR key (16-byte chunks of a 64-byte row) of the W image [s][o][f]: b128 fragment reads of the natural and of the Z
 // projection's permuted rows and the transposing reads of dX are all conflict-free with it
 __host__ __device__ __forceinline__ int gml_wkey3(int o) { return ((o >> 3) & 1) << 1; }
