@@ -1,6 +1,7 @@
 // C-ABI dispatch of the ML3Layer edge-branch kernels + the partial-sum fold.
 #include "gml_edge_mlp_impl.h"
 #include "gml_edge_chain_impl.h"
+#include "gml_edge_chain16_impl.h"
 #include <stdlib.h>
 
 // 2 <= S <= 8 runs on the bf16 matrix cores (gml_edge_chain_impl.h); GML_EDGE_VALU=1 in the environment keeps the
@@ -20,6 +21,26 @@ static bool emlp_use_chain(int S) {
                                                   float*, float*, float*, int64_t, void*, size_t, hipStream_t);
 GML_DECL_ECHAIN(1) GML_DECL_ECHAIN(2) GML_DECL_ECHAIN(3) GML_DECL_ECHAIN(4)
 GML_DECL_ECHAIN(5) GML_DECL_ECHAIN(6) GML_DECL_ECHAIN(7) GML_DECL_ECHAIN(8)
+// 8 < S <= 16 (counting.py: S = 12): the K = 16-slot chain of gml_edge_chain16_impl.h; needs the 64-byte pre-split rows and
+// produces no gradient for the raw supports (those cases stay on the VALU kernels)
+static bool emlp_use_chain16(int S, const void* ea_split, const void* gin) {
+    static const bool valu = [] { const char* e = getenv("GML_EDGE_VALU"); return e && e[0] == '1'; }();
+    return S > 8 && S <= 16 && !valu && ea_split != nullptr && gin == nullptr;
+}
+#define GML_DECL_ECHAIN16(SV)                                                                                \
+    template <> int gml_launch_edge_chain16_fwd<SV>(const uint32_t*, const float*, const float*, const float*, \
+                                                    const float*, float*, const int32_t*, float*, int64_t, hipStream_t); \
+    template <> int gml_launch_edge_chain16_bwd<SV>(const uint32_t*, const float*, const float*, const float*, \
+                                                    const float*, const float*, float*, float*, float*, float*, \
+                                                    int64_t, void*, size_t, hipStream_t);
+GML_DECL_ECHAIN16(9) GML_DECL_ECHAIN16(10) GML_DECL_ECHAIN16(11) GML_DECL_ECHAIN16(12)
+GML_DECL_ECHAIN16(13) GML_DECL_ECHAIN16(14) GML_DECL_ECHAIN16(15) GML_DECL_ECHAIN16(16)
+#define GML_ECHAIN16_SWITCH(CALL)                                                               \
+    switch (S) {                                                                                \
+        case 9: return CALL(9); case 10: return CALL(10); case 11: return CALL(11);             \
+        case 12: return CALL(12); case 13: return CALL(13); case 14: return CALL(14);           \
+        case 15: return CALL(15); case 16: return CALL(16);                                     \
+    }
 #define GML_ECHAIN_SWITCH(CALL)                                                                 \
     switch (S) {                                                                                \
         case 1: return CALL(1); case 2: return CALL(2); case 3: return CALL(3);                 \
@@ -72,6 +93,27 @@ GML_DECL_EMLP(13) GML_DECL_EMLP(14) GML_DECL_EMLP(15) GML_DECL_EMLP(16)
     return GML_E_UNSUPPORTED;
 
 // hi[8] | lo[8] bf16 per edge (32 bytes): the layer-1 operand of the matrix-core kernels, made once per batch
+// 8 < S <= 16: hi[16] | lo[16] per edge (64 bytes), the operand rows of gml_edge_chain16_impl.h
+__global__ __launch_bounds__(256) void gml_k_edge_presplit16(const float* __restrict__ ea, uint32_t* __restrict__ es,
+                                                            int64_t E, int S) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    uint32_t hi[8], lo[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x0 = (2 * j < S) ? ea[e * S + 2 * j] : 0.f, x1 = (2 * j + 1 < S) ? ea[e * S + 2 * j + 1] : 0.f;
+        const float t0 = __uint_as_float(__float_as_uint(x0) & 0xffff0000u);
+        const float t1 = __uint_as_float(__float_as_uint(x1) & 0xffff0000u);
+        hi[j] = gml_pack2(t0, t1);
+        lo[j] = gml_pack2(x0 - t0, x1 - t1);
+    }
+    u32x4* o = reinterpret_cast<u32x4*>(es + e * 16);
+    o[0] = u32x4{hi[0], hi[1], hi[2], hi[3]};
+    o[1] = u32x4{hi[4], hi[5], hi[6], hi[7]};
+    o[2] = u32x4{lo[0], lo[1], lo[2], lo[3]};
+    o[3] = u32x4{lo[4], lo[5], lo[6], lo[7]};
+}
+
 __global__ __launch_bounds__(256) void gml_k_edge_presplit(const float* __restrict__ ea, uint32_t* __restrict__ es,
                                                           int64_t E, int S) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -138,9 +180,14 @@ extern "C" int gml_gather_rows_presplit(const float* in, const int32_t* perm, fl
 
 extern "C" int gml_edge_presplit(const float* ea, void* ea_split, int64_t num_edges, int32_t S, gml_stream_t stream) {
     if (num_edges < 0 || S <= 0) return GML_E_BADARG;
-    if (S > 8) return GML_E_UNSUPPORTED;
+    if (S > 16) return GML_E_UNSUPPORTED;
     if (num_edges == 0) return GML_OK;
     if (!ea || !ea_split || (((uintptr_t)ea_split) & 15) != 0) return GML_E_BADARG;
+    if (S > 8) {
+        hipLaunchKernelGGL(gml_k_edge_presplit16, dim3((unsigned)gml_cdiv(num_edges, 256)), dim3(256), 0, (hipStream_t)stream,
+                           ea, (uint32_t*)ea_split, num_edges, S);
+        return gml_launch_status();
+    }
     hipLaunchKernelGGL(gml_k_edge_presplit, dim3((unsigned)gml_cdiv(num_edges, 256)), dim3(256), 0, (hipStream_t)stream, ea,
                        (uint32_t*)ea_split, num_edges, S);
     return gml_launch_status();
@@ -166,6 +213,11 @@ extern "C" int gml_edge_mlp_fwd(const float* ea, const void* ea_split, const flo
     gml_launch_edge_chain_fwd<SV>(ea, (const uint32_t*)ea_split, w1, w2, w3, w4, out, tpos, out_t, num_edges, st)
         GML_ECHAIN_SWITCH(GML_CALL_CF)
     }
+    if (emlp_use_chain16(S, ea_split, nullptr)) {
+#define GML_CALL_CF16(SV) \
+    gml_launch_edge_chain16_fwd<SV>((const uint32_t*)ea_split, w1, w2, w3, w4, out, tpos, out_t, num_edges, st)
+        GML_ECHAIN16_SWITCH(GML_CALL_CF16)
+    }
 #define GML_CALL_F(SV) gml_launch_edge_mlp_fwd<SV, SV>(ea, w1, w2, w3, w4, out, tpos, out_t, num_edges, st)
     GML_EMLP_SWITCH(GML_CALL_F)
 }
@@ -182,6 +234,7 @@ extern "C" size_t gml_edge_mlp_bwd_workspace_bytes(int64_t num_edges, int32_t S,
     // both kernel families are covered, so the size does not depend on the environment switch
     int64_t parts = emlp_bwd_waves(num_edges, S);
     if (S <= 8 && gml_edge_chain_bwd_groups(num_edges) > parts) parts = gml_edge_chain_bwd_groups(num_edges);
+    if (S > 8 && S <= 16 && gml_edge_chain16_bwd_groups(num_edges) > parts) parts = gml_edge_chain16_bwd_groups(num_edges);
     return (size_t)parts * (size_t)(6 * S * S + Sout * 4 * S) * sizeof(float);
 }
 
@@ -210,6 +263,12 @@ extern "C" int gml_edge_mlp_bwd(const float* ea, const void* ea_split, const flo
     gml_launch_edge_chain_bwd<SV>(ea, (const uint32_t*)ea_split, w1, w2, w3, w4, gout, gin, dw1, dw2, dw3, dw4, \
                                   num_edges, ws, ws_bytes, st)
         GML_ECHAIN_SWITCH(GML_CALL_CB)
+    }
+    if (emlp_use_chain16(S, ea_split, gin)) {
+#define GML_CALL_CB16(SV) \
+    gml_launch_edge_chain16_bwd<SV>((const uint32_t*)ea_split, w1, w2, w3, w4, gout, dw1, dw2, dw3, dw4, num_edges, ws, \
+                                    ws_bytes, st)
+        GML_ECHAIN16_SWITCH(GML_CALL_CB16)
     }
 #define GML_CALL_B(SV) \
     gml_launch_edge_mlp_bwd<SV, SV>(ea, w1, w2, w3, w4, gout, gin, dw1, dw2, dw3, dw4, num_edges, ws, ws_bytes, st)

@@ -26,6 +26,7 @@ PROFILE = None
 import os as _os
 _linear = torch.nn.functional.linear
 F32_MFMA = _os.environ.get('GML_F32_MFMA', '0') not in ('0', '')
+EDGE_VALU = _os.environ.get('GML_EDGE_VALU', '0') == '1'
 
 
 # GML_VERBOSE=1: count which kernel family every layer call takes (shapes off the compiled set degrade in SPEED, never in
@@ -156,11 +157,12 @@ def relu_bwd(gy, gy_off, ldgy, y, ldy, nrows, F):
 
 
 def edge_presplit(ea):
-    """bf16 hi | lo image of the rows of ea (S <= 8) for the matrix-core edge kernels; None when not applicable."""
+    """bf16 hi | lo image of the rows of ea for the matrix-core edge kernels (32 bytes per edge for S <= 8, 64 bytes for
+    8 < S <= 16); None when not applicable."""
     E, S = ea.shape
-    if S > 8 or E == 0:
+    if S > 16 or E == 0:
         return None
-    es = torch.empty(E, 8, dtype=torch.int32, device=ea.device)
+    es = torch.empty(E, 8 if S <= 8 else 16, dtype=torch.int32, device=ea.device)
     _lib.call('gml_edge_presplit', _ptr(ea), _ptr(es), int(E), int(S), _stream(ea.device))
     return es
 
@@ -501,7 +503,7 @@ class ML3LayerFunction(torch.autograd.Function):
                 # when the fused backward will run, the edge branch also emits its output in source order
                 dual = (any(ctx.needs_input_grad) and fused_bwd_available(csr, S, Fin, nout1)
                         and val.numel() * 4 < 0xffffff00)      # (32-bit scatter offsets of the second copy)
-                _path('edge', 'matrix-core chain' if max(val.size(1), w4.size(0)) <= 8 else 'VALU kernels (S > 8)', val.size(1), '-', w4.size(0))
+                _path('edge', 'matrix-core chain' if max(val.size(1), w4.size(0)) <= 8 else ('matrix-core chain16' if max(val.size(1), w4.size(0)) <= 16 and not EDGE_VALU else 'VALU kernels'), val.size(1), '-', w4.size(0))
                 with _Timed('edge_mlp_fwd', 4 * val.numel() * (3 if dual else 2), 20 * val.size(0) * val.size(1) ** 2):
                     ea, ea_t = edge_mlp_fwd(val, w1, w2, w3, w4, csr.tpos if dual else None, csr.presplit(val))
             else:

@@ -180,9 +180,9 @@ class GraphCSR(object):
 
     def presplit(self, val):
         """bf16 hi | lo image of a per-batch value array (cached on the tensor's identity like the other derived
-        arrays); None when the edge kernels do not use one (S > 8)."""
+        arrays); None when the edge kernels do not use one (S > 16)."""
         from .functional import edge_presplit
-        if val.size(1) > 8:
+        if val.size(1) > 16:
             return None
         if val.requires_grad:                                  # trained supports change every step: split, do not cache
             return edge_presplit(val.detach())

@@ -359,6 +359,18 @@ def test_spmm_sddmm_edge_mlp_node_mix_vs_oracle(dev):
                 close(got, w.grad, what='edge mlp (pre-split) %s S=%d' % (n, S))
             r4 = Fn.edge_mlp_bwd(ea.to(dev), *wd, gout.to(dev), False, ea_split=es)
             assert r4[0] is None and all(torch.equal(a_, b_) for a_, b_ in zip(r4[1:], r3[1:]))
+        else:                                              # 8 < S <= 16: K = 16-slot matrix-core chain on the 64-byte pre-split rows
+            es = Fn.edge_presplit(ea.to(dev))
+            assert es.shape == (E2, 16)
+            y3, yt3 = Fn.edge_mlp_fwd(ea.to(dev), *wd, tpos=tp, ea_split=es)
+            close(y3, yo, what='edge chain16 fwd S=%d' % S)
+            assert torch.equal(yt3[tp.long()], y3)
+            r5 = Fn.edge_mlp_bwd(ea.to(dev), *wd, gout.to(dev), False, ea_split=es)
+            assert r5[0] is None
+            for got, w, n in ((r5[1], wo[0], 'dw1'), (r5[2], wo[1], 'dw2'), (r5[3], wo[2], 'dw3'), (r5[4], wo[3], 'dw4')):
+                close(got, w.grad, what='edge chain16 %s S=%d' % (n, S))
+            r6 = Fn.edge_mlp_bwd(ea.to(dev), *wd, gout.to(dev), True, ea_split=es)     # supports' gradient wanted: VALU kernels
+            close(r6[0], eo.grad, what='edge mlp gin (S > 8, pre-split given) S=%d' % S)
 
 
 @pytest.mark.gpu
