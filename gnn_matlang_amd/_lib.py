@@ -28,7 +28,7 @@ SIGNATURES = {
     'gml_spectconv_fwd_group_rows': (ctypes.c_int32, [_i32, _i32, _i32, ctypes.c_uint32]),
     'gml_spectconv_fwd': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _p, _p, _i64,
                                          _i64, _i32, _i32, _i32, _u32, _p]),
-    'gml_ml3_fwd': (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _i64,
+    'gml_ml3_fwd': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _i64,
                                    _i64, _i32, _i32, _i32, _i32, _u32, _p]),
     'gml_spectconv_bwd_group_rows': (ctypes.c_int, [_i32, _i32, _i32, _u32]),
     'gml_spectconv_bwd_workspace_bytes': (_sz, [_i64, _i32, _i32, _i32, _i32, _i32, _u32]),

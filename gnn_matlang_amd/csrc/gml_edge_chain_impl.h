@@ -298,8 +298,17 @@ __global__ __launch_bounds__(256, 2) void gml_k_edge_chain_fwd(const float* __re
                 const f32x4 v = f32x4{fmaxf(T[u].out[0], 0.f), fmaxf(T[u].out[1], 0.f), fmaxf(T[u].out[2], 0.f),
                                       fmaxf(T[u].out[3], 0.f)};
                 const bool q_ok = q0 < S;
+#ifndef GML_FABL
+#define GML_FABL 0
+#endif
+#if !(GML_FABL & 2)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_o, q_ok ? off_o : (int)0xffffff00, 0, /*nt: written once, read by the next kernel from HBM anyway*/ 2);
+#else
+                asm volatile("" :: "v"(v));
+#endif
+#if !(GML_FABL & 1)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_t, q_ok ? off_t : (int)0xffffff00, 0, 0);
+#endif
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {

@@ -44,13 +44,13 @@ extern "C" int gml_node_mix_fwd(const float* x, int64_t ldx, const float* w11, c
                                 int32_t F2, gml_stream_t stream);
 
 // conv (+ optionally the Hadamard branch of the same rows) on the 8-wave kernel; 128-row group records
-static int launch_fwd2(const int32_t* rowptr, const int32_t* col, const int32_t* ginfo, const float* val, const float* x,
+static int launch_fwd2(const int32_t* rowptr, const int32_t* col, const int32_t* ginfo, const int32_t* epos, const float* val, const float* x,
                        int64_t ldx, const float* w, int64_t w_ss, int64_t w_si, int64_t w_so, const float* bias,
                        const float* w11, const float* b11, const float* w12, const float* b12, float* out, int64_t ldo,
                        int64_t num_rows, int32_t S, int32_t Fin, int32_t Fout, int32_t F2, uint32_t flags, hipStream_t st) {
     const bool xv = (ldx % 4 == 0) && (((uintptr_t)x & 15) == 0);
     GmlFwdParams p = {};
-    p.rowptr = rowptr; p.col = col; p.ginfo = ginfo; p.epos = nullptr; p.val = val; p.x = x; p.ldx = ldx;
+    p.rowptr = rowptr; p.col = col; p.ginfo = ginfo; p.epos = epos; p.val = val; p.x = x; p.ldx = ldx;
     p.w = w; p.w_ss = w_ss; p.w_si = w_si; p.w_so = w_so; p.bias = bias; p.out = out; p.ldo = ldo;
     p.nrows = num_rows; p.S = S; p.Fin = Fin; p.Fout = Fout; p.flags = flags; p.s0 = 0; p.npass = 1; p.nchunks = 1;
     p.val_vec = 1;
@@ -80,8 +80,8 @@ extern "C" int gml_spectconv_fwd(const int32_t* rowptr, const int32_t* col, cons
 
     if (flags & GML_GROUPS128) {
         // 128-row / 8-wave kernel: the caller passes 128-row group records (gml_spectconv_fwd_group_rows said 128)
-        if (!fwd2_shape(S, Fin, Fout, flags) || epos != nullptr || (((uintptr_t)val & 15) != 0)) return GML_E_BADARG;
-        return launch_fwd2(rowptr, col, ginfo, val, x, ldx, w, w_ss, w_si, w_so, bias, nullptr, nullptr, nullptr, nullptr,
+        if (!fwd2_shape(S, Fin, Fout, flags) || (((uintptr_t)val & 15) != 0)) return GML_E_BADARG;
+        return launch_fwd2(rowptr, col, ginfo, epos, val, x, ldx, w, w_ss, w_si, w_so, bias, nullptr, nullptr, nullptr, nullptr,
                            out, ldo, num_rows, S, Fin, Fout, 0, flags, st);
     }
 
@@ -152,8 +152,8 @@ extern "C" int gml_spectconv_fwd(const int32_t* rowptr, const int32_t* col, cons
 
 // ML3Layer forward (libs/spect_conv.py:204-212) minus the edge branch: out[:, :nout1] = relu?(conv(x)) and
 // out[:, nout1:nout1+F2] = tanh(fc11 x) * tanh(fc12 x); one launch on the 8-wave kernel when it applies (F2 <= 8).
-extern "C" int gml_ml3_fwd(const int32_t* rowptr, const int32_t* col, const int32_t* ginfo, const float* val,
-                           const float* x, int64_t ldx, const float* w, int64_t w_ss, int64_t w_si, int64_t w_so,
+extern "C" int gml_ml3_fwd(const int32_t* rowptr, const int32_t* col, const int32_t* ginfo, const int32_t* epos,
+                           const float* val, const float* x, int64_t ldx, const float* w, int64_t w_ss, int64_t w_si, int64_t w_so,
                            const float* bias, const float* w11, const float* b11, const float* w12, const float* b12,
                            float* out, int64_t ldo, int64_t num_rows, int32_t S, int32_t Fin, int32_t nout1,
                            int32_t F2, uint32_t flags, gml_stream_t stream) {
@@ -162,11 +162,11 @@ extern "C" int gml_ml3_fwd(const int32_t* rowptr, const int32_t* col, const int3
     if (num_rows > 0 && F2 > 0 && F2 <= 8 && (flags & GML_GROUPS128) && fwd2_shape(S, Fin, nout1, flags) &&
         (((uintptr_t)val & 15) == 0) && !(flags & GML_ACCUM)) {
         if (!rowptr || !ginfo || !x || !w || !out) return GML_E_BADARG;
-        return launch_fwd2(rowptr, col, ginfo, val, x, ldx, w, w_ss, w_si, w_so, bias, w11, b11, w12, b12, out, ldo,
+        return launch_fwd2(rowptr, col, ginfo, epos, val, x, ldx, w, w_ss, w_si, w_so, bias, w11, b11, w12, b12, out, ldo,
                            num_rows, S, Fin, nout1, F2, flags, (hipStream_t)stream);
     }
 #endif
-    int rc = gml_spectconv_fwd(rowptr, col, ginfo, nullptr, val, x, ldx, w, w_ss, w_si, w_so, bias, out, ldo, num_rows, S,
+    int rc = gml_spectconv_fwd(rowptr, col, ginfo, epos, val, x, ldx, w, w_ss, w_si, w_so, bias, out, ldo, num_rows, S,
                                Fin, nout1, flags, stream);
     if (rc != GML_OK || F2 == 0) return rc;
     return gml_node_mix_fwd(x, ldx, w11, b11, w12, b12, out + nout1, ldo, num_rows, Fin, F2, stream);

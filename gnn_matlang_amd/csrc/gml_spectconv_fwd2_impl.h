@@ -32,10 +32,15 @@ struct GmlFwd2Cfg {
 // MIX: the ML3Layer Hadamard branch (F2 <= 8 outputs) of the group's own rows rides along: one more K = 32 MFMA triple
 // per tile against the [w11; w12] rows instead of a second pass over x by another kernel
 // NOB = 0: stand-alone SpMM instantiation (p.hout receives the aggregate H; no W image, no projection)
-template <int S, int NOB, bool XVEC, bool MIX>
+// EP: value rows are gathered through p.epos (row of CSR position k = val[epos[k]]): the ML3Layer edge branch then lives in
+// ONE edge order (the backward's) and writes its output once -- the second, scattered copy cost the HBM-bound edge forward
+// 37 % of its time (profiles/r02_g_edge_fwd_ablation.txt).  The positions are loaded with the other prefetch loads, the
+// value rows they address after the aggregation loop (the positions have arrived by then: no exposed dependent latency).
+template <int S, int NOB, bool XVEC, bool MIX, bool EP = false>
 __global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p) {
     using C = GmlFwd2Cfg<S>;
     constexpr bool HOUT = (NOB == 0);
+    static_assert(!(EP && NOB == 0), "the stand-alone SpMM instantiations take contiguous value rows");
     constexpr int NOBA = HOUT ? 1 : NOB;
     constexpr bool H32 = HOUT && MIX;                          // SpMM instantiations reuse the MIX slot: Fin == 32 (full-line stores)
     constexpr bool MIXB = MIX && !HOUT;
@@ -95,12 +100,14 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p
     const int etot = p.rowptr[p.nrows];
     const int* colb = etot > 0 ? p.col : p.ginfo;              // an edgeless graph reads the (always present) group records
     const f32x4* valb = etot > 0 ? reinterpret_cast<const f32x4*>(p.val) : reinterpret_cast<const f32x4*>(p.ginfo);
+    const int* eposb = (EP && etot > 0) ? p.epos : p.ginfo;
     const int emax = max(etot, 1) - 1;
     const int64_t emax4 = (S % 4 == 0) ? max((int64_t)etot * (S / 4), (int64_t)1) - 1 : 0;
     static_assert(S % 4 == 0, "float4 value rows");
     constexpr bool vec_ok = true;                              // the dispatcher guarantees p.S == S and 16-byte aligned value rows
     const int f4max = ((p.Fin + 3) / 4 * 4 - 4);
     int cv[NC], rpv = 0;
+    int pv[EP ? NE4 : 1];
     f32x4 ev4[NE4], xv4[NX4];
     float xv1[NX1];
     // group records run one stage ahead of the data they describe: rec_* = record of the group whose data loads are
@@ -124,10 +131,16 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p
         const int64_t r0 = (int64_t)g * ROWS;
         rpv = p.rowptr[min(r0 + tid, p.nrows)];
         const int kb = gi_n.x, lo = gi_n.z;
+        if constexpr (EP) {                                    // first in the burst: they gate issue_vals()
+#pragma unroll
+            for (int t = 0; t < NE4; ++t) pv[t] = eposb[min(kb + (tid + 512 * t) / (S / 4), emax)];
+        }
 #pragma unroll
         for (int t = 0; t < NC; ++t) cv[t] = colb[min(kb + tid + 512 * t, emax)];
+        if constexpr (!EP) {
 #pragma unroll
-        for (int t = 0; t < NE4; ++t) ev4[t] = valb[min((int64_t)kb * (S / 4) + tid + 512 * t, emax4)];
+            for (int t = 0; t < NE4; ++t) ev4[t] = valb[min((int64_t)kb * (S / 4) + tid + 512 * t, emax4)];
+        }
         if constexpr (XVEC) {
 #pragma unroll
             for (int t = 0; t < NX4; ++t) {
@@ -144,6 +157,11 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p
             }
         }
         if constexpr (ROT) load_rec(gnext);
+    };
+    auto issue_vals = [&]() {                                  // EP: the value rows at the positions that arrived meanwhile
+#pragma unroll
+        for (int t = 0; t < NE4; ++t)
+            ev4[t] = valb[min((int64_t)(EP ? pv[t] : 0) * (S / 4) + ((tid + 512 * t) % (S / 4)), emax4)];
     };
     // the staged group's description (latched by commit)
     int kb = 0, ne = 0, lo = 0, row = 0;
@@ -191,6 +209,7 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p
     // prefetched registers it has to recycle), the SpMM 2 % slower.
     if constexpr (ROT) load_rec(g0);
     issue(g0, min(g0 + 1, g1 - 1));
+    if constexpr (EP) issue_vals();
     if constexpr (ROT) commit(g0);
     __syncthreads();                                           // W images (and, rotated, the first group's staging) complete
 
@@ -253,12 +272,15 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p
                 for (int t = 0; t < 8; ++t) xb[t] = (8 * kq + t < p.Fin) ? p.x[(int64_t)src * p.ldx + 8 * kq + t] : 0.f;
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
-                    const float e = p.val[(int64_t)k * p.S + p.s0 + s];
+                    const float e = p.val[(int64_t)(EP ? p.epos[k] : k) * p.S + p.s0 + s];
                     const f32x2 e2 = f32x2{e, e};
 #pragma unroll
                     for (int h = 0; h < 4; ++h) acc[s][h] = e2 * f32x2{xb[2 * h], xb[2 * h + 1]} + acc[s][h];
                 }
             }
+        }
+        if constexpr (EP) {
+            if (g + 1 < g1) issue_vals();                      // next group's value rows (their positions were issued at the top)
         }
 
         if constexpr (HOUT) {                                  // stand-alone SpMM: the aggregate is the output
@@ -412,14 +434,15 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p
 template <int S, int NOB>
 int gml_launch_fwd2(const GmlFwdParams& p, dim3 grid, hipStream_t st, bool xvec, bool mix);
 
-#define GML_FWD2_LAUNCH(SV, NOBV, XV, MX)                                                                    \
+#define GML_FWD2_LAUNCH_E(SV, NOBV, XV, MX, EPV)                                                             \
     {                                                                                                        \
-        GML_ALLOW_BIG_LDS(rc_, (&gml_k_spectconv_fwd2<SV, NOBV, XV, MX>), 160 * 1024) \
+        GML_ALLOW_BIG_LDS(rc_, (&gml_k_spectconv_fwd2<SV, NOBV, XV, MX, EPV>), 160 * 1024)                   \
         if (rc_ != hipSuccess) return (int)rc_;                                                              \
-        hipLaunchKernelGGL((gml_k_spectconv_fwd2<SV, NOBV, XV, MX>), grid, dim3(512),                        \
+        hipLaunchKernelGGL((gml_k_spectconv_fwd2<SV, NOBV, XV, MX, EPV>), grid, dim3(512),                   \
                            GmlFwd2Cfg<SV>::lds_bytes(), st, p);                                              \
         return gml_launch_status();                                                                          \
     }
+#define GML_FWD2_LAUNCH(SV, NOBV, XV, MX) GML_FWD2_LAUNCH_E(SV, NOBV, XV, MX, false)
 #define GML_DEFINE_SPMM2(SV)                                                                                 \
     template <>                                                                                              \
     int gml_launch_fwd2<SV, 0>(const GmlFwdParams& p, dim3 grid, hipStream_t st, bool xvec, bool) {          \
@@ -430,6 +453,12 @@ int gml_launch_fwd2(const GmlFwdParams& p, dim3 grid, hipStream_t st, bool xvec,
 #define GML_DEFINE_FWD2(SV, NOBV)                                                                            \
     template <>                                                                                              \
     int gml_launch_fwd2<SV, NOBV>(const GmlFwdParams& p, dim3 grid, hipStream_t st, bool xvec, bool mix) {   \
+        if (p.epos != nullptr) {                                                                             \
+            if (xvec && mix) GML_FWD2_LAUNCH_E(SV, NOBV, true, true, true)                                   \
+            if (xvec) GML_FWD2_LAUNCH_E(SV, NOBV, true, false, true)                                         \
+            if (mix) GML_FWD2_LAUNCH_E(SV, NOBV, false, true, true)                                          \
+            GML_FWD2_LAUNCH_E(SV, NOBV, false, false, true)                                                  \
+        }                                                                                                    \
         if (xvec && mix) GML_FWD2_LAUNCH(SV, NOBV, true, true)                                               \
         if (xvec) GML_FWD2_LAUNCH(SV, NOBV, true, false)                                                     \
         if (mix) GML_FWD2_LAUNCH(SV, NOBV, false, true)                                                      \

@@ -133,6 +133,15 @@ def fwd_groups(csr, x, S, Fin, Fout):
     return csr.ginfo, 0
 
 
+def fwd_gathers(S, Fin, Fout):
+    """True when the forward of this shape runs on the 8-wave kernel, which can take its value rows through a position map
+    (GML_EDGE_DUAL=1 keeps the round-1 scheme -- edge branch in target order, second copy scattered -- for A/B)."""
+    if _os.environ.get('GML_FWD64') or _os.environ.get('GML_EDGE_DUAL'):
+        return False
+    flags = _lib.GML_F32_MFMA if F32_MFMA else 0
+    return int(_lib.lib().gml_spectconv_fwd_group_rows(int(S), int(Fin), int(Fout), flags)) == 128
+
+
 def spmm(csr, val, x, S, Fin):
     h = torch.empty(csr.N, S * Fin, dtype=torch.float32, device=x.device)
     _lib.call('gml_spmm_fwd', _ptr(csr.rowptr), _ptr(csr.col), _ptr(csr.ginfo128), _ptr(None), _ptr(val), _ptr(x), int(x.stride(0)),
@@ -497,15 +506,28 @@ class ML3LayerFunction(torch.autograd.Function):
                              % (tuple(x.shape), tuple(val.shape), tuple(cw.shape), N, csr.E))
         C = nout1 + nout2
         with torch.cuda.device(x.device):
+            epos = None
             if learnedge:
                 w1, w2, w3, w4 = (_f32c(w1, 'fc1_1.weight'), _f32c(w2, 'fc1_2.weight'), _f32c(w3, 'fc1_3.weight'),
                                   _f32c(w4, 'fc1_4.weight'))
-                # when the fused backward will run, the edge branch also emits its output in source order
-                dual = (any(ctx.needs_input_grad) and fused_bwd_available(csr, S, Fin, nout1)
-                        and val.numel() * 4 < 0xffffff00)      # (32-bit scatter offsets of the second copy)
+                # When the fused backward will run, the edge branch lives in SOURCE order (the order that kernel walks): the raw
+                # supports in that order are per-batch data (for source-sorted input: the input itself), the branch writes
+                # its output once, and the forward conv gathers the rows through tpos (target position -> source position).
+                # (r02: emitting both orders from the edge kernel cost it 37 % -- it is HBM-bound and the second copy was a
+                # scattered 32-byte-row write.)
+                fused_b = any(ctx.needs_input_grad) and fused_bwd_available(csr, S, Fin, nout1)
+                src_order = fused_b and fwd_gathers(S, Fin, nout1)
+                # (forward kernels without the gather: both orders from the edge kernel, second copy scattered through tpos)
+                dual = fused_b and not src_order and val.numel() * 4 < 0xffffff00
                 _path('edge', 'matrix-core chain' if max(val.size(1), w4.size(0)) <= 8 else ('matrix-core chain16' if max(val.size(1), w4.size(0)) <= 16 and not EDGE_VALU else 'VALU kernels'), val.size(1), '-', w4.size(0))
-                with _Timed('edge_mlp_fwd', 4 * val.numel() * (3 if dual else 2), 20 * val.size(0) * val.size(1) ** 2):
-                    ea, ea_t = edge_mlp_fwd(val, w1, w2, w3, w4, csr.tpos if dual else None, csr.presplit(val))
+                if src_order:
+                    val_s = csr.to_source_order(val, cache=not val.requires_grad)
+                    with _Timed('edge_mlp_fwd', 4 * val.numel() * 2, 20 * val.size(0) * val.size(1) ** 2):
+                        ea_t, _ = edge_mlp_fwd(val_s, w1, w2, w3, w4, None, csr.presplit(val_s))
+                    ea, epos = ea_t, csr.tpos
+                else:
+                    with _Timed('edge_mlp_fwd', 4 * val.numel() * (3 if dual else 2), 20 * val.size(0) * val.size(1) ** 2):
+                        ea, ea_t = edge_mlp_fwd(val, w1, w2, w3, w4, csr.tpos if dual else None, csr.presplit(val))
             else:
                 ea, ea_t = val, None
             if ea.size(1) != S:
@@ -521,7 +543,7 @@ class ML3LayerFunction(torch.autograd.Function):
             if nout2 > 0:
                 _path('hadamard', 'fused kernels' if mixk else 'library GEMMs (ninp > 64 or nout2 > 24)', '-', Fin, nout2)
             with _Timed('spectconv_fwd', q, f):                    # conv (+ Hadamard branch of the same rows)
-                _lib.call('gml_ml3_fwd', _ptr(csr.rowptr), _ptr(csr.col), _ptr(gi), _ptr(ea), _ptr(x), Fin, _ptr(cw),
+                _lib.call('gml_ml3_fwd', _ptr(csr.rowptr), _ptr(csr.col), _ptr(gi), _ptr(epos), _ptr(ea), _ptr(x), Fin, _ptr(cw),
                           Fin * nout1, nout1, 1, _ptr(cb_), _ptr(w11 if mixk else None),
                           _ptr(b11 if mixk else None), _ptr(w12 if mixk else None),
                           _ptr(b12 if mixk else None), _ptr(out), C, N, S, Fin, nout1, int(nout2) if mixk else 0,
@@ -530,7 +552,8 @@ class ML3LayerFunction(torch.autograd.Function):
                 # ninp > 64 or nout2 > 24 (ptc.py:331-338 has ninp = 80): two plain library GEMMs + elementwise
                 out[:, nout1:] = torch.tanh(_linear(x, w11, b11)) * torch.tanh(_linear(x, w12, b12))
         ctx.csr, ctx.learnedge, ctx.nout2, ctx.has_cb = csr, learnedge, nout2, cb is not None
-        ctx.save_for_backward(x, val, ea if learnedge else None, w1, w2, w3, w4, cw, w11, b11, w12, b12, out, ea_t)
+        ctx.src_order = epos is not None
+        ctx.save_for_backward(x, val, (ea if learnedge and epos is None else None), w1, w2, w3, w4, cw, w11, b11, w12, b12, out, ea_t)
         return out
 
     @staticmethod

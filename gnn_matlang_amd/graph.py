@@ -147,13 +147,9 @@ class GraphCSR(object):
         ea = edge_attr.contiguous()
         out = torch.empty_like(ea)
         S = int(ea.size(1))
-        if cache and S <= 8 and self.E > 0 and (S != 8 or (ea.data_ptr() | out.data_ptr()) % 16 == 0):
-            # per-batch data: the sorted rows and their bf16 pre-split (the matrix-core edge kernels' operand) in one pass
-            es = torch.empty(self.E, 8, dtype=torch.int32, device=ea.device)
-            _lib.call('gml_gather_rows_presplit', _ptr(ea), _ptr(self.perm), _ptr(out), _ptr(es), self.E, S, _stream(ea.device))
-            self._val_cache[('p', out.data_ptr(), out._version, tuple(out.shape))] = (out, es)
-        else:
-            _lib.call('gml_gather_rows', _ptr(ea), _ptr(self.perm), _ptr(out), self.E, S, _stream(ea.device))
+        # (the bf16 pre-split the edge kernels want belongs to the SOURCE-order copy -- the order the edge branch runs in
+        #  when the layer trains, functional.ML3LayerFunction -- and is made by to_source_order / presplit)
+        _lib.call('gml_gather_rows', _ptr(ea), _ptr(self.perm), _ptr(out), self.E, S, _stream(ea.device))
         if cache:
             self._val_cache[key] = (edge_attr, out)        # keep the source alive: its address is the key
             if self.src_sorted and ea is edge_attr:
@@ -170,8 +166,15 @@ class GraphCSR(object):
         if cache and key in self._val_cache:
             return self._val_cache[key][1]
         out = torch.empty_like(val_sorted)
-        _lib.call('gml_gather_rows', _ptr(val_sorted), _ptr(self.pos_t), _ptr(out), self.E, int(val_sorted.size(1)),
-                  _stream(val_sorted.device))
+        S = int(val_sorted.size(1))
+        if cache and S <= 8 and self.E > 0 and (S != 8 or (val_sorted.data_ptr() | out.data_ptr()) % 16 == 0):
+            # per-batch data: the source-order rows and their bf16 pre-split (the matrix-core edge kernels' operand) in one pass
+            es = torch.empty(self.E, 8, dtype=torch.int32, device=out.device)
+            _lib.call('gml_gather_rows_presplit', _ptr(val_sorted), _ptr(self.pos_t), _ptr(out), _ptr(es), self.E, S,
+                      _stream(out.device))
+            self._val_cache[('p', out.data_ptr(), out._version, tuple(out.shape))] = (out, es)
+        else:
+            _lib.call('gml_gather_rows', _ptr(val_sorted), _ptr(self.pos_t), _ptr(out), self.E, S, _stream(out.device))
         if cache:
             self._val_cache[key] = (val_sorted, out)
             while len(self._val_cache) > 12:

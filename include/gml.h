@@ -184,9 +184,12 @@ int gml_edge_mlp_bwd(const float* ea, const void* ea_split, const float* w1, con
 
 /* ---------------------------------------------------------------- ML3Layer forward without the edge branch
  * (libs/spect_conv.py:204-212): out[:, :nout1] = act(SpectConv(x)), out[:, nout1:nout1+F2] = tanh(fc11 x) * tanh(fc12 x).
- * Same arguments as gml_spectconv_fwd (epos = NULL) + the Hadamard weights; one launch on the 8-wave kernel when
- * GML_GROUPS128 applies and F2 <= 8, else gml_spectconv_fwd followed by gml_node_mix_fwd.  F2 = 0: conv only. */
-int gml_ml3_fwd(const int32_t* rowptr, const int32_t* col, const int32_t* ginfo, const float* val,
+ * Same arguments as gml_spectconv_fwd + the Hadamard weights; one launch on the 8-wave kernel when GML_GROUPS128 applies
+ * and F2 <= 8, else gml_spectconv_fwd followed by gml_node_mix_fwd.  F2 = 0: conv only.
+ * epos != NULL: the value row of CSR position k is val[epos[k]] -- with epos = the target-to-source position map the
+ * layer consumes the edge branch's output in SOURCE order (the order the backward walks), so the edge branch writes its
+ * output once instead of once per order. */
+int gml_ml3_fwd(const int32_t* rowptr, const int32_t* col, const int32_t* ginfo, const int32_t* epos, const float* val,
                 const float* x, int64_t ldx, const float* w, int64_t w_ss, int64_t w_si, int64_t w_so,
                 const float* bias, const float* w11, const float* b11, const float* w12, const float* b12,
                 float* out, int64_t ldo, int64_t num_rows, int32_t S, int32_t Fin, int32_t nout1, int32_t F2,
