@@ -142,6 +142,11 @@ def fwd_gathers(S, Fin, Fout):
     return int(_lib.lib().gml_spectconv_fwd_group_rows(int(S), int(Fin), int(Fout), flags)) == 128
 
 
+def ml3_edge_in_source_order(csr, S, Fin, Fout):
+    """True when a training ML3Layer of this shape runs its edge branch in source order (fused backward + gathering forward)."""
+    return fused_bwd_available(csr, S, Fin, Fout) and fwd_gathers(S, Fin, Fout)
+
+
 def spmm(csr, val, x, S, Fin):
     h = torch.empty(csr.N, S * Fin, dtype=torch.float32, device=x.device)
     _lib.call('gml_spmm_fwd', _ptr(csr.rowptr), _ptr(csr.col), _ptr(csr.ginfo128), _ptr(None), _ptr(val), _ptr(x), int(x.stride(0)),
@@ -497,7 +502,9 @@ class ML3LayerFunction(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, val, w1, w2, w3, w4, cw, cb, w11, b11, w12, b12, csr, learnedge, nout2):
+    def forward(ctx, x, val, w1, w2, w3, w4, cw, cb, w11, b11, w12, b12, csr, learnedge, nout2, val_is_source=False):
+        # val_is_source: val holds the raw supports in SOURCE order (the caller checked ml3_edge_in_source_order and that they
+        # carry no gradient); otherwise target-sorted order
         x, val, cw = _f32c(x, 'x'), _f32c(val, 'edge_attr'), _f32c(cw, 'conv1.weight')
         S, Fin, nout1 = cw.shape
         N = csr.N
@@ -516,12 +523,12 @@ class ML3LayerFunction(torch.autograd.Function):
                 # (r02: emitting both orders from the edge kernel cost it 37 % -- it is HBM-bound and the second copy was a
                 # scattered 32-byte-row write.)
                 fused_b = any(ctx.needs_input_grad) and fused_bwd_available(csr, S, Fin, nout1)
-                src_order = fused_b and fwd_gathers(S, Fin, nout1)
+                src_order = bool(val_is_source) or (fused_b and fwd_gathers(S, Fin, nout1))
                 # (forward kernels without the gather: both orders from the edge kernel, second copy scattered through tpos)
                 dual = fused_b and not src_order and val.numel() * 4 < 0xffffff00
                 _path('edge', 'matrix-core chain' if max(val.size(1), w4.size(0)) <= 8 else ('matrix-core chain16' if max(val.size(1), w4.size(0)) <= 16 and not EDGE_VALU else 'VALU kernels'), val.size(1), '-', w4.size(0))
                 if src_order:
-                    val_s = csr.to_source_order(val, cache=not val.requires_grad)
+                    val_s = val if val_is_source else csr.to_source_order(val, cache=not val.requires_grad)
                     with _Timed('edge_mlp_fwd', 4 * val.numel() * 2, 20 * val.size(0) * val.size(1) ** 2):
                         ea_t, _ = edge_mlp_fwd(val_s, w1, w2, w3, w4, None, csr.presplit(val_s))
                     ea, epos = ea_t, csr.tpos
@@ -553,6 +560,7 @@ class ML3LayerFunction(torch.autograd.Function):
                 out[:, nout1:] = torch.tanh(_linear(x, w11, b11)) * torch.tanh(_linear(x, w12, b12))
         ctx.csr, ctx.learnedge, ctx.nout2, ctx.has_cb = csr, learnedge, nout2, cb is not None
         ctx.src_order = epos is not None
+        ctx.val_is_source = bool(val_is_source)
         ctx.save_for_backward(x, val, (ea if learnedge and epos is None else None), w1, w2, w3, w4, cw, w11, b11, w12, b12, out, ea_t)
         return out
 
@@ -566,7 +574,7 @@ class ML3LayerFunction(torch.autograd.Function):
         gy = _f32c(gy, 'grad_out')
         if not learnedge:
             ea = val
-        g = [None] * 15
+        g = [None] * 16
         with torch.cuda.device(x.device):
             need_val = need[1] or (learnedge and any(need[2:6]))
             if not learnedge and fused_bwd_available(csr, S, Fin, nout1):
@@ -610,7 +618,7 @@ class ML3LayerFunction(torch.autograd.Function):
             if learnedge:
                 if need_val:
                     # the edge MLP is per-edge, so it can run in whichever order dea arrived in
-                    val_in = csr.to_source_order(val, cache=not val.requires_grad) if dea_src else val
+                    val_in = val if ctx.val_is_source else (csr.to_source_order(val, cache=not val.requires_grad) if dea_src else val)
                     with _Timed('edge_mlp_bwd', 4 * val.numel() * 2, 60 * val.size(0) * val.size(1) ** 2):
                         gin, g[2], g[3], g[4], g[5] = edge_mlp_bwd(val_in, w1, w2, w3, w4, dea, need[1],
                                                                    csr.presplit(val_in))

@@ -16,6 +16,7 @@ import math
 import torch
 from torch.nn import Parameter
 
+from . import functional as Fn
 from .functional import ML3LayerFunction, SpectConvFunction
 from .graph import csr_for, GraphCSR, _require_cuda
 
@@ -207,7 +208,17 @@ class ML3Layer(torch.nn.Module):
         le, n2 = self.learnedge, self.nout2
         # learnedge: fc1_1..3 are Linear(nedgeinput, .) -- the width must match, as in the reference; otherwise conv1
         # reads the first K columns only
-        val = _sorted_values(csr, edge_index, edge_attr, None if le else self.conv1.weight.size(0))
+        # Training with the edge branch: the branch runs in SOURCE order (functional.ML3LayerFunction).  SpectralDesign emits
+        # source-sorted edges, so the raw supports in that order are the input tensor itself: no value sort at all.
+        raw_src = (le and csr.src_sorted and torch.is_grad_enabled() and edge_attr.dim() == 2 and not edge_attr.requires_grad
+                   and edge_attr.dtype == torch.float32 and edge_attr.is_contiguous() and edge_attr.size(0) == csr.E
+                   and edge_attr.size(1) == self.fc1_1.weight.size(1) and self.fc1_4.weight.size(0) == edge_attr.size(1)
+                   and Fn.ml3_edge_in_source_order(csr, edge_attr.size(1), self.conv1.weight.size(1), self.conv1.weight.size(2)))
+        if raw_src:
+            _require_cuda(edge_attr, 'edge_attr')
+            val = edge_attr.detach()
+        else:
+            val = _sorted_values(csr, edge_index, edge_attr, None if le else self.conv1.weight.size(0))
         return ML3LayerFunction.apply(
             x, val,
             self.fc1_1.weight if le else None, self.fc1_2.weight if le else None,
@@ -215,7 +226,7 @@ class ML3Layer(torch.nn.Module):
             self.conv1.weight, self.conv1.bias,
             self.fc11.weight if n2 > 0 else None, self.fc11.bias if n2 > 0 else None,
             self.fc12.weight if n2 > 0 else None, self.fc12.bias if n2 > 0 else None,
-            csr, le, n2)
+            csr, le, n2, bool(raw_src))
 
 
 __all__ = ['SpectConv', 'SpectConCatConv', 'ML3Layer', 'GraphCSR', 'glorot', 'zeros']
