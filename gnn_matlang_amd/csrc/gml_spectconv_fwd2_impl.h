@@ -12,6 +12,11 @@
 #include "gml_common.h"
 #include "gml_spectconv_impl.h"
 
+// ablation builds (tools/build_variant.py fw<bits> -DGML_FWABL=<bits>): results WRONG, timing says what a phase costs
+//   1 = no aggregation loop, 2 = no projection, 4 = no output stores, 8 = every group loads the workgroup's first group
+#ifndef GML_FWABL
+#define GML_FWABL 0
+#endif
 #define GML_FWD2_ROWS 128
 #define GML_FWD2_ECAP 1024      // staged edges per group
 #define GML_FWD2_XCAP 208       // staged window rows of X (128 rows + 2 x the largest graph of a block-diagonal batch)
@@ -45,6 +50,14 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p
     constexpr bool H32 = HOUT && MIX;                          // SpMM instantiations reuse the MIX slot: Fin == 32 (full-line stores)
     constexpr bool MIXB = MIX && !HOUT;
     constexpr bool ROT = HOUT;                                 // loop shape, see below
+    // group records one stage ahead of the data they describe: only in the rotated shape.  Measured again in round 2
+    // (-DGML_FWD2_REC_AHEAD, tools/ab.sh): with the record prefetched the conv instantiations run 10 % SLOWER (2.34 vs 2.12
+    // ms/step), although the dependent record -> data round trip disappears from the issue burst.
+#ifdef GML_FWD2_REC_AHEAD
+    constexpr bool RECPRE = true;
+#else
+    constexpr bool RECPRE = ROT;
+#endif
     constexpr int LDX = C::LDX, ROWS = GML_FWD2_ROWS;
     constexpr int VAL_ALIGN = (S % 4 == 0) ? 4 : ((S % 2 == 0) ? 2 : 1);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -126,7 +139,7 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p
         rec_outrows = reinterpret_cast<const uint32_t*>(rec + 4)[wave * 4 + kq];
     };
     auto issue = [&](int g, int gnext) {                       // data loads of group g (record in rec_*), record of gnext
-        if constexpr (!ROT) load_rec(g);                       // commit-at-top shape: record and data in one stage
+        if constexpr (!RECPRE) load_rec(g);                    // (record and data in one stage: a dependent round trip per group)
         gi_n = rec_gi; row_n = rec_row; outrows_n = rec_outrows;
         const int64_t r0 = (int64_t)g * ROWS;
         rpv = p.rowptr[min(r0 + tid, p.nrows)];
@@ -156,7 +169,7 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p
                 xv1[t] = p.x[rr * p.ldx + min(i & 31, p.Fin - 1)];
             }
         }
-        if constexpr (ROT) load_rec(gnext);
+        if constexpr (RECPRE) load_rec(gnext);                 // last in the burst: nothing of this stage waits for it
     };
     auto issue_vals = [&]() {                                  // EP: the value rows at the positions that arrived meanwhile
 #pragma unroll
@@ -207,7 +220,7 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p
     // Only the SpMM instantiations (store-bound) are rotated: the conv instantiations measured 4-5 % FASTER with the
     // commit at the loop top and the record fetched with its data (their projection phase already stalls on the
     // prefetched registers it has to recycle), the SpMM 2 % slower.
-    if constexpr (ROT) load_rec(g0);
+    if constexpr (RECPRE) load_rec(g0);
     issue(g0, min(g0 + 1, g1 - 1));
     if constexpr (EP) issue_vals();
     if constexpr (ROT) commit(g0);
@@ -222,7 +235,7 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p
         } else {
             commit(g);
             __syncthreads();
-            if (g + 1 < g1) issue(g + 1, min(g + 2, g1 - 1));
+            if (g + 1 < g1) issue((GML_FWABL & 8) ? g0 : g + 1, min(g + 2, g1 - 1));
         }
         const bool rvalid = row < nr;
         float xrow[MIXB ? 8 : 1];                              // the lane's own x row, features 8*kq..8*kq+7 (Hadamard branch)
@@ -250,7 +263,7 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p
 #pragma unroll
             for (int h = 0; h < 4; ++h) acc[s][h] = f32x2{0.f, 0.f};
         if (staged) {
-            for (int k = kbeg - kb; k < kend - kb; ++k) {
+            for (int k = kbeg - kb; k < ((GML_FWABL & 1) ? kbeg - kb : kend - kb); ++k) {
                 const int srcl = col_l[k];
                 float ev[S];
                 gml_load_row<S, VAL_ALIGN>(ea_l + k * S, ev);
@@ -366,7 +379,7 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p
             };
             frag(0, 0);
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
+            for (int s = 0; s < ((GML_FWABL & 2) ? 0 : S); ++s) {
                 const int st = s & 1;
                 if (s + 1 < S) frag(s + 1, st ^ 1);
                 const float av[8] = {acc[s][0].x, acc[s][0].y, acc[s][1].x, acc[s][1].y, acc[s][2].x, acc[s][2].y, acc[s][3].x, acc[s][3].y};
@@ -399,7 +412,7 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p
                 const int lr = (int)((out_rows >> (8 * reg)) & 255u);
                 float v = oacc[ob][reg] + bias_r[ob];
                 if (relu) v = fmaxf(v, 0.f);
-                const int off = (o < p.Fout && lr < nr) ? (lr * (int)p.ldo + o) * 4 : 0x7fffff00;
+                const int off = (o < p.Fout && lr < nr && !(GML_FWABL & 4)) ? (lr * (int)p.ldo + o) * 4 : 0x7fffff00;
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ors, off, 0, 0);
             }
         }
