@@ -43,6 +43,18 @@ extern "C" int gml_node_mix_fwd(const float* x, int64_t ldx, const float* w11, c
                                 const float* b12, float* out, int64_t ldo, int64_t num_rows, int32_t Fin,
                                 int32_t F2, gml_stream_t stream);
 
+#ifdef GML_FWD2_TIMING
+static unsigned long long* fwd2_prof_buf() {
+    static unsigned long long* b = [] { unsigned long long* q = nullptr; (void)hipMalloc(&q, 128); (void)hipMemset(q, 0, 128); return q; }();
+    return b;
+}
+extern "C" int gml_debug_fwd2_prof(unsigned long long* out, int reset) {
+    hipError_t e = hipMemcpy(out, fwd2_prof_buf(), 128, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && reset) e = hipMemset(fwd2_prof_buf(), 0, 128);
+    return (int)e;
+}
+#endif
+
 // conv (+ optionally the Hadamard branch of the same rows) on the 8-wave kernel; 128-row group records
 static int launch_fwd2(const int32_t* rowptr, const int32_t* col, const int32_t* ginfo, const int32_t* epos, const float* val, const float* x,
                        int64_t ldx, const float* w, int64_t w_ss, int64_t w_si, int64_t w_so, const float* bias,
@@ -55,6 +67,9 @@ static int launch_fwd2(const int32_t* rowptr, const int32_t* col, const int32_t*
     p.nrows = num_rows; p.S = S; p.Fin = Fin; p.Fout = Fout; p.flags = flags; p.s0 = 0; p.npass = 1; p.nchunks = 1;
     p.val_vec = 1;
     p.w11 = w11; p.b11 = b11; p.w12 = w12; p.b12 = b12; p.F2 = F2; p.mix_col = Fout;
+#ifdef GML_FWD2_TIMING
+    p.prof = fwd2_prof_buf();
+#endif
     p.ngroups = (int)gml_cdiv(num_rows, GML_FWD2_ROWS);
     int grid = p.ngroups < GML_NUM_CU ? p.ngroups : GML_NUM_CU;      // one 512-thread workgroup per CU
     p.groups_per_wg = (int)gml_cdiv(p.ngroups, grid);

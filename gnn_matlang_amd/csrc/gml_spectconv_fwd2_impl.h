@@ -17,6 +17,14 @@
 #ifndef GML_FWABL
 #define GML_FWABL 0
 #endif
+// timing build (-DGML_FWD2_TIMING): every wave sums its phase durations in registers and adds them to p.prof at the end
+// (0 commit, 1 barrier, 2 issue, 3 own-row loads + row bounds, 4 aggregation, 5 value gather issue, 6 projection,
+//  7 output stores, 8 Hadamard branch, 9 end barrier); tools/fwd2_phases.py
+#ifdef GML_FWD2_TIMING
+#define GML_TF(i) do { const unsigned t_ = (unsigned)__builtin_readcyclecounter(); tacc_[i] += t_ - tprev_; tprev_ = t_; } while (0)
+#else
+#define GML_TF(i)
+#endif
 #define GML_FWD2_ROWS 128
 #define GML_FWD2_ECAP 1024      // staged edges per group
 #define GML_FWD2_XCAP 208       // staged window rows of X (128 rows + 2 x the largest graph of a block-diagonal batch)
@@ -226,6 +234,10 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p
     if constexpr (ROT) commit(g0);
     __syncthreads();                                           // W images (and, rotated, the first group's staging) complete
 
+#ifdef GML_FWD2_TIMING
+    unsigned tacc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned tprev_ = (unsigned)__builtin_readcyclecounter();
+#endif
     for (int g = g0; g < g1; ++g) {
         const int64_t r0 = (int64_t)g * ROWS;
         const int nr = (int)min((int64_t)ROWS, p.nrows - r0);
@@ -234,8 +246,11 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p
             issue(gn, min(g + 2, g1 - 1));                     // in flight during this group's compute
         } else {
             commit(g);
+            GML_TF(0);
             __syncthreads();
+            GML_TF(1);
             if (g + 1 < g1) issue((GML_FWABL & 8) ? g0 : g + 1, min(g + 2, g1 - 1));
+            GML_TF(2);
         }
         const bool rvalid = row < nr;
         float xrow[MIXB ? 8 : 1];                              // the lane's own x row, features 8*kq..8*kq+7 (Hadamard branch)
@@ -255,6 +270,7 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p
 
         const int kbeg = rvalid ? rp_l[row] : 0;
         const int kend = rvalid ? rp_l[row + 1] : 0;
+        GML_TF(3);
 
         // ---- aggregation (fp32 VALU, packed): acc[s][f] += val[k, s] * x[col[k], f], f = 8*kq .. 8*kq+7
         f32x2 acc[S][4];
@@ -292,9 +308,11 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p
                 }
             }
         }
+        GML_TF(4);
         if constexpr (EP) {
             if (g + 1 < g1) issue_vals();                      // next group's value rows (their positions were issued at the top)
         }
+        GML_TF(5);
 
         if constexpr (HOUT) {                                  // stand-alone SpMM: the aggregate is the output
             // H[row][s][0..Fin) is 4 * Fin bytes: a lane's 8 features are a quarter of it.  Through a per-wave LDS tile
@@ -399,6 +417,7 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p
                 __builtin_amdgcn_sched_group_barrier(0x008, 3 * NOB, 0);
             }
         }
+        GML_TF(6);
         // output stores through a buffer descriptor based at this group's first row: lanes outside (row >= nr,
         // column >= Fout) get an offset beyond the range and are dropped by the hardware -- no predicate, so the
         // compiler counts the stores and the next group's commit does not wait for them (see the SpMM branch above)
@@ -416,6 +435,7 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ors, off, 0, 0);
             }
         }
+        GML_TF(7);
         if constexpr (MIXB) {
             // z[row][c] = x[row] . wmix[c]: A = the lane's row (k = f), D: lane (c = r16, kq) holds rows 4*kq + reg
 #pragma unroll
@@ -436,12 +456,20 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(t * u), ors, off, 0, 0);
             }
         }
+        GML_TF(8);
         __syncthreads();                                       // this group's LDS reads are done
+        GML_TF(9);
         if constexpr (ROT) {
             if (g + 1 < g1) commit(gn);
             __syncthreads();
         }
     }
+#ifdef GML_FWD2_TIMING
+    if (lane == 0 && p.prof != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) atomicAdd(&p.prof[i], (unsigned long long)tacc_[i]);
+    }
+#endif
 }
 
 template <int S, int NOB>

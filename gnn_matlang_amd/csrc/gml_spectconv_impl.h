@@ -47,6 +47,7 @@ struct GmlFwdParams {
     const float* w11; const float* b11; const float* w12; const float* b12;
     int32_t F2, mix_col;
     float* hout;          // stand-alone SpMM on the 8-wave kernel: H [N, S, Fin] receives the aggregate, no projection
+    unsigned long long* prof;   // timing build (-DGML_FWD2_TIMING): per-phase cycle sums
 };
 
 // Per-group staging capacities.  A group = 64 consecutive output rows = the 4 tiles a workgroup
