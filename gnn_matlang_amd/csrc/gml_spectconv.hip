@@ -15,8 +15,11 @@ static bool fwd2_shape(int S, int Fin, int Fout, uint32_t flags) {
     return (flags & GML_F32_MFMA) == 0 && (S == 4 || S == 8 || S == 12) && Fin <= 32 && Fout <= 32;
 }
 
+// GML_FWD_NW=4: the 8-wave kernel family in its 4-wave / 64-row geometry (two workgroups per CU)
+static int fwd2_nw_env() { static const int v = [] { const char* e = getenv("GML_FWD_NW"); return e ? atoi(e) : 8; }(); return v == 4 ? 4 : 8; }
 extern "C" int32_t gml_spectconv_fwd_group_rows(int32_t S, int32_t Fin, int32_t Fout, uint32_t flags) {
-    return fwd2_shape(S, Fin, Fout, flags) ? 128 : 64;
+    if (!fwd2_shape(S, Fin, Fout, flags)) return 64;
+    return fwd2_nw_env() == 4 ? GML_GROUPS64_RANKED : 128;
 }
 
 // ---- families defined in gml_fwd_fam_*.hip ---------------------------------------------------
@@ -70,8 +73,11 @@ static int launch_fwd2(const int32_t* rowptr, const int32_t* col, const int32_t*
 #ifdef GML_FWD2_TIMING
     p.prof = fwd2_prof_buf();
 #endif
-    p.ngroups = (int)gml_cdiv(num_rows, GML_FWD2_ROWS);
-    int grid = p.ngroups < GML_NUM_CU ? p.ngroups : GML_NUM_CU;      // one 512-thread workgroup per CU
+    p.nw = (flags & GML_GROUPS64R) ? 4 : 8;
+    if (p.nw == 4 && !xv) return GML_E_UNSUPPORTED;
+    const int wgs = p.nw == 4 ? 2 * GML_NUM_CU : GML_NUM_CU;         // one 512-thread or two 256-thread workgroups per CU
+    p.ngroups = (int)gml_cdiv(num_rows, 16 * p.nw);
+    int grid = p.ngroups < wgs ? p.ngroups : wgs;
     p.groups_per_wg = (int)gml_cdiv(p.ngroups, grid);
     grid = (int)gml_cdiv(p.ngroups, p.groups_per_wg);
     const int nob = Fout > 16 ? 2 : 1;
@@ -93,8 +99,8 @@ extern "C" int gml_spectconv_fwd(const int32_t* rowptr, const int32_t* col, cons
     if (num_rows > (int64_t)INT32_MAX - 16) return GML_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
 
-    if (flags & GML_GROUPS128) {
-        // 128-row / 8-wave kernel: the caller passes 128-row group records (gml_spectconv_fwd_group_rows said 128)
+    if (flags & (GML_GROUPS128 | GML_GROUPS64R)) {
+        // 128-row / 8-wave kernel (or its 64-row / 4-wave geometry): the caller passes 128-row group records (gml_spectconv_fwd_group_rows said 128)
         if (!fwd2_shape(S, Fin, Fout, flags) || (((uintptr_t)val & 15) != 0)) return GML_E_BADARG;
         return launch_fwd2(rowptr, col, ginfo, epos, val, x, ldx, w, w_ss, w_si, w_so, bias, nullptr, nullptr, nullptr, nullptr,
                            out, ldo, num_rows, S, Fin, Fout, 0, flags, st);
@@ -174,7 +180,7 @@ extern "C" int gml_ml3_fwd(const int32_t* rowptr, const int32_t* col, const int3
                            int32_t F2, uint32_t flags, gml_stream_t stream) {
     if (F2 < 0 || ldo < nout1 + F2 || (F2 > 0 && (!w11 || !w12))) return GML_E_BADARG;
 #ifndef GML_NO_MIXFUSE
-    if (num_rows > 0 && F2 > 0 && F2 <= 8 && (flags & GML_GROUPS128) && fwd2_shape(S, Fin, nout1, flags) &&
+    if (num_rows > 0 && F2 > 0 && F2 <= 8 && (flags & (GML_GROUPS128 | GML_GROUPS64R)) && fwd2_shape(S, Fin, nout1, flags) &&
         (((uintptr_t)val & 15) == 0) && !(flags & GML_ACCUM)) {
         if (!rowptr || !ginfo || !x || !w || !out) return GML_E_BADARG;
         return launch_fwd2(rowptr, col, ginfo, epos, val, x, ldx, w, w_ss, w_si, w_so, bias, w11, b11, w12, b12, out, ldo,

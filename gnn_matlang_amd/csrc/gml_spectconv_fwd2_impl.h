@@ -35,9 +35,14 @@ struct GmlFwd2Cfg {
     static constexpr int W_HALF = S * 32 * 32;                 // bf16 elements of one (hi or lo) W image [s][o][f]
     static constexpr int TILE_BYTES = 8 * 16 * 36 * 4;         // stand-alone SpMM: one [16][36] output tile per wave
     static constexpr int W_BYTES = 2 * W_HALF * 2 > TILE_BYTES ? 2 * W_HALF * 2 : TILE_BYTES;   // (shares the W area)
-    static constexpr size_t lds_bytes() {
-        return (size_t)W_BYTES + 136 * 4 + (size_t)GML_FWD2_ECAP * 4 + (size_t)GML_FWD2_ECAP * S * 4 +
-               (size_t)GML_FWD2_XCAP * LDX * 4;
+    // NW = 8 waves / 128-row groups (one workgroup per CU) or NW = 4 waves / 64-row groups (two independent workgroups
+    // per CU: each one's per-group latency chain -- record, data, commit, barrier -- overlaps the other's arithmetic)
+    static constexpr int rows(int nw) { return 16 * nw; }
+    static constexpr int ecap(int nw) { return 8 * rows(nw); }
+    static constexpr int xcap(int nw) { return nw == 8 ? GML_FWD2_XCAP : 144; }   // 64 rows + 2 x the largest graph
+    static constexpr size_t lds_bytes(int nw = 8) {
+        return (size_t)W_BYTES + (rows(nw) + 8) * 4 + (size_t)ecap(nw) * 4 + (size_t)ecap(nw) * S * 4 +
+               (size_t)xcap(nw) * LDX * 4;
     }
 };
 
@@ -49,11 +54,13 @@ struct GmlFwd2Cfg {
 // ONE edge order (the backward's) and writes its output once -- the second, scattered copy cost the HBM-bound edge forward
 // 37 % of its time (profiles/r02_g_edge_fwd_ablation.txt).  The positions are loaded with the other prefetch loads, the
 // value rows they address after the aggregation loop (the positions have arrived by then: no exposed dependent latency).
-template <int S, int NOB, bool XVEC, bool MIX, bool EP = false>
-__global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p) {
+template <int S, int NOB, bool XVEC, bool MIX, bool EP = false, int NW = 8>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void gml_k_spectconv_fwd2(const GmlFwdParams p) {
     using C = GmlFwd2Cfg<S>;
     constexpr bool HOUT = (NOB == 0);
     static_assert(!(EP && NOB == 0), "the stand-alone SpMM instantiations take contiguous value rows");
+    static_assert(NW == 8 || (NW == 4 && NOB != 0), "4-wave geometry: conv instantiations only");
+    constexpr int NT = 64 * NW, ECAP = C::ecap(NW), XCAP = C::xcap(NW);
     constexpr int NOBA = HOUT ? 1 : NOB;
     constexpr bool H32 = HOUT && MIX;                          // SpMM instantiations reuse the MIX slot: Fin == 32 (full-line stores)
     constexpr bool MIXB = MIX && !HOUT;
@@ -66,15 +73,15 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p
 #else
     constexpr bool RECPRE = ROT;
 #endif
-    constexpr int LDX = C::LDX, ROWS = GML_FWD2_ROWS;
+    constexpr int LDX = C::LDX, ROWS = C::rows(NW);
     constexpr int VAL_ALIGN = (S % 4 == 0) ? 4 : ((S % 2 == 0) ? 2 : 1);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __bf16* Wof_h = reinterpret_cast<__bf16*>(lds_raw);       // [s][o][f], 16-byte chunks XOR-swizzled by gml_wkey(o)
     __bf16* Wof_l = Wof_h + C::W_HALF;
     int* rp_l = reinterpret_cast<int*>(lds_raw + C::W_BYTES);
-    int* col_l = rp_l + 136;
-    float* ea_l = reinterpret_cast<float*>(col_l + GML_FWD2_ECAP);
-    float* xs = ea_l + GML_FWD2_ECAP * S;
+    int* col_l = rp_l + ROWS + 8;
+    float* ea_l = reinterpret_cast<float*>(col_l + ECAP);
+    float* xs = ea_l + ECAP * S;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -84,7 +91,7 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p
     const int g1 = min(g0 + p.groups_per_wg, p.ngroups);
     if (g0 >= g1) return;
 
-    for (int e = tid; e < S * 32 * 32 && !HOUT; e += 512) {
+    for (int e = tid; e < S * 32 * 32 && !HOUT; e += NT) {
         const int f = e & 31, o = (e >> 5) & 31, s = e >> 10;
         const float v = (f < p.Fin && o < p.Fout) ? p.w[(int64_t)(p.s0 + s) * p.w_ss + (int64_t)f * p.w_si + (int64_t)o * p.w_so] : 0.f;
         const __bf16 h = (__bf16)v;
@@ -115,9 +122,9 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p
     // ---- software-pipelined staging.  Every prefetch load is unconditional with indices clamped into the arrays (lanes
     //      outside fetch a valid, unused element): with a load under a predicate or branch the compiler cannot count the
     //      loads in flight and waits for all of them at the next vmcnt it needs.
-    constexpr int NC = GML_FWD2_ECAP / 512, NE4 = (S % 4 == 0) ? GML_FWD2_ECAP * (S / 4) / 512 : 1;
-    constexpr int NX4 = XVEC ? (GML_FWD2_XCAP * 8 + 511) / 512 : 1;
-    constexpr int NX1 = XVEC ? 1 : (GML_FWD2_XCAP * 32 + 511) / 512;
+    constexpr int NC = ECAP / NT, NE4 = (S % 4 == 0) ? ECAP * (S / 4) / NT : 1;
+    constexpr int NX4 = XVEC ? (XCAP * 8 + NT - 1) / NT : 1;
+    constexpr int NX1 = XVEC ? 1 : (XCAP * 32 + NT - 1) / NT;
     const int etot = p.rowptr[p.nrows];
     const int* colb = etot > 0 ? p.col : p.ginfo;              // an edgeless graph reads the (always present) group records
     const f32x4* valb = etot > 0 ? reinterpret_cast<const f32x4*>(p.val) : reinterpret_cast<const f32x4*>(p.ginfo);
@@ -141,7 +148,7 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p
     int row_n = 0;
     uint32_t outrows_n = 0;
     auto load_rec = [&](int g) {
-        const int32_t* rec = p.ginfo + (int64_t)g * GML_GREC_INTS(ROWS);
+        const int32_t* rec = p.ginfo + (int64_t)g * GML_GREC_INTS(NW == 8 ? 128 : GML_GROUPS64_RANKED);
         rec_gi = *reinterpret_cast<const int4*>(rec);
         rec_row = reinterpret_cast<const unsigned char*>(rec + 4)[wave * 16 + r16];
         rec_outrows = reinterpret_cast<const uint32_t*>(rec + 4)[wave * 4 + kq];
@@ -154,25 +161,25 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p
         const int kb = gi_n.x, lo = gi_n.z;
         if constexpr (EP) {                                    // first in the burst: they gate issue_vals()
 #pragma unroll
-            for (int t = 0; t < NE4; ++t) pv[t] = eposb[min(kb + (tid + 512 * t) / (S / 4), emax)];
+            for (int t = 0; t < NE4; ++t) pv[t] = eposb[min(kb + (tid + NT * t) / (S / 4), emax)];
         }
 #pragma unroll
-        for (int t = 0; t < NC; ++t) cv[t] = colb[min(kb + tid + 512 * t, emax)];
+        for (int t = 0; t < NC; ++t) cv[t] = colb[min(kb + tid + NT * t, emax)];
         if constexpr (!EP) {
 #pragma unroll
-            for (int t = 0; t < NE4; ++t) ev4[t] = valb[min((int64_t)kb * (S / 4) + tid + 512 * t, emax4)];
+            for (int t = 0; t < NE4; ++t) ev4[t] = valb[min((int64_t)kb * (S / 4) + tid + NT * t, emax4)];
         }
         if constexpr (XVEC) {
 #pragma unroll
             for (int t = 0; t < NX4; ++t) {
-                const int i = tid + 512 * t;
+                const int i = tid + NT * t;
                 const int64_t rr = min((int64_t)lo + (i >> 3), p.nrows - 1);
                 xv4[t] = *reinterpret_cast<const f32x4*>(p.x + rr * p.ldx + min((i & 7) * 4, f4max));
             }
         } else {
 #pragma unroll
             for (int t = 0; t < NX1; ++t) {
-                const int i = tid + 512 * t;
+                const int i = tid + NT * t;
                 const int64_t rr = min((int64_t)lo + (i >> 5), p.nrows - 1);
                 xv1[t] = p.x[rr * p.ldx + min(i & 31, p.Fin - 1)];
             }
@@ -182,7 +189,7 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p
     auto issue_vals = [&]() {                                  // EP: the value rows at the positions that arrived meanwhile
 #pragma unroll
         for (int t = 0; t < NE4; ++t)
-            ev4[t] = valb[min((int64_t)(EP ? pv[t] : 0) * (S / 4) + ((tid + 512 * t) % (S / 4)), emax4)];
+            ev4[t] = valb[min((int64_t)(EP ? pv[t] : 0) * (S / 4) + ((tid + NT * t) % (S / 4)), emax4)];
     };
     // the staged group's description (latched by commit)
     int kb = 0, ne = 0, lo = 0, row = 0;
@@ -193,20 +200,20 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p
         kb = gi_n.x; ne = gi_n.y; lo = gi_n.z;
         const int nwin = gi_n.w;
         row = row_n; out_rows = outrows_n;
-        staged = vec_ok && ne <= GML_FWD2_ECAP && nwin <= GML_FWD2_XCAP;
+        staged = vec_ok && ne <= ECAP && nwin <= XCAP;
         if (tid <= nr) rp_l[tid] = rpv;
         if (staged) {
 #pragma unroll
-            for (int t = 0; t < NC; ++t) { const int i = tid + 512 * t; if (i < ne) col_l[i] = cv[t] - lo; }
+            for (int t = 0; t < NC; ++t) { const int i = tid + NT * t; if (i < ne) col_l[i] = cv[t] - lo; }
 #pragma unroll
             for (int t = 0; t < NE4; ++t) {
-                const int i = tid + 512 * t;
+                const int i = tid + NT * t;
                 if (i < ne * (S / 4)) reinterpret_cast<f32x4*>(ea_l)[i] = ev4[t];
             }
             if constexpr (XVEC) {
 #pragma unroll
                 for (int t = 0; t < NX4; ++t) {
-                    const int i = tid + 512 * t;
+                    const int i = tid + NT * t;
                     const int f4 = (i & 7) * 4;
                     if (i < nwin * 8)
                         *reinterpret_cast<f32x4*>(xs + (i >> 3) * LDX + f4) = (f4 < p.Fin) ? xv4[t] : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -214,7 +221,7 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p
             } else {
 #pragma unroll
                 for (int t = 0; t < NX1; ++t) {
-                    const int i = tid + 512 * t;
+                    const int i = tid + NT * t;
                     if (i < nwin * 32) xs[(i >> 5) * LDX + (i & 31)] = ((i & 31) < p.Fin) ? xv1[t] : 0.f;
                 }
             }
@@ -475,14 +482,15 @@ __global__ __launch_bounds__(512) void gml_k_spectconv_fwd2(const GmlFwdParams p
 template <int S, int NOB>
 int gml_launch_fwd2(const GmlFwdParams& p, dim3 grid, hipStream_t st, bool xvec, bool mix);
 
-#define GML_FWD2_LAUNCH_E(SV, NOBV, XV, MX, EPV)                                                             \
+#define GML_FWD2_LAUNCH_N(SV, NOBV, XV, MX, EPV, NWV)                                                        \
     {                                                                                                        \
-        GML_ALLOW_BIG_LDS(rc_, (&gml_k_spectconv_fwd2<SV, NOBV, XV, MX, EPV>), 160 * 1024)                   \
+        GML_ALLOW_BIG_LDS(rc_, (&gml_k_spectconv_fwd2<SV, NOBV, XV, MX, EPV, NWV>), 160 * 1024)              \
         if (rc_ != hipSuccess) return (int)rc_;                                                              \
-        hipLaunchKernelGGL((gml_k_spectconv_fwd2<SV, NOBV, XV, MX, EPV>), grid, dim3(512),                   \
-                           GmlFwd2Cfg<SV>::lds_bytes(), st, p);                                              \
+        hipLaunchKernelGGL((gml_k_spectconv_fwd2<SV, NOBV, XV, MX, EPV, NWV>), grid, dim3(64 * NWV),         \
+                           GmlFwd2Cfg<SV>::lds_bytes(NWV), st, p);                                           \
         return gml_launch_status();                                                                          \
     }
+#define GML_FWD2_LAUNCH_E(SV, NOBV, XV, MX, EPV) GML_FWD2_LAUNCH_N(SV, NOBV, XV, MX, EPV, 8)
 #define GML_FWD2_LAUNCH(SV, NOBV, XV, MX) GML_FWD2_LAUNCH_E(SV, NOBV, XV, MX, false)
 #define GML_DEFINE_SPMM2(SV)                                                                                 \
     template <>                                                                                              \
@@ -494,6 +502,13 @@ int gml_launch_fwd2(const GmlFwdParams& p, dim3 grid, hipStream_t st, bool xvec,
 #define GML_DEFINE_FWD2(SV, NOBV)                                                                            \
     template <>                                                                                              \
     int gml_launch_fwd2<SV, NOBV>(const GmlFwdParams& p, dim3 grid, hipStream_t st, bool xvec, bool mix) {   \
+        if (p.nw == 4) {   /* 4-wave geometry: float4-addressable x only (the dispatcher checks) */          \
+            if (!xvec) return GML_E_UNSUPPORTED;                                                             \
+            if (p.epos != nullptr && mix) GML_FWD2_LAUNCH_N(SV, NOBV, true, true, true, 4)                   \
+            if (p.epos != nullptr) GML_FWD2_LAUNCH_N(SV, NOBV, true, false, true, 4)                         \
+            if (mix) GML_FWD2_LAUNCH_N(SV, NOBV, true, true, false, 4)                                       \
+            GML_FWD2_LAUNCH_N(SV, NOBV, true, false, false, 4)                                               \
+        }                                                                                                    \
         if (p.epos != nullptr) {                                                                             \
             if (xvec && mix) GML_FWD2_LAUNCH_E(SV, NOBV, true, true, true)                                   \
             if (xvec) GML_FWD2_LAUNCH_E(SV, NOBV, true, false, true)                                         \

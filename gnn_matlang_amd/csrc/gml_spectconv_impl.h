@@ -48,6 +48,7 @@ struct GmlFwdParams {
     int32_t F2, mix_col;
     float* hout;          // stand-alone SpMM on the 8-wave kernel: H [N, S, Fin] receives the aggregate, no projection
     unsigned long long* prof;   // timing build (-DGML_FWD2_TIMING): per-phase cycle sums
+    int32_t nw;           // 8-wave kernel family: waves per workgroup (8: 128-row groups, 4: ranked 64-row groups)
 };
 
 // Per-group staging capacities.  A group = 64 consecutive output rows = the 4 tiles a workgroup

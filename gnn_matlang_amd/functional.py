@@ -126,7 +126,14 @@ def fwd_groups(csr, x, S, Fin, Fout):
     flags = _lib.GML_F32_MFMA if F32_MFMA else 0
     if _os.environ.get('GML_FWD64'):                         # experiments: force the 4-wave / 64-row kernel family
         return csr.ginfo, 0
-    if int(_lib.lib().gml_spectconv_fwd_group_rows(int(S), int(Fin), int(Fout), flags)) == 128:
+    rows = int(_lib.lib().gml_spectconv_fwd_group_rows(int(S), int(Fin), int(Fout), flags))
+    if rows == 128:
+        _path('conv_fwd', 'fused 8-wave bf16x3', S, Fin, Fout)
+        return csr.ginfo128, _lib.GML_GROUPS128
+    if rows == _lib.GML_GROUPS64_RANKED:
+        if x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0:
+            _path('conv_fwd', 'fused 4-wave geometry of the 8-wave kernel, 2 workgroups per CU, bf16x3', S, Fin, Fout)
+            return csr.ranked64()[0], _lib.GML_GROUPS64R
         _path('conv_fwd', 'fused 8-wave bf16x3', S, Fin, Fout)
         return csr.ginfo128, _lib.GML_GROUPS128
     _path('conv_fwd', 'fused 4-wave (%s)' % ('f32 MFMA' if (F32_MFMA or Fin > 32 or Fout > 32) else 'generic'), S, Fin, Fout)
@@ -139,7 +146,7 @@ def fwd_gathers(S, Fin, Fout):
     if _os.environ.get('GML_FWD64') or _os.environ.get('GML_EDGE_DUAL'):
         return False
     flags = _lib.GML_F32_MFMA if F32_MFMA else 0
-    return int(_lib.lib().gml_spectconv_fwd_group_rows(int(S), int(Fin), int(Fout), flags)) == 128
+    return int(_lib.lib().gml_spectconv_fwd_group_rows(int(S), int(Fin), int(Fout), flags)) in (128, _lib.GML_GROUPS64_RANKED)
 
 
 def ml3_edge_in_source_order(csr, S, Fin, Fout):

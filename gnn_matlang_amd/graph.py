@@ -36,13 +36,14 @@ def _require_cuda(t, name):
 
 class GraphCSR(object):
     __slots__ = ('N', 'E', 'device', 'rowptr', 'col', 'perm', 'rowptr_t', 'col_t', 'pos_t', 'perm_t', 'src_sorted',
-                 '_ginfo', '_ginfo_t', '_gmax', '_gmax_t', 'ginfo_t128', 'gmax_t128', 'ginfo128', 'tpos', '_val_cache', '_keep',
+                 '_ginfo', '_ginfo_t', '_gmax', '_gmax_t', 'ginfo_t128', 'gmax_t128', 'ginfo128', 'tpos', '_val_cache', '_keep', '_r64',
                  '_r64t')
 
     def __init__(self):
         self._val_cache = OrderedDict()
         self._keep = None
         self._r64t = None
+        self._r64 = None
         self._ginfo = self._ginfo_t = self._gmax = self._gmax_t = None
 
     @staticmethod
@@ -125,6 +126,18 @@ class GraphCSR(object):
     ginfo_t = property(lambda self: (self._need64(), self._ginfo_t)[1])
     gmax = property(lambda self: (self._need64(), self._gmax)[1])
     gmax_t = property(lambda self: (self._need64(), self._gmax_t)[1])
+
+    def ranked64(self):
+        """(records, (max edges, max window)) of the TARGET view in ranked 64-row groups: the staging schedule of the forward
+        kernel's 4-wave geometry (GML_FWD_NW=4); built on first use."""
+        if self._r64 is None:
+            with torch.cuda.device(self.device):
+                rec = int(_lib.lib().gml_csr_group_record_ints(_lib.GML_GROUPS64_RANKED))
+                gi = torch.zeros(max((self.N + 63) // 64, 1), rec, dtype=torch.int32, device=self.device)
+                _lib.call('gml_csr_group_info', _ptr(self.rowptr), _ptr(self.col), self.N, _lib.GML_GROUPS64_RANKED,
+                          _ptr(gi), _stream(self.device))
+                self._r64 = (gi, None)
+        return self._r64
 
     def ranked64_t(self):
         """(records, (max edges, max window)) of the source view in ranked 64-row groups: the staging schedule of the

@@ -50,8 +50,10 @@ enum {
     GML_ACCUM = 2,  /* out += result instead of out = result      (gradient accumulation)     */
     GML_F32_MFMA = 4, /* project with the f32-input MFMA (bit-identical to an fmaf chain) instead of the default
                          bf16x3 split on the bf16 matrix cores (fp32-class: ~1e-6 of the output scale)       */
-    GML_GROUPS128 = 8 /* gml_spectconv_fwd: `ginfo` holds 128-row group records (gml_spectconv_fwd_group_rows() = 128,
-                         epos NULL): the 8-wave forward kernel                                                 */
+    GML_GROUPS128 = 8, /* gml_spectconv_fwd: `ginfo` holds 128-row group records (gml_spectconv_fwd_group_rows() = 128):
+                         the 8-wave forward kernel                                                            */
+    GML_GROUPS64R = 16 /* gml_spectconv_fwd: `ginfo` holds ranked 64-row records (gml_spectconv_fwd_group_rows() =
+                         GML_GROUPS64_RANKED): the same kernel in its 4-wave geometry, two workgroups per CU     */
 };
 
 int gml_version(void);
