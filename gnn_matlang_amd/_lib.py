@@ -34,6 +34,9 @@ SIGNATURES = {
     'gml_spectconv_bwd_workspace_bytes': (_sz, [_i64, _i32, _i32, _i32, _i32, _i32, _u32]),
     'gml_spectconv_bwd': (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _i64, _p, _p,
                                          _i64, _i32, _i32, _i32, _i32, _i32, _u32, _p, _sz, _p]),
+    'gml_spectconv_bwd_mix_supported': (ctypes.c_int, [_i32, _i32, _i32, _i32, _u32]),
+    'gml_spectconv_bwd_mix': (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _i32,
+                                             _i64, _i32, _i32, _i32, _i32, _i32, _u32, _p, _sz, _p]),
     'gml_spmm_fwd': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _p, _i64, _i32, _i32, _p]),
     'gml_sddmm': (ctypes.c_int, [_p, _p, _p, _p, _i64, _p, _p, _i64, _i32, _i32, _p]),
     'gml_edge_presplit': (ctypes.c_int, [_p, _p, _i64, _i32, _p]),
@@ -57,6 +60,8 @@ SIGNATURES = {
     'gml_xty_workspace_bytes': (_sz, [_i64, _i32, _i32]),
     'gml_xty': (ctypes.c_int, [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _p, _sz, _p]),
     'gml_ml3_split_bwd_workspace_bytes': (_sz, [_i64, _i32, _i32, _i32]),
+    'gml_ml3_split_bwd_dz': (ctypes.c_int, [_p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _p, _i64, _p, _p,
+                                            _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _sz, _p]),
     'gml_ml3_split_bwd': (ctypes.c_int, [_p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _p, _i64, _p, _i64, _p,
                                          _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _sz, _p]),
 }

@@ -30,6 +30,7 @@ struct GmlSplitBwdParams {
     const float* w11; const float* b11; const float* w12; const float* b12;
     float* G; int64_t ldg;
     float* dx; int64_t lddx;
+    float* dz;                                  // optional (2 F2 <= 4): dz[row][0..3] = (dz11 | dz12) instead of dx (gml_spectconv_bwd_mix)
     float* part;
     int64_t nrows;
     int Fin, nout1, F2, ntiles, CP, npart;      // CP: power of two >= ldg (<= 256); npart: floats per partial
@@ -203,6 +204,12 @@ __global__ __launch_bounds__(SB_ROWS, (FINP <= 32 ? 2 : 1)) void gml_k_ml3_split
                     }
                 }
             }
+            if (p.dz != nullptr) {                             // hand dz over instead of dx: 16 bytes per row, one lane per row
+                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (c < C2) v[c] = gz[tid * LDZ + c];
+                if (tid < nr) *reinterpret_cast<f32x4*>(p.dz + (r0 + tid) * 4) = v;
+            }
             if (p.dx != nullptr) {                             // dx tile through LDS: row-per-lane in, coalesced out
 #pragma unroll
                 for (int f = 0; f < FINP; ++f) xs[tid * LDX + f] = dxr[f];
@@ -319,11 +326,12 @@ extern "C" size_t gml_ml3_split_bwd_workspace_bytes(int64_t num_rows, int32_t Fi
     return sizeof(float) * (size_t)sb_grid(num_rows) * sb_npart(F2 ? Fin : 0, nout1, F2);
 }
 
-extern "C" int gml_ml3_split_bwd(const float* gy, int64_t ldgy, const float* y, int64_t ldy, const float* x, int64_t ldx,
-                                 const float* w11, const float* b11, const float* w12, const float* b12, float* G,
-                                 int64_t ldg, float* dx, int64_t lddx, float* dcb, float* dw11, float* db11, float* dw12,
-                                 float* db12, int64_t num_rows, int32_t Fin, int32_t nout1, int32_t F2, void* ws,
-                                 size_t ws_bytes, gml_stream_t stream) {
+static int split_bwd_impl(const float* gy, int64_t ldgy, const float* y, int64_t ldy, const float* x, int64_t ldx,
+                          const float* w11, const float* b11, const float* w12, const float* b12, float* G,
+                          int64_t ldg, float* dx, int64_t lddx, float* dz, float* dcb, float* dw11, float* db11, float* dw12,
+                          float* db12, int64_t num_rows, int32_t Fin, int32_t nout1, int32_t F2, void* ws,
+                          size_t ws_bytes, gml_stream_t stream) {
+    if (dz != nullptr && (dx != nullptr || F2 < 1 || 2 * F2 > 4 || (((uintptr_t)dz) & 15) != 0)) return GML_E_BADARG;
     if (num_rows < 0 || nout1 <= 0 || F2 < 0 || ldgy < nout1 + F2 || ldy < nout1 || ldg < nout1) return GML_E_BADARG;
     if (F2 > 0 && (Fin <= 0 || ldx < Fin || (dx && lddx < Fin) || !w11 || !w12 || !dw11 || !dw12)) return GML_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
@@ -346,7 +354,7 @@ extern "C" int gml_ml3_split_bwd(const float* gy, int64_t ldgy, const float* y, 
     GmlSplitBwdParams p;
     p.gy = gy; p.ldgy = ldgy; p.y = y; p.ldy = ldy; p.x = x; p.ldx = ldx;
     p.w11 = w11; p.b11 = b11; p.w12 = w12; p.b12 = b12;
-    p.G = G; p.ldg = ldg; p.dx = dx; p.lddx = lddx; p.part = (float*)ws; p.nrows = num_rows;
+    p.G = G; p.ldg = ldg; p.dx = dx; p.lddx = lddx; p.dz = dz; p.part = (float*)ws; p.nrows = num_rows;
     p.Fin = Fin; p.nout1 = nout1; p.F2 = F2; p.ntiles = (int)gml_cdiv(num_rows, SB_ROWS); p.CP = CP;
     p.npart = sb_npart(Fin, nout1, F2);
     const int grid = sb_grid(num_rows);
@@ -366,6 +374,27 @@ extern "C" int gml_ml3_split_bwd(const float* gy, int64_t ldgy, const float* y, 
     hipLaunchKernelGGL(gml_k_split_fold, dim3((unsigned)gml_cdiv(p.npart, 16)), dim3(256), 0, st, (const float*)ws,
                        (int64_t)grid, p.npart, dw11, F2 * Fin, dw12, F2 * Fin, db11, F2, db12, F2, dcb, nout1);
     return gml_launch_status();
+}
+
+extern "C" int gml_ml3_split_bwd(const float* gy, int64_t ldgy, const float* y, int64_t ldy, const float* x, int64_t ldx,
+                                 const float* w11, const float* b11, const float* w12, const float* b12, float* G,
+                                 int64_t ldg, float* dx, int64_t lddx, float* dcb, float* dw11, float* db11, float* dw12,
+                                 float* db12, int64_t num_rows, int32_t Fin, int32_t nout1, int32_t F2, void* ws,
+                                 size_t ws_bytes, gml_stream_t stream) {
+    return split_bwd_impl(gy, ldgy, y, ldy, x, ldx, w11, b11, w12, b12, G, ldg, dx, lddx, nullptr, dcb, dw11, db11, dw12, db12,
+                          num_rows, Fin, nout1, F2, ws, ws_bytes, stream);
+}
+
+// the same with the Hadamard branch's share of dx handed over as dz [num_rows, 4] = (dz11 | dz12), 2 F2 <= 4 (columns beyond
+// 2 F2 zero), for gml_spectconv_bwd_mix: dx = dz [w11; w12] is then formed inside the conv backward and never stored
+extern "C" int gml_ml3_split_bwd_dz(const float* gy, int64_t ldgy, const float* y, int64_t ldy, const float* x, int64_t ldx,
+                                    const float* w11, const float* b11, const float* w12, const float* b12, float* G,
+                                    int64_t ldg, float* dz, float* dcb, float* dw11, float* db11, float* dw12,
+                                    float* db12, int64_t num_rows, int32_t Fin, int32_t nout1, int32_t F2, void* ws,
+                                    size_t ws_bytes, gml_stream_t stream) {
+    if (!dz) return GML_E_BADARG;
+    return split_bwd_impl(gy, ldgy, y, ldy, x, ldx, w11, b11, w12, b12, G, ldg, nullptr, 0, dz, dcb, dw11, db11, dw12, db12,
+                          num_rows, Fin, nout1, F2, ws, ws_bytes, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -132,12 +132,12 @@ extern "C" size_t gml_spectconv_bwd_workspace_bytes(int64_t num_rows, int32_t S,
     return (size_t)pl.grid * S * Fin * Fout * sizeof(float);
 }
 
-extern "C" int gml_spectconv_bwd(const int32_t* rowptr, const int32_t* col, const int32_t* ginfo, const float* val,
-                                 const float* x, int64_t ldx, const float* g, int64_t ldg, const float* w,
-                                 float* dx, int64_t lddx, float* dval, float* dw,
-                                 int64_t num_rows, int32_t S, int32_t Fin, int32_t Fout,
-                                 int32_t max_group_edges, int32_t max_group_window, uint32_t flags,
-                                 void* ws, size_t ws_bytes, gml_stream_t stream) {
+static int spectconv_bwd_impl(const int32_t* rowptr, const int32_t* col, const int32_t* ginfo, const float* val,
+                              const float* x, int64_t ldx, const float* g, int64_t ldg, const float* w,
+                              float* dx, int64_t lddx, float* dval, float* dw,
+                              int64_t num_rows, int32_t S, int32_t Fin, int32_t Fout,
+                              int32_t max_group_edges, int32_t max_group_window, uint32_t flags,
+                              void* ws, size_t ws_bytes, gml_stream_t stream, const float* dz, const float* wmix, int32_t nmix) {
     if (num_rows < 0 || S <= 0 || Fin <= 0 || Fout <= 0 || ldx < Fin || ldg < Fout) return GML_E_BADARG;
     if (dx && lddx < Fin) return GML_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
@@ -156,6 +156,9 @@ extern "C" int gml_spectconv_bwd(const int32_t* rowptr, const int32_t* col, cons
     p.rowptr = rowptr; p.col = col; p.ginfo = ginfo; p.val = val; p.x = x; p.ldx = ldx; p.g = g; p.ldg = ldg;
     p.w = w; p.dx = dx; p.lddx = lddx; p.dval = dval; p.dw_partial = dw ? (float*)ws : nullptr;
     p.nrows = num_rows; p.S = S; p.Fin = Fin; p.Fout = Fout; p.flags = flags;
+    p.dz = dz; p.wmix = wmix; p.nmix = nmix;
+    if (dz != nullptr && (pl.layout != 3 || pl.lds + 512 > 160 * 1024 || (flags & GML_ACCUM) || (((uintptr_t)dz) & 15) != 0))
+        return GML_E_UNSUPPORTED;
 #ifdef GML_BWD2_TIMING
     p.prof = bwd2_prof_buf();
 #endif
@@ -192,6 +195,36 @@ extern "C" int gml_spectconv_bwd(const int32_t* rowptr, const int32_t* col, cons
         return gml_launch_status();
     }
     return GML_OK;
+}
+
+extern "C" int gml_spectconv_bwd(const int32_t* rowptr, const int32_t* col, const int32_t* ginfo, const float* val,
+                                 const float* x, int64_t ldx, const float* g, int64_t ldg, const float* w,
+                                 float* dx, int64_t lddx, float* dval, float* dw,
+                                 int64_t num_rows, int32_t S, int32_t Fin, int32_t Fout,
+                                 int32_t max_group_edges, int32_t max_group_window, uint32_t flags,
+                                 void* ws, size_t ws_bytes, gml_stream_t stream) {
+    return spectconv_bwd_impl(rowptr, col, ginfo, val, x, ldx, g, ldg, w, dx, lddx, dval, dw, num_rows, S, Fin, Fout,
+                              max_group_edges, max_group_window, flags, ws, ws_bytes, stream, nullptr, nullptr, 0);
+}
+
+// 1 when gml_spectconv_bwd_mix serves this shape (the bf16x3 8-wave kernel's DZ instantiation: S = 8, 16 < Fin <= 32)
+extern "C" int gml_spectconv_bwd_mix_supported(int32_t S, int32_t Fin, int32_t Fout, int32_t nmix, uint32_t flags) {
+    if (nmix < 1 || nmix > 4 || S != 8 || Fin <= 16 || Fin > 32 || Fin % 4 != 0) return 0;
+    return bwd2_shape(S, Fin, Fout, flags) && bwd_layout_env() != 2 && bwd3_nw(S) == 8;
+}
+
+// gml_spectconv_bwd with dx = conv part + dz wmix: dz [num_rows, 4] (contiguous, 16-byte aligned; columns >= nmix ignored),
+// wmix [nmix, Fin].  The ML3Layer's Hadamard branch hands its share of dx over as the 4 pre-activation gradients per row
+// (gml_ml3_split_bwd's dz output) instead of a written-then-re-read [N, Fin] array.  dx must be wanted and float4-addressable.
+extern "C" int gml_spectconv_bwd_mix(const int32_t* rowptr, const int32_t* col, const int32_t* ginfo, const float* val,
+                                     const float* x, int64_t ldx, const float* g, int64_t ldg, const float* w,
+                                     float* dx, int64_t lddx, float* dval, float* dw, const float* dz, const float* wmix,
+                                     int32_t nmix, int64_t num_rows, int32_t S, int32_t Fin, int32_t Fout,
+                                     int32_t max_group_edges, int32_t max_group_window, uint32_t flags,
+                                     void* ws, size_t ws_bytes, gml_stream_t stream) {
+    if (!dz || !wmix || !dx || !gml_spectconv_bwd_mix_supported(S, Fin, Fout, nmix, flags)) return GML_E_UNSUPPORTED;
+    return spectconv_bwd_impl(rowptr, col, ginfo, val, x, ldx, g, ldg, w, dx, lddx, dval, dw, num_rows, S, Fin, Fout,
+                              max_group_edges, max_group_window, flags, ws, ws_bytes, stream, dz, wmix, nmix);
 }
 
 #ifdef GML_BWD2_TIMING

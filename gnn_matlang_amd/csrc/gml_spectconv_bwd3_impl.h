@@ -68,7 +68,8 @@ struct GmlBwd3Cfg {
 #define GML_T3(i)
 #endif
 
-template <int S, int NFB, int NW, bool XV>
+// DZ: dx starts from dz[row] . wmix (see GmlBwdParams) instead of zero / the old dx values
+template <int S, int NFB, int NW, bool XV, bool DZ = false>
 __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdParams p) {
     using C = GmlBwd3Cfg<S, NFB, NW>;
     constexpr int LDG = C::LDG, ROWS = C::ROWS, NT = C::NT, SS = C::SS, BPW = C::BPW;
@@ -83,6 +84,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
     float* gs = ea_l + (size_t)p.ecap * S;
     unsigned char* pT = rreg;                                // [hi, lo][se][position] 64-byte rows (after the dval rows left)
     unsigned char* xT = rreg + C::r_bytes(p.ecap, p.xcap);   // [hi, lo][position]     64-byte rows (own region)
+    float* wm_l = reinterpret_cast<float*>(xT + C::XT_BYTES);  // DZ: [4][32] rows of wmix, zero padded (host adds the 512 bytes)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -91,6 +93,9 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
     const int g0 = wg * p.groups_per_wg;
     const int g1 = min(g0 + p.groups_per_wg, p.ngroups);
 
+    if constexpr (DZ) {
+        if (tid < 128) wm_l[tid] = ((tid >> 5) < p.nmix && (tid & 31) < p.Fin) ? p.wmix[(tid >> 5) * p.Fin + (tid & 31)] : 0.f;
+    }
     // W -> bf16 (hi, lo) image, zero padded to 32 x 32
     for (int e = tid; e < S * 32 * 32; e += NT) {
         const int f = e & 31, o = (e >> 5) & 31, s = e >> 10;
@@ -208,10 +213,14 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
         }
         __syncthreads();
         GML_T3(1);
-        // old dx values (accumulate mode): the lane's own row, features 16 fb + 4 kq .. + 3 (D rows of dX^T)
+        // old dx values (accumulate mode): the lane's own row, features 16 fb + 4 kq .. + 3 (D rows of dX^T);
+        // DZ: the row's 4 Hadamard-branch gradients instead (one 16-byte load; dx then starts from dz . wmix)
         f32x4 dxa[NFB];
+        f32x4 dzv = f32x4{0.f, 0.f, 0.f, 0.f};
         const bool dxv = p.dx && p.dxvec;                    // dx rows float4-addressable (Fin % 4 == 0, aligned rows)
-        {
+        if constexpr (DZ) {
+            dzv = *reinterpret_cast<const f32x4*>(p.dz + min(r0 + row, p.nrows - 1) * 4);
+        } else {
             const float* dxb = p.dx ? p.dx : p.x;            // (no dx wanted: any readable rows, the values are dropped)
             const int64_t ldb = p.dx ? p.lddx : p.ldx;
             const float* dr = dxb + min(r0 + row, p.nrows - 1) * ldb;
@@ -358,7 +367,15 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
         // ---- dX^T = W P^T: A[i = f][k = o] = W_s[f][o] comes transposed out of the [s][o][f] image: lane (t, kq) passes the
         //      address of row o = 8 kq + 4 h + (t >> 2), 8-byte chunk 4 fb + (t & 3), and receives W[8 kq + 4 h + j][16 fb + t]
         if (p.dx && !(GML_ABL & 32)) {
-            if (!(p.flags & GML_ACCUM)) {
+            if constexpr (DZ) {
+#pragma unroll
+                for (int fb = 0; fb < NFB; ++fb) {
+                    f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a += dzv[q] * *reinterpret_cast<const f32x4*>(wm_l + q * 32 + 16 * fb + 4 * kqo);
+                    dxa[fb] = a;
+                }
+            } else if (!(p.flags & GML_ACCUM)) {
 #pragma unroll
                 for (int fb = 0; fb < NFB; ++fb) dxa[fb] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
@@ -528,10 +545,29 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
 template <int S, int NFB, int NW>
 int gml_launch_bwd3(const GmlBwdParams& p, dim3 grid, size_t lds, hipStream_t st);
 
+// the DZ form (dx = conv part + dz . wmix) is compiled for the shape class that uses it: ZINC's layers (S = 8, Fin <= 32,
+// 2 x nout2 = 4 Hadamard columns); float4-addressable x / dx rows
+template <int S, int NFB, int NW, bool EN>
+struct GmlBwd3Dz {
+    static int go(const GmlBwdParams&, dim3, size_t, hipStream_t) { return GML_E_UNSUPPORTED; }
+};
+template <int S, int NFB, int NW>
+struct GmlBwd3Dz<S, NFB, NW, true> {
+    static int go(const GmlBwdParams& p, dim3 grid, size_t lds, hipStream_t st) {
+        if (!p.xvec || !p.dxvec || p.nmix < 1 || p.nmix > 4 || !p.wmix || !p.dx) return GML_E_UNSUPPORTED;
+        GML_ALLOW_BIG_LDS(rc, (&gml_k_spectconv_bwd3<S, NFB, NW, true, true>), 160 * 1024)
+        if (rc != hipSuccess) return (int)rc;
+        hipLaunchKernelGGL((gml_k_spectconv_bwd3<S, NFB, NW, true, true>), grid, dim3(64 * NW), lds + 512, st, p);
+        return gml_launch_status();
+    }
+};
+#define GML_BWD3_HAS_DZ(SV, NFBV, NWV) ((SV) == 8 && (NFBV) == 2 && (NWV) == 8)
+
 #define GML_DEFINE_BWD3(SV, NFBV, NWV)                                                                       \
     template <>                                                                                              \
     int gml_launch_bwd3<SV, NFBV, NWV>(const GmlBwdParams& p, dim3 grid, size_t lds, hipStream_t st) {       \
         static_assert(GmlBwd3Cfg<SV, NFBV, NWV>::OK, "unsupported shape");                                   \
+        if (p.dz != nullptr) return GmlBwd3Dz<SV, NFBV, NWV, GML_BWD3_HAS_DZ(SV, NFBV, NWV)>::go(p, grid, lds, st);  \
         GML_ALLOW_BIG_LDS(rc1, (&gml_k_spectconv_bwd3<SV, NFBV, NWV, true>), 160 * 1024)                     \
         GML_ALLOW_BIG_LDS(rc0, (&gml_k_spectconv_bwd3<SV, NFBV, NWV, false>), 160 * 1024)                    \
         if (rc1 != hipSuccess) return (int)rc1;                                                              \

@@ -44,6 +44,11 @@ struct GmlBwdParams {
     int32_t ecap, xcap;      // LDS capacities (edges per group, G-window rows), multiples of 4
     int32_t xvec, gvec;      // x / g rows may be read as aligned float4
     int32_t dxvec;           // dx rows may be read / written as aligned float4 (bwd3)
+    // bwd3, optional: dx = conv part + dz wmix (dz [N, 4] contiguous, wmix [nmix <= 4, Fin]): the ML3Layer Hadamard branch's
+    // share of dx handed over as its 4 pre-activation gradients per row instead of a written and re-read [N, Fin] array
+    const float* dz;
+    const float* wmix;
+    int32_t nmix;
 #ifdef GML_BWD2_TIMING
     unsigned long long* prof;    // debug build: per-phase cycle sums
 #endif

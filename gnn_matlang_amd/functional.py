@@ -245,10 +245,11 @@ def node_mix_native(Fin, F2):
     return int(_lib.lib().gml_node_mix_bwd_workspace_bytes(1, int(Fin), int(F2))) != 0
 
 
-def ml3_split_bwd(gy, y, nout1, x=None, w11=None, b11=None, w12=None, b12=None, need_dx=False, need_dcb=False):
+def ml3_split_bwd(gy, y, nout1, x=None, w11=None, b11=None, w12=None, b12=None, need_dx=False, need_dcb=False, dz_out=False):
     """One pass over the rows for the backward of  cat[relu(conv), tanh(fc11 x) * tanh(fc12 x)]  (or of a plain
     relu(conv) when w11 is None): returns G [N, nout1] (view of a zero-padded buffer), dx (Hadamard-branch part
-    only, or None), dcb, dw11, db11, dw12, db12."""
+    only, or None), dcb, dw11, db11, dw12, db12.  dz_out (2 nout2 <= 4): the second result is dz [N, 4] = (dz11 | dz12)
+    instead of dx = dz [w11; w12] (the operand of fused_conv_bwd(..., mix=))."""
     N = gy.size(0)
     F2 = 0 if w11 is None else int(w11.size(0))
     Fin = int(x.size(1)) if F2 else 0
@@ -259,18 +260,25 @@ def ml3_split_bwd(gy, y, nout1, x=None, w11=None, b11=None, w12=None, b12=None, 
     ld = (nout1 + 3) // 4 * 4                                # zero padded: float4-readable rows
     G = torch.empty(N, ld, dtype=torch.float32, device=dev)
     ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=dev)
-    dx = torch.empty(N, Fin, dtype=torch.float32, device=dev) if (need_dx and F2) else None
+    dx = torch.empty(N, Fin, dtype=torch.float32, device=dev) if (need_dx and F2 and not dz_out) else None
+    dz = torch.empty(N, 4, dtype=torch.float32, device=dev) if (dz_out and F2) else None
     dcb = torch.empty(nout1, dtype=torch.float32, device=dev) if need_dcb else None
     dw11 = torch.empty_like(w11) if F2 else None
     dw12 = torch.empty_like(w12) if F2 else None
     db11 = torch.empty_like(b11) if (F2 and b11 is not None) else None
     db12 = torch.empty_like(b12) if (F2 and b12 is not None) else None
-    with _Timed('ml3_split_bwd', 4 * N * (3 * (nout1 + F2) + (2 * Fin if dx is not None else Fin))):
-        _lib.call('gml_ml3_split_bwd', _ptr(gy), int(gy.stride(0)), _ptr(y), int(y.stride(0)), _ptr(x),
-                  int(x.stride(0)) if F2 else 0, _ptr(w11), _ptr(b11), _ptr(w12), _ptr(b12), _ptr(G), ld, _ptr(dx), Fin,
-                  _ptr(dcb), _ptr(dw11), _ptr(db11), _ptr(dw12), _ptr(db12), int(N), Fin, int(nout1), F2, _ptr(ws),
-                  ws.numel(), _stream(dev))
-    return G[:, :nout1], dx, dcb, dw11, db11, dw12, db12
+    with _Timed('ml3_split_bwd', 4 * N * (3 * (nout1 + F2) + (2 * Fin if dx is not None else Fin) + (4 if dz is not None else 0))):
+        if dz is not None:
+            _lib.call('gml_ml3_split_bwd_dz', _ptr(gy), int(gy.stride(0)), _ptr(y), int(y.stride(0)), _ptr(x),
+                      int(x.stride(0)), _ptr(w11), _ptr(b11), _ptr(w12), _ptr(b12), _ptr(G), ld, _ptr(dz),
+                      _ptr(dcb), _ptr(dw11), _ptr(db11), _ptr(dw12), _ptr(db12), int(N), Fin, int(nout1), F2, _ptr(ws),
+                      ws.numel(), _stream(dev))
+        else:
+            _lib.call('gml_ml3_split_bwd', _ptr(gy), int(gy.stride(0)), _ptr(y), int(y.stride(0)), _ptr(x),
+                      int(x.stride(0)) if F2 else 0, _ptr(w11), _ptr(b11), _ptr(w12), _ptr(b12), _ptr(G), ld, _ptr(dx), Fin,
+                      _ptr(dcb), _ptr(dw11), _ptr(db11), _ptr(dw12), _ptr(db12), int(N), Fin, int(nout1), F2, _ptr(ws),
+                      ws.numel(), _stream(dev))
+    return G[:, :nout1], (dz if dz is not None else dx), dcb, dw11, db11, dw12, db12
 
 
 def xty(a, b):
@@ -385,8 +393,17 @@ def fused_bwd_available(csr, S, Fin, Fout):
     return _bwd_plan(csr, S, Fin, Fout) is not None
 
 
-def fused_conv_bwd(csr, val_t, x, G, weight, need_x, need_val, need_w, dx_accum_into=None):
-    """one launch: dX, dval (source order), dW.  val_t: supports in source order."""
+def conv_bwd_takes_dz(csr, S, Fin, Fout, nmix):
+    """True when the fused backward of this shape can form  dx = conv part + dz wmix  itself (gml_spectconv_bwd_mix)."""
+    if _os.environ.get('GML_NO_DZ') or not (1 <= nmix <= 4):
+        return False
+    plan = _bwd_plan(csr, S, Fin, Fout)
+    return plan is not None and bool(_lib.lib().gml_spectconv_bwd_mix_supported(int(S), int(Fin), int(Fout), int(nmix), plan[0]))
+
+
+def fused_conv_bwd(csr, val_t, x, G, weight, need_x, need_val, need_w, dx_accum_into=None, mix=None):
+    """one launch: dX, dval (source order), dW.  val_t: supports in source order.  mix = (dz [N, 4], wmix [nmix, Fin]):
+    dX = conv part + dz wmix (instead of accumulating into a dx another kernel wrote)."""
     S, Fin, Fout = weight.shape
     dev = x.device
     flags, ginfo, gmax, nbytes, _ = _bwd_plan(csr, S, Fin, Fout)
@@ -405,16 +422,23 @@ def fused_conv_bwd(csr, val_t, x, G, weight, need_x, need_val, need_w, dx_accum_
     dw = torch.empty(S, Fin, Fout, dtype=torch.float32, device=dev) if need_w else None
     q, f = conv_cost_bwd(csr.N, csr.E, S, Fin, Fout) if PROFILE is not None else (0, 0)
     with _Timed('spectconv_bwd', q, f):
-        _lib.call('gml_spectconv_bwd', _ptr(csr.rowptr_t), _ptr(csr.col_t), _ptr(ginfo), _ptr(val_t),
-                  _ptr(x), int(x.stride(0)), _ptr(G), int(G.stride(0)), _ptr(weight), _ptr(dx), Fin, _ptr(dval_t),
-                  _ptr(dw), csr.N, S, Fin, Fout, gmax[0], gmax[1], flags, _ptr(ws),
-                  ws.numel() if ws is not None else 0, _stream(dev))
+        if mix is not None:
+            dz, wmix = mix
+            _lib.call('gml_spectconv_bwd_mix', _ptr(csr.rowptr_t), _ptr(csr.col_t), _ptr(ginfo), _ptr(val_t),
+                      _ptr(x), int(x.stride(0)), _ptr(G), int(G.stride(0)), _ptr(weight), _ptr(dx), Fin, _ptr(dval_t),
+                      _ptr(dw), _ptr(dz), _ptr(wmix), int(wmix.size(0)), csr.N, S, Fin, Fout, gmax[0], gmax[1], flags, _ptr(ws),
+                      ws.numel() if ws is not None else 0, _stream(dev))
+        else:
+            _lib.call('gml_spectconv_bwd', _ptr(csr.rowptr_t), _ptr(csr.col_t), _ptr(ginfo), _ptr(val_t),
+                      _ptr(x), int(x.stride(0)), _ptr(G), int(G.stride(0)), _ptr(weight), _ptr(dx), Fin, _ptr(dval_t),
+                      _ptr(dw), csr.N, S, Fin, Fout, gmax[0], gmax[1], flags, _ptr(ws),
+                      ws.numel() if ws is not None else 0, _stream(dev))
     return dx, dval_t, dw
 
 
 # ---------------------------------------------------------------------------- shared backward pieces
 def _conv_backward(csr, x, val, weight, G, need_x, need_val, need_w, val_t=None, want_source_order=False,
-                   dx_accum_into=None):
+                   dx_accum_into=None, mix=None):
     """G [N,Fout] contiguous = gradient at the (pre-activation) conv output.
     Returns dx, dval, dw; dval is in source order when want_source_order (and the fused kernel ran).
     dx_accum_into: [N,Fin] buffer that already holds a partial dx; the conv contribution is added to it."""
@@ -428,7 +452,7 @@ def _conv_backward(csr, x, val, weight, G, need_x, need_val, need_w, val_t=None,
         if val_t is None:
             with _Timed('val_to_source_order'):
                 val_t = csr.to_source_order(val)
-        dx, dval_t, dw = fused_conv_bwd(csr, val_t, x, G, weight, need_x, need_val, need_w, dx_accum_into)
+        dx, dval_t, dw = fused_conv_bwd(csr, val_t, x, G, weight, need_x, need_val, need_w, dx_accum_into, mix)
         if need_val and not want_source_order:
             with _Timed('dval_from_source_order'):
                 dval_t = csr.from_source_order(dval_t)
@@ -588,13 +612,18 @@ class ML3LayerFunction(torch.autograd.Function):
                 ea_t = csr.to_source_order(val, cache=not val.requires_grad)   # raw supports: per-batch data (trained ones change)
             want_cb = ctx.has_cb and need[7]
             mixk = nout2 > 0 and node_mix_native(Fin, nout2)
-            r = ml3_split_bwd(gy, out, nout1, x, w11, b11, w12, b12, need_dx=need[0], need_dcb=want_cb) \
+            # 2 nout2 <= 4 (Zinc12k.py's 30+2 layers): the Hadamard branch hands its share of dx to the conv backward as 4 numbers
+            # per row (dz) instead of writing a [N, Fin] array the conv kernel reads back
+            use_dz = bool(mixk and need[0] and conv_bwd_takes_dz(csr, S, Fin, nout1, 2 * nout2))
+            r = ml3_split_bwd(gy, out, nout1, x, w11, b11, w12, b12, need_dx=need[0], need_dcb=want_cb, dz_out=use_dz) \
                 if mixk else ml3_split_bwd(gy, out, nout1, need_dcb=want_cb)
             if r is not None:
                 # one pass: relu mask, conv1.bias gradient, Hadamard branch (its dx written, conv adds to it)
                 G, dx0, g[7], g[8], g[9], g[10], g[11] = r
+                mix = (dx0, torch.cat([w11, w12], 0).contiguous()) if use_dz else None
                 dx, dea, dcw, dea_src = _conv_backward(csr, x, ea, cw, G, need[0], need_val, need[6], val_t=ea_t,
-                                                       want_source_order=learnedge, dx_accum_into=dx0)
+                                                       want_source_order=learnedge,
+                                                       dx_accum_into=None if use_dz else dx0, mix=mix)
                 g[6] = dcw
             else:
                 G = relu_bwd(gy, 0, C, out, C, N, nout1)

@@ -868,3 +868,32 @@ def test_dense_support_mm_vs_fp64(dev, n, S, F):
     assert float((rec[..., :n] - blocks).abs().max()) <= 2.0 ** -16 * float(blocks.abs().max())
     assert float(rec[..., n:].abs().max() if sup.KP > n else 0.0) == 0.0
     assert torch.equal(sup.bwd.view(torch.bfloat16)[..., :n], sup.fwd.view(torch.bfloat16)[..., :n].transpose(-1, -2))
+
+
+def test_ml3_hadamard_dx_handover_matches_accumulate(dev, monkeypatch):
+    """2 nout2 <= 4 (Zinc12k.py's 30+2 layers): the Hadamard branch's share of dx reaches the conv backward as dz [N, 4]
+    (gml_ml3_split_bwd_dz + gml_spectconv_bwd_mix) instead of a written dx the conv kernel accumulates into: same gradients."""
+    from gnn_matlang_amd import ML3Layer, functional as Fn
+    rng = np.random.default_rng(21)
+    torch.manual_seed(21)
+    N, S = 700, 8
+    ei = _random_graph(rng, N, 6)
+    order = np.lexsort((ei[1], ei[0]))
+    ei = ei[:, order]                                        # source-sorted, as SpectralDesign emits
+    layer = ML3Layer(True, S, S, 32, 30, 2).to(dev)
+    x0, ea = torch.randn(N, 32, device=dev), torch.randn(ei.shape[1], S, device=dev)
+    gout = torch.randn(N, 32, device=dev)
+    res = {}
+    for mode in ('dz', 'accumulate'):
+        if mode == 'accumulate':
+            monkeypatch.setenv('GML_NO_DZ', '1')
+        layer.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        Fn.PATHS.clear()
+        (layer(x, T(ei).to(dev), ea) * gout).sum().backward()
+        res[mode] = [x.grad.clone()] + [p.grad.clone() for p in layer.parameters()]
+    monkeypatch.delenv('GML_NO_DZ')
+    from gnn_matlang_amd.graph import csr_for
+    assert Fn.conv_bwd_takes_dz(csr_for(T(ei).to(dev), N), S, 32, 30, 4)          # the hand-over form did run
+    for a, b in zip(res['dz'], res['accumulate']):
+        close(a, b, tol=2e-5, what='dz hand-over vs accumulate')
