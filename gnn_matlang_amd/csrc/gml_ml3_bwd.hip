@@ -25,6 +25,8 @@
 
 struct GmlSplitBwdParams {
     const float* gy; int64_t ldgy;
+    const int32_t* gyseg;                       // optional: gy has one row per SEGMENT (graph) and row r reads gy[gyseg[r]] -- the
+                                                // gradient of a global add / mean pool that directly follows the layer, never expanded
     const float* y; int64_t ldy;
     const float* x; int64_t ldx;
     const float* w11; const float* b11; const float* w12; const float* b12;
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(SB_ROWS, (FINP <= 32 ? 2 : 1)) void gml_k_ml3_split
         const int nr = (int)min((int64_t)SB_ROWS, p.nrows - r0);
         __syncthreads();                                       // previous tile's readers of xs / gz / gi are done
         // tile-relative 32-bit element offsets from uniform bases (row < 2^8, ld < 2^24: 24-bit multiply-add)
-        const float* gyb = p.gy + r0 * p.ldgy;
+        const float* gyb = p.gyseg ? p.gy : p.gy + r0 * p.ldgy;
         const float* yb = p.y + r0 * p.ldy;
         float* Gb = p.G + r0 * p.ldg;
         if constexpr (FINP > 0) {                              // x tile: lane <-> VX features, 8 / 16 loads in flight
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(SB_ROWS, (FINP <= 32 ? 2 : 1)) void gml_k_ml3_split
             for (int j = 0; j < SB_CHUNK; ++j) {               // clamped addresses: unconditional, batched loads
                 {
                     const int rr = min(ra + (j0 + j) * RPS, nr - 1);
-                    const int og = __umul24(rr, ldgy) + fa_y, oy = __umul24(rr, ldy) + fa_o;
+                    const int og = (p.gyseg ? p.gyseg[r0 + rr] * ldgy : __umul24(rr, ldgy)) + fa_y, oy = __umul24(rr, ldy) + fa_o;
                     if constexpr (VEC == 4) {
                         const f32x4 a4 = *reinterpret_cast<const f32x4*>(gyb + og);
                         const f32x4 b4 = *reinterpret_cast<const f32x4*>(yb + oy);
@@ -326,7 +328,7 @@ extern "C" size_t gml_ml3_split_bwd_workspace_bytes(int64_t num_rows, int32_t Fi
     return sizeof(float) * (size_t)sb_grid(num_rows) * sb_npart(F2 ? Fin : 0, nout1, F2);
 }
 
-static int split_bwd_impl(const float* gy, int64_t ldgy, const float* y, int64_t ldy, const float* x, int64_t ldx,
+static int split_bwd_impl(const float* gy, int64_t ldgy, const int32_t* gy_seg, const float* y, int64_t ldy, const float* x, int64_t ldx,
                           const float* w11, const float* b11, const float* w12, const float* b12, float* G,
                           int64_t ldg, float* dx, int64_t lddx, float* dz, float* dcb, float* dw11, float* db11, float* dw12,
                           float* db12, int64_t num_rows, int32_t Fin, int32_t nout1, int32_t F2, void* ws,
@@ -352,7 +354,7 @@ static int split_bwd_impl(const float* gy, int64_t ldgy, const float* y, int64_t
     const size_t need = gml_ml3_split_bwd_workspace_bytes(num_rows, Fin, nout1, F2);
     if (!ws || ws_bytes < need) return GML_E_WORKSPACE;
     GmlSplitBwdParams p;
-    p.gy = gy; p.ldgy = ldgy; p.y = y; p.ldy = ldy; p.x = x; p.ldx = ldx;
+    p.gy = gy; p.ldgy = ldgy; p.gyseg = gy_seg; p.y = y; p.ldy = ldy; p.x = x; p.ldx = ldx;
     p.w11 = w11; p.b11 = b11; p.w12 = w12; p.b12 = b12;
     p.G = G; p.ldg = ldg; p.dx = dx; p.lddx = lddx; p.dz = dz; p.part = (float*)ws; p.nrows = num_rows;
     p.Fin = Fin; p.nout1 = nout1; p.F2 = F2; p.ntiles = (int)gml_cdiv(num_rows, SB_ROWS); p.CP = CP;
@@ -381,19 +383,21 @@ extern "C" int gml_ml3_split_bwd(const float* gy, int64_t ldgy, const float* y, 
                                  int64_t ldg, float* dx, int64_t lddx, float* dcb, float* dw11, float* db11, float* dw12,
                                  float* db12, int64_t num_rows, int32_t Fin, int32_t nout1, int32_t F2, void* ws,
                                  size_t ws_bytes, gml_stream_t stream) {
-    return split_bwd_impl(gy, ldgy, y, ldy, x, ldx, w11, b11, w12, b12, G, ldg, dx, lddx, nullptr, dcb, dw11, db11, dw12, db12,
+    return split_bwd_impl(gy, ldgy, nullptr, y, ldy, x, ldx, w11, b11, w12, b12, G, ldg, dx, lddx, nullptr, dcb, dw11, db11, dw12, db12,
                           num_rows, Fin, nout1, F2, ws, ws_bytes, stream);
 }
 
-// the same with the Hadamard branch's share of dx handed over as dz [num_rows, 4] = (dz11 | dz12), 2 F2 <= 4 (columns beyond
-// 2 F2 zero), for gml_spectconv_bwd_mix: dx = dz [w11; w12] is then formed inside the conv backward and never stored
-extern "C" int gml_ml3_split_bwd_dz(const float* gy, int64_t ldgy, const float* y, int64_t ldy, const float* x, int64_t ldx,
-                                    const float* w11, const float* b11, const float* w12, const float* b12, float* G,
-                                    int64_t ldg, float* dz, float* dcb, float* dw11, float* db11, float* dw12,
-                                    float* db12, int64_t num_rows, int32_t Fin, int32_t nout1, int32_t F2, void* ws,
-                                    size_t ws_bytes, gml_stream_t stream) {
-    if (!dz) return GML_E_BADARG;
-    return split_bwd_impl(gy, ldgy, y, ldy, x, ldx, w11, b11, w12, b12, G, ldg, nullptr, 0, dz, dcb, dw11, db11, dw12, db12,
+// the general form.  dz != NULL (then dx == NULL; 2 F2 <= 4): the Hadamard branch's share of dx is handed over as
+// dz [num_rows, 4] = (dz11 | dz12) (columns beyond 2 F2 zero) for gml_spectconv_bwd_mix -- dx = dz [w11; w12] is formed
+// inside the conv backward and never stored.  gy_seg != NULL: gy has one row per segment (graph) and row r reads
+// gy[gy_seg[r]]: the gradient of the global add pool that follows the last layer (Zinc12k.py:343) is never expanded to
+// [num_rows, C] (for a mean pool the caller divides the pooled gradient by the segment sizes first).
+extern "C" int gml_ml3_split_bwd_ex(const float* gy, int64_t ldgy, const int32_t* gy_seg, const float* y, int64_t ldy,
+                                    const float* x, int64_t ldx, const float* w11, const float* b11, const float* w12,
+                                    const float* b12, float* G, int64_t ldg, float* dx, int64_t lddx, float* dz, float* dcb,
+                                    float* dw11, float* db11, float* dw12, float* db12, int64_t num_rows, int32_t Fin,
+                                    int32_t nout1, int32_t F2, void* ws, size_t ws_bytes, gml_stream_t stream) {
+    return split_bwd_impl(gy, ldgy, gy_seg, y, ldy, x, ldx, w11, b11, w12, b12, G, ldg, dx, lddx, dz, dcb, dw11, db11, dw12, db12,
                           num_rows, Fin, nout1, F2, ws, ws_bytes, stream);
 }
 

@@ -245,12 +245,14 @@ def node_mix_native(Fin, F2):
     return int(_lib.lib().gml_node_mix_bwd_workspace_bytes(1, int(Fin), int(F2))) != 0
 
 
-def ml3_split_bwd(gy, y, nout1, x=None, w11=None, b11=None, w12=None, b12=None, need_dx=False, need_dcb=False, dz_out=False):
+def ml3_split_bwd(gy, y, nout1, x=None, w11=None, b11=None, w12=None, b12=None, need_dx=False, need_dcb=False, dz_out=False,
+                  gy_seg=None):
     """One pass over the rows for the backward of  cat[relu(conv), tanh(fc11 x) * tanh(fc12 x)]  (or of a plain
     relu(conv) when w11 is None): returns G [N, nout1] (view of a zero-padded buffer), dx (Hadamard-branch part
     only, or None), dcb, dw11, db11, dw12, db12.  dz_out (2 nout2 <= 4): the second result is dz [N, 4] = (dz11 | dz12)
-    instead of dx = dz [w11; w12] (the operand of fused_conv_bwd(..., mix=))."""
-    N = gy.size(0)
+    instead of dx = dz [w11; w12] (the operand of fused_conv_bwd(..., mix=)).  gy_seg (int32 [N]): gy has one row per
+    segment and row r reads gy[gy_seg[r]] (the un-expanded gradient of a global add pool that follows the layer)."""
+    N = y.size(0)
     F2 = 0 if w11 is None else int(w11.size(0))
     Fin = int(x.size(1)) if F2 else 0
     dev = gy.device
@@ -268,11 +270,11 @@ def ml3_split_bwd(gy, y, nout1, x=None, w11=None, b11=None, w12=None, b12=None, 
     db11 = torch.empty_like(b11) if (F2 and b11 is not None) else None
     db12 = torch.empty_like(b12) if (F2 and b12 is not None) else None
     with _Timed('ml3_split_bwd', 4 * N * (3 * (nout1 + F2) + (2 * Fin if dx is not None else Fin) + (4 if dz is not None else 0))):
-        if dz is not None:
-            _lib.call('gml_ml3_split_bwd_dz', _ptr(gy), int(gy.stride(0)), _ptr(y), int(y.stride(0)), _ptr(x),
-                      int(x.stride(0)), _ptr(w11), _ptr(b11), _ptr(w12), _ptr(b12), _ptr(G), ld, _ptr(dz),
-                      _ptr(dcb), _ptr(dw11), _ptr(db11), _ptr(dw12), _ptr(db12), int(N), Fin, int(nout1), F2, _ptr(ws),
-                      ws.numel(), _stream(dev))
+        if dz is not None or gy_seg is not None:
+            _lib.call('gml_ml3_split_bwd_ex', _ptr(gy), int(gy.stride(0)), _ptr(gy_seg), _ptr(y), int(y.stride(0)), _ptr(x),
+                      int(x.stride(0)) if F2 else 0, _ptr(w11), _ptr(b11), _ptr(w12), _ptr(b12), _ptr(G), ld, _ptr(dx), Fin,
+                      _ptr(dz), _ptr(dcb), _ptr(dw11), _ptr(db11), _ptr(dw12), _ptr(db12), int(N), Fin, int(nout1), F2,
+                      _ptr(ws), ws.numel(), _stream(dev))
         else:
             _lib.call('gml_ml3_split_bwd', _ptr(gy), int(gy.stride(0)), _ptr(y), int(y.stride(0)), _ptr(x),
                       int(x.stride(0)) if F2 else 0, _ptr(w11), _ptr(b11), _ptr(w12), _ptr(b12), _ptr(G), ld, _ptr(dx), Fin,
@@ -533,7 +535,10 @@ class ML3LayerFunction(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, val, w1, w2, w3, w4, cw, cb, w11, b11, w12, b12, csr, learnedge, nout2, val_is_source=False):
+    def forward(ctx, x, val, w1, w2, w3, w4, cw, cb, w11, b11, w12, b12, csr, learnedge, nout2, val_is_source=False,
+                pool_ptr=None, pool_seg=None, pool_mean=False):
+        # pool_ptr / pool_seg (int32 [B+1] / [N]): the layer is directly followed by global_add_pool / global_mean_pool
+        # (Zinc12k.py:343): the pooled [B, C] tensor is returned and the pool's gradient is never expanded to [N, C]
         # val_is_source: val holds the raw supports in SOURCE order (the caller checked ml3_edge_in_source_order and that they
         # carry no gradient); otherwise target-sorted order
         x, val, cw = _f32c(x, 'x'), _f32c(val, 'edge_attr'), _f32c(cw, 'conv1.weight')
@@ -592,7 +597,10 @@ class ML3LayerFunction(torch.autograd.Function):
         ctx.csr, ctx.learnedge, ctx.nout2, ctx.has_cb = csr, learnedge, nout2, cb is not None
         ctx.src_order = epos is not None
         ctx.val_is_source = bool(val_is_source)
+        ctx.pool = (pool_ptr, pool_seg, bool(pool_mean)) if pool_ptr is not None else None
         ctx.save_for_backward(x, val, (ea if learnedge and epos is None else None), w1, w2, w3, w4, cw, w11, b11, w12, b12, out, ea_t)
+        if ctx.pool is not None:
+            return segment_sum(out, pool_ptr, pool_mean)
         return out
 
     @staticmethod
@@ -605,7 +613,19 @@ class ML3LayerFunction(torch.autograd.Function):
         gy = _f32c(gy, 'grad_out')
         if not learnedge:
             ea = val
-        g = [None] * 16
+        g = [None] * 19
+        gy_seg = None
+        if ctx.pool is not None:                               # gy is the POOLED gradient [B, C]
+            pptr, pseg, pmean = ctx.pool
+            mixk_ = nout2 > 0 and node_mix_native(Fin, nout2)
+            nb_ = int(_lib.lib().gml_ml3_split_bwd_workspace_bytes(int(N), Fin if mixk_ else 0, int(nout1), int(nout2) if mixk_ else 0))
+            if nb_ > 0 and (mixk_ or nout2 == 0) and not _os.environ.get('GML_NO_POOL_FUSE'):
+                if pmean:
+                    cnt = (pptr[1:] - pptr[:-1]).clamp(min=1).to(gy.dtype).unsqueeze(1)
+                    gy = gy / cnt
+                gy_seg = pseg
+            else:
+                gy = segment_bcast(gy, pptr, N, pmean)
         with torch.cuda.device(x.device):
             need_val = need[1] or (learnedge and any(need[2:6]))
             if not learnedge and fused_bwd_available(csr, S, Fin, nout1):
@@ -615,8 +635,8 @@ class ML3LayerFunction(torch.autograd.Function):
             # 2 nout2 <= 4 (Zinc12k.py's 30+2 layers): the Hadamard branch hands its share of dx to the conv backward as 4 numbers
             # per row (dz) instead of writing a [N, Fin] array the conv kernel reads back
             use_dz = bool(mixk and need[0] and conv_bwd_takes_dz(csr, S, Fin, nout1, 2 * nout2))
-            r = ml3_split_bwd(gy, out, nout1, x, w11, b11, w12, b12, need_dx=need[0], need_dcb=want_cb, dz_out=use_dz) \
-                if mixk else ml3_split_bwd(gy, out, nout1, need_dcb=want_cb)
+            r = ml3_split_bwd(gy, out, nout1, x, w11, b11, w12, b12, need_dx=need[0], need_dcb=want_cb, dz_out=use_dz, gy_seg=gy_seg) \
+                if mixk else ml3_split_bwd(gy, out, nout1, need_dcb=want_cb, gy_seg=gy_seg)
             if r is not None:
                 # one pass: relu mask, conv1.bias gradient, Hadamard branch (its dx written, conv adds to it)
                 G, dx0, g[7], g[8], g[9], g[10], g[11] = r
@@ -626,6 +646,7 @@ class ML3LayerFunction(torch.autograd.Function):
                                                        dx_accum_into=None if use_dz else dx0, mix=mix)
                 g[6] = dcw
             else:
+                assert gy_seg is None, 'pooled gradient without the one-pass output-stage kernel'
                 G = relu_bwd(gy, 0, C, out, C, N, nout1)
                 dx, dea, dcw, dea_src = _conv_backward(csr, x, ea, cw, G, need[0], need_val, need[6], val_t=ea_t,
                                                        want_source_order=learnedge)

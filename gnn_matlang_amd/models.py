@@ -9,7 +9,7 @@ edge_index2, edge_attr2, batch, ptr, y).
 import torch
 import torch.nn.functional as F
 
-from .functional import segment_bcast, segment_max, segment_max_bwd, segment_sum, tall_linear
+from .functional import segment_bcast, segment_max, segment_max_bwd, segment_sum, tall_linear, _ptr32
 from .spect_conv import ML3Layer, SpectConv
 
 
@@ -96,15 +96,23 @@ class GNNML3(torch.nn.Module):
                 data._spT = dense_supports(data.edge_index2, data.edge_attr2, data.ptr, self.dense_n)
         else:
             csr = data.csr('edge_index2')
+        pooled = False
         for i in range(self.nlayers):
             layer = getattr(self, 'conv%d' % (i + 1))
             if self.dense_n:
                 x = F.relu(spectconv_dense(x, data._spT, layer.conv1.weight, layer.conv1.bias, self.dense_n))
+            elif i == self.nlayers - 1 and not self.bn and self.pool in ('add', 'mean') and torch.is_grad_enabled():
+                # the pool directly follows the last layer: one autograd node, the pool's gradient is not expanded to [N, C]
+                if getattr(data, '_batch_i32', None) is None:
+                    data._batch_i32 = data.batch.to(torch.int32).contiguous()
+                x = layer.forward_pooled(x, csr, data.edge_attr2, _ptr32(data.ptr), data._batch_i32, self.pool == 'mean')
+                pooled = True
             else:
                 x = layer(x, csr, data.edge_attr2)
             if self.bn:
                 x = getattr(self, 'bn%d' % (i + 1))(x)
-        x = {'add': global_add_pool, 'mean': global_mean_pool, 'max': global_max_pool}[self.pool](x, data)
+        if not pooled:
+            x = {'add': global_add_pool, 'mean': global_mean_pool, 'max': global_max_pool}[self.pool](x, data)
         if self.readout_bn:
             x = self.bnr(x)
         if self.head == 'mlp32':

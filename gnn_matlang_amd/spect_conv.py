@@ -202,7 +202,13 @@ class ML3Layer(torch.nn.Module):
             self.fc11 = torch.nn.Linear(ninp, nout2)
             self.fc12 = torch.nn.Linear(ninp, nout2)
 
-    def forward(self, x, edge_index, edge_attr):
+    def forward_pooled(self, x, edge_index, edge_attr, ptr, batch, mean=False):
+        """global_add_pool / global_mean_pool (mean=True) of forward(...) in one autograd node: [B, nout1 + nout2].  Same
+        values as pooling the layer's output (Zinc12k.py:338-343); the pool's gradient then reaches the layer's backward
+        un-expanded ([B, C] + the node -> graph map instead of [N, C]).  ptr [B+1] / batch [N]: int32, grouped per graph."""
+        return self.forward(x, edge_index, edge_attr, _pool=(ptr, batch, bool(mean)))
+
+    def forward(self, x, edge_index, edge_attr, _pool=None):
         _require_cuda(x, 'x')
         csr = csr_for(edge_index, x.size(0))
         le, n2 = self.learnedge, self.nout2
@@ -226,7 +232,7 @@ class ML3Layer(torch.nn.Module):
             self.conv1.weight, self.conv1.bias,
             self.fc11.weight if n2 > 0 else None, self.fc11.bias if n2 > 0 else None,
             self.fc12.weight if n2 > 0 else None, self.fc12.bias if n2 > 0 else None,
-            csr, le, n2, bool(raw_src))
+            csr, le, n2, bool(raw_src), *(_pool if _pool is not None else (None, None, False)))
 
 
 __all__ = ['SpectConv', 'SpectConCatConv', 'ML3Layer', 'GraphCSR', 'glorot', 'zeros']

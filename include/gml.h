@@ -152,7 +152,7 @@ int gml_spectconv_bwd(const int32_t* rowptr, const int32_t* col, const int32_t* 
 
 /* gml_spectconv_bwd with  dx = conv part + dz wmix : dz [num_rows, 4] (contiguous, 16-byte aligned, columns >= nmix ignored),
  * wmix [nmix <= 4, Fin].  The ML3Layer Hadamard branch (2 nout2 <= 4 columns: Zinc12k.py's 30+2 layers) hands its share of
- * dx over as its pre-activation gradients (gml_ml3_split_bwd_dz) instead of a written-then-re-read [N, Fin] array.
+ * dx over as its pre-activation gradients (gml_ml3_split_bwd_ex) instead of a written-then-re-read [N, Fin] array.
  * dx must be wanted and float4-addressable; GML_ACCUM is not combined with it.  gml_spectconv_bwd_mix_supported: 1 when
  * the shape has this form (the 8-wave bf16x3 kernel, S = 8, 16 < Fin <= 32), else the caller uses dx + GML_ACCUM. */
 int gml_spectconv_bwd_mix_supported(int32_t S, int32_t Fin, int32_t Fout, int32_t nmix, uint32_t flags);
@@ -241,11 +241,12 @@ int gml_ml3_split_bwd(const float* gy, int64_t ldgy, const float* y, int64_t ldy
                       int64_t num_rows, int32_t Fin, int32_t nout1, int32_t F2,
                       void* ws, size_t ws_bytes, gml_stream_t stream);
 
-/* the same with dz [num_rows, 4] = (dz11 | dz12) written instead of dx (2 F2 <= 4; columns beyond 2 F2 zero): the operand of
- * gml_spectconv_bwd_mix */
-int gml_ml3_split_bwd_dz(const float* gy, int64_t ldgy, const float* y, int64_t ldy, const float* x, int64_t ldx,
-                         const float* w11, const float* b11, const float* w12, const float* b12,
-                         float* G, int64_t ldg, float* dz, float* dcb,
+/* general form.  dz != NULL (then dx == NULL; 2 F2 <= 4): dz [num_rows, 4] = (dz11 | dz12) is written instead of dx (columns
+ * beyond 2 F2 zero): the operand of gml_spectconv_bwd_mix.  gy_seg != NULL: gy holds one row per SEGMENT and row r reads
+ * gy[gy_seg[r]] -- the gradient of a global add pool that directly follows the layer (Zinc12k.py:343), never expanded. */
+int gml_ml3_split_bwd_ex(const float* gy, int64_t ldgy, const int32_t* gy_seg, const float* y, int64_t ldy,
+                         const float* x, int64_t ldx, const float* w11, const float* b11, const float* w12, const float* b12,
+                         float* G, int64_t ldg, float* dx, int64_t lddx, float* dz, float* dcb,
                          float* dw11, float* db11, float* dw12, float* db12,
                          int64_t num_rows, int32_t Fin, int32_t nout1, int32_t F2,
                          void* ws, size_t ws_bytes, gml_stream_t stream);

@@ -897,3 +897,36 @@ def test_ml3_hadamard_dx_handover_matches_accumulate(dev, monkeypatch):
     assert Fn.conv_bwd_takes_dz(csr_for(T(ei).to(dev), N), S, 32, 30, 4)          # the hand-over form did run
     for a, b in zip(res['dz'], res['accumulate']):
         close(a, b, tol=2e-5, what='dz hand-over vs accumulate')
+
+
+@pytest.mark.parametrize('mean', [False, True])
+def test_ml3_forward_pooled_matches_layer_then_pool(dev, mean):
+    """ML3Layer.forward_pooled (the layer and the global add / mean pool that follows it as one autograd node: the pool's
+    gradient is consumed un-expanded by gml_ml3_split_bwd_ex) against the layer followed by the pooling op."""
+    from gnn_matlang_amd import ML3Layer, models
+    from gnn_matlang_amd.graph import Batch
+    rng = np.random.default_rng(31)
+    torch.manual_seed(31)
+    sizes = torch.tensor([5, 1, 17, 64, 3, 130, 2])
+    N = int(sizes.sum())
+    ptr = torch.cat([torch.zeros(1, dtype=torch.long), sizes.cumsum(0)]).int().to(dev)
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), sizes).to(dev)
+    ei = _random_graph(rng, N, 5)
+    ei = ei[:, np.lexsort((ei[1], ei[0]))]
+    layer = ML3Layer(True, 8, 8, 32, 30, 2).to(dev)
+    x0, ea = torch.randn(N, 32, device=dev), torch.randn(ei.shape[1], 8, device=dev)
+    gp = torch.randn(len(sizes), 32, device=dev)
+    data = Batch(x=x0, edge_index=T(ei).to(dev), edge_index2=T(ei).to(dev), edge_attr2=ea, batch=batch, ptr=ptr, y=torch.zeros(len(sizes), device=dev))
+    res = []
+    for fused in (True, False):
+        layer.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        if fused:
+            out = layer.forward_pooled(x, T(ei).to(dev), ea, ptr, batch.int(), mean)
+        else:
+            out = (models.global_mean_pool if mean else models.global_add_pool)(layer(x, T(ei).to(dev), ea), data)
+        (out * gp).sum().backward()
+        res.append([out.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in layer.parameters()])
+    assert torch.equal(res[0][0], res[1][0])                             # same kernels forward: same bits
+    for a, b in zip(res[0][1:], res[1][1:]):
+        close(a, b, tol=2e-5, what='pooled layer vs layer + pool (mean=%s)' % mean)
