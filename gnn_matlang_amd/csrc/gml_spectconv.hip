@@ -108,7 +108,12 @@ extern "C" int gml_spectconv_fwd(const int32_t* rowptr, const int32_t* col, cons
 
     // features per lane per chunk: 8 unless 4 pads the contraction less
     const int pad8 = (Fin + 31) / 32 * 32, pad4 = (Fin + 15) / 16 * 16;
-    const int FPL = (pad4 < pad8) ? 4 : 8;
+    // The bf16x3 projection needs 8 features per lane, so outside the exact-fp32 mode the wider padding is taken even where
+    // 4 per lane would pad less (Fin = 48: sr25 / mutag GNNML3 forward -22 % / -15 %; GML_FWD_FPL4=1 restores the old choice)
+    static const bool fpl4 = [] { const char* e = getenv("GML_FWD_FPL4"); return e && e[0] == '1'; }();
+    // (narrow inputs, Fin <= 16, keep 4 per lane = exact products: with so few terms per output the split's 2^-17 is not
+    //  averaged and mutag GNNML1's batch-normalised gradients left the 1e-4 bar, 1.5e-4)
+    const int FPL = (pad4 < pad8 && (fpl4 || (flags & GML_F32_MFMA) || Fin <= 32)) ? 4 : 8;
     const int CH = 4 * FPL;
     const int nchunks = (Fin + CH - 1) / CH;
     const bool xvec = (Fin % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)x & 15) == 0);

@@ -136,7 +136,7 @@ def fwd_groups(csr, x, S, Fin, Fout):
             return csr.ranked64()[0], _lib.GML_GROUPS64R
         _path('conv_fwd', 'fused 8-wave bf16x3', S, Fin, Fout)
         return csr.ginfo128, _lib.GML_GROUPS128
-    _path('conv_fwd', 'fused 4-wave (%s)' % ('f32 MFMA' if (F32_MFMA or Fin > 32 or Fout > 32) else 'generic'), S, Fin, Fout)
+    _path('conv_fwd', 'fused 4-wave (%s)' % ('f32 MFMA' if (F32_MFMA or Fin <= 16 or Fout > 32) else 'bf16x3'), S, Fin, Fout)
     return csr.ginfo, 0
 
 
