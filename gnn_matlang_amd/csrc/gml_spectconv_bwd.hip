@@ -84,6 +84,7 @@ static BwdPlan plan_bwd(int64_t num_rows, int S, int Fin, int Fout, int max_edge
         GML_BWD3_LDS(8, 2, 8) GML_BWD3_LDS(8, 1, 8) GML_BWD3_LDS(6, 2, 8) GML_BWD3_LDS(6, 1, 8)
         GML_BWD3_LDS(4, 2, 8) GML_BWD3_LDS(4, 1, 8) GML_BWD3_LDS(2, 2, 8) GML_BWD3_LDS(2, 1, 8)
         GML_BWD3_LDS(8, 2, 4) GML_BWD3_LDS(8, 1, 4)
+        if (pl.lds > 0) pl.lds += 512;                      /* the DZ instantiation's wmix rows (gml_spectconv_bwd_mix) */
         /* (a group too large for the LDS: not ok -- the caller then asks for the f32-MFMA kernel with ITS group records) */
         pl.ok = pl.lds > 0 && pl.lds <= (pl.nw == 4 ? 80 : 160) * 1024;
         return pl;
@@ -157,7 +158,7 @@ static int spectconv_bwd_impl(const int32_t* rowptr, const int32_t* col, const i
     p.w = w; p.dx = dx; p.lddx = lddx; p.dval = dval; p.dw_partial = dw ? (float*)ws : nullptr;
     p.nrows = num_rows; p.S = S; p.Fin = Fin; p.Fout = Fout; p.flags = flags;
     p.dz = dz; p.wmix = wmix; p.nmix = nmix;
-    if (dz != nullptr && (pl.layout != 3 || pl.lds + 512 > 160 * 1024 || (flags & GML_ACCUM) || (((uintptr_t)dz) & 15) != 0))
+    if (dz != nullptr && (pl.layout != 3 || (flags & GML_ACCUM) || (((uintptr_t)dz) & 15) != 0))
         return GML_E_UNSUPPORTED;
 #ifdef GML_BWD2_TIMING
     p.prof = bwd2_prof_buf();

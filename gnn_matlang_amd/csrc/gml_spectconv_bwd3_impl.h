@@ -84,7 +84,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
     float* gs = ea_l + (size_t)p.ecap * S;
     unsigned char* pT = rreg;                                // [hi, lo][se][position] 64-byte rows (after the dval rows left)
     unsigned char* xT = rreg + C::r_bytes(p.ecap, p.xcap);   // [hi, lo][position]     64-byte rows (own region)
-    float* wm_l = reinterpret_cast<float*>(xT + C::XT_BYTES);  // DZ: [4][32] rows of wmix, zero padded (host adds the 512 bytes)
+    float* wm_l = reinterpret_cast<float*>(xT + C::XT_BYTES);  // DZ: [4][32] rows of wmix, zero padded (the plan's lds includes these 512 bytes)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -557,7 +557,7 @@ struct GmlBwd3Dz<S, NFB, NW, true> {
         if (!p.xvec || !p.dxvec || p.nmix < 1 || p.nmix > 4 || !p.wmix || !p.dx) return GML_E_UNSUPPORTED;
         GML_ALLOW_BIG_LDS(rc, (&gml_k_spectconv_bwd3<S, NFB, NW, true, true>), 160 * 1024)
         if (rc != hipSuccess) return (int)rc;
-        hipLaunchKernelGGL((gml_k_spectconv_bwd3<S, NFB, NW, true, true>), grid, dim3(64 * NW), lds + 512, st, p);
+        hipLaunchKernelGGL((gml_k_spectconv_bwd3<S, NFB, NW, true, true>), grid, dim3(64 * NW), lds, st, p);   /* (lds includes the 512 bytes) */
         return gml_launch_status();
     }
 };
