@@ -872,7 +872,7 @@ def test_dense_support_mm_vs_fp64(dev, n, S, F):
 
 def test_ml3_hadamard_dx_handover_matches_accumulate(dev, monkeypatch):
     """2 nout2 <= 4 (Zinc12k.py's 30+2 layers): the Hadamard branch's share of dx reaches the conv backward as dz [N, 4]
-    (gml_ml3_split_bwd_dz + gml_spectconv_bwd_mix) instead of a written dx the conv kernel accumulates into: same gradients."""
+    (gml_ml3_split_bwd_ex + gml_spectconv_bwd_mix) instead of a written dx the conv kernel accumulates into: same gradients."""
     from gnn_matlang_amd import ML3Layer, functional as Fn
     rng = np.random.default_rng(21)
     torch.manual_seed(21)
