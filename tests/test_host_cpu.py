@@ -207,3 +207,13 @@ def test_raw_readers_reproduce_the_reference_datasets():
             assert np.array_equal(x, z['x'][nptr[i]:nptr[i + 1]]) and x.dtype == np.float32, (fname, i)
             assert np.array_equal(ei, z['edge_index'][:, eptr[i]:eptr[i + 1]]) and ei.dtype == np.int64, (fname, i)
             assert float(y) == float(z['y'][i])
+
+
+def test_dense_block_row_slabs():
+    """dense_block._splits: the weight-gradient GEMM is cut into <= 64 row slabs of >= 1024 rows that divide the row count."""
+    from gnn_matlang_amd.dense_block import _splits
+    for rows in (76800, 307200, 75 * 125, 75, 1024, 2048, 75 * 1000, 97 * 75):
+        p = _splits(rows)
+        assert 1 <= p <= 64 and rows % p == 0
+        assert p == 1 or rows // p >= 1024
+    assert _splits(76800) == 64 and _splits(75) == 1
