@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gnn_matlang_amd import SpectralDesign, collate, models, synthetic, dense_block
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+ONLY = sys.argv[2] if len(sys.argv) > 2 else None          # e.g. `dense`: profile one path alone
 dev = torch.device('cuda:0')
 raw = synthetic.make_graphs('mnist75', 64, seed=1)
 pool = SpectralDesign(recfield=3, dv=10, nfreq=5).design_many(raw)
@@ -18,6 +19,8 @@ data = collate([pool[i % 64] for i in range(B)]).to(dev)
 data.y = torch.randint(0, 10, (B,), device=dev)
 out = {}
 for name, dn in (('sparse', 0), ('dense_lib', 75), ('dense', 75)):
+    if ONLY and name != ONLY:
+        continue
     dense_block.USE_LIBRARY = name == 'dense_lib'
     torch.manual_seed(0)
     m = models.mnist_gnnml3(dense_n=dn).to(dev).train()
