@@ -327,8 +327,8 @@ def test_spmm_sddmm_edge_mlp_node_mix_vs_oracle(dev):
         h = Fn.spmm(csr2, csr2.sort_values(ea.to(dev), cache=False), x.to(dev), S, fin).view(N2, S, fin)
         href = torch.stack([O.propagate_add(x, T(ei2), ea[:, s]) for s in range(S)], 1)
         close(h, href, what='spmm small N=%d S=%d' % (N2, S))
-    for S in range(1, 17):
-        E2 = 1000 + S
+    # (the last cases: fewer edges than one 16-edge tile, and exactly one tile)
+    for S, E2 in [(S, 1000 + S) for S in range(1, 17)] + [(12, 7), (9, 1), (8, 1), (16, 16), (6, 15)]:
         ea = torch.randn(E2, S)
         ws = [torch.randn(2 * S, S) * 0.7 for _ in range(3)] + [torch.randn(S, 4 * S) * 0.5]
         ea = make_safe_edges(ea, *ws)                      # no relu argument within rounding of zero
@@ -907,7 +907,7 @@ def test_ml3_forward_pooled_matches_layer_then_pool(dev, mean):
     from gnn_matlang_amd.graph import Batch
     rng = np.random.default_rng(31)
     torch.manual_seed(31)
-    sizes = torch.tensor([5, 1, 17, 64, 3, 130, 2])
+    sizes = torch.tensor([5, 1, 17, 0, 64, 3, 130, 2])              # (one empty graph)
     N = int(sizes.sum())
     ptr = torch.cat([torch.zeros(1, dtype=torch.long), sizes.cumsum(0)]).int().to(dev)
     batch = torch.repeat_interleave(torch.arange(len(sizes)), sizes).to(dev)
