@@ -15,7 +15,7 @@ HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 
 def main():
     name, extra = sys.argv[1], sys.argv[2:]
-    objdir = os.path.join(ROOT, 'gnn_matlang_amd', 'csrc', '_obj_' + name)
+    objdir = os.path.join(os.environ.get('GML_VARIANT_OBJ', '/tmp/gml_variant_obj'), name)   # outside the tree: objects never travel to the GPU box
     os.makedirs(objdir, exist_ok=True)
     os.makedirs(os.path.join(ROOT, '_ab'), exist_ok=True)
     flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I', CSRC, '-I', INCLUDE, '-Wno-unused-result'] + extra
