@@ -1,0 +1,4 @@
+// explicit instantiations of the 128-row forward kernel with the LDS-DMA landing ring, S = 8
+#include "gml_spectconv_fwd3_impl.h"
+GML_DEFINE_FWD3(8, 2)
+GML_DEFINE_FWD3(8, 1)

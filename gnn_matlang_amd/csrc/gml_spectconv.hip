@@ -1,11 +1,18 @@
 // Dispatch of the fused forward kernel families + the unfused SpMM / SDDMM kernels.
 #include "gml_spectconv_impl.h"
 #include "gml_spectconv_fwd2_impl.h"
+#include "gml_spectconv_fwd3_impl.h"
 
 #define GML_DECL_FWD2(S, B) template <> int gml_launch_fwd2<S, B>(const GmlFwdParams&, dim3, hipStream_t, bool, bool);
 GML_DECL_FWD2(8, 2) GML_DECL_FWD2(8, 1) GML_DECL_FWD2(4, 2) GML_DECL_FWD2(4, 1)
 GML_DECL_FWD2(8, 0) GML_DECL_FWD2(4, 0)            /* NOB = 0: the stand-alone SpMM instantiation */
 GML_DECL_FWD2(12, 2) GML_DECL_FWD2(12, 1) GML_DECL_FWD2(12, 0)  /* counting.py's 12 supports */
+
+#define GML_DECL_FWD3(S, B) template <> int gml_launch_fwd3<S, B>(const GmlFwdParams&, dim3, hipStream_t, bool);
+GML_DECL_FWD3(8, 2) GML_DECL_FWD3(8, 1) GML_DECL_FWD3(4, 2) GML_DECL_FWD3(4, 1)
+
+// GML_FWD_DMA=0: the register-staged 8-wave kernel (fwd2) instead of the LDS-DMA ring (fwd3), for A/B runs
+static bool fwd3_env() { static const bool v = [] { const char* e = getenv("GML_FWD_DMA"); return !(e && e[0] == '0'); }(); return v; }
 
 static bool fwd2_shape(int S, int Fin, int Fout, uint32_t flags) {
 #ifdef GML_NO_FWD2
@@ -48,12 +55,12 @@ extern "C" int gml_node_mix_fwd(const float* x, int64_t ldx, const float* w11, c
 
 #ifdef GML_FWD2_TIMING
 static unsigned long long* fwd2_prof_buf() {
-    static unsigned long long* b = [] { unsigned long long* q = nullptr; (void)hipMalloc(&q, 128); (void)hipMemset(q, 0, 128); return q; }();
+    static unsigned long long* b = [] { unsigned long long* q = nullptr; (void)hipMalloc(&q, 256); (void)hipMemset(q, 0, 256); return q; }();
     return b;
 }
 extern "C" int gml_debug_fwd2_prof(unsigned long long* out, int reset) {
-    hipError_t e = hipMemcpy(out, fwd2_prof_buf(), 128, hipMemcpyDeviceToHost);
-    if (e == hipSuccess && reset) e = hipMemset(fwd2_prof_buf(), 0, 128);
+    hipError_t e = hipMemcpy(out, fwd2_prof_buf(), 256, hipMemcpyDeviceToHost);   /* [0,16): fwd2, [16,32): fwd3 */
+    if (e == hipSuccess && reset) e = hipMemset(fwd2_prof_buf(), 0, 256);
     return (int)e;
 }
 #endif
@@ -82,6 +89,13 @@ static int launch_fwd2(const int32_t* rowptr, const int32_t* col, const int32_t*
     grid = (int)gml_cdiv(p.ngroups, p.groups_per_wg);
     const int nob = Fout > 16 ? 2 : 1;
     const bool mix = F2 > 0;
+    // LDS-DMA landing ring: float4-addressable x, no accumulate mode, 32-bit buffer offsets
+    // (value rows beyond 4 GB are handled inside the kernel: it reads the edge count itself)
+    if (p.nw == 8 && xv && fwd3_env() && (S == 8 || S == 4) && !(flags & GML_ACCUM) &&
+        (num_rows + 16) * ldx * 4 < (int64_t)INT32_MAX) {
+#define GML_FWD3_GO(SV, B) if (S == SV && nob == B) return gml_launch_fwd3<SV, B>(p, dim3(grid), st, mix);
+        GML_FWD3_GO(8, 2) GML_FWD3_GO(8, 1) GML_FWD3_GO(4, 2) GML_FWD3_GO(4, 1)
+    }
 #define GML_FWD2_GO(SV, B) if (S == SV && nob == B) return gml_launch_fwd2<SV, B>(p, dim3(grid), st, xv, mix);
     GML_FWD2_GO(8, 2) GML_FWD2_GO(8, 1) GML_FWD2_GO(4, 2) GML_FWD2_GO(4, 1) GML_FWD2_GO(12, 2) GML_FWD2_GO(12, 1)
     return GML_E_UNSUPPORTED;

@@ -14,7 +14,7 @@ torch.manual_seed(0)
 model = models.zinc_gnnml3().to(dev)
 L = _lib.lib()
 L.gml_debug_fwd2_prof.restype = ctypes.c_int
-buf = (ctypes.c_ulonglong * 16)()
+buf = (ctypes.c_ulonglong * 32)()
 for it in range(3):
     loss = models.zinc_loss(model(data), data.y)
     loss.backward()
@@ -22,7 +22,13 @@ for it in range(3):
     L.gml_debug_fwd2_prof(buf, 1)
 names = ['commit (waits for the prefetched registers)', 'barrier', 'issue next group (record, then loads)', 'own-row loads + row bounds',
          'aggregation', 'value gather issue', 'projection', 'output stores', 'Hadamard branch', 'end barrier']
-tot = float(sum(buf))
-for n, v in zip(names, buf):
-    print('%-48s %14d  %5.1f%%' % (n, v, 100.0 * v / tot if tot else 0))
-print('cycles per launch per wave: %.0f' % (tot / 4 / 256 / 8))
+names3 = ['wait for the landing DMAs (vmcnt)', 'barrier', 'issue next group (records from LDS, DMA)', 'row bounds', 'aggregation (+ own x row)',
+          '-', 'projection', 'output stores', 'Hadamard branch', '-']
+for title, nm, b in (('fwd2 (register staging)', names, buf[:16]), ('fwd3 (LDS-DMA ring)', names3, buf[16:])):
+    tot = float(sum(b))
+    if not tot:
+        continue
+    print('# ' + title)
+    for n, v in zip(nm, b):
+        print('%-48s %14d  %5.1f%%' % (n, v, 100.0 * v / tot if tot else 0))
+    print('cycles per step per wave (all launches of this kernel): %.0f' % (tot / 256 / 8))
