@@ -59,7 +59,10 @@ __device__ __forceinline__ void gml_dma16(u32x4 rs, uint32_t lds_addr, int voff)
 
 template <int S>
 struct GmlFwd3Cfg {
-    static constexpr int ROWS = 128, NT = 512;
+    static constexpr int ROWS = 128;
+    static constexpr int NLOAD = 4;                            // loader waves (one wave's LDS-DMA stream tops out near 1 KiB per ~100 cycles)
+    static constexpr int NT = 512 + 64 * NLOAD;                // 8 compute waves + the loader waves: 3 waves per SIMD
+    static constexpr int NTC = 512;
     static constexpr int XCAP = 200;                           // staged window rows incl. the <= 7 rows of alignment slack
     static constexpr int XBLK = 1040;                          // bytes between 8-row blocks of the window
     static constexpr int W_HALF = S * 32 * 32;                 // bf16 elements of one (hi or lo) W image [s][o][f]
@@ -68,27 +71,25 @@ struct GmlFwd3Cfg {
     static constexpr int RP_BYTES = 528;                       // 132 row pointers
     static constexpr int X_BYTES = XCAP / 8 * XBLK;
     static constexpr int AVAIL = 160 * 1024 - W_BYTES - REC_BYTES - 2 * (RP_BYTES + X_BYTES);
-    static constexpr int ECAP_RAW = AVAIL / (2 * (4 + 4 * S) + 4);
-    static constexpr int ECAP = ECAP_RAW >= 1024 ? 1024 : ECAP_RAW / 32 * 32;      // staged edges per group (S = 8: 992)
-    static constexpr int CHUNK = ECAP / 8;                     // edges whose value rows one wave brings in
+    static constexpr int ECAP_RAW = AVAIL / (2 * (4 + 4 * S) + 8);
+    static constexpr int ECAP = ECAP_RAW >= 1024 ? 1024 : ECAP_RAW / 64 * 64;      // staged edges per group (S = 8: 960)
     static constexpr int COL_BYTES = ECAP * 4, VAL_BYTES = ECAP * S * 4;
     static constexpr int SLOT_BYTES = RP_BYTES + COL_BYTES + VAL_BYTES + X_BYTES;
-    static constexpr int OFF_REC = W_BYTES, OFF_EPOS = OFF_REC + REC_BYTES, OFF_SLOT = OFF_EPOS + COL_BYTES;
+    static constexpr int OFF_REC = W_BYTES, OFF_EPOS = OFF_REC + REC_BYTES, OFF_SLOT = OFF_EPOS + 2 * COL_BYTES;   // two position buffers
     static constexpr int OFF_COL = RP_BYTES, OFF_VAL = OFF_COL + COL_BYTES, OFF_X = OFF_VAL + VAL_BYTES;   // inside a slot
     static constexpr size_t lds_bytes() { return (size_t)OFF_SLOT + 2 * (size_t)SLOT_BYTES; }
-    static_assert(CHUNK % 4 == 0 && SLOT_BYTES % 16 == 0 && OFF_SLOT % 16 == 0, "16-byte aligned landing zones");
+    static_assert(SLOT_BYTES % 16 == 0 && OFF_SLOT % 16 == 0, "16-byte aligned landing zones");
 };
 
 // MIX: the ML3Layer Hadamard branch (F2 <= 8) of the group's own rows rides along (see fwd2); EP: value rows through p.epos
 template <int S, int NOB, bool MIX, bool EP>
-__global__ __launch_bounds__(512, 1) void gml_k_spectconv_fwd3(const GmlFwdParams p) {
+__global__ __launch_bounds__(GmlFwd3Cfg<S>::NT, 1) void gml_k_spectconv_fwd3(const GmlFwdParams p) {
     using C = GmlFwd3Cfg<S>;
     static_assert(S % 4 == 0, "float4 value rows");
-    constexpr int ROWS = C::ROWS, ECAP = C::ECAP, XCAP = C::XCAP, CHUNK = C::CHUNK;
+    constexpr int ROWS = C::ROWS, ECAP = C::ECAP, XCAP = C::XCAP;
     constexpr int VROW = S * 4;                                // bytes of a value row
     constexpr int LPE = S / 4;                                 // lanes (16 bytes each) per value row
-    constexpr int NVI = (CHUNK * VROW + 1023) / 1024;          // value-row instructions per wave
-    constexpr int NST = NOB * 4 + (MIX ? 4 : 0);               // stores a wave issues per group, after its DMA
+    constexpr int EPI = 64 / LPE;                              // value rows per DMA instruction
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __bf16* Wof_h = reinterpret_cast<__bf16*>(lds_raw);       // [s][o][f], 16-byte chunks XOR-swizzled by gml_wkey(o)
     __bf16* Wof_l = Wof_h + C::W_HALF;
@@ -100,8 +101,7 @@ __global__ __launch_bounds__(512, 1) void gml_k_spectconv_fwd3(const GmlFwdParam
     const int g0 = wg * p.groups_per_wg;
     const int g1 = min(g0 + p.groups_per_wg, p.ngroups);
     if (g0 >= g1) return;
-    const int etot = p.rowptr[p.nrows];
-    const bool big = (uint64_t)etot * (S * 4) > 0xffffff00ull;  // value rows beyond 32-bit byte offsets: every group gathers from global
+    const bool loader = wave >= 8;
 
     // ---- once per workgroup: W image, zeroed X areas (chunks at or beyond Fin are never written by a DMA and stay zero)
     for (int e = tid; e < S * 32 * 32; e += C::NT) {
@@ -117,37 +117,10 @@ __global__ __launch_bounds__(512, 1) void gml_k_spectconv_fwd3(const GmlFwdParam
     for (int sl = 0; sl < 2; ++sl)
         for (int i = tid; i < C::X_BYTES / 16; i += C::NT)
             *reinterpret_cast<f32x4*>(lds_raw + C::OFF_SLOT + sl * C::SLOT_BYTES + C::OFF_X + i * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
-    float bias_r[NOB];
-#pragma unroll
-    for (int ob = 0; ob < NOB; ++ob) bias_r[ob] = (p.bias && ob * 16 + r16 < p.Fout) ? p.bias[ob * 16 + r16] : 0.f;
-    bf16x8 mwh, mwl;                                           // B[k = f][n = c]: c < F2 -> w11 row c, F2 <= c < 2 F2 -> w12 row c - F2
-    float mbias = 0.f;
-    if constexpr (MIX) {
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int f = 8 * kq + j;
-            const bool ok = f < p.Fin && r16 < 2 * p.F2;
-            v[j] = ok ? (r16 < p.F2 ? p.w11[r16 * p.Fin + f] : p.w12[(r16 - p.F2) * p.Fin + f]) : 0.f;
-        }
-        gml_split8(v, mwh, mwl);
-        if (r16 < p.F2) mbias = p.b11 ? p.b11[r16] : 0.f;
-        else if (r16 < 2 * p.F2) mbias = p.b12 ? p.b12[r16 - p.F2] : 0.f;
-    }
 
-    // ---- buffer descriptors: the hardware range check replaces every index clamp (out-of-range lanes read zeros)
-    const u32x4 rs_rec = gml_raw_rsrc(p.ginfo, (uint32_t)p.ngroups * (GML_GREC_INTS(128) * 4));
-    const u32x4 rs_rp = gml_raw_rsrc(p.rowptr, (uint32_t)(p.nrows + 1) * 4u);
-    const u32x4 rs_col = gml_raw_rsrc(p.col, big ? 0u : (uint32_t)etot * 4u);
-    const u32x4 rs_val = gml_raw_rsrc(p.val, big ? 0u : (uint32_t)etot * VROW);
-    const u32x4 rs_epos = gml_raw_rsrc(p.epos, (EP && !big) ? (uint32_t)etot * 4u : 0u);
-    const u32x4 rs_x = gml_raw_rsrc(p.x, (uint32_t)(p.nrows * p.ldx) * 4u);
-    const uint32_t lds0 = (uint32_t)(uintptr_t)((gml_lds_void*)lds_raw);   // LDS byte address of the dynamic segment
-    const int ldxb = (int)p.ldx * 4;
-
-    // a group's geometry from its record (wave-uniform)
+    // a group's geometry from its record in the ring (wave-uniform)
     struct Geo { int kb4, ne4, lo8, nwin8; bool staged; };
-    auto geo_of = [&](int g) -> Geo {
+    auto geo_of = [&](int g, bool bigv) -> Geo {
         const int4 v = *reinterpret_cast<const int4*>(lds_raw + C::OFF_REC + (g & 3) * 256);
         const int kb = __builtin_amdgcn_readfirstlane(v.x), ne = __builtin_amdgcn_readfirstlane(v.y);
         const int lo = __builtin_amdgcn_readfirstlane(v.z), nwin = __builtin_amdgcn_readfirstlane(v.w);
@@ -158,259 +131,320 @@ __global__ __launch_bounds__(512, 1) void gml_k_spectconv_fwd3(const GmlFwdParam
         Geo q;
         q.kb4 = kb & ~3; q.ne4 = ne + (kb & 3);
         q.lo8 = wlo & ~7; q.nwin8 = whi - q.lo8;
-        q.staged = q.ne4 <= ECAP && q.nwin8 <= XCAP && !big;
+        q.staged = q.ne4 <= ECAP && q.nwin8 <= XCAP && !bigv;
         return q;
     };
-    auto dma_rec = [&](int g) {                                // wave 1: record of group g -> ring entry g & 3
-        if (wave == 1 && lane < 9) gml_dma16(rs_rec, lds0 + C::OFF_REC + (g & 3) * 256, g * (GML_GREC_INTS(128) * 4) + lane * 16);
-    };
-    auto dma_epos = [&](const Geo& q) {                        // the wave's chunk of the group's value positions
-        const int e = wave * CHUNK + 4 * lane;
-        if (4 * lane < CHUNK && e < q.ne4) gml_dma16(rs_epos, lds0 + C::OFF_EPOS + wave * (CHUNK * 4), (q.kb4 + e) * 4);
-    };
-    // data of group g -> slot (needs, with EP, the positions of g in the epos buffer); then positions of g + 1, record of g + 2
-    auto issue = [&](int g, const Geo& q) {
-        const uint32_t slot = lds0 + C::OFF_SLOT + (g & 1) * C::SLOT_BYTES;
-        if (q.staged && !(GML_FWABL & 16)) {
-            // value rows first: with EP they need the positions this wave reads from LDS
-#pragma unroll
-            for (int j = 0; j < NVI; ++j) {
-                const int u = j * 64 + lane;                   // 16-byte unit inside the wave's chunk
-                const int el = u / LPE;                        // edge inside the chunk
-                const int e = wave * CHUNK + el;
-                if (el < CHUNK && e < q.ne4) {
-                    int voff;
-                    if constexpr (EP) voff = reinterpret_cast<const int*>(lds_raw + C::OFF_EPOS)[e] * VROW + (u % LPE) * 16;
-                    else voff = (q.kb4 + e) * VROW + (u % LPE) * 16;
-                    gml_dma16(rs_val, slot + C::OFF_VAL + wave * (CHUNK * VROW) + j * 1024, voff);
-                }
-            }
-            // X window: 8 rows per instruction, round robin over the waves
-            const int nxi = (q.nwin8 + 7) >> 3;
-            for (int i = (wave + 5) & 7; i < nxi; i += 8) {
-                const int rr = q.lo8 + 8 * i + (lane >> 3), c4 = (lane & 7) * 4;
-                if (c4 < p.Fin) gml_dma16(rs_x, slot + C::OFF_X + i * C::XBLK, rr * ldxb + c4 * 4);
-            }
-            // column ids: 256 per instruction
-            const int nci = (q.ne4 + 255) >> 8;
-            const int jc = (wave - 2) & 7;
-            if (jc < nci && 256 * jc + 4 * lane < q.ne4) gml_dma16(rs_col, slot + C::OFF_COL + jc * 1024, (q.kb4 + 256 * jc + 4 * lane) * 4);
-        }
-        if (wave == 0 && lane < 33) gml_dma16(rs_rp, slot, (g * ROWS + 4 * lane) * 4);
-        if constexpr (EP) {
-            if (g + 1 < g1) { const Geo q1 = geo_of(g + 1); if (q1.staged) dma_epos(q1); }
-        }
-        if (g + 2 < g1) dma_rec(g + 2);
-        asm volatile("" ::: "memory");
-    };
-
-    // ---- prologue: records g0, g0 + 1 -> positions of g0 -> data of g0
-    dma_rec(g0);
-    if (g0 + 1 < g1) dma_rec(g0 + 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                           // records landed, W image and zeroed X areas complete
-    {
-        const Geo q = geo_of(g0);
-        if constexpr (EP) {
-            if (q.staged) dma_epos(q);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // wave-private chunk: no barrier
-        }
-        issue(g0, q);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // value rows beyond 32-bit byte offsets: every group takes the global-gather path (all waves must agree)
+    const int etot = p.rowptr[p.nrows];
+    const bool bigv = (uint64_t)etot * VROW > 0xffffff00ull;
 
 #ifdef GML_FWD2_TIMING
     unsigned tacc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned tprev_ = (unsigned)__builtin_readcyclecounter();
+    unsigned tprev_ = 0;
 #endif
-    // ---- the two halves of the workgroup run one phase apart.  Waves 0-3 (one per SIMD) aggregate, project and store group
-    //      g inside trip g; waves 4-7 aggregate g at the END of trip g, carry their accumulators over the barrier and
-    //      project / store them at the start of trip g + 1.  Every SIMD hosts one wave of each half, so the VALU-bound
-    //      aggregation of one wave runs beside the matrix-pipe / store phase of its partner instead of both fighting for
-    //      the same unit in lock-step (measured with both halves in phase: aggregation 33 %, projection 16 %, stores 12 % of
-    //      the wave time, each at about twice its solo duration).  No extra LDS or barrier: the lagging half only reads
-    //      the W image and registers after the barrier.
-    const bool lag = wave >= 4;
-    f32x2 acc[S][4];
-    float xrow[MIX ? 8 : 1];                                   // the lane's own x row, features 8*kq..8*kq+7 (Hadamard branch)
-    uint32_t out_rows = 0;
-    int nr = 0;
-    int64_t r0 = 0;
 
-    auto aggregate = [&](int g, const Geo& q) {
-        const unsigned char* slot = lds_raw + C::OFF_SLOT + (g & 1) * C::SLOT_BYTES;
-        const int* rp_l = reinterpret_cast<const int*>(slot);
-        const int* col_l = reinterpret_cast<const int*>(slot + C::OFF_COL);
-        const float* ea_l = reinterpret_cast<const float*>(slot + C::OFF_VAL);
-        const unsigned char* rec = lds_raw + C::OFF_REC + (g & 3) * 256;
-        const int row = rec[16 + wave * 16 + r16];
-        out_rows = reinterpret_cast<const uint32_t*>(rec + 16)[wave * 4 + kq];
-        r0 = (int64_t)g * ROWS;
-        nr = (int)min((int64_t)ROWS, p.nrows - r0);
-        const bool rvalid = row < nr;
-        // byte offset of (row c, features 8 kq ..) in the window: xoff + 128 c + 2 (c & ~7)
-        const int xoff = C::OFF_SLOT + (g & 1) * C::SLOT_BYTES + C::OFF_X + kq * 32 - q.lo8 * 130;
-        const int kbeg = rvalid ? rp_l[row] : 0;
-        const int kend = rvalid ? rp_l[row + 1] : 0;
-        GML_TF3(3);
-        // aggregation (fp32 VALU, packed): acc[s][f] += val[k, s] * x[col[k], f], f = 8*kq .. 8*kq+7
+    if (loader) {
+        // =====================================================================================================
+        // Loader wave: all LDS-DMA of the workgroup.  Trip g: (barrier) -> data of group g + 1 into the other slot, value
+        // positions of g + 2, record of g + 3 -> wait until everything has landed -> (next barrier).  The compute waves
+        // never issue or wait for a memory instruction except their output stores.
+        // =====================================================================================================
+        const uint32_t lds0 = (uint32_t)(uintptr_t)((gml_lds_void*)lds_raw);   // LDS byte address of the dynamic segment
+        // buffer descriptors: the hardware range check replaces every index clamp (out-of-range lanes read zeros)
+        const u32x4 rs_rec = gml_raw_rsrc(p.ginfo, (uint32_t)p.ngroups * (GML_GREC_INTS(128) * 4));
+        const u32x4 rs_rp = gml_raw_rsrc(p.rowptr, (uint32_t)(p.nrows + 1) * 4u);
+        const u32x4 rs_col = gml_raw_rsrc(p.col, bigv ? 0u : (uint32_t)etot * 4u);
+        const u32x4 rs_val = gml_raw_rsrc(p.val, bigv ? 0u : (uint32_t)etot * VROW);
+        const u32x4 rs_epos = gml_raw_rsrc(p.epos, (EP && !bigv) ? (uint32_t)etot * 4u : 0u);
+        const u32x4 rs_x = gml_raw_rsrc(p.x, (uint32_t)(p.nrows * p.ldx) * 4u);
+        const int ldxb = (int)p.ldx * 4;
+        constexpr int NL = C::NLOAD;
+        const int li = wave - 8;                               // the DMA instructions of a group are dealt round robin to the loaders
+        auto dma_rec = [&](int g) {                            // record of group g -> ring entry g & 3
+            if (li == NL - 1 && lane < 9) gml_dma16(rs_rec, lds0 + C::OFF_REC + (g & 3) * 256, g * (GML_GREC_INTS(128) * 4) + lane * 16);
+        };
+        auto dma_epos = [&](int g, const Geo& q) {             // group g's value positions (256 per instruction) -> buffer g & 1
+            const int nci = (q.ne4 + 255) >> 8;
+            for (int j = li; j < nci; j += NL)
+                if (256 * j + 4 * lane < q.ne4) gml_dma16(rs_epos, lds0 + C::OFF_EPOS + (g & 1) * C::COL_BYTES + j * 1024, (q.kb4 + 256 * j + 4 * lane) * 4);
+        };
+        // data of group g -> slot g & 1 (needs, with EP, the positions of g in the epos buffer); then positions of g + 1, record of g + 2
+        auto issue = [&](int g, const Geo& q) {
+            const uint32_t slot = lds0 + C::OFF_SLOT + (g & 1) * C::SLOT_BYTES;
+            if (q.staged && !(GML_FWABL & 16)) {
+                // value rows: four instructions per batch (with EP: their four position reads first, one wait)
+                const int nvi = (q.ne4 + EPI - 1) / EPI;
+                const int part = (lane % LPE) * 16;
+                const int* epos_l = reinterpret_cast<const int*>(lds_raw + C::OFF_EPOS + (g & 1) * C::COL_BYTES);
+                for (int j0 = 4 * li; j0 < nvi; j0 += 4 * NL) {
+                    int voff[4];
 #pragma unroll
-        for (int s = 0; s < S; ++s)
+                    for (int u = 0; u < 4; ++u) {
+                        const int e = min((j0 + u) * EPI + lane / LPE, ECAP - 1);
+                        if constexpr (EP) voff[u] = epos_l[e] * VROW + part;
+                        else voff[u] = (q.kb4 + e) * VROW + part;
+                    }
 #pragma unroll
-            for (int h = 0; h < 4; ++h) acc[s][h] = f32x2{0.f, 0.f};
-        if (q.staged) {
-            for (int k = kbeg - q.kb4; k < ((GML_FWABL & 1) ? kbeg - q.kb4 : kend - q.kb4); ++k) {
-                const int c = col_l[k];
-                float ev[S];
-                gml_load_row<S, 4>(ea_l + k * S, ev);
-                const int off = xoff + c * 128 + ((c & ~7) << 1);
-                const f32x4 t0 = *reinterpret_cast<const f32x4*>(lds_raw + off);
-                const f32x4 t1 = *reinterpret_cast<const f32x4*>(lds_raw + off + 16);
-                const f32x2 xv[4] = {f32x2{t0.x, t0.y}, f32x2{t0.z, t0.w}, f32x2{t1.x, t1.y}, f32x2{t1.z, t1.w}};
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    const f32x2 e2 = f32x2{ev[s], ev[s]};
-#pragma unroll
-                    for (int h = 0; h < 4; ++h) acc[s][h] = e2 * xv[h] + acc[s][h];
+                    for (int u = 0; u < 4; ++u) {
+                        const int e = (j0 + u) * EPI + lane / LPE;
+                        if (e < q.ne4) gml_dma16(rs_val, slot + C::OFF_VAL + (j0 + u) * 1024, voff[u]);
+                    }
                 }
-            }
-            if constexpr (MIX) {
-                const int c = (int)r0 + min(row, nr - 1);
-                const int off = xoff + c * 128 + ((c & ~7) << 1);
-                const f32x4 t0 = *reinterpret_cast<const f32x4*>(lds_raw + off);
-                const f32x4 t1 = *reinterpret_cast<const f32x4*>(lds_raw + off + 16);
-                xrow[0] = t0.x; xrow[1] = t0.y; xrow[2] = t0.z; xrow[3] = t0.w;
-                xrow[4] = t1.x; xrow[5] = t1.y; xrow[6] = t1.z; xrow[7] = t1.w;
-            }
-        } else {                                               // group outside the LDS capacities: global gathers
-            for (int k = kbeg; k < kend; ++k) {
-                const int src = p.col[k];
-                float xb[8];
-#pragma unroll
-                for (int t = 0; t < 8; ++t) xb[t] = (8 * kq + t < p.Fin) ? p.x[(int64_t)src * p.ldx + 8 * kq + t] : 0.f;
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    const float e = p.val[(int64_t)(EP ? p.epos[k] : k) * p.S + p.s0 + s];
-                    const f32x2 e2 = f32x2{e, e};
-#pragma unroll
-                    for (int h = 0; h < 4; ++h) acc[s][h] = e2 * f32x2{xb[2 * h], xb[2 * h + 1]} + acc[s][h];
+                // X window: 8 rows per instruction
+                const int nxi = (q.nwin8 + 7) >> 3;
+                const int c4 = (lane & 7) * 4;
+                const int i0 = (NL - 1 - li);                  // (the loaders with fewer value batches first)
+                int xo = (q.lo8 + 8 * i0 + (lane >> 3)) * ldxb + c4 * 4;
+                uint32_t xd = slot + C::OFF_X + i0 * C::XBLK;
+                for (int i = i0; i < nxi; i += NL) {
+                    if (c4 < p.Fin) gml_dma16(rs_x, xd, xo);
+                    xo += 8 * NL * ldxb; xd += NL * C::XBLK;
                 }
+                // column ids: 256 per instruction
+                const int nci = (q.ne4 + 255) >> 8;
+                for (int j = (li + 2) % NL; j < nci; j += NL)
+                    if (256 * j + 4 * lane < q.ne4) gml_dma16(rs_col, slot + C::OFF_COL + j * 1024, (q.kb4 + 256 * j + 4 * lane) * 4);
             }
-            if constexpr (MIX) {
-                const float* xr = p.x + (r0 + min(row, nr - 1)) * p.ldx;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    xrow[j] = (8 * kq + j < p.Fin) ? xr[8 * kq + j] : 0.f;
-                    asm volatile("" : "+v"(xrow[j]));          // used here: the compiler's wait for these loads stays in this branch
-                }
+            if (li == NL - 1 && lane < 33) gml_dma16(rs_rp, slot, (g * ROWS + 4 * lane) * 4);
+            if constexpr (EP) {
+                if (g + 1 < g1) { const Geo q1 = geo_of(g + 1, bigv); if (q1.staged) dma_epos(g + 1, q1); }
             }
-        }
-        GML_TF3(4);
-    };
+            if (g + 2 < g1) dma_rec(g + 2);
+        };
 
-    auto project_store = [&]() {
-        // projection: out tile = sum_s acc_s W_s (acc split on the fly = A fragments, k = f = 8*kq + j)
-        f32x4 oacc[NOB];
-#pragma unroll
-        for (int ob = 0; ob < NOB; ++ob) oacc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dma_rec(g0);
+        if (g0 + 1 < g1) dma_rec(g0 + 1);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                          // (A) records landed, W image and zeroed X areas complete
         {
-            bf16x8 wh[2][NOB], wl[2][NOB];
-            auto frag = [&](int s, int st) {
-#pragma unroll
-                for (int ob = 0; ob < NOB; ++ob) {
-                    const int o = ob * 16 + r16;               // B[k = f][n = o]: 8 consecutive f of column o
-                    const int off = (s * 32 + o) * 32 + (((kq ^ gml_wkey(o)) & 3) << 3);
-                    wh[st][ob] = *reinterpret_cast<const bf16x8*>(Wof_h + off);
-                    wl[st][ob] = *reinterpret_cast<const bf16x8*>(Wof_l + off);
-                }
-            };
-            frag(0, 0);
-#pragma unroll
-            for (int s = 0; s < ((GML_FWABL & 2) ? 0 : S); ++s) {
-                const int st = s & 1;
-                if (s + 1 < S) frag(s + 1, st ^ 1);
-                const float av[8] = {acc[s][0].x, acc[s][0].y, acc[s][1].x, acc[s][1].y, acc[s][2].x, acc[s][2].y, acc[s][3].x, acc[s][3].y};
-                bf16x8 ah, al;
-                gml_split8(av, ah, al);
-#pragma unroll
-                for (int ob = 0; ob < NOB; ++ob) oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wh[st][ob], oacc[ob], 0, 0, 0);
-#pragma unroll
-                for (int ob = 0; ob < NOB; ++ob) oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wl[st][ob], oacc[ob], 0, 0, 0);
-#pragma unroll
-                for (int ob = 0; ob < NOB; ++ob) oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wh[st][ob], oacc[ob], 0, 0, 0);
+            const Geo q = geo_of(g0, bigv);
+            if constexpr (EP) {
+                if (q.staged) dma_epos(g0, q);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                  // (A2) every loader's share of the first positions has landed
             }
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * NOB, 0);
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                if (s + 1 < S) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NOB, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 3 * NOB, 0);
-            }
+            issue(g0, q);
         }
-        GML_TF3(6);
-        // output stores through a buffer descriptor based at this group's first row: lanes outside (row >= nr, column >=
-        // Fout) get an offset beyond the range and are dropped by the hardware -- no predicate, NST stores per wave and
-        // group whatever the data (the count the wait at the loop top relies on)
-        const auto ors = __builtin_amdgcn_make_buffer_rsrc(p.out + r0 * p.ldo, 0, 0x7ffffe00, 0x00020000);
-        const bool relu = (p.flags & GML_RELU) != 0;
-#pragma unroll
-        for (int ob = 0; ob < NOB; ++ob) {
-            const int o = ob * 16 + r16;
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int lr = (int)((out_rows >> (8 * reg)) & 255u);
-                float v = oacc[ob][reg] + bias_r[ob];
-                if (relu) v = fmaxf(v, 0.f);
-                const int off = (o < p.Fout && lr < nr && !(GML_FWABL & 4)) ? (lr * (int)p.ldo + o) * 4 : 0x7fffff00;
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ors, off, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef GML_FWD2_TIMING
+        tprev_ = (unsigned)__builtin_readcyclecounter();
+#endif
+        for (int g = g0; g < g1; ++g) {
+            __builtin_amdgcn_s_barrier();                      // (B) slot g & 1 complete; every wave has left slot (g + 1) & 1
+            asm volatile("" ::: "memory");
+            GML_TF3(5);
+            if (g + 1 < g1) {
+                const Geo qn = geo_of((GML_FWABL & 8) ? g0 : g + 1, bigv);
+                issue(g + 1, qn);
             }
+            GML_TF3(2);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            GML_TF3(0);
         }
-        GML_TF3(7);
+    } else {
+        // =====================================================================================================
+        // Compute waves: one 16-row tile each
+        // =====================================================================================================
+        float bias_r[NOB];
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob) bias_r[ob] = (p.bias && ob * 16 + r16 < p.Fout) ? p.bias[ob * 16 + r16] : 0.f;
+        bf16x8 mwh, mwl;                                       // B[k = f][n = c]: c < F2 -> w11 row c, F2 <= c < 2 F2 -> w12 row c - F2
+        float mbias = 0.f;
         if constexpr (MIX) {
-            // z[row][c] = x[row] . wmix[c]: A = the lane's row (k = f), D: lane (c = r16, kq) holds rows 4*kq + reg
-            bf16x8 xh, xl;
-            gml_split8(xrow, xh, xl);
-            f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
-            z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, mwh, z, 0, 0, 0);
-            z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, mwl, z, 0, 0, 0);
-            z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, mwh, z, 0, 0, 0);
+            float v[8];
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const float t = gml_tanh(z[reg] + mbias);
-                const float u = __shfl(t, lane + p.F2);        // partner column c + F2 of the same 16-lane row group
-                const int lr = (int)((out_rows >> (8 * reg)) & 255u);
-                const int off = (r16 < p.F2 && lr < nr) ? (lr * (int)p.ldo + p.mix_col + r16) * 4 : 0x7fffff00;
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(t * u), ors, off, 0, 0);
+            for (int j = 0; j < 8; ++j) {
+                const int f = 8 * kq + j;
+                const bool ok = f < p.Fin && r16 < 2 * p.F2;
+                v[j] = ok ? (r16 < p.F2 ? p.w11[r16 * p.Fin + f] : p.w12[(r16 - p.F2) * p.Fin + f]) : 0.f;
             }
+            gml_split8(v, mwh, mwl);
+            if (r16 < p.F2) mbias = p.b11 ? p.b11[r16] : 0.f;
+            else if (r16 < 2 * p.F2) mbias = p.b12 ? p.b12[r16 - p.F2] : 0.f;
         }
-        GML_TF3(8);
-    };
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                          // (A)
+        if constexpr (EP) __builtin_amdgcn_s_barrier();        // (A2)
+#ifdef GML_FWD2_TIMING
+        tprev_ = (unsigned)__builtin_readcyclecounter();
+#endif
+        for (int g = g0; g < g1; ++g) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                      // (B)
+            asm volatile("" ::: "memory");
+            GML_TF3(1);
+            const Geo q = geo_of(g, bigv);
+            const unsigned char* slot = lds_raw + C::OFF_SLOT + (g & 1) * C::SLOT_BYTES;
+            const int* rp_l = reinterpret_cast<const int*>(slot);
+            const int* col_l = reinterpret_cast<const int*>(slot + C::OFF_COL);
+            const float* ea_l = reinterpret_cast<const float*>(slot + C::OFF_VAL);
+            const unsigned char* rec = lds_raw + C::OFF_REC + (g & 3) * 256;
+            const int row = rec[16 + wave * 16 + r16];
+            const uint32_t out_rows = reinterpret_cast<const uint32_t*>(rec + 16)[wave * 4 + kq];
+            const int64_t r0 = (int64_t)g * ROWS;
+            const int nr = (int)min((int64_t)ROWS, p.nrows - r0);
+            const bool rvalid = row < nr;
+            // byte offset of (row c, features 8 kq ..) in the window: xoff + 128 c + 2 (c & ~7)
+            const int xoff = C::OFF_SLOT + (g & 1) * C::SLOT_BYTES + C::OFF_X + kq * 32 - q.lo8 * 130;
+            const int kbeg = rvalid ? rp_l[row] : 0;
+            const int kend = rvalid ? rp_l[row + 1] : 0;
+            float xrow[MIX ? 8 : 1];                           // the lane's own x row, features 8*kq..8*kq+7 (Hadamard branch)
+            GML_TF3(3);
 
-    for (int g = g0; g < g1; ++g) {
-        // everything this wave issued for group g (and the positions / record riding along) has landed once at most its
-        // NST younger stores are outstanding (the lagging half has issued no stores yet when it enters its second trip);
-        // the barrier extends that to the other waves' shares and says that every wave is done reading the slot the
-        // next DMAs overwrite
-        if (lag && g == g0 + 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(NST) : "memory");
-        GML_TF3(0);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        GML_TF3(1);
-        const Geo q = geo_of(g);
-        if (g + 1 < g1) {
-            const Geo qn = geo_of((GML_FWABL & 8) ? g0 : g + 1);
-            issue(g + 1, qn);
-        }
-        GML_TF3(2);
-        if (lag) {
-            if (g > g0) project_store();                       // group g - 1, from the registers carried over the barrier
-            aggregate(g, q);
-        } else {
-            aggregate(g, q);
-            project_store();
+            // ---- aggregation (fp32 VALU, packed): acc[s][f] += val[k, s] * x[col[k], f], f = 8*kq .. 8*kq+7
+            f32x2 acc[S][4];
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int h = 0; h < 4; ++h) acc[s][h] = f32x2{0.f, 0.f};
+            if (q.staged) {
+                // Software pipeline over the lane's edges: the operands of edge k + 1 (value row, two x chunks) and the
+                // column id of edge k + 2 are requested before the 32 packed FMAs of edge k, so the two dependent LDS
+                // round trips of an edge (column id -> x row) hide behind arithmetic; two register sets, no rotation moves.
+                int k = kbeg - q.kb4;
+                const int ke = ((GML_FWABL & 1) ? kbeg : kend) - q.kb4;
+                if (k < ke) {
+                    struct Ops { f32x4 e[S / 4]; f32x4 t0, t1; };
+                    auto fetch = [&](Ops& o, int kk, int c) {
+#pragma unroll
+                        for (int i = 0; i < S / 4; ++i) o.e[i] = *reinterpret_cast<const f32x4*>(ea_l + kk * S + 4 * i);
+                        const int off = xoff + c * 128 + ((c & ~7) << 1);
+                        o.t0 = *reinterpret_cast<const f32x4*>(lds_raw + off);
+                        o.t1 = *reinterpret_cast<const f32x4*>(lds_raw + off + 16);
+                    };
+                    auto fma = [&](const Ops& o) {
+                        const f32x2 xv[4] = {f32x2{o.t0.x, o.t0.y}, f32x2{o.t0.z, o.t0.w}, f32x2{o.t1.x, o.t1.y}, f32x2{o.t1.z, o.t1.w}};
+#pragma unroll
+                        for (int s = 0; s < S; ++s) {
+                            const float ev = o.e[s >> 2][s & 3];
+                            const f32x2 e2 = f32x2{ev, ev};
+#pragma unroll
+                            for (int h = 0; h < 4; ++h) acc[s][h] = e2 * xv[h] + acc[s][h];
+                        }
+                    };
+                    Ops A, B;
+                    const int klast = ke - 1;
+                    fetch(A, k, col_l[k]);
+                    int cn = col_l[min(k + 1, klast)];
+                    for (;;) {
+                        const int c2 = col_l[min(k + 2, klast)];
+                        fetch(B, min(k + 1, klast), cn);
+                        fma(A);
+                        if (++k >= ke) break;
+                        cn = col_l[min(k + 2, klast)];
+                        fetch(A, min(k + 1, klast), c2);
+                        fma(B);
+                        if (++k >= ke) break;
+                    }
+                }
+                if constexpr (MIX) {
+                    const int c = (int)r0 + min(row, nr - 1);
+                    const int off = xoff + c * 128 + ((c & ~7) << 1);
+                    const f32x4 t0 = *reinterpret_cast<const f32x4*>(lds_raw + off);
+                    const f32x4 t1 = *reinterpret_cast<const f32x4*>(lds_raw + off + 16);
+                    xrow[0] = t0.x; xrow[1] = t0.y; xrow[2] = t0.z; xrow[3] = t0.w;
+                    xrow[4] = t1.x; xrow[5] = t1.y; xrow[6] = t1.z; xrow[7] = t1.w;
+                }
+            } else {                                           // group outside the LDS capacities: global gathers
+                for (int k = kbeg; k < kend; ++k) {
+                    const int src = p.col[k];
+                    float xb[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) xb[t] = (8 * kq + t < p.Fin) ? p.x[(int64_t)src * p.ldx + 8 * kq + t] : 0.f;
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        const float e = p.val[(int64_t)(EP ? p.epos[k] : k) * p.S + p.s0 + s];
+                        const f32x2 e2 = f32x2{e, e};
+#pragma unroll
+                        for (int h = 0; h < 4; ++h) acc[s][h] = e2 * f32x2{xb[2 * h], xb[2 * h + 1]} + acc[s][h];
+                    }
+                }
+                if constexpr (MIX) {
+                    const float* xr = p.x + (r0 + min(row, nr - 1)) * p.ldx;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        xrow[j] = (8 * kq + j < p.Fin) ? xr[8 * kq + j] : 0.f;
+                        asm volatile("" : "+v"(xrow[j]));      // used here: the compiler's wait for these loads stays in this branch
+                    }
+                }
+            }
+            GML_TF3(4);
+
+            // ---- projection: out tile = sum_s acc_s W_s (acc split on the fly = A fragments, k = f = 8*kq + j)
+            f32x4 oacc[NOB];
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob) oacc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+            {
+                bf16x8 wh[2][NOB], wl[2][NOB];
+                auto frag = [&](int s, int st) {
+#pragma unroll
+                    for (int ob = 0; ob < NOB; ++ob) {
+                        const int o = ob * 16 + r16;           // B[k = f][n = o]: 8 consecutive f of column o
+                        const int off = (s * 32 + o) * 32 + (((kq ^ gml_wkey(o)) & 3) << 3);
+                        wh[st][ob] = *reinterpret_cast<const bf16x8*>(Wof_h + off);
+                        wl[st][ob] = *reinterpret_cast<const bf16x8*>(Wof_l + off);
+                    }
+                };
+                frag(0, 0);
+#pragma unroll
+                for (int s = 0; s < ((GML_FWABL & 2) ? 0 : S); ++s) {
+                    const int st = s & 1;
+                    if (s + 1 < S) frag(s + 1, st ^ 1);
+                    const float av[8] = {acc[s][0].x, acc[s][0].y, acc[s][1].x, acc[s][1].y, acc[s][2].x, acc[s][2].y, acc[s][3].x, acc[s][3].y};
+                    bf16x8 ah, al;
+                    gml_split8(av, ah, al);
+#pragma unroll
+                    for (int ob = 0; ob < NOB; ++ob) oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wh[st][ob], oacc[ob], 0, 0, 0);
+#pragma unroll
+                    for (int ob = 0; ob < NOB; ++ob) oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wl[st][ob], oacc[ob], 0, 0, 0);
+#pragma unroll
+                    for (int ob = 0; ob < NOB; ++ob) oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wh[st][ob], oacc[ob], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * NOB, 0);
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    if (s + 1 < S) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NOB, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3 * NOB, 0);
+                }
+            }
+            GML_TF3(6);
+            // output stores through a buffer descriptor based at this group's first row: lanes outside (row >= nr, column
+            // >= Fout) get an offset beyond the range and are dropped by the hardware -- no predicate
+            const auto ors = __builtin_amdgcn_make_buffer_rsrc(p.out + r0 * p.ldo, 0, 0x7ffffe00, 0x00020000);
+            const bool relu = (p.flags & GML_RELU) != 0;
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob) {
+                const int o = ob * 16 + r16;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int lr = (int)((out_rows >> (8 * reg)) & 255u);
+                    float v = oacc[ob][reg] + bias_r[ob];
+                    if (relu) v = fmaxf(v, 0.f);
+                    const int off = (o < p.Fout && lr < nr && !(GML_FWABL & 4)) ? (lr * (int)p.ldo + o) * 4 : 0x7fffff00;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ors, off, 0, 0);
+                }
+            }
+            GML_TF3(7);
+            if constexpr (MIX) {
+                // z[row][c] = x[row] . wmix[c]: A = the lane's row (k = f), D: lane (c = r16, kq) holds rows 4*kq + reg
+                bf16x8 xh, xl;
+                gml_split8(xrow, xh, xl);
+                f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+                z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, mwh, z, 0, 0, 0);
+                z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, mwl, z, 0, 0, 0);
+                z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, mwh, z, 0, 0, 0);
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const float t = gml_tanh(z[reg] + mbias);
+                    const float u = __shfl(t, lane + p.F2);    // partner column c + F2 of the same 16-lane row group
+                    const int lr = (int)((out_rows >> (8 * reg)) & 255u);
+                    const int off = (r16 < p.F2 && lr < nr) ? (lr * (int)p.ldo + p.mix_col + r16) * 4 : 0x7fffff00;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(t * u), ors, off, 0, 0);
+                }
+            }
+            GML_TF3(8);
         }
     }
-    if (lag) project_store();
 #ifdef GML_FWD2_TIMING
     if (lane == 0 && p.prof != nullptr) {
 #pragma unroll
@@ -426,7 +460,7 @@ int gml_launch_fwd3(const GmlFwdParams& p, dim3 grid, hipStream_t st, bool mix);
     {                                                                                                        \
         GML_ALLOW_BIG_LDS(rc_, (&gml_k_spectconv_fwd3<SV, NOBV, MX, EPV>), 160 * 1024)                       \
         if (rc_ != hipSuccess) return (int)rc_;                                                              \
-        hipLaunchKernelGGL((gml_k_spectconv_fwd3<SV, NOBV, MX, EPV>), grid, dim3(512),                       \
+        hipLaunchKernelGGL((gml_k_spectconv_fwd3<SV, NOBV, MX, EPV>), grid, dim3(GmlFwd3Cfg<SV>::NT),                       \
                            GmlFwd3Cfg<SV>::lds_bytes(), st, p);                                              \
         return gml_launch_status();                                                                          \
     }

@@ -24,6 +24,8 @@ PROFILE = None
 # Projection arithmetic of the fused kernels: default = bf16x3 split on the bf16 matrix cores (fp32-class,
 # ~1e-6 of the output scale); F32_MFMA = True (or env GML_F32_MFMA=1) = f32-input MFMA, bit-identical to fmaf.
 import os as _os
+import collections as _collections
+import weakref as _weakref
 _linear = torch.nn.functional.linear
 F32_MFMA = _os.environ.get('GML_F32_MFMA', '0') not in ('0', '')
 EDGE_VALU = _os.environ.get('GML_EDGE_VALU', '0') == '1'
@@ -101,6 +103,33 @@ def _f32c(t, name):
     if t.dtype != torch.float32:
         raise TypeError('%s must be float32, got %s' % (name, t.dtype))
     return t if t.is_contiguous() else t.contiguous()
+
+
+# rows of x as the 8-wave kernels want them: float4-addressable (leading dimension a multiple of 4 floats, 16-byte aligned
+# base), which is what the LDS-DMA landing ring of the forward (csrc/gml_spectconv_fwd3_impl.h) and the vector paths of the
+# backward kernels copy.  Zinc12k.py's 21 + 4 = 25 input features (libs/utils.py:253-259) are not: the first layer's input is
+# copied once into a zero-padded [N, 28] buffer; for a tensor that carries no gradient (per-batch data) the copy is kept per
+# tensor object, so a batch that is stepped on repeatedly, or a data set that hands out padded rows itself, pays it once.
+_ROWS4_CACHE = _collections.OrderedDict()
+
+
+def rows4(x):
+    if x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0:
+        return x
+    key = id(x)
+    ent = _ROWS4_CACHE.get(key)
+    if ent is not None and ent[0]() is x and ent[1] == x._version:
+        _ROWS4_CACHE.move_to_end(key)
+        return ent[2]
+    F = int(x.size(1))
+    buf = torch.zeros(x.size(0), (F + 3) // 4 * 4, dtype=x.dtype, device=x.device)
+    buf[:, :F] = x
+    v = buf[:, :F]
+    if not x.requires_grad:
+        _ROWS4_CACHE[key] = (_weakref.ref(x), x._version, v)
+        while len(_ROWS4_CACHE) > 4:
+            _ROWS4_CACHE.popitem(last=False)
+    return v
 
 
 # ---------------------------------------------------------------------------- raw launches
@@ -499,8 +528,9 @@ class SpectConvFunction(torch.autograd.Function):
             bias = _f32c(bias, 'bias')
         with torch.cuda.device(x.device):
             out = torch.empty(csr.N, Fout, dtype=torch.float32, device=x.device)
+            x = rows4(x)
             gi, gflag = fwd_groups(csr, x, S, Fin, Fout)
-            fused_conv(csr.rowptr, csr.col, gi, None, val, x, Fin, weight, (Fin * Fout, Fout, 1), bias, out,
+            fused_conv(csr.rowptr, csr.col, gi, None, val, x, int(x.stride(0)), weight, (Fin * Fout, Fout, 1), bias, out,
                        Fout, csr.N, S, Fin, Fout, (_lib.GML_RELU if relu else 0) | gflag)
         ctx.csr, ctx.relu, ctx.has_bias = csr, relu, bias is not None
         ctx.save_for_backward(x, val, weight, out if relu else None)
@@ -549,6 +579,7 @@ class ML3LayerFunction(torch.autograd.Function):
                              % (tuple(x.shape), tuple(val.shape), tuple(cw.shape), N, csr.E))
         C = nout1 + nout2
         with torch.cuda.device(x.device):
+            x = rows4(x)
             epos = None
             if learnedge:
                 w1, w2, w3, w4 = (_f32c(w1, 'fc1_1.weight'), _f32c(w2, 'fc1_2.weight'), _f32c(w3, 'fc1_3.weight'),
@@ -586,7 +617,7 @@ class ML3LayerFunction(torch.autograd.Function):
             if nout2 > 0:
                 _path('hadamard', 'fused kernels' if mixk else 'library GEMMs (ninp > 64 or nout2 > 24)', '-', Fin, nout2)
             with _Timed('spectconv_fwd', q, f):                    # conv (+ Hadamard branch of the same rows)
-                _lib.call('gml_ml3_fwd', _ptr(csr.rowptr), _ptr(csr.col), _ptr(gi), _ptr(epos), _ptr(ea), _ptr(x), Fin, _ptr(cw),
+                _lib.call('gml_ml3_fwd', _ptr(csr.rowptr), _ptr(csr.col), _ptr(gi), _ptr(epos), _ptr(ea), _ptr(x), int(x.stride(0)), _ptr(cw),
                           Fin * nout1, nout1, 1, _ptr(cb_), _ptr(w11 if mixk else None),
                           _ptr(b11 if mixk else None), _ptr(w12 if mixk else None),
                           _ptr(b12 if mixk else None), _ptr(out), C, N, S, Fin, nout1, int(nout2) if mixk else 0,
@@ -659,7 +690,7 @@ class ML3LayerFunction(torch.autograd.Function):
                     g[8], g[9], g[10], g[11] = (torch.empty_like(w11), torch.empty_like(b11), torch.empty_like(w12),
                                                 torch.empty_like(b12))
                     with _Timed('node_mix_bwd'):
-                        _lib.call('gml_node_mix_bwd', _ptr(x), Fin, _ptr(w11), _ptr(b11), _ptr(w12), _ptr(b12),
+                        _lib.call('gml_node_mix_bwd', _ptr(x), int(x.stride(0)), _ptr(w11), _ptr(b11), _ptr(w12), _ptr(b12),
                                   _off(gy, nout1), C, _ptr(dx) if need[0] else _ptr(None), Fin, _ptr(g[8]), _ptr(g[9]),
                                   _ptr(g[10]), _ptr(g[11]), N, Fin, nout2, _ptr(ws), ws.numel(), _stream(x.device))
             if nout2 > 0 and not mixk:                              # wide Hadamard branch: library GEMMs (see forward)

@@ -22,8 +22,8 @@ for it in range(3):
     L.gml_debug_fwd2_prof(buf, 1)
 names = ['commit (waits for the prefetched registers)', 'barrier', 'issue next group (record, then loads)', 'own-row loads + row bounds',
          'aggregation', 'value gather issue', 'projection', 'output stores', 'Hadamard branch', 'end barrier']
-names3 = ['wait for the landing DMAs (vmcnt)', 'barrier', 'issue next group (records from LDS, DMA)', 'row bounds', 'aggregation (+ own x row)',
-          '-', 'projection', 'output stores', 'Hadamard branch', '-']
+names3 = ['LOADER: wait for the landing DMAs (vmcnt)', 'barrier (compute waves)', 'LOADER: issue next group (records from LDS, DMA)', 'row bounds',
+          'aggregation (+ own x row)', 'LOADER: barrier', 'projection', 'output stores', 'Hadamard branch', '-']
 for title, nm, b in (('fwd2 (register staging)', names, buf[:16]), ('fwd3 (LDS-DMA ring)', names3, buf[16:])):
     tot = float(sum(b))
     if not tot:
