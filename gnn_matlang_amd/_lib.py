@@ -66,7 +66,7 @@ SIGNATURES = {
                                          _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _sz, _p]),
 }
 
-GML_RELU, GML_ACCUM, GML_F32_MFMA, GML_GROUPS128, GML_GROUPS64R = 1, 2, 4, 8, 16
+GML_RELU, GML_ACCUM, GML_F32_MFMA, GML_GROUPS128, GML_GROUPS64R, GML_DMA_RING = 1, 2, 4, 8, 16, 32
 GML_GROUPS64_RANKED = 1064      # group kind of gml_csr_group_info: 64-row groups with rank bytes
 
 _lib = None

@@ -1,6 +1,7 @@
 // C-ABI dispatch of the fused backward kernel + the deterministic partial fold.
 #include "gml_spectconv_bwd2_impl.h"
 #include "gml_spectconv_bwd3_impl.h"
+#include "gml_spectconv_bwd4_impl.h"
 #include <stdlib.h>
 
 __global__ __launch_bounds__(256) void gml_k_reduce_rows(const float* __restrict__ partial, int64_t nparts, int64_t n,
@@ -38,6 +39,13 @@ GML_DECL_BWD2(4, 2) GML_DECL_BWD2(4, 1) GML_DECL_BWD2(2, 2) GML_DECL_BWD2(2, 1)
 GML_DECL_BWD3(8, 2, 8) GML_DECL_BWD3(8, 1, 8) GML_DECL_BWD3(6, 2, 8) GML_DECL_BWD3(6, 1, 8)
 GML_DECL_BWD3(4, 2, 8) GML_DECL_BWD3(4, 1, 8) GML_DECL_BWD3(2, 2, 8) GML_DECL_BWD3(2, 1, 8)
 GML_DECL_BWD3(8, 2, 4) GML_DECL_BWD3(8, 1, 4)
+
+#define GML_DECL_BWD4(S, A) template <> int gml_launch_bwd4<S, A>(const GmlBwdParams&, dim3, hipStream_t);
+GML_DECL_BWD4(8, 2) GML_DECL_BWD4(8, 1) GML_DECL_BWD4(4, 2) GML_DECL_BWD4(4, 1)
+/* bwd4 (LDS-DMA landing ring) runs when the caller sets GML_DMA_RING in flags or the process was started with GML_BWD_DMA=1.
+   It is NOT the default: at ZINC shapes it measures 3-4 % slower than bwd3 (profiles/r03_bwd4_vs_bwd3_phases.txt: what the ring
+   saves -- commit and the barriers around it, 4 % -- the two-supports-per-slab dW phase it forces gives back). */
+static bool bwd4_env() { static const bool v = [] { const char* e = getenv("GML_BWD_DMA"); return e && e[0] == '1'; }(); return v; }
 
 struct BwdPlan {
     int ok, S, nfb, nob, grid, groups_per_wg, ecap, xcap, rows;   /* rows: 64 (f32 MFMA kernel) or 128 / 64 (bf16x3 kernels) */
@@ -172,7 +180,18 @@ static int spectconv_bwd_impl(const int32_t* rowptr, const int32_t* col, const i
     p.ngroups = (int)gml_cdiv(num_rows, pl.rows); p.groups_per_wg = pl.groups_per_wg; p.ecap = pl.ecap; p.xcap = pl.xcap;
     const int nfb = pl.nfb, nob = pl.nob;
     int rc = GML_E_UNSUPPORTED;
-    if (pl.layout == 3) {
+    /* LDS-DMA landing ring (bwd4): 8 waves, float4-addressable x / g rows, dx from dz or from zero, every group inside the
+       kernel's staging capacities (+3 edges / +7 window rows of alignment slack), 32-bit row offsets */
+    bool dma = pl.layout == 3 && pl.nw == 8 && (bwd4_env() || (flags & GML_DMA_RING)) && (S == 8 || S == 4) && p.xvec && p.gvec && !(flags & GML_ACCUM) &&
+               (!dx || p.dxvec || dz == nullptr) && (num_rows + 16) * (ldg > ldx ? ldg : ldx) * 4 < (int64_t)INT32_MAX;
+    if (dma) {
+        const int ecap4 = S == 8 ? (pl.nfb == 2 ? GmlBwd4Cfg<8, 2>::ECAP : GmlBwd4Cfg<8, 1>::ECAP) : (pl.nfb == 2 ? GmlBwd4Cfg<4, 2>::ECAP : GmlBwd4Cfg<4, 1>::ECAP);
+        dma = max_group_edges + 3 <= ecap4 && max_group_window + 7 <= GmlBwd4Cfg<8, 2>::XCAP;
+    }
+    if (dma) {
+#define GML_BWD4_GO(SV, A) if (S == SV && nfb == A) rc = gml_launch_bwd4<SV, A>(p, dim3(pl.grid), st);
+        GML_BWD4_GO(8, 2) GML_BWD4_GO(8, 1) GML_BWD4_GO(4, 2) GML_BWD4_GO(4, 1)
+    } else if (pl.layout == 3) {
 #define GML_BWD3_GO(SV, A, W) if (S == SV && nfb == A && pl.nw == W) rc = gml_launch_bwd3<SV, A, W>(p, dim3(pl.grid), pl.lds, st);
         GML_BWD3_GO(8, 2, 8) GML_BWD3_GO(8, 1, 8) GML_BWD3_GO(6, 2, 8) GML_BWD3_GO(6, 1, 8)
         GML_BWD3_GO(4, 2, 8) GML_BWD3_GO(4, 1, 8) GML_BWD3_GO(2, 2, 8) GML_BWD3_GO(2, 1, 8)

@@ -432,12 +432,17 @@ def conv_bwd_takes_dz(csr, S, Fin, Fout, nmix):
     return plan is not None and bool(_lib.lib().gml_spectconv_bwd_mix_supported(int(S), int(Fin), int(Fout), int(nmix), plan[0]))
 
 
+BWD_DMA = _os.environ.get('GML_BWD_DMA') == '1'     # fused backward on the LDS-DMA ring kernel (bwd4) where it applies; A/B switch
+
+
 def fused_conv_bwd(csr, val_t, x, G, weight, need_x, need_val, need_w, dx_accum_into=None, mix=None):
     """one launch: dX, dval (source order), dW.  val_t: supports in source order.  mix = (dz [N, 4], wmix [nmix, Fin]):
     dX = conv part + dz wmix (instead of accumulating into a dx another kernel wrote)."""
     S, Fin, Fout = weight.shape
     dev = x.device
     flags, ginfo, gmax, nbytes, _ = _bwd_plan(csr, S, Fin, Fout)
+    if BWD_DMA:
+        flags |= _lib.GML_DMA_RING
     ld4 = (Fout + 3) // 4 * 4
     if G.stride(0) % 4 != 0 or G.stride(0) < ld4 or G.data_ptr() % 16 != 0:
         # the 8-wave kernel reads the g window as float4: rows padded (with zeros) to a multiple of 4 floats

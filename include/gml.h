@@ -52,8 +52,10 @@ enum {
                          bf16x3 split on the bf16 matrix cores (fp32-class: ~1e-6 of the output scale)       */
     GML_GROUPS128 = 8, /* gml_spectconv_fwd: `ginfo` holds 128-row group records (gml_spectconv_fwd_group_rows() = 128):
                          the 8-wave forward kernel                                                            */
-    GML_GROUPS64R = 16 /* gml_spectconv_fwd: `ginfo` holds ranked 64-row records (gml_spectconv_fwd_group_rows() =
+    GML_GROUPS64R = 16, /* gml_spectconv_fwd: `ginfo` holds ranked 64-row records (gml_spectconv_fwd_group_rows() =
                          GML_GROUPS64_RANKED): the same kernel in its 4-wave geometry, two workgroups per CU     */
+    GML_DMA_RING = 32   /* gml_spectconv_bwd / _bwd_mix: take the LDS-DMA landing-ring kernel (bwd4) where it applies; the
+                         forward uses its ring kernel (fwd3) by default (GML_FWD_DMA=0 in the environment turns it off)   */
 };
 
 int gml_version(void);

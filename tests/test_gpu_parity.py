@@ -23,15 +23,18 @@ def dev():
     return torch.device('cuda:0')
 
 
-@pytest.fixture(params=['bf16x3', 'f32'])
+@pytest.fixture(params=['bf16x3', 'f32', 'bf16x3-ring'])
 def arith(request):
     """projection arithmetic of the fused kernels: the default bf16 hi/lo split on the matrix cores (three products per
-    fp32 product, ~2^-17 operand residual) and the exact f32-input MFMA (GML_F32_MFMA).  The golden suites run in both."""
+    fp32 product, ~2^-17 operand residual) and the exact f32-input MFMA (GML_F32_MFMA).  The golden suites run in both --
+    and a third time with the fused backward on its LDS-DMA landing-ring kernel (bwd4, opt-in: GML_DMA_RING), so that the
+    non-default kernel stays parity-checked (the forward's ring kernel, fwd3, is the default wherever it applies)."""
     from gnn_matlang_amd import functional as Fn
-    old = Fn.F32_MFMA
+    old, old_ring = Fn.F32_MFMA, Fn.BWD_DMA
     Fn.F32_MFMA = request.param == 'f32'
-    yield request.param
-    Fn.F32_MFMA = old
+    Fn.BWD_DMA = request.param.endswith('-ring')
+    yield request.param.split('-')[0]
+    Fn.F32_MFMA, Fn.BWD_DMA = old, old_ring
 
 
 def cu(a, dev):

@@ -8,7 +8,7 @@ import bench
 from gnn_matlang_amd import _lib, functional as Fn, models
 
 dev = torch.device('cuda:0')
-data, _ = bench.build_batch(32768, 2048, seed=1000, device=dev)
+data, _ = bench.build_batch(int(sys.argv[1]) if len(sys.argv) > 1 else 32768, 2048, seed=1000, device=dev)
 csr = data.csr('edge_index2')
 torch.manual_seed(0)
 model = models.zinc_gnnml3().to(dev)
