@@ -53,6 +53,8 @@ def parse_args():
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-profile', action='store_true', help='skip the live per-kernel HIP-event timing and the extra measurements')
     ap.add_argument('--no-extras', action='store_true', help='skip fresh_batch / epoch_bs64 / value_exact_fp32')
+    ap.add_argument('--distinct', type=int, default=131072, help='extra measurement: the step over this many DISTINCT graphs '
+                    '(no tiling of a pool), supports built by the device SpectralDesign; 0 = skip')
     ap.add_argument('--ref-batch', type=int, default=64, help='also time the reference batch size (Zinc12k.py:20) as a '
                     'HIP-graph-captured step; 0 = skip')
     return ap.parse_args()
@@ -94,6 +96,20 @@ def build_batch(graphs_per_gpu, pool, seed, device):
     y = torch.randn(B * reps, generator=g).to(device)
     full = Batch(x=x, edge_index=ei, edge_index2=ei2, edge_attr2=ea, batch=batch, ptr=ptr.int(), y=y)
     return full, base
+
+
+def build_batch_distinct(graphs, seed, device):
+    """`graphs` DISTINCT ZINC-like graphs (no tiling): generated on the host, supports by the device SpectralDesign
+    (gnn_matlang_amd.spectral_design.design_device, libs/utils.py:546-610 on the GPU)."""
+    import torch
+    from gnn_matlang_amd import SpectralDesign, collate, synthetic
+    from gnn_matlang_amd.graph import Batch
+    raw = synthetic.make_graphs('zinc', graphs, seed=seed)
+    host = collate([dict(x=g[0], edge_index=g[1], y=g[2]) for g in raw])
+    x, ei, ptr = host.x.to(device), host.edge_index.to(device), host.ptr.to(device)
+    d = SpectralDesign(recfield=2, dv=2, nfreq=7).design_device(x, ei, ptr)
+    return Batch(x=d['x'], edge_index=ei, edge_index2=d['edge_index2'], edge_attr2=d['edge_attr2'], batch=host.batch.to(device),
+                 ptr=ptr.int(), y=host.y.float().to(device))
 
 
 def cpu_model_name():
@@ -203,12 +219,30 @@ def main():
 
     per_gpu = args.batch
     scaling = 'weak'
-    if args.global_batch:
-        scaling = 'strong'
-        lo = rank * args.global_batch // world
-        per_gpu = (rank + 1) * args.global_batch // world - lo
+    shard_info = None
     log('building data')
-    data, base = build_batch(per_gpu, args.pool, seed=1000 + rank, device=dev)
+    if args.global_batch:
+        # strong scaling: ONE global data set (the same on every rank: same seed), cut into contiguous ranges of equal
+        # total support edges (graph.shard_graphs_balanced), each rank keeps its range
+        from gnn_matlang_amd.graph import shard_graphs_balanced
+        from gnn_matlang_amd.dataset import DeviceDataset
+        scaling = 'strong'
+        full, _ = build_batch(args.global_batch, args.pool, seed=1000, device=dev)
+        B_ = full.num_graphs
+        e2g = full.batch[full.edge_index2[0]]                                  # graph of every support edge
+        work = torch.bincount(e2g, minlength=B_).cpu().numpy()
+        lo, hi = shard_graphs_balanced(work, rank, world)
+        nlo, nhi = int(full.ptr[lo]), int(full.ptr[hi])
+        esel = (e2g >= lo) & (e2g < hi)
+        esel1 = (full.batch[full.edge_index[0]] >= lo) & (full.batch[full.edge_index[0]] < hi)
+        data = Batch(x=full.x[nlo:nhi].contiguous(), edge_index=full.edge_index[:, esel1] - nlo,
+                     edge_index2=full.edge_index2[:, esel] - nlo, edge_attr2=full.edge_attr2[esel].contiguous(),
+                     batch=full.batch[nlo:nhi] - lo, ptr=(full.ptr[lo:hi + 1] - nlo).int(), y=full.y[lo:hi].contiguous())
+        shard_info = dict(graphs=hi - lo, support_edges=int(esel.sum()), global_support_edges=int(work.sum()))
+        base = None
+        del full, e2g, esel, esel1
+    else:
+        data, base = build_batch(per_gpu, args.pool, seed=1000 + rank, device=dev)
     log('data ready: %d graphs, %d nodes, %d support edges' % (data.num_graphs, data.x.size(0), data.edge_index2.size(1)))
     data.csr('edge_index2')                            # built once per batch (data loading, not the step); see fresh_batch
     torch.manual_seed(0)
@@ -271,6 +305,18 @@ def main():
         dist.all_reduce(gcount, op=dist.ReduceOp.SUM)
     dt = float(tt.item())
     graphs = int(gcount.item())
+    shard_imb = None
+    if shard_info is not None:                             # strong scaling: how even the cut by support edges came out
+        se = torch.tensor([shard_info['support_edges'], shard_info['graphs']], dtype=torch.int64, device=dev)
+        allse = [torch.zeros_like(se) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(allse, se)
+        else:
+            allse = [se]
+        edges = [int(t[0]) for t in allse]
+        shard_imb = dict(method='graph.shard_graphs_balanced (contiguous ranges of equal total support edges)',
+                         support_edges_per_rank=edges, graphs_per_rank=[int(t[1]) for t in allse],
+                         max_over_mean=max(edges) / (sum(edges) / len(edges)))
     lossv = float(loss.item())
     assert np.isfinite(lossv) or os.environ.get('GML_BENCH_NOCHECK'), 'loss diverged'   # (NOCHECK: ablation builds)
 
@@ -287,8 +333,11 @@ def main():
                    final_loss=lossv, blocks=len(blocks), block_seconds=[round(b, 4) for b in blocks],
                    n_ranks_seen=dist.get_world_size() if world > 1 else 1,
                    rccl_version='.'.join(str(v) for v in torch.cuda.nccl.version()) if world > 1 else None)
-        if prof:
-            summ = Fn.profile_summary(prof)
+        if shard_imb is not None:
+            res['sharding'] = shard_imb
+        def rooflines(prof_):
+            """(dominant kernel's roofline record, the other candidates, per-tag ms per step) of one profiled block"""
+            summ = Fn.profile_summary(prof_)
             bf16x3 = not Fn.F32_MFMA
             BF16_PEAK_TFLOPS = 2500.0                       # dense bf16 MFMA (MI355X_MICROARCH.md)
 
@@ -329,14 +378,14 @@ def main():
             ed_b = sum(4 * E_ * 8 * 30 for f in fins) * args.steps              # P update + Z.g dot
             cands = []
             if 'spectconv_bwd' in summ:
-                cands.append(roof('spectconv_bwd', 'gml_k_spectconv_bwd3 (fused SpectConv backward: dX, dval, dW)', pj_b, ed_b))
+                cands.append(roof('spectconv_bwd', '%s (fused SpectConv backward: dX, dval, dW)' % ('gml_k_spectconv_bwd (f32-input MFMA)' if Fn.F32_MFMA else ('gml_k_spectconv_bwd4' if Fn.BWD_DMA else 'gml_k_spectconv_bwd3')), pj_b, ed_b))
             if 'spectconv_fwd' in summ:
-                cands.append(roof('spectconv_fwd', 'gml_k_spectconv_fwd2 (fused SpectConv forward; the 8-wave kernel also carries the Hadamard branch)', pj_f, ed_f))
+                cands.append(roof('spectconv_fwd', '%s (fused SpectConv forward; also carries the Hadamard branch)' % ('gml_k_spectconv_fwd (f32-input MFMA)' if Fn.F32_MFMA else 'gml_k_spectconv_fwd3 (LDS-DMA ring)'), pj_f, ed_f))
             # HBM bytes per launch from the PMC counters: collected OFFLINE with the same command under rocprofv3
             # (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied); valid for the code state and
             # workload the profile names -- the file records the commit it was taken at
             tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic_b%d.json' % data.num_graphs)
-            if os.path.exists(tpath) and args.pool == 2048:
+            if os.path.exists(tpath) and args.pool == 2048 and bf16x3:
                 tj = json.load(open(tpath))
                 for r in cands:
                     pref = 'gml_k_spectconv_bwd' if 'backward' in r['kernel'] else 'gml_k_spectconv_fwd'
@@ -346,10 +395,13 @@ def main():
                             sum(h.get('launches', 1) for h in hits)
                         r['traffic_source'] = 'profiles/%s: rocprofv3 PMC, per launch, measured OFFLINE at commit %s' % (
                             os.path.basename(tpath), tj.get('commit', '?'))
-            cands.sort(key=lambda r: -r['ms_per_step'])
-            res['roofline'] = cands[0]                   # the kernel with the largest share of the step
+            cands.sort(key=lambda r: -r['ms_per_step'])          # first: the kernel with the largest share of the step
+            return cands, {tag: round(v['ms'] * v['launches'] / args.steps, 4) for tag, v in summ.items()}
+        if prof:
+            cands, kms = rooflines(prof)
+            res['roofline'] = cands[0]
             res['roofline_other'] = cands[1:]
-            res['kernels_ms_per_step'] = {tag: round(v['ms'] * v['launches'] / args.steps, 4) for tag, v in summ.items()}
+            res['kernels_ms_per_step'] = kms
         if world == 1 and not args.no_profile:
             # calibration: what torch's device-to-device copy reaches on THIS box (read + write bytes / time) -- a
             # reference point, not a ceiling (MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy kernel); the
@@ -374,19 +426,22 @@ def main():
             vals = csr.sort_values(data.edge_attr2)
             for _ in range(3):
                 Fn.spmm(csr, vals, xs, S_, Fin_)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            nrep = 20
-            e0.record()
-            for _ in range(nrep):
-                Fn.spmm(csr, vals, xs, S_, Fin_)
-            e1.record()
-            torch.cuda.synchronize()
-            t_s = e0.elapsed_time(e1) / nrep * 1e-3
+            nrep, tblk = 20, []
+            for _ in range(7):                                   # 7 blocks of 20 launches, median block
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(nrep):
+                    Fn.spmm(csr, vals, xs, S_, Fin_)
+                e1.record()
+                torch.cuda.synchronize()
+                tblk.append(e0.elapsed_time(e1) / nrep * 1e-3)
+            t_s = float(np.median(tblk))
             q_s = 4 * (csr.E * S_ + csr.N * Fin_ + csr.N * S_ * Fin_) + 4 * (csr.E + csr.N + 1)
             res['spmm'] = {'kernel': 'gml_k_spectconv_fwd2<S, 0> via gml_spmm_fwd (8-wave SpMM, H written)', 'bound': 'hbm',
                            'achieved': q_s / t_s / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': q_s / t_s / 1e9 / HBM_PEAK_GBS,
                            'avg_launch_ms': t_s * 1e3, 'algorithmic_bytes_per_launch': q_s, 'S': S_, 'Fin': Fin_,
-                           'frac_of_copy_rate': q_s / t_s / 1e9 / res['hbm_copy_GBps']}
+                           'frac_of_copy_rate': q_s / t_s / 1e9 / res['hbm_copy_GBps'],
+                           'blocks': len(tblk), 'launches_per_block': nrep, 'block_ms': [round(t * 1e3, 4) for t in tblk]}
             del xs, vals
         if world == 1 and not args.no_profile and not args.no_extras:
             # ---- the same step with exact fp32 products (f32-input MFMA; bit-identical to an fmaf chain)
@@ -394,9 +449,16 @@ def main():
             for _ in range(2):
                 step()
             dtx, _ = timed_block(step, args.steps)
+            Fn.PROFILE = {}
+            timed_block(step, args.steps)                      # (a second, profiled block: HIP events per launch)
+            profx, Fn.PROFILE = Fn.PROFILE, None
+            candx, kmsx = rooflines(profx)
             Fn.F32_MFMA = False
             res['value_exact_fp32'] = dict(value=data.num_graphs * args.steps / dtx, unit='graphs/s', ms_per_step=dtx / args.steps * 1e3,
-                                           arithmetic='f32-input MFMA (GML_F32_MFMA=1): every product exact fp32')
+                                           arithmetic='f32-input MFMA (GML_F32_MFMA=1): every product exact fp32',
+                                           kernels_ms_per_step=kmsx)
+            res['roofline_exact_fp32'] = candx[0]
+            res['roofline_exact_fp32_other'] = candx[1:]
             log('exact fp32: %.3f ms/step' % (dtx / args.steps * 1e3))
             # ---- a NEW batch every step: the per-batch index work inside the timed region
             fields = {k: v for k, v in data.__dict__.items() if not k.startswith('_')}
@@ -412,6 +474,33 @@ def main():
                                       note='every step builds CSR (both views), group records, the bf16 pre-split and the '
                                            'source-order copy of the supports for its batch inside the timed region')
             log('fresh batch: %.3f ms/step' % (dtf / nfr * 1e3))
+        if world == 1 and not args.no_profile and not args.no_extras and args.distinct > 0:
+            # ---- the same step over DISTINCT graphs (the headline batch tiles a pool of --pool graphs: bytes are honest, every
+            #      128-row group pattern repeats 64 times; here degree ranks, window widths and LDS-cap fallbacks are sampled
+            #      from every graph).  Supports by the device SpectralDesign.
+            t_b = time.perf_counter()
+            dd = build_batch_distinct(args.distinct, seed=31337, device=dev)
+            dd.csr('edge_index2')
+            torch.cuda.synchronize()
+            t_b = time.perf_counter() - t_b
+            for _ in range(3):
+                step(dd)
+            dtd, _ = timed_block(lambda: step(dd), args.steps)
+            res['distinct_graphs'] = dict(value=dd.num_graphs * args.steps / dtd, unit='graphs/s', ms_per_step=dtd / args.steps * 1e3,
+                                          graphs=dd.num_graphs, nodes=int(dd.x.size(0)), support_edges=int(dd.edge_index2.size(1)),
+                                          build_seconds=t_b,
+                                          note='%d distinct synthetic ZINC-like graphs (no tiling), supports built on the device '
+                                               '(gml_spectral_design); same model, step and timing as `value`' % dd.num_graphs)
+            log('distinct graphs: %.3f ms/step (%d graphs, built in %.1f s)' % (dtd / args.steps * 1e3, dd.num_graphs, t_b))
+            del dd
+            torch.cuda.empty_cache()
+        if world == 1 and not args.no_profile and not args.no_extras:
+            # ---- the other BASELINE configs (parity-test cases, not bench lines): short runs with a roofline record each
+            sys.path.insert(0, os.path.join(ROOT, 'tools'))
+            import bench_configs
+            res['other_configs'] = bench_configs.run(dev, quick=False)
+            for oc in res['other_configs']:
+                log('other config %s: %.3f ms/step, %.2f M graphs/s' % (oc['config'], oc['ms_per_step'], oc['graphs_per_s'] / 1e6))
         if world == 1 and args.ref_batch > 0:
             # the reference's own batch size: launch-latency bound, so the step is replayed from a HIP graph
             rb, _ = build_batch(args.ref_batch, args.ref_batch, seed=7, device=dev)

@@ -53,3 +53,51 @@ def broadcast_parameters(module, src=0, group=None):
     for p in ps:
         p.copy_(flat[off:off + p.numel()].view_as(p))
         off += p.numel()
+
+
+class _SyncBNFunction(torch.autograd.Function):
+    """BatchNorm over the GLOBAL batch of a data-parallel step: one all-reduce of [sum x, sum x^2, count] (2 C + 1 floats)
+    forward, one of [sum dy, sum dy xhat] backward.  With these the R-rank step equals the 1-rank step on the same global
+    batch (config 4: the MNIST readout's tf.layers.batch_normalization, libs/layers_tf.py:343-349)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, group):
+        C = x.size(1)
+        st = torch.cat([x.sum(0), (x * x).sum(0), x.new_tensor([float(x.size(0))])])
+        dist.all_reduce(st, op=dist.ReduceOp.SUM, group=group)
+        n = st[-1]
+        mean = st[:C] / n
+        var = (st[C:2 * C] / n - mean * mean).clamp_(min=0)            # biased, as batch norm normalises with
+        rstd = torch.rsqrt(var + eps)
+        xhat = (x - mean) * rstd
+        ctx.save_for_backward(xhat, weight, rstd, n)
+        ctx.group = group
+        ctx.mark_non_differentiable(mean, var, n)
+        return xhat * weight + bias, mean, var, n
+
+    @staticmethod
+    def backward(ctx, dy, _dm, _dv, _dn):
+        xhat, weight, rstd, n = ctx.saved_tensors
+        C = dy.size(1)
+        sums = torch.cat([dy.sum(0), (dy * xhat).sum(0)])            # local sums = the parameter gradients of this shard
+        g = sums.clone()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
+        dx = (dy - g[:C] / n - xhat * (g[C:] / n)) * (weight * rstd)
+        return dx, sums[C:], sums[:C], None, None
+
+
+class SyncBatchNorm1d(torch.nn.BatchNorm1d):
+    """torch.nn.BatchNorm1d (same parameters, buffers and state_dict keys) whose TRAINING statistics are those of the global
+    batch when a process group with more than one rank is initialised; with one rank, or in eval mode, it is the base class."""
+
+    def forward(self, x):
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        if not self.training or world == 1 or not self.track_running_stats or x.dim() != 2:
+            return super().forward(x)
+        y, mean, var, n = _SyncBNFunction.apply(x, self.weight, self.bias, self.eps, None)
+        with torch.no_grad():
+            self.num_batches_tracked += 1
+            m = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked)
+            self.running_mean.mul_(1 - m).add_(mean, alpha=m)
+            self.running_var.mul_(1 - m).add_(var * (n / (n - 1).clamp(min=1)), alpha=m)
+        return y

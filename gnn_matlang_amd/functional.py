@@ -86,11 +86,13 @@ def conv_cost(N, E, S, Fin, Fout):
     return q, f
 
 
-def conv_cost_bwd(N, E, S, Fin, Fout):
+def conv_cost_bwd(N, E, S, Fin, Fout, need_x=True, need_val=True):
     """compulsory traffic / flops of one SpectConv backward incl. d/dval (SURVEY s8d):
-       Q = 4 (2 E S + 2 N Fin + N Fout + 2 S Fin Fout + Fout) + 4 (E + N + 1);  F = 6 E S Fin + 4 N S Fin Fout."""
-    q = 4 * (2 * E * S + 2 * N * Fin + N * Fout + 2 * S * Fin * Fout + Fout) + 4 * (E + N + 1)
-    f = 6 * E * S * Fin + 4 * N * S * Fin * Fout
+       Q = 4 (2 E S + 2 N Fin + N Fout + 2 S Fin Fout + Fout) + 4 (E + N + 1);  F = 6 E S Fin + 4 N S Fin Fout.
+    A launch that produces no dX (the first layer: its input is data) is charged one N Fin (x is still read for dW and
+    dval), one that produces no dval one E S: the bytes it actually has to move (VERDICT r02 weak #10)."""
+    q = 4 * ((2 if need_val else 1) * E * S + (2 if need_x else 1) * N * Fin + N * Fout + 2 * S * Fin * Fout + Fout) + 4 * (E + N + 1)
+    f = (6 if need_val else 4) * E * S * Fin + (4 if need_x else 2) * N * S * Fin * Fout
     return q, f
 
 
@@ -456,7 +458,7 @@ def fused_conv_bwd(csr, val_t, x, G, weight, need_x, need_val, need_w, dx_accum_
         dx = torch.empty(csr.N, Fin, dtype=torch.float32, device=dev) if need_x else None
     dval_t = torch.empty(csr.E, S, dtype=torch.float32, device=dev) if need_val else None
     dw = torch.empty(S, Fin, Fout, dtype=torch.float32, device=dev) if need_w else None
-    q, f = conv_cost_bwd(csr.N, csr.E, S, Fin, Fout) if PROFILE is not None else (0, 0)
+    q, f = conv_cost_bwd(csr.N, csr.E, S, Fin, Fout, need_x, need_val) if PROFILE is not None else (0, 0)
     with _Timed('spectconv_bwd', q, f):
         if mix is not None:
             dz, wmix = mix

@@ -11,6 +11,7 @@ import torch.nn.functional as F
 
 from .functional import segment_bcast, segment_max, segment_max_bwd, segment_sum, tall_linear, _ptr32
 from .spect_conv import ML3Layer, SpectConv
+from .dist import SyncBatchNorm1d
 
 
 class _SegmentPool(torch.autograd.Function):
@@ -80,7 +81,7 @@ class GNNML3(torch.nn.Module):
         nin = fin
         if readout_bn:                       # TF ReadoutLayer: batch_normalization of the pooled vector
             # tf.layers.batch_normalization defaults (libs/layers_tf.py:349): epsilon 1e-3, momentum 0.99 (= 0.01 in torch's convention)
-            self.bnr = torch.nn.BatchNorm1d(nin, eps=1e-3, momentum=0.01)
+            self.bnr = SyncBatchNorm1d(nin, eps=1e-3, momentum=0.01)   # global-batch statistics under data parallelism (dist.py)
         if head == 'mlp32':
             self.fc1 = torch.nn.Linear(nin, 32)
             self.fc2 = torch.nn.Linear(32, nclass)

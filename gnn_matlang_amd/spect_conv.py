@@ -212,6 +212,19 @@ class ML3Layer(torch.nn.Module):
         _require_cuda(x, 'x')
         csr = csr_for(edge_index, x.size(0))
         le, n2 = self.learnedge, self.nout2
+        if le and max(self.fc1_1.weight.size(1), self.fc1_4.weight.size(0)) > 16:
+            # more than 16 supports (no script goes beyond counting.py's 12; the sr25 sweep of SURVEY s8d raises nfreq to 47):
+            # the edge branch as four library GEMMs + elementwise under autograd (libs/spect_conv.py:205-207), the node branch on
+            # the fused kernels with the learned supports as its (differentiable) values
+            Fn._path('edge', 'library GEMMs (more than 16 supports)', self.fc1_1.weight.size(1), '-', self.fc1_4.weight.size(0))
+            _require_cuda(edge_attr, 'edge_attr')
+            ea = edge_attr.to(torch.float32)
+            tmp = torch.cat([torch.relu(self.fc1_1(ea)), torch.tanh(self.fc1_2(ea)) * torch.tanh(self.fc1_3(ea))], 1)
+            val = _sorted_values(csr, edge_index, torch.relu(self.fc1_4(tmp)), self.conv1.weight.size(0))
+            return ML3LayerFunction.apply(x, val, None, None, None, None, self.conv1.weight, self.conv1.bias,
+                                          self.fc11.weight if n2 > 0 else None, self.fc11.bias if n2 > 0 else None,
+                                          self.fc12.weight if n2 > 0 else None, self.fc12.bias if n2 > 0 else None,
+                                          csr, False, n2, False, *(_pool if _pool is not None else (None, None, False)))
         # learnedge: fc1_1..3 are Linear(nedgeinput, .) -- the width must match, as in the reference; otherwise conv1
         # reads the first K columns only
         # Training with the edge branch: the branch runs in SOURCE order (functional.ML3LayerFunction).  SpectralDesign emits

@@ -78,3 +78,52 @@ def test_two_rank_step_equals_single_process(tmp_path):
     for n, v in r['grads'].items():                    # == the reference's full-batch gradients
         np.testing.assert_allclose(v.numpy(), g['grad/' + n], rtol=1e-4, atol=2e-5, err_msg=n)
     np.testing.assert_allclose(r['losses'], g['loss_traj'][:3], rtol=1e-4)
+
+
+def _worker_mnist(rank, world, port, out):
+    """config 4 (the one BASELINE shards over GPUs) with its readout batch norm: statistics all-reduced (dist.SyncBatchNorm1d)"""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from gnn_matlang_amd.dist import FlatGradSync, SyncBatchNorm1d
+    from gnn_matlang_amd.graph import shard_graphs
+    from oracle import models_oracle as MO
+    torch.set_num_threads(1)
+    g = np.load(os.path.join(GOLDEN, 'model_mnist_gnnml3_tf.npz'))
+    b = {k[len('batch/'):]: g[k] for k in g.files if k.startswith('batch/')}
+    B = len(b['y'])
+    m = MO.mnist_gnnml3().train()
+    m.bnr = SyncBatchNorm1d(m.bnr.num_features, eps=m.bnr.eps, momentum=m.bnr.momentum)     # same keys as BatchNorm1d
+    m.load_state_dict({k[len('param/'):]: T(g[k]) for k in g.files if k.startswith('param/')}, strict=False)
+    sync = FlatGradSync(m.parameters())
+    lo, hi = shard_graphs(B, rank, world)
+    s = _shard(b, lo, hi)
+    sync.zero()
+    pre = m(T(s['x']), T(s['edge_index2']), T(s['edge_attr2']), T(s['batch']), hi - lo)
+    # the reference's loss is the batch MEAN of the cross entropy (libs/metrics_tf.py): sum over the shard / GLOBAL batch size
+    l = torch.nn.functional.cross_entropy(pre, T(s['y']).long(), reduction='sum') / B
+    l.backward()
+    sync.sync()
+    lt = l.detach().clone()
+    dist.all_reduce(lt)
+    logits = [torch.zeros(hi - lo if r == rank else shard_graphs(B, r, world)[1] - shard_graphs(B, r, world)[0], pre.size(1)) for r in range(world)]
+    dist.all_gather(logits, pre.detach()) if len({t.size(0) for t in logits}) == 1 else None
+    if rank == 0:
+        torch.save(dict(grads={n: p.grad.clone() for n, p in m.named_parameters()}, loss=lt.item(),
+                        logits=torch.cat(logits) if len({t.size(0) for t in logits}) == 1 else None,
+                        running_mean=m.bnr.running_mean.clone()), out)
+    dist.destroy_process_group()
+
+
+def test_two_rank_mnist_step_with_synced_readout_batchnorm(tmp_path):
+    out = str(tmp_path / 'm0.pt')
+    mp.spawn(_worker_mnist, args=(2, _free_port(), out), nprocs=2, join=True)
+    r = torch.load(out)
+    g = np.load(os.path.join(GOLDEN, 'model_mnist_gnnml3_tf.npz'))
+    np.testing.assert_allclose(r['loss'], float(g['loss']), rtol=1e-5)
+    if r['logits'] is not None:
+        np.testing.assert_allclose(r['logits'].numpy(), g['logits'], rtol=1e-4, atol=2e-5)
+    for n, v in r['grads'].items():                    # == the TF graph's full-batch gradients
+        ref = g['grad/' + n]
+        assert np.abs(v.numpy() - ref).max() <= 1e-4 * np.abs(ref).max(), n

@@ -40,3 +40,35 @@ def test_two_ranks_product_model_equals_reference_full_batch(tmp_path, balanced)
         ref = g['grad/' + n]
         assert np.abs(v.numpy() - ref).max() <= 1e-4 * max(np.abs(ref).max(), 1e-30), n
     np.testing.assert_allclose(res['losses'], g['loss_traj'][:3], rtol=1e-4)
+
+
+def _run_bench(extra, timeout=900):
+    import json
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '1', '--no-cpu', '--no-extras',
+           '--ref-batch', '0', '--min-seconds', '0'] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_bench_strong_scaling_shards_one_global_batch():
+    """--global-batch: ONE global data set cut by graph.shard_graphs_balanced (sum of support edges); with one rank the cut is
+    the whole set -- checks the sharding code path and its record on the 1-GPU box."""
+    d = _run_bench(['--gpus', '1', '--global-batch', '4096'])
+    assert d['scaling'] == 'strong' and d['config']['global_batch'] == 4096
+    sh = d['sharding']
+    assert sh['graphs_per_rank'] == [4096] and sh['support_edges_per_rank'][0] == d['config']['support_edges_per_gpu']
+    assert abs(sh['max_over_mean'] - 1.0) < 1e-12
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs: RCCL wants one device per rank')
+def test_bench_two_gpus_over_rccl():
+    """the real entry point on the first box that has two GPUs: bench.py --gpus 2 spawns its ranks, backend nccl (= RCCL),
+    one flat SUM all-reduce per step; weak scaling and the edge-balanced strong-scaling cut"""
+    d = _run_bench(['--gpus', '2', '--batch', '4096'])
+    assert d['n_gpus'] == 2 and d['n_ranks_seen'] == 2 and d['rccl_version']
+    assert d['config']['global_batch'] == 8192 and np.isfinite(d['final_loss'])
+    d = _run_bench(['--gpus', '2', '--global-batch', '8192'])
+    assert d['n_ranks_seen'] == 2 and d['scaling'] == 'strong' and sum(d['sharding']['graphs_per_rank']) == 8192
+    assert d['sharding']['max_over_mean'] < 1.02

@@ -559,9 +559,11 @@ def test_model_step_golden(dev, golden, fname, ctor, loss, arith):
     l.backward()
     close(pre, g['logits'], what='logits')
     assert abs(l.item() - float(g['loss'])) <= TOL * abs(float(g['loss']))
-    gtol = 2e-4 if (arith == 'bf16x3' and fname == 'model_mutag_gnnml3.npz') else TOL
+    # the exception, tensor by tensor (measured 1.61e-4 / 1.34e-4, profiles/r02_parity_report.jsonl): only these two sit above
+    # 1e-4, and they may not drift past the measured values + 25 %
+    over = {'conv1.conv1.weight': 2.0e-4, 'conv1.conv1.bias': 1.7e-4} if (arith == 'bf16x3' and fname == 'model_mutag_gnnml3.npz') else {}
     for n, p in m.named_parameters():
-        close(p.grad, g['grad/' + n], tol=gtol, what='grad ' + n)
+        close(p.grad, g['grad/' + n], tol=over.get(n, TOL), what='grad ' + n)
     opt = torch.optim.Adam(m.parameters(), lr=1e-3)
     traj = []
     for _ in range(5):
@@ -698,7 +700,8 @@ def test_mnist75_gnnml3_tf_golden(dev, golden, arith):
             traj.append(l.item())
         # (lr = 0.01 Adam turns the round-off-level gradients of dead first-layer units into +-lr steps: the loss after ONE
         #  update already differs by ~1e-4 between any two float32 summation orders; tests/test_oracle_golden.py)
-        np.testing.assert_allclose(traj, g['loss_traj'][:2], rtol=5e-4)
+        np.testing.assert_allclose(traj[:1], g['loss_traj'][:1], rtol=TOL)       # before any update: the 1e-4 bar
+        np.testing.assert_allclose(traj[1:], g['loss_traj'][1:2], rtol=5e-4)     # after ONE lr = 0.01 step (the oracle itself: 1.4e-4)
 
 
 # ------------------------------------------------------------------------------------------ full size
@@ -933,3 +936,70 @@ def test_ml3_forward_pooled_matches_layer_then_pool(dev, mean):
     assert torch.equal(res[0][0], res[1][0])                             # same kernels forward: same bits
     for a, b in zip(res[0][1:], res[1][1:]):
         close(a, b, tol=2e-5, what='pooled layer vs layer + pool (mean=%s)' % mean)
+
+
+# ------------------------------------------------------------------------------------------ term-sum criterion
+def _termsum_close(got, ref, tsum, what):
+    """|got - ref| <= 1e-4 * T elementwise, T = the sum of the ABSOLUTE values of the terms the element is a sum of (fp64).
+    n u T bounds the round-off of ANY fp32 evaluation order of that sum -- the reference's own included -- so this bar stays
+    meaningful for elements whose terms cancel, which the max-norm metric of ``close`` averages away."""
+    got = got.detach().cpu().double().numpy() if isinstance(got, torch.Tensor) else np.asarray(got, np.float64)
+    ref, t = np.asarray(ref, np.float64), np.asarray(tsum, np.float64)
+    bad = np.abs(got - ref) > TOL * t + 1e-30
+    assert not bad.any(), '%s: %d elements beyond 1e-4 of their term sum, worst %.3e' % (
+        what, int(bad.sum()), float((np.abs(got - ref) / np.maximum(t, 1e-300)).max()))
+
+
+def test_spectconv_golden_termsum(dev, golden, arith):
+    """forward output and d/dx of every default-branch SpectConv golden case against the reference's vectors under the
+    term-sum criterion: T_out = sum_s sum_e |val| |x[src]| |W_s| (+ |x| |W_self| + |b|), T_gx = sum_s sum_e |val| (|gout[dst]| |W_s|^T)"""
+    from gnn_matlang_amd import SpectConv
+    from oracle.spect_conv_oracle import spectconv_forward
+    g = golden('spectconv.npz')
+    for k in range(int(g['ncases'])):
+        c = g.sub('case%03d/' % k)
+        S, fin, fout, selfconn, depthwise, bias = [int(v) for v in c['meta']]
+        if depthwise:
+            continue                                      # (mapped onto the default branch through a weight transform)
+        m = SpectConv(fin, fout, S, selfconn=bool(selfconn), bias=bool(bias)).to(dev)
+        sd = {'weight': T(c['weight'])}
+        if bias:
+            sd['bias'] = T(c['bias'])
+        m.load_state_dict(sd)
+        x = cu(c['x'], dev).requires_grad_(True)
+        y = m(x, cu(c['edge_index'], dev), cu(c['edge_attr'], dev))
+        (y * cu(c['gout'], dev)).sum().backward()
+        xa, va, wa = T(c['x']).double().abs(), T(c['edge_attr']).double().abs(), T(c['weight']).double().abs()
+        ei = T(c['edge_index'])
+        t_out = spectconv_forward(xa, ei, va, wa, T(c['bias']).double().abs() if bias else None, selfconn=bool(selfconn))
+        ga = T(c['gout']).double().abs()
+        t_gx = torch.zeros_like(xa)
+        ns = wa.size(0) - (1 if selfconn else 0)
+        for s in range(ns):
+            t_gx.index_add_(0, ei[0], va[:, s:s + 1] * (ga @ wa[s].t())[ei[1]])
+        if selfconn:
+            t_gx += ga @ wa[-1].t()
+        what = 'case %d meta %s' % (k, c['meta'])
+        _termsum_close(y, c['out'], t_out.numpy(), what + ' out')
+        _termsum_close(x.grad, c['g_x'], t_gx.numpy(), what + ' g_x')
+
+
+def test_tanh_approximation_bound(dev):
+    """gml_tanh (csrc/gml_common.h: 1 - 2 / (exp2(2 log2(e) x) + 1) on v_exp_f32 / v_rcp_f32) against tanh in fp64 through the
+    Hadamard-branch kernel (out = tanh(x w11 + b11) * tanh(x w12 + b12) with w11 = 1, w12 = 0, b12 = large: the second
+    factor is 1 to the last bit): absolute error <= 4e-7 over [-12, 12] -- a few ulp of 1.0, the bound DESIGN s6 states."""
+    from gnn_matlang_amd import functional as Fn, _lib
+    from gnn_matlang_amd.graph import _ptr, _stream
+    n = 1 << 16
+    xs = torch.linspace(-12, 12, n, dtype=torch.float64)
+    xs = torch.cat([xs, torch.tensor([0.0, 1e-4, -1e-4, 1e-8, 30.0, -30.0], dtype=torch.float64)])
+    x = xs.float().view(-1, 1).contiguous().to(dev)
+    w11 = torch.ones(1, 1, device=dev)
+    b11 = torch.zeros(1, device=dev)
+    w12 = torch.zeros(1, 1, device=dev)
+    b12 = torch.full((1,), 40.0, device=dev)
+    out = torch.empty(x.size(0), 1, device=dev)
+    _lib.call('gml_node_mix_fwd', _ptr(x), 1, _ptr(w11), _ptr(b11), _ptr(w12), _ptr(b12), _ptr(out), 1, x.size(0), 1, 1, _stream(dev))
+    ref = torch.tanh(x.cpu().double().view(-1))
+    err = (out.cpu().double().view(-1) - ref).abs().max().item()
+    assert err <= 4e-7, 'tanh approximation: max abs error %.3e' % err
