@@ -437,7 +437,7 @@ def main():
                 tblk.append(e0.elapsed_time(e1) / nrep * 1e-3)
             t_s = float(np.median(tblk))
             q_s = 4 * (csr.E * S_ + csr.N * Fin_ + csr.N * S_ * Fin_) + 4 * (csr.E + csr.N + 1)
-            res['spmm'] = {'kernel': 'gml_k_spectconv_fwd2<S, 0> via gml_spmm_fwd (8-wave SpMM, H written)', 'bound': 'hbm',
+            res['spmm'] = {'kernel': 'gml_k_spectconv_fwd2<S, 0> via gml_spmm_fwd_ex (8-wave SpMM, H written; groups beyond its staging: gml_k_spmm3)', 'bound': 'hbm',
                            'achieved': q_s / t_s / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': q_s / t_s / 1e9 / HBM_PEAK_GBS,
                            'avg_launch_ms': t_s * 1e3, 'algorithmic_bytes_per_launch': q_s, 'S': S_, 'Fin': Fin_,
                            'frac_of_copy_rate': q_s / t_s / 1e9 / res['hbm_copy_GBps'],
@@ -501,6 +501,13 @@ def main():
             res['other_configs'] = bench_configs.run(dev, quick=False)
             for oc in res['other_configs']:
                 log('other config %s: %.3f ms/step, %.2f M graphs/s' % (oc['config'], oc['ms_per_step'], oc['graphs_per_s'] / 1e6))
+            # ---- config 5 as SURVEY s8(d) specifies it: the 15 real sr25 graphs tiled to >= 1 M nodes, S in {6, 12, 24, 48}:
+            #      stand-alone SpMM GB/s against the roof per S + the forward-only model (sr25.py:282-300)
+            import bench_sr25_sweep
+            res['sr25_sweep'] = bench_sr25_sweep.run(dev)
+            for r5 in res['sr25_sweep']:
+                log('sr25 sweep S=%d: SpMM %.2f of the HBM roof (Fin 32), %.2f (Fin 48); forward %.2f ms' % (
+                    r5['S'], r5['spmm_Fin32']['frac'], r5['spmm_Fin48']['frac'], r5['forward']['ms']))
         if world == 1 and args.ref_batch > 0:
             # the reference's own batch size: launch-latency bound, so the step is replayed from a HIP graph
             rb, _ = build_batch(args.ref_batch, args.ref_batch, seed=7, device=dev)

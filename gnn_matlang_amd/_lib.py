@@ -38,6 +38,7 @@ SIGNATURES = {
     'gml_spectconv_bwd_mix': (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _i32,
                                              _i64, _i32, _i32, _i32, _i32, _i32, _u32, _p, _sz, _p]),
     'gml_spmm_fwd': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _p, _i64, _i32, _i32, _p]),
+    'gml_spmm_fwd_ex': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _p, _i64, _i32, _i32, _i32, _p]),
     'gml_sddmm': (ctypes.c_int, [_p, _p, _p, _p, _i64, _p, _p, _i64, _i32, _i32, _p]),
     'gml_edge_presplit': (ctypes.c_int, [_p, _p, _i64, _i32, _p]),
     'gml_edge_mlp_fwd': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),

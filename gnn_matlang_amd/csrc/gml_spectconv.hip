@@ -2,6 +2,7 @@
 #include "gml_spectconv_impl.h"
 #include "gml_spectconv_fwd2_impl.h"
 #include "gml_spectconv_fwd3_impl.h"
+#include "gml_spmm3_impl.h"
 
 #define GML_DECL_FWD2(S, B) template <> int gml_launch_fwd2<S, B>(const GmlFwdParams&, dim3, hipStream_t, bool, bool);
 GML_DECL_FWD2(8, 2) GML_DECL_FWD2(8, 1) GML_DECL_FWD2(4, 2) GML_DECL_FWD2(4, 1)
@@ -256,13 +257,45 @@ static int launch_spmm(const int32_t* rowptr, const int32_t* col, const int32_t*
     return gml_launch_status();
 }
 
+extern "C" int gml_spmm_fwd_ex(const int32_t* rowptr, const int32_t* col, const int32_t* ginfo128, const int32_t* epos,
+                               const float* val, const float* x, int64_t ldx, float* h, int64_t num_rows, int32_t S,
+                               int32_t Fin, int32_t max_group_edges, gml_stream_t stream);
 extern "C" int gml_spmm_fwd(const int32_t* rowptr, const int32_t* col, const int32_t* ginfo128, const int32_t* epos,
                             const float* val, const float* x, int64_t ldx, float* h, int64_t num_rows, int32_t S,
                             int32_t Fin, gml_stream_t stream) {
+    return gml_spmm_fwd_ex(rowptr, col, ginfo128, epos, val, x, ldx, h, num_rows, S, Fin, -1, stream);
+}
+
+extern "C" int gml_spmm_fwd_ex(const int32_t* rowptr, const int32_t* col, const int32_t* ginfo128, const int32_t* epos,
+                               const float* val, const float* x, int64_t ldx, float* h, int64_t num_rows, int32_t S,
+                               int32_t Fin, int32_t max_group_edges, gml_stream_t stream) {
     if (num_rows < 0 || S <= 0 || Fin <= 0 || ldx < Fin) return GML_E_BADARG;
     if (num_rows == 0) return GML_OK;
     if (!rowptr || !x || !h) return GML_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
+    // ring kernel (gml_spmm3_impl.h): any S (chunks of 4, 2, 1 supports), any Fin (chunks of 32 features), degrees up to ~16 per
+    // row on average staged in LDS.  GML_SPMM3=0: the r02 paths below, for A/B runs.
+    static const bool spmm3_on = [] { const char* e = getenv("GML_SPMM3"); return !(e && e[0] == '0'); }();
+    // Shapes the register-staged 8-wave kernel (fwd2, NOB = 0) covers keep it while every group fits its 1024-edge staging
+    // (ZINC: 0.65 vs 0.61 of the roof at 131,072 graphs); unknown group sizes (max_group_edges < 0): as before r03.
+    const bool fwd2_fits = fwd2_shape(S, Fin, 16, 0) && (((uintptr_t)val & 15) == 0) && (max_group_edges < 0 || max_group_edges <= GML_FWD2_ECAP);
+    if (spmm3_on && !fwd2_fits && ginfo128 != nullptr && epos == nullptr && (ldx % 4 == 0) && (((uintptr_t)x & 15) == 0) && Fin % 4 == 0 &&
+        (((uintptr_t)h & 15) == 0) && (((uintptr_t)val & 3) == 0) && (num_rows + 16) * ldx * 4 < (int64_t)INT32_MAX &&
+        (int64_t)128 * S * Fin * 4 < (int64_t)INT32_MAX && (int64_t)S * 4 * 24 <= GmlSpmm3Cfg::VAL_BYTES) {
+        GmlSpmm3Params q = {};
+        q.rowptr = rowptr; q.col = col; q.ginfo = ginfo128; q.val = val; q.ldx = ldx; q.h = h; q.nrows = num_rows; q.S = S; q.hs = Fin;
+        q.ngroups = (int)gml_cdiv(num_rows, 128);
+        int grid = q.ngroups < GML_NUM_CU ? q.ngroups : GML_NUM_CU;
+        q.groups_per_wg = (int)gml_cdiv(q.ngroups, grid);
+        grid = (int)gml_cdiv(q.ngroups, q.groups_per_wg);
+        for (int f0 = 0; f0 < Fin; f0 += 32) {                  // (feature chunks of 32: separate launches, the value rows are read again)
+            q.x = x + f0; q.Fin = (Fin - f0 < 32) ? Fin - f0 : 32; q.hf0 = f0;
+            const int rc = (S % 4 == 0) ? gml_launch_spmm3<4>(q, dim3(grid), st)
+                         : ((S % 2 == 0) ? gml_launch_spmm3<2>(q, dim3(grid), st) : gml_launch_spmm3<1>(q, dim3(grid), st));
+            if (rc != GML_OK) return rc;
+        }
+        return GML_OK;
+    }
     if (ginfo128 != nullptr && epos == nullptr && fwd2_shape(S, Fin, 16, 0) && (((uintptr_t)val & 15) == 0) &&
         (((uintptr_t)h & 15) == 0)) {
         // the 8-wave kernel's staged, degree-ranked aggregation; H written straight from the accumulators

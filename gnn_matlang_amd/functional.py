@@ -187,8 +187,11 @@ def ml3_edge_in_source_order(csr, S, Fin, Fout):
 
 def spmm(csr, val, x, S, Fin):
     h = torch.empty(csr.N, S * Fin, dtype=torch.float32, device=x.device)
-    _lib.call('gml_spmm_fwd', _ptr(csr.rowptr), _ptr(csr.col), _ptr(csr.ginfo128), _ptr(None), _ptr(val), _ptr(x), int(x.stride(0)),
-              _ptr(h), csr.N, int(S), int(Fin), _stream(x.device))
+    # hint for the kernel choice: the largest 128-row group (of the source view -- SpectralDesign's masks are symmetric, so of
+    # this view too; only the choice depends on it)
+    gm = csr.gmax_t128[0] if getattr(csr, 'gmax_t128', None) is not None else -1
+    _lib.call('gml_spmm_fwd_ex', _ptr(csr.rowptr), _ptr(csr.col), _ptr(csr.ginfo128), _ptr(None), _ptr(val), _ptr(x), int(x.stride(0)),
+              _ptr(h), csr.N, int(S), int(Fin), int(gm), _stream(x.device))
     return h
 
 

@@ -166,11 +166,18 @@ int gml_spectconv_bwd_mix(const int32_t* rowptr, const int32_t* col, const int32
                           void* ws, size_t ws_bytes, gml_stream_t stream);
 
 /* H[r, s, :] = sum_{k in row r} val[pos(k), s] * x[col[k], :]     H is [N, S, Fin] contiguous.
- * ginfo128 (optional): 128-row group records of this CSR -> staged, degree-ranked aggregation of the 8-wave kernel
- * (S in {4, 8, 12}, Fin <= 32, epos NULL); NULL: one-row-per-lane-group kernel for any shape. */
+ * ginfo128 (optional): 128-row group records of this CSR -> the LDS-DMA ring kernel (gml_spmm3_impl.h): any S, any Fin % 4 == 0,
+ * float4-addressable x rows, epos NULL, groups of up to ~2048 staged edges (larger ones gather from global memory, same
+ * results); NULL or an unsupported layout: one-row-per-lane-group kernel for any shape. */
 int gml_spmm_fwd(const int32_t* rowptr, const int32_t* col, const int32_t* ginfo128, const int32_t* epos,
                  const float* val, const float* x, int64_t ldx, float* h,
                  int64_t num_rows, int32_t S, int32_t Fin, gml_stream_t stream);
+/* the same with a hint: max_group_edges = the largest edge count of a 128-row group (max of ginfo128[:, 1]; < 0 = unknown).
+ * Only the kernel choice depends on it (the register-staged 8-wave kernel while every group fits its staging, else the ring
+ * kernel), never the result. */
+int gml_spmm_fwd_ex(const int32_t* rowptr, const int32_t* col, const int32_t* ginfo128, const int32_t* epos,
+                    const float* val, const float* x, int64_t ldx, float* h,
+                    int64_t num_rows, int32_t S, int32_t Fin, int32_t max_group_edges, gml_stream_t stream);
 
 /* dval[pos(k), s] = < x[col[k], :], gw[r, s, :] >  for k in row r;   gw is [N, S, Fin] contiguous */
 int gml_sddmm(const int32_t* rowptr, const int32_t* col, const int32_t* epos,

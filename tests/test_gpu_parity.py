@@ -1003,3 +1003,28 @@ def test_tanh_approximation_bound(dev):
     ref = torch.tanh(x.cpu().double().view(-1))
     err = (out.cpu().double().view(-1) - ref).abs().max().item()
     assert err <= 4e-7, 'tanh approximation: max abs error %.3e' % err
+
+
+@pytest.mark.parametrize('deg', [3, 13, 40])
+def test_spmm_ring_kernel_any_support_count(dev, deg):
+    """gml_spmm_fwd on the LDS-DMA ring kernel (csrc/gml_spmm3_impl.h): any S (value rows of 4 .. 192 bytes, every alignment
+    class), any Fin % 4 == 0 (feature chunks of 32), row degrees from sparse to beyond the staging capacity (deg = 40: blocks
+    that gather from global memory), partly filled last groups -- against the oracle's propagate (libs/spect_conv.py:77)."""
+    from gnn_matlang_amd import functional as Fn
+    from gnn_matlang_amd.graph import GraphCSR
+    from oracle import spect_conv_oracle as O
+    rng = np.random.default_rng(deg)
+    torch.manual_seed(deg)
+    for N in (333, 1000):
+        dst = np.repeat(np.arange(N), rng.integers(max(deg - 3, 0), deg + 4, N))
+        lo = np.maximum(dst - 30, 0)
+        src = lo + rng.integers(0, 61, dst.size) % np.minimum(61, N - lo)          # banded like a block-diagonal batch
+        o = np.lexsort((dst, src))
+        ei = np.stack([src[o], dst[o]]).astype(np.int64)
+        csr = GraphCSR.from_edge_index(T(ei).to(dev), N)
+        for S, fin in ((6, 32), (12, 48), (24, 32), (48, 32), (48, 48), (1, 4), (2, 20), (3, 32), (5, 64), (7, 8), (16, 12)):
+            ea, x = torch.randn(ei.shape[1], S), torch.randn(N, fin)
+            val = csr.sort_values(ea.to(dev), cache=False)
+            h = Fn.spmm(csr, val, x.to(dev), S, fin).view(N, S, fin)
+            href = torch.stack([O.propagate_add(x.double(), T(ei), ea[:, s].double()) for s in range(S)], 1)
+            close(h, href, what='spmm ring N=%d deg=%d S=%d Fin=%d' % (N, deg, S, fin))
