@@ -54,6 +54,9 @@ SIGNATURES = {
     'gml_segment_max': (ctypes.c_int, [_p, _i64, _p, _p, _i64, _p, _i64, _i32, _p]),
     'gml_segment_max_bwd': (ctypes.c_int, [_p, _i64, _p, _p, _p, _i64, _i64, _i32, _p]),
     'gml_dense_pack': (ctypes.c_int, [_p, _p, _i64, _i32, _i32, _i32, _p]),
+    'gml_dense_wimg_elems': (_sz, [_i32, _i32, _i32]),
+    'gml_dense_pack_w': (ctypes.c_int, [_p, _p, _i32, _i32, _i32, _p]),
+    'gml_dense_conv_fwd': (ctypes.c_int, [_p, _p, _i64, _p, _p, _p, _i64, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     'gml_dense_support_mm': (ctypes.c_int, [_p, _p, _i64, _i32, _p, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     'gml_spectral_count': (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i32, _i32, _p, _p]),
     'gml_spectral_design': (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i32, _i32, _i32, ctypes.c_double, _i32, ctypes.c_double,

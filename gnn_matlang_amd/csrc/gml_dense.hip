@@ -149,6 +149,241 @@ __global__ __launch_bounds__(384) void gml_k_dense_support_mm(GmlDenseParams p) 
     if constexpr (ACC) store(0);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Chained forward (libs/layers_tf.py:231-236 does `matmul(support, x)` THEN `tensordot(., W_i)` in one
+// op sequence): out = sum_s (D_s X) W_s + bias with the support product's accumulators as the projection's operand -- Hcat
+// [B n, S Fin] (230 KB per graph at MNIST's third layer) is neither written nor re-read by a library GEMM on this path
+// (WRITE_H: it is still written when the caller wants it for the weight gradient H^T g).
+//
+// The support product leaves (D_s X)^T in MFMA D layout: lane (row j, kq) holds features 16 ft + 4 kq + reg.  The k-slot
+// order of an MFMA is free as long as both operands use the same one, so the projection's K = 32 step t takes slot (kq, i)
+// = feature 32 t + 4 kq + i (i < 4) | 32 t + 16 + 4 kq + i - 4 (i >= 4): exactly what the lane already holds of tiles 2 t and
+// 2 t + 1 -- split to bf16 (hi, lo), no data movement.  The weights come pre-arranged in that order by gml_dense_pack_w:
+// wimg[s][t][ot][hi | lo][lane][8] (lane (o = 16 ot + (lane & 15), kq)), one 16-byte load per lane and fragment from L2
+// (Wcat 768 x 128 as bf16 hi / lo = 393 KB).  out^T = W^T H^T again lands transposed: a lane stores 4 consecutive outputs of
+// its own row.  bf16x3 throughout.
+template <int NFT, int NOT, bool WRITE_H>
+__global__ __launch_bounds__(384) void gml_k_dense_conv_fwd(GmlDenseParams p, const uint16_t* __restrict__ wimg,
+                                                            const float* __restrict__ bias, float* __restrict__ out2,
+                                                            int64_t ldo2, int Fout, int relu) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dn_lds[];
+    constexpr int PA = dn_pitch(NFT);
+    constexpr int NCH = 4 * NFT;
+    constexpr int KSMAX = 3;
+    constexpr int KT = (NFT + 1) / 2;                        // K = 32 steps of the projection
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
+    const int t16 = lane & 15, kq = lane >> 4;
+    const int b = blockIdx.x, n = p.n, KP = p.KP, KS = KP >> 5, F = p.F;
+    unsigned char* img_h = dn_lds;
+    unsigned char* img_l = dn_lds + KP * PA;
+    // W_s fragments of the current support, shared by the workgroup's waves: [t][ot][hi | lo][lane][16 bytes] (lane-linear:
+    // conflict-free ds_read_b128).  A first version loaded every fragment from L2 per wave and use (1.9 MB per graph at
+    // 128 x 128): no faster than the library GEMM it replaced.
+    constexpr int WS_BYTES = KT * NOT * 2 * 64 * 16;
+    unsigned char* wl_s = dn_lds + 2 * KP * PA;
+    const int row = wave * 16 + t16;
+    const int rowc = row < n ? row : n - 1;
+    const float* actb = p.act + (int64_t)b * n * p.lda;
+    float* outr = p.out + ((int64_t)b * n + rowc) * p.ldo;
+
+    for (int idx = tid; idx < KP * NCH; idx += nthr) {       // X of this graph -> (hi, lo) images [k][f], once
+        const int k = idx / NCH, ch = idx % NCH;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (k < n && 4 * ch < F) {
+            const float* q = actb + (int64_t)k * p.lda + 4 * ch;
+            if (p.vec_in) v = *reinterpret_cast<const f32x4*>(q);
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (4 * ch + j < F) v[j] = q[j];
+            }
+        }
+        const uint32_t h0 = dn_pack2(v[0], v[1]), h1 = dn_pack2(v[2], v[3]);
+        const uint32_t l0 = dn_pack2(v[0] - __uint_as_float(h0 << 16), v[1] - __uint_as_float(h0 & 0xffff0000u));
+        const uint32_t l1 = dn_pack2(v[2] - __uint_as_float(h1 << 16), v[3] - __uint_as_float(h1 & 0xffff0000u));
+        *reinterpret_cast<uint2*>(img_h + k * PA + 8 * ch) = uint2{h0, h1};
+        *reinterpret_cast<uint2*>(img_l + k * PA + 8 * ch) = uint2{l0, l1};
+    }
+    u32x4 bh[KSMAX], bl[KSMAX];
+    auto load_rows = [&](int s) {
+        const uint16_t* base = p.dimg + ((int64_t)(b * p.S + s) * 2 * n + rowc) * KP + 8 * kq;
+#pragma unroll
+        for (int ks = 0; ks < KSMAX; ++ks) {
+            const int kc = ks < KS ? ks : KS - 1;
+            bh[ks] = *reinterpret_cast<const u32x4*>(base + 32 * kc);
+            bl[ks] = *reinterpret_cast<const u32x4*>(base + (int64_t)n * KP + 32 * kc);
+        }
+    };
+    const int aoff = (8 * kq + (t16 >> 2)) * PA + 8 * (t16 & 3);
+    f32x4 oacc[NOT];
+#pragma unroll
+    for (int ot = 0; ot < NOT; ++ot) oacc[ot] = f32x4{0.f, 0.f, 0.f, 0.f};
+    load_rows(0);
+    __syncthreads();
+    for (int s = 0; s < p.S; ++s) {
+        f32x4 acc[NFT];
+#pragma unroll
+        for (int ft = 0; ft < NFT; ++ft) acc[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+        u32x4 ch[KSMAX], cl[KSMAX];
+#pragma unroll
+        for (int ks = 0; ks < KSMAX; ++ks) { ch[ks] = bh[ks]; cl[ks] = bl[ks]; }
+        if (s + 1 < p.S) load_rows(s + 1);
+#pragma unroll
+        for (int ks = 0; ks < KSMAX; ++ks) {
+            if (ks < KS) {
+                const bf16x8 Bh = __builtin_bit_cast(bf16x8, ch[ks]), Bl = __builtin_bit_cast(bf16x8, cl[ks]);
+                const unsigned char* ah = img_h + 32 * ks * PA + aoff;
+                const unsigned char* al = img_l + 32 * ks * PA + aoff;
+#pragma unroll
+                for (int ft = 0; ft < NFT; ++ft) {
+                    const bf16x8 Ah = dn_tr_frag(ah + 32 * ft, ah + 32 * ft + 4 * PA);
+                    const bf16x8 Al = dn_tr_frag(al + 32 * ft, al + 32 * ft + 4 * PA);
+                    acc[ft] = DN_MFMA(Al, Bh, acc[ft]);
+                    acc[ft] = DN_MFMA(Ah, Bl, acc[ft]);
+                    acc[ft] = DN_MFMA(Ah, Bh, acc[ft]);
+                }
+            }
+        }
+        if constexpr (WRITE_H) {                              // Hcat for the weight gradient (see the header)
+            if (row < n) {
+                float* o = outr + s * p.so + 4 * kq;
+#pragma unroll
+                for (int ft = 0; ft < NFT; ++ft) {
+                    const int f0 = 16 * ft + 4 * kq;
+                    if (f0 >= F) continue;
+                    if (p.vec_out) *reinterpret_cast<f32x4*>(o + 16 * ft) = acc[ft];
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) if (f0 + j < F) o[16 * ft + j] = acc[ft][j];
+                    }
+                }
+            }
+        }
+        // ---- projection of this support: out^T += W_s^T (D_s X)^T; the support's fragments through LDS
+        if (s > 0) __syncthreads();                          // every wave is done with the previous support's fragments
+        {
+            const u32x4* src = reinterpret_cast<const u32x4*>(wimg + (int64_t)s * (WS_BYTES / 2));
+            for (int i = tid; i < WS_BYTES / 16; i += nthr) reinterpret_cast<u32x4*>(wl_s)[i] = src[i];
+        }
+        __syncthreads();
+        const unsigned char* wb = wl_s + lane * 16;
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            const float hv[8] = {acc[2 * t][0], acc[2 * t][1], acc[2 * t][2], acc[2 * t][3],
+                                 (2 * t + 1 < NFT) ? acc[(2 * t + 1 < NFT) ? 2 * t + 1 : 0][0] : 0.f,
+                                 (2 * t + 1 < NFT) ? acc[(2 * t + 1 < NFT) ? 2 * t + 1 : 0][1] : 0.f,
+                                 (2 * t + 1 < NFT) ? acc[(2 * t + 1 < NFT) ? 2 * t + 1 : 0][2] : 0.f,
+                                 (2 * t + 1 < NFT) ? acc[(2 * t + 1 < NFT) ? 2 * t + 1 : 0][3] : 0.f};
+            bf16x8 hh, hl;
+            gml_split8(hv, hh, hl);
+#pragma unroll
+            for (int ot = 0; ot < NOT; ++ot) {
+                const unsigned char* wq = wb + (t * NOT + ot) * 2 * 64 * 16;
+                const bf16x8 Wh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wq));
+                const bf16x8 Wl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wq + 64 * 16));
+                oacc[ot] = DN_MFMA(Wl, hh, oacc[ot]);
+                oacc[ot] = DN_MFMA(Wh, hl, oacc[ot]);
+                oacc[ot] = DN_MFMA(Wh, hh, oacc[ot]);
+            }
+        }
+    }
+    if (row < n) {
+        float* o = out2 + ((int64_t)b * n + row) * ldo2 + 4 * kq;
+#pragma unroll
+        for (int ot = 0; ot < NOT; ++ot) {
+            const int o0 = 16 * ot + 4 * kq;
+            if (o0 >= Fout) continue;
+            f32x4 v = oacc[ot];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (bias != nullptr && o0 + j < Fout) v[j] += bias[o0 + j];
+                if (relu) v[j] = fmaxf(v[j], 0.f);
+            }
+            if (Fout % 4 == 0 && ldo2 % 4 == 0) *reinterpret_cast<f32x4*>(o + 16 * ot) = v;
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (o0 + j < Fout) o[16 * ot + j] = v[j];
+            }
+        }
+    }
+}
+
+// weight [S][Fin][Fout] fp32 -> projection fragments wimg[s][t][ot][hi | lo][lane][8] in the k-slot order of the chained kernel
+__global__ __launch_bounds__(256) void gml_k_dense_pack_w(const float* __restrict__ w, uint16_t* __restrict__ wimg, int S, int Fin,
+                                                          int Fout, int KT, int NOT) {
+    const int64_t total = (int64_t)S * KT * NOT * 64 * 8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int slot = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        const int64_t blk = i >> 9;                          // (s * KT + t) * NOT + ot
+        const int ot = (int)(blk % NOT), t = (int)((blk / NOT) % KT), s = (int)(blk / ((int64_t)NOT * KT));
+        const int o = 16 * ot + (lane & 15), kq = lane >> 4;
+        const int f = 32 * t + (slot < 4 ? 4 * kq + slot : 16 + 4 * kq + slot - 4);
+        const float v = (f < Fin && o < Fout) ? w[((int64_t)s * Fin + f) * Fout + o] : 0.f;
+        const uint32_t h = dn_pack2(v, 0.f) & 0xffffu;
+        const uint32_t l = dn_pack2(v - __uint_as_float(h << 16), 0.f) & 0xffffu;
+        wimg[((blk * 2) * 64 + lane) * 8 + slot] = (uint16_t)h;
+        wimg[((blk * 2 + 1) * 64 + lane) * 8 + slot] = (uint16_t)l;
+    }
+}
+
+extern "C" size_t gml_dense_wimg_elems(int32_t S, int32_t Fin, int32_t Fout) {
+    const int KT = ((Fin + 15) / 16 + 1) / 2, NOT = Fout <= 64 ? 4 : 8;
+    return (size_t)S * KT * NOT * 2 * 64 * 8;
+}
+
+extern "C" int gml_dense_pack_w(const float* w, uint16_t* wimg, int32_t S, int32_t Fin, int32_t Fout, void* stream) {
+    if (w == nullptr || wimg == nullptr) return GML_E_BADARG;
+    if (S < 1 || Fin < 1 || Fin > 128 || Fout < 1 || Fout > 128) return GML_E_UNSUPPORTED;
+    const int nft = (Fin + 15) / 16, NFT = nft <= 1 ? 1 : (nft <= 2 ? 2 : (nft <= 4 ? 4 : 8));
+    const int KT = (NFT + 1) / 2, NOT = Fout <= 64 ? 4 : 8;
+    const int64_t total = (int64_t)S * KT * NOT * 64 * 8;
+    hipLaunchKernelGGL(gml_k_dense_pack_w, dim3((unsigned)gml_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, wimg, S, Fin,
+                       Fout, KT, NOT);
+    return gml_launch_status();
+}
+
+template <int NFT, int NOT>
+static int dn_launch_conv(const GmlDenseParams& p, const uint16_t* wimg, const float* bias, float* out2, int64_t ldo2, int Fout,
+                          int relu, bool write_h, hipStream_t st) {
+    const size_t lds = (size_t)2 * p.KP * dn_pitch(NFT) + (size_t)((NFT + 1) / 2) * NOT * 2 * 64 * 16;
+    {
+        GML_ALLOW_BIG_LDS(rc1, (gml_k_dense_conv_fwd<NFT, NOT, true>), 160 * 1024);
+        GML_ALLOW_BIG_LDS(rc0, (gml_k_dense_conv_fwd<NFT, NOT, false>), 160 * 1024);
+        if (rc1 != hipSuccess) return (int)rc1;
+        if (rc0 != hipSuccess) return (int)rc0;
+    }
+    const int nwaves = (p.n + 15) / 16;
+    if (write_h) hipLaunchKernelGGL((gml_k_dense_conv_fwd<NFT, NOT, true>), dim3((unsigned)p.B), dim3(64 * nwaves), lds, st, p, wimg, bias, out2, ldo2, Fout, relu);
+    else hipLaunchKernelGGL((gml_k_dense_conv_fwd<NFT, NOT, false>), dim3((unsigned)p.B), dim3(64 * nwaves), lds, st, p, wimg, bias, out2, ldo2, Fout, relu);
+    return gml_launch_status();
+}
+
+// out2[(b n + r) ldo2 + o] = act?( sum_s sum_f (sum_k D[b][s][r][k] x[(b n + k) ldx + f]) W[s][f][o] + bias[o] );  hcat (optional):
+// [B n, S Fin] receives D_s X as gml_dense_support_mm(sum_s = 0) would write it.  wimg from gml_dense_pack_w.  Fin, Fout <= 128.
+extern "C" int gml_dense_conv_fwd(const uint16_t* dimg, const float* x, int64_t ldx, const uint16_t* wimg, const float* bias,
+                                  float* out2, int64_t ldo2, float* hcat, int32_t B, int32_t S, int32_t n, int32_t KP, int32_t Fin,
+                                  int32_t Fout, int32_t relu, void* stream) {
+    if (dimg == nullptr || x == nullptr || wimg == nullptr || out2 == nullptr || ldx < Fin || ldo2 < Fout) return GML_E_BADARG;
+    if (n < 1 || n > 96 || KP % 32 != 0 || KP < n || KP > 96 || Fin < 1 || Fin > 128 || Fout < 1 || Fout > 128 || S < 1 || B < 0)
+        return GML_E_UNSUPPORTED;
+    if (B == 0) return GML_OK;
+    GmlDenseParams p;
+    p.dimg = dimg; p.act = x; p.out = hcat; p.lda = ldx; p.ldo = (int64_t)S * Fin; p.sa = 0; p.so = Fin;
+    p.B = B; p.S = S; p.n = n; p.KP = KP; p.F = Fin;
+    p.vec_in = (Fin % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)x & 15) == 0) ? 1 : 0;
+    p.vec_out = (hcat != nullptr && Fin % 4 == 0 && ((uintptr_t)hcat & 15) == 0) ? 1 : 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int nft = (Fin + 15) / 16;
+    const bool wh = hcat != nullptr;
+#define DN_CONV(NFT)                                                                                             \
+    return Fout <= 64 ? dn_launch_conv<NFT, 4>(p, wimg, bias, out2, ldo2, Fout, relu, wh, st)                     \
+                      : dn_launch_conv<NFT, 8>(p, wimg, bias, out2, ldo2, Fout, relu, wh, st)
+    if (nft <= 1) { DN_CONV(1); }
+    if (nft <= 2) { DN_CONV(2); }
+    if (nft <= 4) { DN_CONV(4); }
+    DN_CONV(8);
+#undef DN_CONV
+}
+
 // fp32 blocks [B][S][n][n] (row-major; transpose = 1 takes block^T) -> bf16 (hi, lo) images [B][S][2][n][KP]
 __global__ __launch_bounds__(256) void gml_k_dense_pack(const float* __restrict__ blocks, uint16_t* __restrict__ img,
                                                         int64_t nblocks, int n, int KP, int transpose) {
@@ -183,7 +418,7 @@ extern "C" int gml_dense_pack(const float* blocks, uint16_t* img, int64_t nblock
 template <int NFT, bool ACC>
 static int dn_launch(const GmlDenseParams& p, hipStream_t st) {
     const size_t lds = (size_t)2 * p.KP * dn_pitch(NFT);
-    GML_ALLOW_BIG_LDS(rc, (gml_k_dense_support_mm<NFT, ACC>), lds);
+    GML_ALLOW_BIG_LDS(rc, (gml_k_dense_support_mm<NFT, ACC>), 2 * 96 * dn_pitch(NFT));   // (the attribute latches per device: the largest n)
     if (rc != hipSuccess) return (int)rc;
     const int nwaves = (p.n + 15) / 16;
     hipLaunchKernelGGL((gml_k_dense_support_mm<NFT, ACC>), dim3((unsigned)p.B), dim3(64 * nwaves), lds, st, p);

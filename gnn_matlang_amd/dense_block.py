@@ -126,6 +126,53 @@ class _TallGemm(torch.autograd.Function):
         return dh, dw, db
 
 
+CHAIN = os.environ.get('GML_DENSE_CHAIN', '1') not in ('0', '')      # projection chained behind the support product (gml_dense_conv_fwd)
+
+
+class _DenseConv(torch.autograd.Function):
+    """out = sum_s (D_s X) W_s + bias in ONE launch: the support product's accumulators are the projection's operand
+    (csrc/gml_dense.hip: gml_k_dense_conv_fwd), as libs/layers_tf.py:231-236 forms the layer.  Hcat is written only as the
+    saved tensor of the weight gradient dW = Hcat^T g (row-slab batched GEMM, see _TallGemm); dX = sum_s D_s^T (g W_s^T) is
+    the library GEMM g Wcat^T followed by the support product on the transposed images."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, sup):
+        S, Fin, Fout = weight.shape
+        x = x.contiguous()
+        dev = x.device
+        rows = sup.B * sup.n
+        wimg = torch.empty(int(_lib.lib().gml_dense_wimg_elems(S, Fin, Fout)), dtype=torch.int16, device=dev)
+        _lib.call('gml_dense_pack_w', _ptr(weight.contiguous()), _ptr(wimg), S, Fin, Fout, _stream(dev))
+        need_h = ctx.needs_input_grad[1]
+        hcat = torch.empty(rows, S * Fin, dtype=torch.float32, device=dev) if need_h else None
+        out = torch.empty(rows, Fout, dtype=torch.float32, device=dev)
+        Fn._path('dense', 'support product + projection chained (bf16x3 HIP)', S, Fin, Fout)
+        _lib.call('gml_dense_conv_fwd', _ptr(sup.fwd), _ptr(x), int(x.stride(0)), _ptr(wimg), _ptr(bias), _ptr(out), Fout,
+                  _ptr(hcat), sup.B, S, sup.n, sup.KP, Fin, Fout, 0, _stream(dev))
+        ctx.save_for_backward(hcat, weight)
+        ctx.sup, ctx.has_bias = sup, bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        hcat, weight = ctx.saved_tensors
+        sup = ctx.sup
+        S, Fin, Fout = weight.shape
+        g = g.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dh = g.mm(weight.reshape(S * Fin, Fout).t())
+            dx = support_mm(sup.bwd, dh, sup, Fin, Fin, 0, True)
+        if ctx.needs_input_grad[1]:
+            rows = int(hcat.size(0))
+            P = _splits(rows)
+            dw = (torch.bmm(hcat.view(P, rows // P, S * Fin).transpose(1, 2), g.view(P, rows // P, Fout)).sum(0) if P > 1
+                  else hcat.t().mm(g)).view(S, Fin, Fout)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = g.sum(0)
+        return dx, dw, db, None
+
+
 def spectconv_dense(x, sup, weight, bias, n):
     """x [B*n, Fin], sup from dense_supports, weight [S, Fin, Fout] -> [B*n, Fout] = sum_s (D_s x) W_s + bias."""
     S, Fin, Fout = weight.shape
@@ -139,5 +186,7 @@ def spectconv_dense(x, sup, weight, bias, n):
     else:
         if Fin > 128:
             raise ValueError('the dense-block kernel covers Fin <= 128, got %d' % Fin)
+        if CHAIN and Fout <= 128:
+            return _DenseConv.apply(x, weight, bias, sup)
         h = _SupportProduct.apply(x, sup)
     return _TallGemm.apply(h, weight.reshape(S * Fin, Fout), bias)

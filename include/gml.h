@@ -295,6 +295,16 @@ int gml_dense_pack(const float* blocks, uint16_t* img, int64_t nblocks, int32_t 
 int gml_dense_support_mm(const uint16_t* dimg, const float* act, int64_t lda, int32_t sa, float* out, int64_t ldo,
                          int32_t so, int32_t sum_s, int32_t B, int32_t S, int32_t n, int32_t KP, int32_t F,
                          gml_stream_t stream);
+/* The layer in ONE launch, as libs/layers_tf.py:231-236 forms it (matmul(support, x) then the projection by W_i): the support
+ * product's accumulators are the projection's operand, Hcat never goes through a library GEMM.
+ *   gml_dense_pack_w   : weight [S][Fin][Fout] fp32 -> bf16 (hi, lo) projection fragments (gml_dense_wimg_elems int16 elements)
+ *   gml_dense_conv_fwd : out2[(b n + r) ldo2 + o] = act?( sum_s sum_f (sum_k D[b][s][r][k] x[(b n + k) ldx + f]) W[s][f][o] + bias[o] );
+ *                        hcat (optional, [B n, S Fin] contiguous) receives D_s X for the caller's weight gradient. Fin, Fout <= 128. */
+size_t gml_dense_wimg_elems(int32_t S, int32_t Fin, int32_t Fout);
+int gml_dense_pack_w(const float* w, uint16_t* wimg, int32_t S, int32_t Fin, int32_t Fout, void* stream);
+int gml_dense_conv_fwd(const uint16_t* dimg, const float* x, int64_t ldx, const uint16_t* wimg, const float* bias,
+                       float* out2, int64_t ldo2, float* hcat, int32_t B, int32_t S, int32_t n, int32_t KP, int32_t Fin,
+                       int32_t Fout, int32_t relu, void* stream);
 
 /* ---------------------------------------------------------------- support precompute on the device (adjacent step, P1)
  * SpectralDesign.__call__ (libs/utils.py:546-610) for a batch of graphs with at most 80 nodes each (larger: host
