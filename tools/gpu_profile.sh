@@ -16,3 +16,15 @@ rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/${tag}_fetch -o ${tag}_fetch --output-format csv -- $BENCH > $out/${tag}_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/${tag}_write -o ${tag}_write --output-format csv -- $BENCH > $out/${tag}_write.log 2>&1
 find $out/${tag}_* -name '*.csv' | head -40
+# ---- round 3 additions: stand-alone SpMM traffic (both kernels), sr25 sweep, other configs, MNIST-75
+SPMM="python3 tools/bench_spmm.py"
+$SPMM > $out/${tag}_spmm.json 2> $out/${tag}_spmm.log
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/${tag}_spmm_fetch -o ${tag}_spmm_fetch --output-format csv -- $SPMM > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/${tag}_spmm_write -o ${tag}_spmm_write --output-format csv -- $SPMM > /dev/null 2>&1
+python3 tools/bench_sr25_sweep.py > $out/${tag}_sr25_sweep.jsonl 2> $out/${tag}_sr25_sweep.log
+SWEEP="python3 tools/bench_sr25_sweep.py --S 48 --nodes 500000"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/${tag}_sr25_fetch -o ${tag}_sr25_fetch --output-format csv -- $SWEEP > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/${tag}_sr25_write -o ${tag}_sr25_write --output-format csv -- $SWEEP > /dev/null 2>&1
+python3 tools/bench_configs.py > $out/${tag}_other_configs.jsonl 2> /dev/null
+python3 tools/bench_mnist.py 1024 > $out/${tag}_mnist_1024.json 2> /dev/null
+python3 tools/bench_mnist.py 4096 > $out/${tag}_mnist_4096.json 2> /dev/null

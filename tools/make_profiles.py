@@ -46,6 +46,17 @@ fz = [open(os.path.join(G, '%s_fuzz_%s.log' % (tag, s))).read().strip().splitlin
       if os.path.exists(os.path.join(G, '%s_fuzz_%s.log' % (tag, s)))]
 if fz:
     open(os.path.join(P, '%s_fuzz_parity.jsonl' % pre), 'w').write('\n'.join(fz) + '\n')
+for what, title in (('spmm', 'tools/bench_spmm.py (32,768 ZINC-like graphs, S = 8, Fin = 32: gml_spmm_fwd -> the 8-wave SpMM)'),
+                    ('sr25', 'tools/bench_sr25_sweep.py --S 48 --nodes 500000 (real sr25 graphs tiled, S = 48: gml_spmm_fwd_ex -> gml_k_spmm3)')):
+    fcsv = os.path.join(G, '%s_%s_fetch' % (tag, what), '%s_%s_fetch_counter_collection.csv' % (tag, what))
+    wcsv = os.path.join(G, '%s_%s_write' % (tag, what), '%s_%s_write_counter_collection.csv' % (tag, what))
+    if os.path.exists(fcsv) and os.path.exists(wcsv):
+        run('tools/hbm_traffic.py', fcsv, wcsv, os.path.join(P, '%s_%s_hbm_traffic' % (pre, 'spmm' if what == 'spmm' else 'sr25_spmm')),
+            title + ', commit %s' % commit)
+for name in ('spmm.json', 'sr25_sweep.jsonl'):
+    src = os.path.join(G, '%s_%s' % (tag, name))
+    if os.path.exists(src):
+        open(os.path.join(P, '%s_%s' % (pre, name.replace('spmm.json', 'spmm_bench.json'))), 'w').write(open(src).read())
 b = json.load(open(os.path.join(P, '%s_bench_default.json' % pre)))
 print('commit', commit, 'value', b['value'], 'ms/step', b['ms_per_step'])
 print(b['kernels_ms_per_step'])
