@@ -57,6 +57,25 @@ __device__ __forceinline__ void gml_dma16(u32x4 rs, uint32_t lds_addr, int voff)
                  : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rs) : "memory");
 }
 
+// 4 x 4 transpose between the registers of a lane and the lanes of its quad: out[r] of quad lane b = in[b] of quad lane r
+// (two butterfly stages of DPP quad_perm moves, 16 VALU operations)
+__device__ __forceinline__ void gml_quad_transpose(f32x4& v, int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2;
+    auto xch = [](float send, int ctrl_is_b1) {
+        const int x = __float_as_int(send);
+        return __int_as_float(ctrl_is_b1 ? __builtin_amdgcn_mov_dpp(x, 0x4E, 0xf, 0xf, true)      // quad_perm [2,3,0,1]
+                                         : __builtin_amdgcn_mov_dpp(x, 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+    };
+    {   // stage 1: 2 x 2 blocks, partner lane ^ 1, register pairs (0,1) and (2,3)
+        const float y0 = xch(b0 ? v[0] : v[1], 0), y1 = xch(b0 ? v[2] : v[3], 0);
+        if (b0) { v[0] = y0; v[2] = y1; } else { v[1] = y0; v[3] = y1; }
+    }
+    {   // stage 2: partner lane ^ 2, register pairs (0,2) and (1,3)
+        const float y0 = xch(b1 ? v[0] : v[2], 1), y1 = xch(b1 ? v[1] : v[3], 1);
+        if (b1) { v[0] = y0; v[1] = y1; } else { v[2] = y0; v[3] = y1; }
+    }
+}
+
 template <int S>
 struct GmlFwd3Cfg {
     static constexpr int ROWS = 128;
@@ -248,19 +267,36 @@ __global__ __launch_bounds__(GmlFwd3Cfg<S>::NT, 1) void gml_k_spectconv_fwd3(con
         float bias_r[NOB];
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob) bias_r[ob] = (p.bias && ob * 16 + r16 < p.Fout) ? p.bias[ob * 16 + r16] : 0.f;
-        bf16x8 mwh, mwl;                                       // B[k = f][n = c]: c < F2 -> w11 row c, F2 <= c < 2 F2 -> w12 row c - F2
+        // Wide output stores (one 16-byte store per lane and 16-column block instead of four 4-byte ones, the Hadamard columns
+        // merged into the conv tile they complete): possible when the row is written in whole float4 chunks -- columns
+        // [0, Fout (+ F2)) with mix_col = Fout, a multiple of 4 in total, float4-addressable rows.  ZINC: 30 + 2 = 32.
+        const int ncols = p.Fout + (MIX ? p.F2 : 0);
+        const int m0 = MIX ? (p.mix_col & 15) : 0;
+        const bool wide = !(GML_FWABL & 32) && ncols % 4 == 0 && p.ldo % 4 == 0 && ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0) &&
+                          (!MIX || (p.mix_col == p.Fout && (p.mix_col >> 4) == NOB - 1 && m0 + p.F2 <= 16 && p.F2 <= 8));
+        // B[k = f][n = c] of the Hadamard product.  Narrow stores: c < F2 -> w11 row c, F2 <= c < 2 F2 -> w12 row c - F2 (partner
+        // column c + F2).  Wide stores: w11 row i at column m0 + i -- where the product belongs in the conv tile -- and
+        // w12 row i at column (m0 + i) ^ 8 (partner = lane ^ 8).
+        bf16x8 mwh, mwl;
         float mbias = 0.f;
         if constexpr (MIX) {
+            int r11 = -1, r12 = -1;                            // the w11 / w12 row this lane's column carries
+            if (wide) {
+                if (r16 >= m0 && r16 < m0 + p.F2) r11 = r16 - m0;
+                else if ((r16 ^ 8) >= m0 && (r16 ^ 8) < m0 + p.F2) r12 = (r16 ^ 8) - m0;
+            } else {
+                if (r16 < p.F2) r11 = r16;
+                else if (r16 < 2 * p.F2) r12 = r16 - p.F2;
+            }
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int f = 8 * kq + j;
-                const bool ok = f < p.Fin && r16 < 2 * p.F2;
-                v[j] = ok ? (r16 < p.F2 ? p.w11[r16 * p.Fin + f] : p.w12[(r16 - p.F2) * p.Fin + f]) : 0.f;
+                v[j] = (f < p.Fin && r11 >= 0) ? p.w11[r11 * p.Fin + f] : ((f < p.Fin && r12 >= 0) ? p.w12[r12 * p.Fin + f] : 0.f);
             }
             gml_split8(v, mwh, mwl);
-            if (r16 < p.F2) mbias = p.b11 ? p.b11[r16] : 0.f;
-            else if (r16 < 2 * p.F2) mbias = p.b12 ? p.b12[r16 - p.F2] : 0.f;
+            if (r11 >= 0) mbias = p.b11 ? p.b11[r11] : 0.f;
+            else if (r12 >= 0) mbias = p.b12 ? p.b12[r12] : 0.f;
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                          // (A)
@@ -408,38 +444,73 @@ __global__ __launch_bounds__(GmlFwd3Cfg<S>::NT, 1) void gml_k_spectconv_fwd3(con
                 }
             }
             GML_TF3(6);
-            // output stores through a buffer descriptor based at this group's first row: lanes outside (row >= nr, column
-            // >= Fout) get an offset beyond the range and are dropped by the hardware -- no predicate
+            // output stores through a buffer descriptor based at this group's first row: lanes outside (row >= nr, column >=
+            // Fout) get an offset beyond the range and are dropped by the hardware -- no predicate
             const auto ors = __builtin_amdgcn_make_buffer_rsrc(p.out + r0 * p.ldo, 0, 0x7ffffe00, 0x00020000);
             const bool relu = (p.flags & GML_RELU) != 0;
+            if (wide) {
+                f32x4 ov[NOB];
 #pragma unroll
-            for (int ob = 0; ob < NOB; ++ob) {
-                const int o = ob * 16 + r16;
+                for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int lr = (int)((out_rows >> (8 * reg)) & 255u);
-                    float v = oacc[ob][reg] + bias_r[ob];
-                    if (relu) v = fmaxf(v, 0.f);
-                    const int off = (o < p.Fout && lr < nr && !(GML_FWABL & 4)) ? (lr * (int)p.ldo + o) * 4 : 0x7fffff00;
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ors, off, 0, 0);
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const float v = oacc[ob][reg] + bias_r[ob];
+                        ov[ob][reg] = relu ? fmaxf(v, 0.f) : v;
+                    }
+                if constexpr (MIX) {
+                    // z[row][c] = x[row] . wmix[c]: A = the lane's row (k = f), D: lane (c = r16, kq) holds rows 4*kq + reg
+                    bf16x8 xh, xl;
+                    gml_split8(xrow, xh, xl);
+                    f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+                    z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, mwh, z, 0, 0, 0);
+                    z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, mwl, z, 0, 0, 0);
+                    z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, mwh, z, 0, 0, 0);
+                    const bool mine = r16 >= m0 && r16 < m0 + p.F2;
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const float t = gml_tanh(z[reg] + mbias);
+                        const float u = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t), 0x128, 0xf, 0xf, true));   // row_ror:8 = lane ^ 8
+                        if (mine) ov[NOB - 1][reg] = t * u;
+                    }
                 }
-            }
-            GML_TF3(7);
-            if constexpr (MIX) {
-                // z[row][c] = x[row] . wmix[c]: A = the lane's row (k = f), D: lane (c = r16, kq) holds rows 4*kq + reg
-                bf16x8 xh, xl;
-                gml_split8(xrow, xh, xl);
-                f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
-                z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, mwh, z, 0, 0, 0);
-                z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, mwl, z, 0, 0, 0);
-                z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, mwh, z, 0, 0, 0);
+                const int lr = (int)((out_rows >> (8 * (r16 & 3))) & 255u);        // after the transpose: the row of register r16 & 3
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const float t = gml_tanh(z[reg] + mbias);
-                    const float u = __shfl(t, lane + p.F2);    // partner column c + F2 of the same 16-lane row group
-                    const int lr = (int)((out_rows >> (8 * reg)) & 255u);
-                    const int off = (r16 < p.F2 && lr < nr) ? (lr * (int)p.ldo + p.mix_col + r16) * 4 : 0x7fffff00;
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(t * u), ors, off, 0, 0);
+                for (int ob = 0; ob < NOB; ++ob) {
+                    gml_quad_transpose(ov[ob], lane);
+                    const int c = 16 * ob + 4 * (r16 >> 2);
+                    const int off = (c < ncols && lr < nr && !(GML_FWABL & 4)) ? (lr * (int)p.ldo + c) * 4 : 0x7fffff00;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov[ob]), ors, off, 0, 0);
+                }
+                GML_TF3(7);
+            } else {
+#pragma unroll
+                for (int ob = 0; ob < NOB; ++ob) {
+                    const int o = ob * 16 + r16;
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int lr = (int)((out_rows >> (8 * reg)) & 255u);
+                        float v = oacc[ob][reg] + bias_r[ob];
+                        if (relu) v = fmaxf(v, 0.f);
+                        const int off = (o < p.Fout && lr < nr && !(GML_FWABL & 4)) ? (lr * (int)p.ldo + o) * 4 : 0x7fffff00;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ors, off, 0, 0);
+                    }
+                }
+                GML_TF3(7);
+                if constexpr (MIX) {
+                    bf16x8 xh, xl;
+                    gml_split8(xrow, xh, xl);
+                    f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+                    z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, mwh, z, 0, 0, 0);
+                    z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, mwl, z, 0, 0, 0);
+                    z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, mwh, z, 0, 0, 0);
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const float t = gml_tanh(z[reg] + mbias);
+                        const float u = __shfl(t, lane + p.F2);    // partner column c + F2 of the same 16-lane row group
+                        const int lr = (int)((out_rows >> (8 * reg)) & 255u);
+                        const int off = (r16 < p.F2 && lr < nr) ? (lr * (int)p.ldo + p.mix_col + r16) * 4 : 0x7fffff00;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(t * u), ors, off, 0, 0);
+                    }
                 }
             }
             GML_TF3(8);
