@@ -39,10 +39,12 @@ __device__ __forceinline__ bf16x8 gml_tr_frag(const unsigned char* p0, const uns
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-// return code of the last launch on this thread (no sync).  Peek, not Get: the runtime's sticky error state is left
-// for whoever else checks it (torch), an unrelated earlier error is neither swallowed nor cleared here.
+// return code of the last launch on this thread (no sync).  hipGetLastError: reads AND clears the thread's last-error word,
+// so a failed launch is reported once, by the call that caused it -- with Peek (r02) a non-sticky error left behind by one
+// failed launch, or by any third-party call, made every later gml_* call return that stale code although its own launch
+// succeeded.  Sticky (device-fault) errors survive the read and keep failing every call, as they must.
 static inline int gml_launch_status() {
-    hipError_t e = hipPeekAtLastError();
+    hipError_t e = hipGetLastError();
     return e == hipSuccess ? GML_OK : (int)e;
 }
 

@@ -122,8 +122,9 @@ class DeviceDataset(object):
         ea2 = self.edge_attr2[epos] * eok.unsqueeze(1).to(self.edge_attr2.dtype)
         ptr = torch.cat([nptr, torch.full((1,), n_pad, dtype=torch.int64, device=dev)]).int()
         y = torch.cat([torch.where(has, self.y[idc], torch.zeros_like(self.y[idc])), torch.zeros(1, dtype=self.y.dtype, device=dev)])
-        b = Batch(x=x, edge_index=ei2, edge_index2=ei2, edge_attr2=ea2, batch=nseg, ptr=ptr, y=y,
-                  graph_valid=has.to(self.x.dtype))
+        # (no `edge_index`: the raw adjacency is not padded here -- a consumer of data.csr('edge_index'), e.g. a GNNML1 model or a
+        #  K = 1 raw-adjacency conv, must fail loudly on a padded batch instead of computing on the support edges)
+        b = Batch(x=x, edge_index2=ei2, edge_attr2=ea2, batch=nseg, ptr=ptr, y=y, graph_valid=has.to(self.x.dtype))
         b.static_caps = bounds['caps']
         return b
 

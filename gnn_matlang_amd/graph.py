@@ -37,7 +37,7 @@ def _require_cuda(t, name):
 class GraphCSR(object):
     __slots__ = ('N', 'E', 'device', 'rowptr', 'col', 'perm', 'rowptr_t', 'col_t', 'pos_t', 'perm_t', 'src_sorted',
                  '_ginfo', '_ginfo_t', '_gmax', '_gmax_t', 'ginfo_t128', 'gmax_t128', 'ginfo128', 'tpos', '_val_cache', '_keep', '_r64',
-                 '_r64t')
+                 '_r64t', '_bad')
 
     def __init__(self):
         self._val_cache = OrderedDict()
@@ -45,6 +45,7 @@ class GraphCSR(object):
         self._r64t = None
         self._r64 = None
         self._ginfo = self._ginfo_t = self._gmax = self._gmax_t = None
+        self._bad = None
 
     @staticmethod
     def from_edge_index(edge_index, num_nodes, assume_source_sorted=True, static_caps=None):
@@ -97,6 +98,7 @@ class GraphCSR(object):
             if static_caps is not None:
                 g.gmax_t128 = (int(static_caps[0]), int(static_caps[1]))
                 g.src_sorted = bool(assume_source_sorted)
+                g._bad = bad.clone()                           # not read here (no host read): see check()
                 return g
             mx = torch.stack([g.ginfo_t128[:, 1].max(), g.ginfo_t128[:, 3].max(), bad[0]]).tolist()
             g.gmax_t128 = (int(mx[0]), int(mx[1]))
@@ -107,9 +109,31 @@ class GraphCSR(object):
             g.src_sorted = bool(assume_source_sorted)
         return g
 
+    def check(self):
+        """Deferred validation of a CSR built with ``static_caps`` (the build itself reads nothing back, so that a HIP graph can
+        capture it): raises if the index kernels flagged node ids out of range (they were clamped) or unsorted source keys
+        (the source view then is NOT the one the kernels assume: gradients would be wrong).  One host read; call it once per
+        epoch, or after replaying a captured step on new data."""
+        bad = getattr(self, '_bad', None)
+        if bad is None:
+            return self
+        v = int(bad.item())
+        if v & 1:
+            raise IndexError('edge_index holds node ids outside [0, %d)' % self.N)
+        if v & 2:
+            raise ValueError('edge_index is not sorted by source: a static-shape batch must be (SpectralDesign emits it so)')
+        return self
+
+    @staticmethod
+    def _no_capture(what):
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('%s needs a device->host read (per-batch group maxima): not possible while a HIP graph is being '
+                               'captured -- this shape is outside the kernels served by static-shape batches' % what)
+
     def _need64(self):
         """64-row group records of both views (the 4-wave kernel families: shapes off the 8-wave kernels' set) + maxima"""
         if self._ginfo is None:
+            self._no_capture('GraphCSR: 64-row group records')
             with torch.cuda.device(self.device):
                 st = _stream(self.device)
                 i32 = dict(dtype=torch.int32, device=self.device)
@@ -131,6 +155,7 @@ class GraphCSR(object):
         """(records, (max edges, max window)) of the TARGET view in ranked 64-row groups: the staging schedule of the forward
         kernel's 4-wave geometry (GML_FWD_NW=4); built on first use."""
         if self._r64 is None:
+            self._no_capture('GraphCSR: ranked 64-row group records')
             with torch.cuda.device(self.device):
                 rec = int(_lib.lib().gml_csr_group_record_ints(_lib.GML_GROUPS64_RANKED))
                 gi = torch.zeros(max((self.N + 63) // 64, 1), rec, dtype=torch.int32, device=self.device)
@@ -143,6 +168,7 @@ class GraphCSR(object):
         """(records, (max edges, max window)) of the source view in ranked 64-row groups: the staging schedule of the
         4-wave backward kernel (two workgroups per CU); built on first use."""
         if self._r64t is None:
+            self._no_capture('GraphCSR: ranked 64-row group records')
             with torch.cuda.device(self.device):
                 rec = int(_lib.lib().gml_csr_group_record_ints(_lib.GML_GROUPS64_RANKED))
                 gi = torch.zeros(max((self.N + 63) // 64, 1), rec, dtype=torch.int32, device=self.device)

@@ -1028,3 +1028,43 @@ def test_spmm_ring_kernel_any_support_count(dev, deg):
             h = Fn.spmm(csr, val, x.to(dev), S, fin).view(N, S, fin)
             href = torch.stack([O.propagate_add(x.double(), T(ei), ea[:, s].double()) for s in range(S)], 1)
             close(h, href, what='spmm ring N=%d deg=%d S=%d Fin=%d' % (N, deg, S, fin))
+
+
+@pytest.mark.parametrize('n,S,Fin,Fout', [(75, 6, 2, 64), (75, 6, 64, 128), (75, 6, 128, 128), (5, 4, 48, 10), (33, 3, 7, 30), (64, 2, 20, 64),
+                                           (96, 2, 33, 100), (20, 1, 16, 16)])
+def test_dense_conv_chained_vs_fp64(dev, n, S, Fin, Fout):
+    """gml_dense_conv_fwd (csrc/gml_dense.hip: support product and projection in one launch, libs/layers_tf.py:231-236) through
+    dense_block._DenseConv: output, Hcat-based weight gradient and dX against fp64 einsum; ragged n, odd widths, mixed n in one
+    process (the big-LDS attribute of the kernels latches per device)."""
+    from gnn_matlang_amd import dense_block as DB
+    g = torch.Generator().manual_seed(7 * n + Fin + Fout)
+    B = 4
+    blocks = (torch.randn(B, S, n, n, generator=g) * (torch.rand(B, S, n, n, generator=g) < 0.8)).to(dev)
+    x = torch.randn(B * n, Fin, generator=g).to(dev).requires_grad_(True)
+    w = (torch.randn(S, Fin, Fout, generator=g) * 0.3).to(dev).requires_grad_(True)
+    b = torch.randn(Fout, generator=g).to(dev).requires_grad_(True)
+    sup = DB.DenseSupports(blocks, keep_blocks=False)
+    out = DB._DenseConv.apply(x, w, b, sup)
+    h = torch.einsum('bsji,bif->bjsf', blocks.double(), x.detach().double().view(B, n, Fin))
+    ref = torch.einsum('bjsf,sfo->bjo', h, w.detach().double()).reshape(B * n, Fout) + b.detach().double()
+    close(out, ref.float(), what='chained out n=%d S=%d %d->%d' % (n, S, Fin, Fout))
+    go = torch.randn(B * n, Fout, generator=g).to(dev)
+    out.backward(go)
+    gd = go.double().view(B, n, Fout)
+    close(w.grad, torch.einsum('bjsf,bjo->sfo', h, gd).float(), what='chained dW')
+    close(b.grad, gd.sum((0, 1)).float(), what='chained db')
+    dh = torch.einsum('bjo,sfo->bjsf', gd, w.detach().double())
+    close(x.grad, torch.einsum('bsji,bjsf->bif', blocks.double(), dh).reshape(B * n, Fin).float(), what='chained dX')
+
+
+def test_static_caps_csr_deferred_check(dev):
+    """GraphCSR built with static_caps reads nothing back (capturable); check() reports what the index kernels flagged"""
+    from gnn_matlang_amd.graph import GraphCSR
+    ei = torch.tensor([[0, 0, 1, 2, 2], [0, 1, 1, 0, 2]], device=dev)
+    GraphCSR.from_edge_index(ei, 3, static_caps=(8, 8)).check()                       # sorted, in range: fine
+    bad = GraphCSR.from_edge_index(torch.tensor([[1, 0, 2], [0, 1, 2]], device=dev), 3, static_caps=(8, 8))
+    with pytest.raises(ValueError):
+        bad.check()
+    oob = GraphCSR.from_edge_index(torch.tensor([[0, 1, 2], [0, 7, 2]], device=dev), 3, static_caps=(8, 8))
+    with pytest.raises(IndexError):
+        oob.check()
