@@ -37,6 +37,8 @@ SIGNATURES = {
     'gml_spectconv_bwd_mix_supported': (ctypes.c_int, [_i32, _i32, _i32, _i32, _u32]),
     'gml_spectconv_bwd_mix': (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _i32,
                                              _i64, _i32, _i32, _i32, _i32, _i32, _u32, _p, _sz, _p]),
+    'gml_spectconv_fwd_epi': (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _p, _p, _i64, _i64, _i32, _i32, _i32,
+                                             ctypes.c_uint32, _i32, _p, _i32, _p]),
     'gml_spmm_fwd': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _p, _i64, _i32, _i32, _p]),
     'gml_spmm_fwd_ex': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _p, _i64, _i32, _i32, _i32, _p]),
     'gml_sddmm': (ctypes.c_int, [_p, _p, _p, _p, _i64, _p, _p, _i64, _i32, _i32, _p]),
@@ -70,6 +72,7 @@ SIGNATURES = {
                                          _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _sz, _p]),
 }
 
+GML_OK, GML_E_BADARG, GML_E_UNSUPPORTED, GML_E_WORKSPACE = 0, -1, -2, -3
 GML_RELU, GML_ACCUM, GML_F32_MFMA, GML_GROUPS128, GML_GROUPS64R, GML_DMA_RING = 1, 2, 4, 8, 16, 32
 GML_GROUPS64_RANKED = 1064      # group kind of gml_csr_group_info: 64-row groups with rank bytes
 

@@ -102,6 +102,43 @@ static int launch_fwd2(const int32_t* rowptr, const int32_t* col, const int32_t*
     return GML_E_UNSUPPORTED;
 }
 
+// SpectConCatConv / depthwise SpectConv forward on the ring kernel's epilogues (see GmlFwdParams::epl).  epilogue = 1: out has
+// (S + self_term) column blocks of Fout, support s writes block s + self_term (+ bias of that block; block 0 of a selfconn layer,
+// x W_last, is the caller's GEMM); epilogue = 2: w is ONE [Fin, Fout] matrix (w_ss ignored), ds [S + self_term, Fin] the
+// per-feature scales (row 0 = 1 + DSweight[0]; last row = the self term's scale when self_term): out = (sum_s ds_s . H_s +
+// ds_self . x) W + bias.  GML_E_UNSUPPORTED outside the kernel's shape class (S in {4, 8}, Fin, Fout <= 32, float4-addressable
+// x): the caller then uses the weight-transform mapping onto gml_spectconv_fwd.
+extern "C" int gml_spectconv_fwd_epi(const int32_t* rowptr, const int32_t* col, const int32_t* ginfo128, const float* val,
+                                     const float* x, int64_t ldx, const float* w, int64_t w_ss, int64_t w_si, int64_t w_so,
+                                     const float* bias, float* out, int64_t ldo, int64_t num_rows, int32_t S, int32_t Fin,
+                                     int32_t Fout, uint32_t flags, int32_t epilogue, const float* ds, int32_t self_term,
+                                     gml_stream_t stream) {
+    if (num_rows < 0 || S <= 0 || Fin <= 0 || Fout <= 0 || ldx < Fin) return GML_E_BADARG;
+    if (epilogue != 1 && epilogue != 2) return GML_E_BADARG;
+    if (epilogue == 2 && ds == nullptr) return GML_E_BADARG;
+    if (ldo < (epilogue == 1 ? (int64_t)(S + (self_term ? 1 : 0)) * Fout : Fout)) return GML_E_BADARG;
+    if (num_rows == 0) return GML_OK;
+    if (!rowptr || !ginfo128 || !x || !w || !out) return GML_E_BADARG;
+    const bool xv = (ldx % 4 == 0) && (((uintptr_t)x & 15) == 0);
+    if (!fwd2_shape(S, Fin, Fout, flags) || !(S == 8 || S == 4) || !xv || !fwd3_env() || (flags & GML_ACCUM) ||
+        (((uintptr_t)val & 15) != 0) || (num_rows + 16) * ldx * 4 >= (int64_t)INT32_MAX)
+        return GML_E_UNSUPPORTED;
+    GmlFwdParams p = {};
+    p.rowptr = rowptr; p.col = col; p.ginfo = ginfo128; p.val = val; p.x = x; p.ldx = ldx;
+    p.w = w; p.w_ss = w_ss; p.w_si = w_si; p.w_so = w_so; p.bias = bias; p.out = out; p.ldo = ldo;
+    p.nrows = num_rows; p.S = S; p.Fin = Fin; p.Fout = Fout; p.flags = flags; p.npass = 1; p.nchunks = 1; p.val_vec = 1;
+    p.nw = 8; p.epl = epilogue; p.ds = ds; p.ds_self = self_term ? 1 : 0; p.cc_off = self_term ? 1 : 0;
+    p.ngroups = (int)gml_cdiv(num_rows, 128);
+    int grid = p.ngroups < GML_NUM_CU ? p.ngroups : GML_NUM_CU;
+    p.groups_per_wg = (int)gml_cdiv(p.ngroups, grid);
+    grid = (int)gml_cdiv(p.ngroups, p.groups_per_wg);
+    const int nob = Fout > 16 ? 2 : 1;
+    hipStream_t st = (hipStream_t)stream;
+#define GML_FWD3_EPI(SV, B) if (S == SV && nob == B) return gml_launch_fwd3<SV, B>(p, dim3(grid), st, false);
+    GML_FWD3_EPI(8, 2) GML_FWD3_EPI(8, 1) GML_FWD3_EPI(4, 2) GML_FWD3_EPI(4, 1)
+    return GML_E_UNSUPPORTED;
+}
+
 extern "C" int gml_spectconv_fwd(const int32_t* rowptr, const int32_t* col, const int32_t* ginfo, const int32_t* epos,
                                  const float* val, const float* x, int64_t ldx,
                                  const float* w, int64_t w_ss, int64_t w_si, int64_t w_so,

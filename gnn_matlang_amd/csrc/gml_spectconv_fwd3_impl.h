@@ -101,10 +101,14 @@ struct GmlFwd3Cfg {
 };
 
 // MIX: the ML3Layer Hadamard branch (F2 <= 8) of the group's own rows rides along (see fwd2); EP: value rows through p.epos
-template <int S, int NOB, bool MIX, bool EP>
+// EPL: epilogue (GmlFwdParams::epl): 0 sum over supports, 1 ConCat column blocks, 2 depthwise scale-then-one-projection
+template <int S, int NOB, bool MIX, bool EP, int EPL = 0>
 __global__ __launch_bounds__(GmlFwd3Cfg<S>::NT, 1) void gml_k_spectconv_fwd3(const GmlFwdParams p) {
     using C = GmlFwd3Cfg<S>;
     static_assert(S % 4 == 0, "float4 value rows");
+    static_assert(EPL == 0 || (!MIX && !EP), "epilogue variants: plain SpectConv calls");
+    constexpr bool OWNX = MIX || EPL == 2;                     // the lane's own x row is needed (Hadamard branch / depthwise self term)
+    constexpr int SW = EPL == 2 ? 1 : S;                       // W images (depthwise: one matrix)
     constexpr int ROWS = C::ROWS, ECAP = C::ECAP, XCAP = C::XCAP;
     constexpr int VROW = S * 4;                                // bytes of a value row
     constexpr int LPE = S / 4;                                 // lanes (16 bytes each) per value row
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(GmlFwd3Cfg<S>::NT, 1) void gml_k_spectconv_fwd3(con
     const bool loader = wave >= 8;
 
     // ---- once per workgroup: W image, zeroed X areas (chunks at or beyond Fin are never written by a DMA and stay zero)
-    for (int e = tid; e < S * 32 * 32; e += C::NT) {
+    for (int e = tid; e < SW * 32 * 32; e += C::NT) {
         const int f = e & 31, o = (e >> 5) & 31, s = e >> 10;
         const float v = (f < p.Fin && o < p.Fout) ? p.w[(int64_t)(p.s0 + s) * p.w_ss + (int64_t)f * p.w_si + (int64_t)o * p.w_so] : 0.f;
         const __bf16 h = (__bf16)v;
@@ -131,6 +135,13 @@ __global__ __launch_bounds__(GmlFwd3Cfg<S>::NT, 1) void gml_k_spectconv_fwd3(con
         const int iof = (s * 32 + o) * 32 + ((((f >> 3) ^ gml_wkey(o)) & 3) << 3) + (f & 7);
         Wof_h[iof] = h;
         Wof_l[iof] = l;
+    }
+    float* ds_l = reinterpret_cast<float*>(lds_raw + 8192);   // depthwise: [S + 1][32] scales behind the single W image (4 KB hi + lo)
+    if constexpr (EPL == 2) {
+        for (int e = tid; e < (S + 1) * 32; e += C::NT) {
+            const int f = e & 31, s = e >> 5;
+            ds_l[e] = (f < p.Fin && (s < S || p.ds_self)) ? p.ds[s * p.Fin + f] : 0.f;
+        }
     }
 #pragma unroll
     for (int sl = 0; sl < 2; ++sl)
@@ -146,7 +157,7 @@ __global__ __launch_bounds__(GmlFwd3Cfg<S>::NT, 1) void gml_k_spectconv_fwd3(con
         const int r0 = g * ROWS;
         const int nr = (int)min((int64_t)ROWS, p.nrows - (int64_t)r0);
         int wlo = ne > 0 ? lo : r0, whi = ne > 0 ? lo + nwin : r0;
-        if constexpr (MIX) { wlo = min(wlo, r0); whi = max(whi, r0 + nr); }      // the group's own rows (Hadamard branch)
+        if constexpr (OWNX) { wlo = min(wlo, r0); whi = max(whi, r0 + nr); }     // the group's own rows (Hadamard branch, depthwise self term)
         Geo q;
         q.kb4 = kb & ~3; q.ne4 = ne + (kb & 3);
         q.lo8 = wlo & ~7; q.nwin8 = whi - q.lo8;
@@ -324,7 +335,7 @@ __global__ __launch_bounds__(GmlFwd3Cfg<S>::NT, 1) void gml_k_spectconv_fwd3(con
             const int xoff = C::OFF_SLOT + (g & 1) * C::SLOT_BYTES + C::OFF_X + kq * 32 - q.lo8 * 130;
             const int kbeg = rvalid ? rp_l[row] : 0;
             const int kend = rvalid ? rp_l[row + 1] : 0;
-            float xrow[MIX ? 8 : 1];                           // the lane's own x row, features 8*kq..8*kq+7 (Hadamard branch)
+            float xrow[OWNX ? 8 : 1];                          // the lane's own x row, features 8*kq..8*kq+7
             GML_TF3(3);
 
             // ---- aggregation (fp32 VALU, packed): acc[s][f] += val[k, s] * x[col[k], f], f = 8*kq .. 8*kq+7
@@ -373,7 +384,7 @@ __global__ __launch_bounds__(GmlFwd3Cfg<S>::NT, 1) void gml_k_spectconv_fwd3(con
                         if (++k >= ke) break;
                     }
                 }
-                if constexpr (MIX) {
+                if constexpr (OWNX) {
                     const int c = (int)r0 + min(row, nr - 1);
                     const int off = xoff + c * 128 + ((c & ~7) << 1);
                     const f32x4 t0 = *reinterpret_cast<const f32x4*>(lds_raw + off);
@@ -395,7 +406,7 @@ __global__ __launch_bounds__(GmlFwd3Cfg<S>::NT, 1) void gml_k_spectconv_fwd3(con
                         for (int h = 0; h < 4; ++h) acc[s][h] = e2 * f32x2{xb[2 * h], xb[2 * h + 1]} + acc[s][h];
                     }
                 }
-                if constexpr (MIX) {
+                if constexpr (OWNX) {
                     const float* xr = p.x + (r0 + min(row, nr - 1)) * p.ldx;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
@@ -410,7 +421,58 @@ __global__ __launch_bounds__(GmlFwd3Cfg<S>::NT, 1) void gml_k_spectconv_fwd3(con
             f32x4 oacc[NOB];
 #pragma unroll
             for (int ob = 0; ob < NOB; ++ob) oacc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
-            {
+            if constexpr (EPL == 2) {
+                // depthwise (libs/spect_conv.py:81-91): scale the aggregates per feature, add the scaled own row, project ONCE
+                float hs[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) hs[j] = ds_l[S * 32 + 8 * kq + j] * xrow[j];
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const f32x4 d0 = *reinterpret_cast<const f32x4*>(ds_l + s * 32 + 8 * kq);
+                    const f32x4 d1 = *reinterpret_cast<const f32x4*>(ds_l + s * 32 + 8 * kq + 4);
+                    hs[0] += d0.x * acc[s][0].x; hs[1] += d0.y * acc[s][0].y; hs[2] += d0.z * acc[s][1].x; hs[3] += d0.w * acc[s][1].y;
+                    hs[4] += d1.x * acc[s][2].x; hs[5] += d1.y * acc[s][2].y; hs[6] += d1.z * acc[s][3].x; hs[7] += d1.w * acc[s][3].y;
+                }
+                bf16x8 ah, al;
+                gml_split8(hs, ah, al);
+#pragma unroll
+                for (int ob = 0; ob < NOB; ++ob) {
+                    const int o = ob * 16 + r16;
+                    const int off = o * 32 + (((kq ^ gml_wkey(o)) & 3) << 3);
+                    const bf16x8 wh = *reinterpret_cast<const bf16x8*>(Wof_h + off), wl = *reinterpret_cast<const bf16x8*>(Wof_l + off);
+                    oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wh, oacc[ob], 0, 0, 0);
+                    oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wl, oacc[ob], 0, 0, 0);
+                    oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wh, oacc[ob], 0, 0, 0);
+                }
+            } else if constexpr (EPL == 1) {
+                // ConCat (libs/spect_conv.py:137-158): support s projects into its own column block s + cc_off of the output row
+                const auto crs = __builtin_amdgcn_make_buffer_rsrc(p.out + r0 * p.ldo, 0, 0x7ffffe00, 0x00020000);
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const float av[8] = {acc[s][0].x, acc[s][0].y, acc[s][1].x, acc[s][1].y, acc[s][2].x, acc[s][2].y, acc[s][3].x, acc[s][3].y};
+                    bf16x8 ah, al;
+                    gml_split8(av, ah, al);
+                    const int cb = (s + p.cc_off) * p.Fout;
+#pragma unroll
+                    for (int ob = 0; ob < NOB; ++ob) {
+                        const int o = ob * 16 + r16;
+                        const int off = (s * 32 + o) * 32 + (((kq ^ gml_wkey(o)) & 3) << 3);
+                        const bf16x8 wh = *reinterpret_cast<const bf16x8*>(Wof_h + off), wl = *reinterpret_cast<const bf16x8*>(Wof_l + off);
+                        f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+                        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wh, d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wl, d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wh, d, 0, 0, 0);
+                        const float bv = (p.bias && o < p.Fout) ? p.bias[cb + o] : 0.f;
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) {
+                            const int lr = (int)((out_rows >> (8 * reg)) & 255u);
+                            const int offb = (o < p.Fout && lr < nr) ? (lr * (int)p.ldo + cb + o) * 4 : 0x7fffff00;
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d[reg] + bv), crs, offb, 0, 0);
+                        }
+                    }
+                }
+                continue;                                      // (every block is stored: nothing left for the common epilogue)
+            } else {
                 bf16x8 wh[2][NOB], wl[2][NOB];
                 auto frag = [&](int s, int st) {
 #pragma unroll
@@ -527,17 +589,23 @@ __global__ __launch_bounds__(GmlFwd3Cfg<S>::NT, 1) void gml_k_spectconv_fwd3(con
 template <int S, int NOB>
 int gml_launch_fwd3(const GmlFwdParams& p, dim3 grid, hipStream_t st, bool mix);
 
-#define GML_FWD3_LAUNCH(SV, NOBV, MX, EPV)                                                                   \
+#define GML_FWD3_LAUNCH_L(SV, NOBV, MX, EPV, EPLV)                                                           \
     {                                                                                                        \
-        GML_ALLOW_BIG_LDS(rc_, (&gml_k_spectconv_fwd3<SV, NOBV, MX, EPV>), 160 * 1024)                       \
+        GML_ALLOW_BIG_LDS(rc_, (&gml_k_spectconv_fwd3<SV, NOBV, MX, EPV, EPLV>), 160 * 1024)                 \
         if (rc_ != hipSuccess) return (int)rc_;                                                              \
-        hipLaunchKernelGGL((gml_k_spectconv_fwd3<SV, NOBV, MX, EPV>), grid, dim3(GmlFwd3Cfg<SV>::NT),                       \
+        hipLaunchKernelGGL((gml_k_spectconv_fwd3<SV, NOBV, MX, EPV, EPLV>), grid, dim3(GmlFwd3Cfg<SV>::NT),  \
                            GmlFwd3Cfg<SV>::lds_bytes(), st, p);                                              \
         return gml_launch_status();                                                                          \
     }
+#define GML_FWD3_LAUNCH(SV, NOBV, MX, EPV) GML_FWD3_LAUNCH_L(SV, NOBV, MX, EPV, 0)
 #define GML_DEFINE_FWD3(SV, NOBV)                                                                            \
     template <>                                                                                              \
     int gml_launch_fwd3<SV, NOBV>(const GmlFwdParams& p, dim3 grid, hipStream_t st, bool mix) {              \
+        if (p.epl != 0) {   /* ConCat / depthwise epilogues: plain SpectConv calls (no Hadamard branch, no position map) */  \
+            if (mix || p.epos != nullptr) return GML_E_UNSUPPORTED;                                          \
+            if (p.epl == 1) GML_FWD3_LAUNCH_L(SV, NOBV, false, false, 1)                                     \
+            GML_FWD3_LAUNCH_L(SV, NOBV, false, false, 2)                                                     \
+        }                                                                                                    \
         if (p.epos != nullptr) {                                                                             \
             if (mix) GML_FWD3_LAUNCH(SV, NOBV, true, true)                                                   \
             GML_FWD3_LAUNCH(SV, NOBV, false, true)                                                           \

@@ -49,6 +49,10 @@ struct GmlFwdParams {
     float* hout;          // stand-alone SpMM on the 8-wave kernel: H [N, S, Fin] receives the aggregate, no projection
     unsigned long long* prof;   // timing build (-DGML_FWD2_TIMING): per-phase cycle sums
     int32_t nw;           // 8-wave kernel family: waves per workgroup (8: 128-row groups, 4: ranked 64-row groups)
+    // epilogues of the ring kernel (gml_spectconv_fwd_epi): 0 = sum_s H_s W_s; 1 = SpectConCatConv: H_s W_s written to column block
+    // s + cc_off (libs/spect_conv.py:137-158); 2 = depthwise: (sum_s ds[s] . H_s + ds[S] . x) W_0 (libs/spect_conv.py:81-91)
+    const float* ds;      // depthwise: [S (+ 1 if ds_self), Fin] scales (row 0 already holds 1 + DSweight[0])
+    int32_t epl, ds_self, cc_off;
 };
 
 // Per-group staging capacities.  A group = 64 consecutive output rows = the 4 tiles a workgroup

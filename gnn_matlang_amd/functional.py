@@ -151,6 +151,30 @@ def _fused_conv(rowptr, col, ginfo, epos, val, x, ldx, w, w_strides, bias, out, 
               int(flags) | (_lib.GML_F32_MFMA if F32_MFMA else 0), _stream(x.device))
 
 
+def conv_epilogue_applies(S, Fin, Fout):
+    """shape class of gml_spectconv_fwd_epi (the ring kernel's ConCat / depthwise epilogues); GML_NO_EPILOGUE=1: the mapping"""
+    return (not F32_MFMA) and S in (4, 8) and Fin <= 32 and Fout <= 32 and not _os.environ.get('GML_NO_EPILOGUE') \
+        and not _os.environ.get('GML_FWD64') and _os.environ.get('GML_FWD_DMA', '1') != '0'
+
+
+def conv_epilogue(csr, x, val, w, bias, S, epilogue, ds, self_term, ncols):
+    """one launch of gml_spectconv_fwd_epi: epilogue 1 = ConCat column blocks, 2 = depthwise; returns out [N, ncols] or None when
+    the library reports the shape unsupported.  x: float4-addressable rows (rows4), val: target-sorted supports [E, S]."""
+    Fin, Fout = int(w.size(-2)), int(w.size(-1))
+    N = csr.N
+    out = torch.empty(N, int(ncols), dtype=torch.float32, device=x.device)
+    w = w.contiguous()
+    b = _f32c(bias.detach(), 'bias') if bias is not None else None
+    rc = _lib.lib().gml_spectconv_fwd_epi(_ptr(csr.rowptr), _ptr(csr.col), _ptr(csr.ginfo128), _ptr(val), _ptr(x), int(x.stride(0)),
+                                          _ptr(w), Fin * Fout, Fout, 1, _ptr(b), _ptr(out), int(ncols), N, int(S), Fin, Fout, 0,
+                                          int(epilogue), _ptr(ds), 1 if self_term else 0, _stream(x.device))
+    if rc == _lib.GML_E_UNSUPPORTED:
+        return None
+    _lib.check(rc)
+    _path('conv_fwd', 'ring kernel, %s epilogue' % ('ConCat' if epilogue == 1 else 'depthwise'), S, Fin, Fout)
+    return out
+
+
 def fwd_groups(csr, x, S, Fin, Fout):
     """(group records, extra flags) the forward kernel wants for this shape: the 8-wave kernel on 128-row records when
     the shape is compiled for it, else the 64-row kernel."""

@@ -107,28 +107,44 @@ class SpectConv(torch.nn.Module):
         if self.depthwise:
             zeros(self.DSweight)
 
-    def _effective(self):
+    def _effective(self, weight=None, dsw=None):
         """(support weights [S, Fin, Fout], self weight [Fin, Fout] or None) of the equivalent plain form."""
+        weight = self.weight if weight is None else weight
         if not self.depthwise:
             if self.selfconn:
-                return self.weight[:-1], self.weight[-1]
-            return self.weight, None
-        ds = self.DSweight
+                return weight[:-1], weight[-1]
+            return weight, None
+        ds = self.DSweight if dsw is None else dsw
         nsup = self.nsup - 1 if self.selfconn else self.nsup
         scale = torch.cat([1 + ds[0:1], ds[1:nsup]], 0)                 # [S, Fin]
-        w = scale.unsqueeze(-1) * self.weight[0].unsqueeze(0)           # diag(scale_s) W_0
-        wself = ds[-1].unsqueeze(-1) * self.weight[0] if self.selfconn else None
+        w = scale.unsqueeze(-1) * weight[0].unsqueeze(0)                # diag(scale_s) W_0
+        wself = ds[-1].unsqueeze(-1) * weight[0] if self.selfconn else None
         return w, wself
+
+    def _mapped(self, x, csr, edge_index, edge_attr, weight=None, bias=None, dsw=None):
+        """the layer through the default-branch kernels and (for depthwise) effective weights diag(DS_s) W_0; differentiable"""
+        bias = self.bias if (bias is None and weight is None) else bias
+        w, wself = self._effective(weight, dsw)
+        val = _sorted_values(csr, edge_index, edge_attr, w.size(0))
+        out = SpectConvFunction.apply(x, val, w.contiguous(), None if wself is not None else bias, csr, False)
+        if wself is not None:
+            out = torch.addmm(bias, x, wself) + out if bias is not None else torch.mm(x, wself) + out
+        return out
+
+    def _epilogue(self, x, csr, val):
+        """depthwise branch in ONE launch on the ring kernel's epilogue (scale-then-one-projection, libs/spect_conv.py:81-91);
+        None when the shape is outside that kernel"""
+        ds = self.DSweight
+        nsup = self.nsup - 1 if self.selfconn else self.nsup
+        scale = torch.cat([1 + ds[0:1], ds[1:nsup]] + ([ds[-1:]] if self.selfconn else []), 0).detach().contiguous()
+        return Fn.conv_epilogue(csr, x, val, self.weight[0].detach(), self.bias, nsup, 2, scale, self.selfconn, self.out_channels)
 
     def forward(self, x, edge_index, edge_attr, edge_weight=None, batch=None, lambda_max=None):
         _require_cuda(x, 'x')
         csr = csr_for(edge_index, x.size(0))
-        w, wself = self._effective()
-        val = _sorted_values(csr, edge_index, edge_attr, w.size(0))
-        out = SpectConvFunction.apply(x, val, w.contiguous(), None if wself is not None else self.bias, csr, False)
-        if wself is not None:
-            out = torch.addmm(self.bias, x, wself) + out if self.bias is not None else torch.mm(x, wself) + out
-        return out
+        if self.depthwise and Fn.conv_epilogue_applies(self.nsup - 1 if self.selfconn else self.nsup, self.in_channels, self.out_channels):
+            return _EpilogueFn.apply(self, csr, edge_index, x, edge_attr, self.weight, self.bias, self.DSweight)
+        return self._mapped(x, csr, edge_index, edge_attr)
 
     def __repr__(self):
         return '{}({}, {}, K={})'.format(self.__class__.__name__, self.in_channels, self.out_channels,
@@ -158,29 +174,83 @@ class SpectConCatConv(torch.nn.Module):
         glorot(self.weight)
         zeros(self.bias)
 
-    def forward(self, x, edge_index, edge_attr, edge_weight=None, batch=None, lambda_max=None):
-        _require_cuda(x, 'x')
-        csr = csr_for(edge_index, x.size(0))
-        Kp, Fin, Fout = self.weight.shape
+    def _mapped(self, x, csr, edge_index, edge_attr, weight=None, bias=None, dsw=None):
+        """the layer through the default-branch kernels and block-structured weights (S x the projection flops); differentiable"""
+        bias = self.bias if (bias is None and weight is None) else bias
+        weight = self.weight if weight is None else weight
+        Kp, Fin, Fout = weight.shape
         S = Kp - 1 if self.selfconn else Kp
         val = _sorted_values(csr, edge_index, edge_attr, S)
         # block-structured weights: support i only feeds output columns [i*Fout, (i+1)*Fout)
         off = 1 if self.selfconn else 0
         wbig = x.new_zeros(S, Fin, Kp * Fout)
         for i in range(S):
-            wbig[i, :, (i + off) * Fout:(i + off + 1) * Fout] = self.weight[i]
+            wbig[i, :, (i + off) * Fout:(i + off + 1) * Fout] = weight[i]
         out = SpectConvFunction.apply(x, val, wbig, None, csr, False)
         if self.selfconn:
             pad = x.new_zeros(Fin, Kp * Fout)
-            pad[:, :Fout] = self.weight[-1]
+            pad[:, :Fout] = weight[-1]
             out = out + torch.mm(x, pad)
-        if self.bias is not None:
-            out = out + self.bias
+        if bias is not None:
+            out = out + bias
         return out
+
+    def _epilogue(self, x, csr, val):
+        """per-support column blocks written by ONE launch of the ring kernel (projection flops 1 x, libs/spect_conv.py:137-158);
+        the selfconn block x W_last is one GEMM into block 0; None when the shape is outside that kernel"""
+        Kp, Fin, Fout = self.weight.shape
+        S = Kp - 1 if self.selfconn else Kp
+        out = Fn.conv_epilogue(csr, x, val, self.weight[:S].detach(), self.bias, S, 1, None, self.selfconn, Kp * Fout)
+        if out is not None and self.selfconn:
+            blk = torch.mm(x, self.weight[-1].detach())
+            out[:, :Fout] = blk + self.bias[:Fout].detach() if self.bias is not None else blk
+        return out
+
+    def forward(self, x, edge_index, edge_attr, edge_weight=None, batch=None, lambda_max=None):
+        _require_cuda(x, 'x')
+        csr = csr_for(edge_index, x.size(0))
+        Kp, Fin, Fout = self.weight.shape
+        if Fn.conv_epilogue_applies(Kp - 1 if self.selfconn else Kp, Fin, Fout):
+            return _EpilogueFn.apply(self, csr, edge_index, x, edge_attr, self.weight, self.bias, None)
+        return self._mapped(x, csr, edge_index, edge_attr)
 
     def __repr__(self):
         return '{}({}, {}, K={})'.format(self.__class__.__name__, self.in_channels, self.out_channels,
                                          self.weight.size(0))
+
+
+class _EpilogueFn(torch.autograd.Function):
+    """SpectConCatConv / depthwise SpectConv: forward = one launch of the ring kernel with the layer's own epilogue
+    (gml_spectconv_fwd_epi); backward = autograd of the equivalent mapping onto the default-branch kernels (module._mapped: the
+    form round 1-2 also ran the forward on), re-evaluated inside backward.  Falls back to the mapping altogether when the
+    library reports the shape unsupported."""
+
+    @staticmethod
+    def forward(ctx, module, csr, edge_index, x, edge_attr, weight, bias, dsw):
+        S = (weight.size(0) - 1 if module.selfconn else weight.size(0)) if not getattr(module, 'depthwise', False) else \
+            (module.nsup - 1 if module.selfconn else module.nsup)
+        with torch.no_grad():
+            val = _sorted_values(csr, edge_index, edge_attr.detach(), S)
+            out = module._epilogue(Fn.rows4(x.detach().contiguous()), csr, val)
+            if out is None:                                     # shape outside the epilogue kernel: the mapping
+                Fn._path('conv_fwd', 'weight-transform mapping (epilogue kernel does not cover the shape)')
+                out = module._mapped(x.detach(), csr, edge_index, edge_attr.detach(), weight.detach(),
+                                     None if bias is None else bias.detach(), None if dsw is None else dsw.detach())
+        ctx.module, ctx.csr, ctx.edge_index = module, csr, edge_index
+        ctx.save_for_backward(x, edge_attr, weight, bias, dsw)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, edge_attr, weight, bias, dsw = ctx.saved_tensors
+        need = ctx.needs_input_grad[3:]
+        ins = [t.detach().requires_grad_(bool(n)) if t is not None else None for t, n in zip((x, edge_attr, weight, bias, dsw), need)]
+        with torch.enable_grad():
+            out = ctx.module._mapped(ins[0], ctx.csr, ctx.edge_index, ins[1], ins[2], ins[3], ins[4])
+        wanted = [t for t in ins if t is not None and t.requires_grad]
+        got = iter(torch.autograd.grad(out, wanted, g, allow_unused=True)) if wanted else iter(())
+        grads = [next(got) if (t is not None and t.requires_grad) else None for t in ins]
+        return (None, None, None) + tuple(grads)
 
 
 class ML3Layer(torch.nn.Module):

@@ -125,6 +125,19 @@ int gml_spectconv_fwd(const int32_t* rowptr, const int32_t* col, const int32_t* 
                       int64_t num_rows, int32_t S, int32_t Fin, int32_t Fout,
                       uint32_t flags, gml_stream_t stream);
 
+/* The two other forward forms of the reference's operator family on the ring kernel's epilogues (one launch, projection flops
+ * 1x): epilogue = 1, SpectConCatConv.forward (libs/spect_conv.py:137-158): out [N, (S + self_term) Fout], support s writes column
+ * block s + self_term (+ that block's bias; block 0 of a selfconn layer = x W_last is the caller's GEMM); epilogue = 2,
+ * SpectConv.forward depthwise branch (libs/spect_conv.py:81-91): w is ONE [Fin, Fout] matrix (w_ss ignored), ds
+ * [S + self_term, Fin] the per-feature scales (row 0 = 1 + DSweight[0]; last row: scale of the self term when self_term):
+ * out = (sum_s ds_s . H_s + ds_self . x) W + bias.  ginfo128: 128-row group records.  GML_E_UNSUPPORTED outside S in {4, 8},
+ * Fin, Fout <= 32, float4-addressable x rows: the caller then maps onto gml_spectconv_fwd through transformed weights. */
+int gml_spectconv_fwd_epi(const int32_t* rowptr, const int32_t* col, const int32_t* ginfo128, const float* val,
+                          const float* x, int64_t ldx, const float* w, int64_t w_ss, int64_t w_si, int64_t w_so,
+                          const float* bias, float* out, int64_t ldo, int64_t num_rows, int32_t S, int32_t Fin,
+                          int32_t Fout, uint32_t flags, int32_t epilogue, const float* ds, int32_t self_term,
+                          gml_stream_t stream);
+
 /* ---------------------------------------------------------------- fused backward of the layer above
  * CSR keyed by SOURCE row (rowptr/col = targets, ginfo of it), val [E, S] in that order.
  *   dx[r, :]   (op)= sum_s ( sum_{e out of r} val[e, s] g[col[e], :] ) @ W[s]^T          (NULL: skip)
