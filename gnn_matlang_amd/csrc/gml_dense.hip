@@ -162,31 +162,47 @@ __global__ __launch_bounds__(384) void gml_k_dense_support_mm(GmlDenseParams p) 
 // wimg[s][t][ot][hi | lo][lane][8] (lane (o = 16 ot + (lane & 15), kq)), one 16-byte load per lane and fragment from L2
 // (Wcat 768 x 128 as bf16 hi / lo = 393 KB).  out^T = W^T H^T again lands transposed: a lane stores 4 consecutive outputs of
 // its own row.  bf16x3 throughout.
+// Work items of the projection: (support s, group q of DN_ITEM_T K = 32 steps); a ring of three LDS buffers receives the items'
+// weight fragments by LDS-DMA from DN_NLD loader waves, two items ahead of their use.
+template <int NFT>
+struct DnChain {
+    static constexpr int KT = (NFT + 1) / 2;                 // K = 32 steps of the projection
+    static constexpr int ITEM_T = KT >= 4 ? 2 : KT;          // steps per work item
+    static constexpr int NQ = KT / ITEM_T;                   // items per support
+};
+#define DN_NLD 3
+
+__device__ __forceinline__ void dn_dma16(u32x4 rs, uint32_t lds_addr, int voff) {      // (see gml_dma16, gml_spectconv_fwd3_impl.h)
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 2\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rs) : "memory");
+}
+
 template <int NFT, int NOT, bool WRITE_H>
-__global__ __launch_bounds__(384) void gml_k_dense_conv_fwd(GmlDenseParams p, const uint16_t* __restrict__ wimg,
+__global__ __launch_bounds__(576) void gml_k_dense_conv_fwd(GmlDenseParams p, const uint16_t* __restrict__ wimg,
                                                             const float* __restrict__ bias, float* __restrict__ out2,
                                                             int64_t ldo2, int Fout, int relu) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dn_lds[];
+    using CH = DnChain<NFT>;
     constexpr int PA = dn_pitch(NFT);
     constexpr int NCH = 4 * NFT;
     constexpr int KSMAX = 3;
-    constexpr int KT = (NFT + 1) / 2;                        // K = 32 steps of the projection
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
+    constexpr int KT = CH::KT, ITEM_T = CH::ITEM_T, NQ = CH::NQ;
+    constexpr int ITEM_BYTES = ITEM_T * NOT * 2 * 64 * 16;   // fragments of one work item: [t][ot][hi | lo][lane][16 bytes]
+    constexpr int NINST = ITEM_BYTES / 1024;                 // DMA instructions per item
+    static_assert(NINST % DN_NLD == 0 || NINST < DN_NLD || true, "");
+    const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ncw = (int)(blockDim.x >> 6) - DN_NLD;         // compute waves (one per 16 support rows)
     const int t16 = lane & 15, kq = lane >> 4;
     const int b = blockIdx.x, n = p.n, KP = p.KP, KS = KP >> 5, F = p.F;
     unsigned char* img_h = dn_lds;
     unsigned char* img_l = dn_lds + KP * PA;
-    // W_s fragments of the current support, shared by the workgroup's waves: [t][ot][hi | lo][lane][16 bytes] (lane-linear:
-    // conflict-free ds_read_b128).  A first version loaded every fragment from L2 per wave and use (1.9 MB per graph at
-    // 128 x 128): no faster than the library GEMM it replaced.
-    constexpr int WS_BYTES = KT * NOT * 2 * 64 * 16;
-    unsigned char* wl_s = dn_lds + 2 * KP * PA;
-    const int row = wave * 16 + t16;
-    const int rowc = row < n ? row : n - 1;
+    unsigned char* ring = dn_lds + 2 * KP * PA;              // 3 x ITEM_BYTES
+    const int nitems = p.S * NQ;
     const float* actb = p.act + (int64_t)b * n * p.lda;
-    float* outr = p.out + ((int64_t)b * n + rowc) * p.ldo;
 
-    for (int idx = tid; idx < KP * NCH; idx += nthr) {       // X of this graph -> (hi, lo) images [k][f], once
+    for (int idx = tid; idx < KP * NCH; idx += nthr) {       // X of this graph -> (hi, lo) images [k][f], once (every wave helps)
         const int k = idx / NCH, ch = idx % NCH;
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
         if (k < n && 4 * ch < F) {
@@ -203,6 +219,39 @@ __global__ __launch_bounds__(384) void gml_k_dense_conv_fwd(GmlDenseParams p, co
         *reinterpret_cast<uint2*>(img_h + k * PA + 8 * ch) = uint2{h0, h1};
         *reinterpret_cast<uint2*>(img_l + k * PA + 8 * ch) = uint2{l0, l1};
     }
+
+    if (wave >= ncw) {
+        // ---- loader waves: item i -> ring[i % 3], issued two items ahead; (barrier i) = item i landed and everyone left item i - 1
+        const int li = wave - ncw;
+        const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) void*)dn_lds) + 2 * KP * PA;
+        const uint64_t wa = reinterpret_cast<uint64_t>(wimg);
+        const u32x4 rs = u32x4{(uint32_t)wa, (uint32_t)(wa >> 32) & 0xffffu, (uint32_t)(p.S * KT * NOT * 2 * 64 * 16), 0x00020000u};
+        constexpr int CW = (NINST + DN_NLD - 1) / DN_NLD;    // instructions per loader and item (a static count: the waits rely on it)
+        auto issue = [&](int i) {
+#pragma unroll
+            for (int c = 0; c < CW; ++c) {
+                const int j = min(li + DN_NLD * c, NINST - 1);   // (the last ones repeat a piece: the count stays static)
+                dn_dma16(rs, lds0 + (i % 3) * ITEM_BYTES + j * 1024, i * ITEM_BYTES + j * 1024 + lane * 16);
+            }
+        };
+        issue(0);
+        if (nitems > 1) issue(1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // (A) X images complete
+        for (int i = 0; i < nitems; ++i) {
+            if (i + 1 < nitems) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(CW) : "memory");   // item i landed (item i + 1 may be in flight)
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                    // (B i)
+            asm volatile("" ::: "memory");
+            if (i + 2 < nitems) issue(i + 2);
+        }
+        return;
+    }
+
+    // ---- compute waves
+    const int row = wave * 16 + t16;
+    const int rowc = row < n ? row : n - 1;
+    float* outr = p.out + ((int64_t)b * n + rowc) * p.ldo;
     u32x4 bh[KSMAX], bl[KSMAX];
     auto load_rows = [&](int s) {
         const uint16_t* base = p.dimg + ((int64_t)(b * p.S + s) * 2 * n + rowc) * KP + 8 * kq;
@@ -218,7 +267,10 @@ __global__ __launch_bounds__(384) void gml_k_dense_conv_fwd(GmlDenseParams p, co
 #pragma unroll
     for (int ot = 0; ot < NOT; ++ot) oacc[ot] = f32x4{0.f, 0.f, 0.f, 0.f};
     load_rows(0);
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                            // (A)
+    asm volatile("" ::: "memory");
+    int item = 0;
     for (int s = 0; s < p.S; ++s) {
         f32x4 acc[NFT];
 #pragma unroll
@@ -258,31 +310,32 @@ __global__ __launch_bounds__(384) void gml_k_dense_conv_fwd(GmlDenseParams p, co
                 }
             }
         }
-        // ---- projection of this support: out^T += W_s^T (D_s X)^T; the support's fragments through LDS
-        if (s > 0) __syncthreads();                          // every wave is done with the previous support's fragments
-        {
-            const u32x4* src = reinterpret_cast<const u32x4*>(wimg + (int64_t)s * (WS_BYTES / 2));
-            for (int i = tid; i < WS_BYTES / 16; i += nthr) reinterpret_cast<u32x4*>(wl_s)[i] = src[i];
-        }
-        __syncthreads();
-        const unsigned char* wb = wl_s + lane * 16;
+        // ---- projection of this support: out^T += W_s^T (D_s X)^T, one ring buffer per group of ITEM_T K steps
 #pragma unroll
-        for (int t = 0; t < KT; ++t) {
-            const float hv[8] = {acc[2 * t][0], acc[2 * t][1], acc[2 * t][2], acc[2 * t][3],
-                                 (2 * t + 1 < NFT) ? acc[(2 * t + 1 < NFT) ? 2 * t + 1 : 0][0] : 0.f,
-                                 (2 * t + 1 < NFT) ? acc[(2 * t + 1 < NFT) ? 2 * t + 1 : 0][1] : 0.f,
-                                 (2 * t + 1 < NFT) ? acc[(2 * t + 1 < NFT) ? 2 * t + 1 : 0][2] : 0.f,
-                                 (2 * t + 1 < NFT) ? acc[(2 * t + 1 < NFT) ? 2 * t + 1 : 0][3] : 0.f};
-            bf16x8 hh, hl;
-            gml_split8(hv, hh, hl);
+        for (int q = 0; q < NQ; ++q, ++item) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                    // (B item): fragments landed; every wave has left the previous item
+            asm volatile("" ::: "memory");
+            const unsigned char* wb = ring + (item % 3) * ITEM_BYTES + lane * 16;
 #pragma unroll
-            for (int ot = 0; ot < NOT; ++ot) {
-                const unsigned char* wq = wb + (t * NOT + ot) * 2 * 64 * 16;
-                const bf16x8 Wh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wq));
-                const bf16x8 Wl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wq + 64 * 16));
-                oacc[ot] = DN_MFMA(Wl, hh, oacc[ot]);
-                oacc[ot] = DN_MFMA(Wh, hl, oacc[ot]);
-                oacc[ot] = DN_MFMA(Wh, hh, oacc[ot]);
+            for (int tt = 0; tt < ITEM_T; ++tt) {
+                const int t = q * ITEM_T + tt;
+                const float hv[8] = {acc[2 * t][0], acc[2 * t][1], acc[2 * t][2], acc[2 * t][3],
+                                     (2 * t + 1 < NFT) ? acc[(2 * t + 1 < NFT) ? 2 * t + 1 : 0][0] : 0.f,
+                                     (2 * t + 1 < NFT) ? acc[(2 * t + 1 < NFT) ? 2 * t + 1 : 0][1] : 0.f,
+                                     (2 * t + 1 < NFT) ? acc[(2 * t + 1 < NFT) ? 2 * t + 1 : 0][2] : 0.f,
+                                     (2 * t + 1 < NFT) ? acc[(2 * t + 1 < NFT) ? 2 * t + 1 : 0][3] : 0.f};
+                bf16x8 hh, hl;
+                gml_split8(hv, hh, hl);
+#pragma unroll
+                for (int ot = 0; ot < NOT; ++ot) {
+                    const unsigned char* wq = wb + (tt * NOT + ot) * 2 * 64 * 16;
+                    const bf16x8 Wh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wq));
+                    const bf16x8 Wl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wq + 64 * 16));
+                    oacc[ot] = DN_MFMA(Wl, hh, oacc[ot]);
+                    oacc[ot] = DN_MFMA(Wh, hl, oacc[ot]);
+                    oacc[ot] = DN_MFMA(Wh, hh, oacc[ot]);
+                }
             }
         }
     }
@@ -344,7 +397,7 @@ extern "C" int gml_dense_pack_w(const float* w, uint16_t* wimg, int32_t S, int32
 template <int NFT, int NOT>
 static int dn_launch_conv(const GmlDenseParams& p, const uint16_t* wimg, const float* bias, float* out2, int64_t ldo2, int Fout,
                           int relu, bool write_h, hipStream_t st) {
-    const size_t lds = (size_t)2 * p.KP * dn_pitch(NFT) + (size_t)((NFT + 1) / 2) * NOT * 2 * 64 * 16;
+    const size_t lds = (size_t)2 * p.KP * dn_pitch(NFT) + (size_t)3 * DnChain<NFT>::ITEM_T * NOT * 2 * 64 * 16;
     {
         GML_ALLOW_BIG_LDS(rc1, (gml_k_dense_conv_fwd<NFT, NOT, true>), 160 * 1024);
         GML_ALLOW_BIG_LDS(rc0, (gml_k_dense_conv_fwd<NFT, NOT, false>), 160 * 1024);
@@ -352,8 +405,8 @@ static int dn_launch_conv(const GmlDenseParams& p, const uint16_t* wimg, const f
         if (rc0 != hipSuccess) return (int)rc0;
     }
     const int nwaves = (p.n + 15) / 16;
-    if (write_h) hipLaunchKernelGGL((gml_k_dense_conv_fwd<NFT, NOT, true>), dim3((unsigned)p.B), dim3(64 * nwaves), lds, st, p, wimg, bias, out2, ldo2, Fout, relu);
-    else hipLaunchKernelGGL((gml_k_dense_conv_fwd<NFT, NOT, false>), dim3((unsigned)p.B), dim3(64 * nwaves), lds, st, p, wimg, bias, out2, ldo2, Fout, relu);
+    if (write_h) hipLaunchKernelGGL((gml_k_dense_conv_fwd<NFT, NOT, true>), dim3((unsigned)p.B), dim3(64 * (nwaves + DN_NLD)), lds, st, p, wimg, bias, out2, ldo2, Fout, relu);
+    else hipLaunchKernelGGL((gml_k_dense_conv_fwd<NFT, NOT, false>), dim3((unsigned)p.B), dim3(64 * (nwaves + DN_NLD)), lds, st, p, wimg, bias, out2, ldo2, Fout, relu);
     return gml_launch_status();
 }
 
