@@ -58,6 +58,9 @@ SIGNATURES = {
     'gml_dense_pack': (ctypes.c_int, [_p, _p, _i64, _i32, _i32, _i32, _p]),
     'gml_dense_wimg_elems': (_sz, [_i32, _i32, _i32]),
     'gml_dense_pack_w': (ctypes.c_int, [_p, _p, _i32, _i32, _i32, _p]),
+    'gml_dense_wimgt_elems': (_sz, [_i32, _i32, _i32]),
+    'gml_dense_pack_wt': (ctypes.c_int, [_p, _p, _i32, _i32, _i32, _p]),
+    'gml_dense_conv_bwd_x': (ctypes.c_int, [_p, _p, _i64, _p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     'gml_dense_conv_fwd': (ctypes.c_int, [_p, _p, _i64, _p, _p, _p, _i64, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     'gml_dense_support_mm': (ctypes.c_int, [_p, _p, _i64, _i32, _p, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     'gml_spectral_count': (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i32, _i32, _p, _p]),

@@ -360,6 +360,258 @@ __global__ __launch_bounds__(576) void gml_k_dense_conv_fwd(GmlDenseParams p, co
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Chained backward for dX = sum_s D_s^T (G W_s^T)   (autograd of the layer above w.r.t. x): the projection G W_s^T runs per
+// wave on its own 16 rows (B operand = the lane's own G row, 8 consecutive o per K step straight from HBM, split to bf16 once
+// per graph; A = W_s fragments [f rows][o slots] from the loader waves' ring), its result -- (G W_s^T)^T in D layout, what the
+// forward's support product produced -- goes into the LDS images, and the support product with the TRANSPOSED blocks
+// contracts over the graph's rows.  d Hcat [B n, S Fin] is neither written nor read.
+template <int NFT, int NOT>
+__global__ __launch_bounds__(576) void gml_k_dense_conv_bwdx(GmlDenseParams p, const uint16_t* __restrict__ wimgT,
+                                                             int64_t ldg, int Fout) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dn_lds[];
+    constexpr int PA = dn_pitch(NFT);
+    constexpr int KSMAX = 3;
+    constexpr int KT2 = NOT / 2;                             // K = 32 steps over o
+    constexpr int FQ = NFT >= 8 ? 2 : 1;                     // work items per support (groups of NFT / FQ feature tiles)
+    constexpr int FT_I = NFT / FQ;
+    constexpr int ITEM_BYTES = FT_I * KT2 * 2 * 64 * 16;     // [ft][t][hi | lo][lane][16 bytes]
+    constexpr int NINST = ITEM_BYTES / 1024;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ncw = (int)(blockDim.x >> 6) - DN_NLD;
+    const int t16 = lane & 15, kq = lane >> 4;
+    const int b = blockIdx.x, n = p.n, KP = p.KP, KS = KP >> 5, F = p.F;
+    unsigned char* img_h = dn_lds;
+    unsigned char* img_l = dn_lds + KP * PA;
+    unsigned char* ring = dn_lds + 2 * KP * PA;
+    const int nitems = p.S * FQ;
+    // image rows n .. KP - 1 (the K padding of the product) are zero and stay so: only rows < n are ever written
+    for (int idx = tid; idx < 2 * KP * PA / 16; idx += blockDim.x) reinterpret_cast<u32x4*>(dn_lds)[idx] = u32x4{0u, 0u, 0u, 0u};
+
+    if (wave >= ncw) {
+        const int li = wave - ncw;
+        const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) void*)dn_lds) + 2 * KP * PA;
+        const uint64_t wa = reinterpret_cast<uint64_t>(wimgT);
+        const u32x4 rs = u32x4{(uint32_t)wa, (uint32_t)(wa >> 32) & 0xffffu, (uint32_t)(p.S * NFT * KT2 * 2 * 64 * 16), 0x00020000u};
+        constexpr int CW = (NINST + DN_NLD - 1) / DN_NLD;
+        auto issue = [&](int i) {
+#pragma unroll
+            for (int c = 0; c < CW; ++c) {
+                const int j = min(li + DN_NLD * c, NINST - 1);
+                dn_dma16(rs, lds0 + (i % 3) * ITEM_BYTES + j * 1024, i * ITEM_BYTES + j * 1024 + lane * 16);
+            }
+        };
+        issue(0);
+        if (nitems > 1) issue(1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // (A) images zeroed
+        int i = 0;
+        for (int s = 0; s < p.S; ++s) {
+            for (int q = 0; q < FQ; ++q, ++i) {
+                if (i + 1 < nitems) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(CW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                // (B i)
+                asm volatile("" ::: "memory");
+                if (i + 2 < nitems) issue(i + 2);
+            }
+            __builtin_amdgcn_s_barrier();                    // (C s) images of support s complete
+            __builtin_amdgcn_s_barrier();                    // (D s) product of support s done in every wave
+        }
+        return;
+    }
+
+    const int row = wave * 16 + t16;
+    const int rowc = row < n ? row : n - 1;
+    // the lane's own G row, split once: K step t covers o = 32 t + 8 kq .. + 7
+    bf16x8 gh[KT2], gl[KT2];
+    {
+        const float* gr = p.act + ((int64_t)b * n + rowc) * ldg;
+#pragma unroll
+        for (int t = 0; t < KT2; ++t) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int o = 32 * t + 8 * kq + j;
+                v[j] = (row < n && o < Fout) ? gr[o] : 0.f;
+            }
+            gml_split8(v, gh[t], gl[t]);
+        }
+    }
+    u32x4 bh[KSMAX], bl[KSMAX];
+    auto load_rows = [&](int s) {
+        const uint16_t* base = p.dimg + ((int64_t)(b * p.S + s) * 2 * n + rowc) * KP + 8 * kq;
+#pragma unroll
+        for (int ks = 0; ks < KSMAX; ++ks) {
+            const int kc = ks < KS ? ks : KS - 1;
+            bh[ks] = *reinterpret_cast<const u32x4*>(base + 32 * kc);
+            bl[ks] = *reinterpret_cast<const u32x4*>(base + (int64_t)n * KP + 32 * kc);
+        }
+    };
+    const int aoff = (8 * kq + (t16 >> 2)) * PA + 8 * (t16 & 3);
+    f32x4 dxacc[NFT];
+#pragma unroll
+    for (int ft = 0; ft < NFT; ++ft) dxacc[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+    load_rows(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                            // (A)
+    asm volatile("" ::: "memory");
+    int item = 0;
+    for (int s = 0; s < p.S; ++s) {
+        // ---- T_s^T = W_s G^T for the wave's rows: D[i = f][j = row]
+        f32x4 tacc[NFT];
+#pragma unroll
+        for (int q = 0; q < FQ; ++q, ++item) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                    // (B item)
+            asm volatile("" ::: "memory");
+            const unsigned char* wb = ring + (item % 3) * ITEM_BYTES + lane * 16;
+#pragma unroll
+            for (int fi = 0; fi < FT_I; ++fi) {
+                f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < KT2; ++t) {
+                    const unsigned char* wq = wb + (fi * KT2 + t) * 2 * 64 * 16;
+                    const bf16x8 Wh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wq));
+                    const bf16x8 Wl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wq + 64 * 16));
+                    d = DN_MFMA(Wl, gh[t], d);
+                    d = DN_MFMA(Wh, gl[t], d);
+                    d = DN_MFMA(Wh, gh[t], d);
+                }
+                tacc[q * FT_I + fi] = d;
+            }
+        }
+        // ---- the wave's rows of T_s -> (hi, lo) images [k = row][f]
+        if (row < n) {
+#pragma unroll
+            for (int ft = 0; ft < NFT; ++ft) {
+                const f32x4 v = tacc[ft];
+                const uint32_t h0 = dn_pack2(v[0], v[1]), h1 = dn_pack2(v[2], v[3]);
+                const uint32_t l0 = dn_pack2(v[0] - __uint_as_float(h0 << 16), v[1] - __uint_as_float(h0 & 0xffff0000u));
+                const uint32_t l1 = dn_pack2(v[2] - __uint_as_float(h1 << 16), v[3] - __uint_as_float(h1 & 0xffff0000u));
+                *reinterpret_cast<uint2*>(img_h + row * PA + 32 * ft + 8 * kq) = uint2{h0, h1};
+                *reinterpret_cast<uint2*>(img_l + row * PA + 32 * ft + 8 * kq) = uint2{l0, l1};
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // (C s)
+        asm volatile("" ::: "memory");
+        // ---- dX^T += T_s^T D_s: the support product on the transposed blocks
+        u32x4 ch[KSMAX], cl[KSMAX];
+#pragma unroll
+        for (int ks = 0; ks < KSMAX; ++ks) { ch[ks] = bh[ks]; cl[ks] = bl[ks]; }
+        if (s + 1 < p.S) load_rows(s + 1);
+#pragma unroll
+        for (int ks = 0; ks < KSMAX; ++ks) {
+            if (ks < KS) {
+                const bf16x8 Bh = __builtin_bit_cast(bf16x8, ch[ks]), Bl = __builtin_bit_cast(bf16x8, cl[ks]);
+                const unsigned char* ah = img_h + 32 * ks * PA + aoff;
+                const unsigned char* al = img_l + 32 * ks * PA + aoff;
+#pragma unroll
+                for (int ft = 0; ft < NFT; ++ft) {
+                    const bf16x8 Ah = dn_tr_frag(ah + 32 * ft, ah + 32 * ft + 4 * PA);
+                    const bf16x8 Al = dn_tr_frag(al + 32 * ft, al + 32 * ft + 4 * PA);
+                    dxacc[ft] = DN_MFMA(Al, Bh, dxacc[ft]);
+                    dxacc[ft] = DN_MFMA(Ah, Bl, dxacc[ft]);
+                    dxacc[ft] = DN_MFMA(Ah, Bh, dxacc[ft]);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // (D s)
+        asm volatile("" ::: "memory");
+    }
+    if (row < n) {
+        float* o = p.out + ((int64_t)b * n + row) * p.ldo + 4 * kq;
+#pragma unroll
+        for (int ft = 0; ft < NFT; ++ft) {
+            const int f0 = 16 * ft + 4 * kq;
+            if (f0 >= F) continue;
+            if (p.vec_out) *reinterpret_cast<f32x4*>(o + 16 * ft) = dxacc[ft];
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (f0 + j < F) o[16 * ft + j] = dxacc[ft][j];
+            }
+        }
+    }
+}
+
+// weight [S][Fin][Fout] -> fragments of A = W_s [f rows][o slots] for the chained backward: wimgT[s][ft][t][hi | lo][lane][8],
+// lane (f = 16 ft + (lane & 15), kq), slot j: o = 32 t + 8 kq + j
+__global__ __launch_bounds__(256) void gml_k_dense_pack_wT(const float* __restrict__ w, uint16_t* __restrict__ wimg, int S, int Fin,
+                                                           int Fout, int NFT, int KT2) {
+    const int64_t total = (int64_t)S * NFT * KT2 * 64 * 8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int slot = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        const int64_t blk = i >> 9;                          // (s * NFT + ft) * KT2 + t
+        const int t = (int)(blk % KT2), ft = (int)((blk / KT2) % NFT), s = (int)(blk / ((int64_t)KT2 * NFT));
+        const int f = 16 * ft + (lane & 15), o = 32 * t + 8 * (lane >> 4) + slot;
+        const float v = (f < Fin && o < Fout) ? w[((int64_t)s * Fin + f) * Fout + o] : 0.f;
+        const uint32_t h = dn_pack2(v, 0.f) & 0xffffu;
+        const uint32_t l = dn_pack2(v - __uint_as_float(h << 16), 0.f) & 0xffffu;
+        wimg[((blk * 2) * 64 + lane) * 8 + slot] = (uint16_t)h;
+        wimg[((blk * 2 + 1) * 64 + lane) * 8 + slot] = (uint16_t)l;
+    }
+}
+
+static void dn_bwd_shape(int Fin, int Fout, int& NFT, int& NOT) {
+    const int nft = (Fin + 15) / 16;
+    NFT = nft <= 1 ? 1 : (nft <= 2 ? 2 : (nft <= 4 ? 4 : 8));
+    NOT = Fout <= 64 ? 4 : 8;
+}
+
+extern "C" size_t gml_dense_wimgt_elems(int32_t S, int32_t Fin, int32_t Fout) {
+    int NFT, NOT;
+    dn_bwd_shape(Fin, Fout, NFT, NOT);
+    return (size_t)S * NFT * (NOT / 2) * 2 * 64 * 8;
+}
+
+extern "C" int gml_dense_pack_wt(const float* w, uint16_t* wimg, int32_t S, int32_t Fin, int32_t Fout, void* stream) {
+    if (w == nullptr || wimg == nullptr) return GML_E_BADARG;
+    if (S < 1 || Fin < 1 || Fin > 128 || Fout < 1 || Fout > 128) return GML_E_UNSUPPORTED;
+    int NFT, NOT;
+    dn_bwd_shape(Fin, Fout, NFT, NOT);
+    const int64_t total = (int64_t)S * NFT * (NOT / 2) * 64 * 8;
+    hipLaunchKernelGGL(gml_k_dense_pack_wT, dim3((unsigned)gml_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, wimg, S, Fin,
+                       Fout, NFT, NOT / 2);
+    return gml_launch_status();
+}
+
+template <int NFT, int NOT>
+static int dn_launch_bwdx(const GmlDenseParams& p, const uint16_t* wimgT, int64_t ldg, int Fout, hipStream_t st) {
+    constexpr int FQ = NFT >= 8 ? 2 : 1;
+    const size_t lds = (size_t)2 * p.KP * dn_pitch(NFT) + (size_t)3 * (NFT / FQ) * (NOT / 2) * 2 * 64 * 16;
+    GML_ALLOW_BIG_LDS(rc, (gml_k_dense_conv_bwdx<NFT, NOT>), 160 * 1024);
+    if (rc != hipSuccess) return (int)rc;
+    const int nwaves = (p.n + 15) / 16;
+    hipLaunchKernelGGL((gml_k_dense_conv_bwdx<NFT, NOT>), dim3((unsigned)p.B), dim3(64 * (nwaves + DN_NLD)), lds, st, p, wimgT, ldg, Fout);
+    return gml_launch_status();
+}
+
+// dx[(b n + i) lddx + f] = sum_s sum_j D[b][s][j][i] (sum_o g[(b n + j) ldg + o] W[s][f][o]);  dimgT: the packed TRANSPOSED blocks
+// (gml_dense_pack(transpose = 1)), wimgT from gml_dense_pack_wt.  Fin, Fout <= 128.
+extern "C" int gml_dense_conv_bwd_x(const uint16_t* dimgT, const float* g, int64_t ldg, const uint16_t* wimgT, float* dx, int64_t lddx,
+                                    int32_t B, int32_t S, int32_t n, int32_t KP, int32_t Fin, int32_t Fout, void* stream) {
+    if (dimgT == nullptr || g == nullptr || wimgT == nullptr || dx == nullptr || ldg < Fout || lddx < Fin) return GML_E_BADARG;
+    if (n < 1 || n > 96 || KP % 32 != 0 || KP < n || KP > 96 || Fin < 1 || Fin > 128 || Fout < 1 || Fout > 128 || S < 1 || B < 0)
+        return GML_E_UNSUPPORTED;
+    if (B == 0) return GML_OK;
+    GmlDenseParams p;
+    p.dimg = dimgT; p.act = g; p.out = dx; p.lda = ldg; p.ldo = lddx; p.sa = 0; p.so = 0;
+    p.B = B; p.S = S; p.n = n; p.KP = KP; p.F = Fin;
+    p.vec_in = 0;
+    p.vec_out = (Fin % 4 == 0 && lddx % 4 == 0 && ((uintptr_t)dx & 15) == 0) ? 1 : 0;
+    hipStream_t st = (hipStream_t)stream;
+    int NFT, NOT;
+    dn_bwd_shape(Fin, Fout, NFT, NOT);
+#define DN_BWDX(A) return NOT == 4 ? dn_launch_bwdx<A, 4>(p, wimgT, ldg, Fout, st) : dn_launch_bwdx<A, 8>(p, wimgT, ldg, Fout, st)
+    if (NFT == 1) { DN_BWDX(1); }
+    if (NFT == 2) { DN_BWDX(2); }
+    if (NFT == 4) { DN_BWDX(4); }
+    DN_BWDX(8);
+#undef DN_BWDX
+}
+
 // weight [S][Fin][Fout] fp32 -> projection fragments wimg[s][t][ot][hi | lo][lane][8] in the k-slot order of the chained kernel
 __global__ __launch_bounds__(256) void gml_k_dense_pack_w(const float* __restrict__ w, uint16_t* __restrict__ wimg, int S, int Fin,
                                                           int Fout, int KT, int NOT) {

@@ -127,6 +127,7 @@ class _TallGemm(torch.autograd.Function):
 
 
 CHAIN = os.environ.get('GML_DENSE_CHAIN', '1') not in ('0', '')      # projection chained behind the support product (gml_dense_conv_fwd)
+CHAIN_BWD = os.environ.get('GML_DENSE_CHAIN_BWD', '1') not in ('0', '')   # and the dX path: projection in front of the transposed product
 
 
 class _DenseConv(torch.autograd.Function):
@@ -161,8 +162,18 @@ class _DenseConv(torch.autograd.Function):
         g = g.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dh = g.mm(weight.reshape(S * Fin, Fout).t())
-            dx = support_mm(sup.bwd, dh, sup, Fin, Fin, 0, True)
+            if CHAIN_BWD:
+                # dX = sum_s D_s^T (g W_s^T) in one launch: d Hcat stays on the CU (gml_k_dense_conv_bwdx)
+                dev = g.device
+                wimgT = torch.empty(int(_lib.lib().gml_dense_wimgt_elems(S, Fin, Fout)), dtype=torch.int16, device=dev)
+                _lib.call('gml_dense_pack_wt', _ptr(weight.contiguous()), _ptr(wimgT), S, Fin, Fout, _stream(dev))
+                dx = torch.empty(sup.B * sup.n, Fin, dtype=torch.float32, device=dev)
+                Fn._path('dense', 'projection + support product chained, backward (bf16x3 HIP)', S, Fin, Fout)
+                _lib.call('gml_dense_conv_bwd_x', _ptr(sup.bwd), _ptr(g), int(g.stride(0)), _ptr(wimgT), _ptr(dx), Fin,
+                          sup.B, S, sup.n, sup.KP, Fin, Fout, _stream(dev))
+            else:
+                dh = g.mm(weight.reshape(S * Fin, Fout).t())
+                dx = support_mm(sup.bwd, dh, sup, Fin, Fin, 0, True)
         if ctx.needs_input_grad[1]:
             rows = int(hcat.size(0))
             P = _splits(rows)

@@ -318,6 +318,13 @@ int gml_dense_pack_w(const float* w, uint16_t* wimg, int32_t S, int32_t Fin, int
 int gml_dense_conv_fwd(const uint16_t* dimg, const float* x, int64_t ldx, const uint16_t* wimg, const float* bias,
                        float* out2, int64_t ldo2, float* hcat, int32_t B, int32_t S, int32_t n, int32_t KP, int32_t Fin,
                        int32_t Fout, int32_t relu, void* stream);
+/* and its gradient w.r.t. x in one launch: dx[(b n + i) lddx + f] = sum_s sum_j D[b][s][j][i] (sum_o g[(b n + j) ldg + o] W[s][f][o])
+ * -- the projection g W_s^T per row tile, then the support product on the TRANSPOSED packed blocks (gml_dense_pack(transpose = 1));
+ * d Hcat is never materialised.  wimgT: gml_dense_pack_wt (gml_dense_wimgt_elems int16 elements). */
+size_t gml_dense_wimgt_elems(int32_t S, int32_t Fin, int32_t Fout);
+int gml_dense_pack_wt(const float* w, uint16_t* wimgT, int32_t S, int32_t Fin, int32_t Fout, void* stream);
+int gml_dense_conv_bwd_x(const uint16_t* dimgT, const float* g, int64_t ldg, const uint16_t* wimgT, float* dx, int64_t lddx,
+                         int32_t B, int32_t S, int32_t n, int32_t KP, int32_t Fin, int32_t Fout, void* stream);
 
 /* ---------------------------------------------------------------- support precompute on the device (adjacent step, P1)
  * SpectralDesign.__call__ (libs/utils.py:546-610) for a batch of graphs with at most 80 nodes each (larger: host
