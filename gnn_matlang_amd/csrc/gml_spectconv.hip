@@ -203,7 +203,7 @@ extern "C" int gml_spectconv_fwd(const int32_t* rowptr, const int32_t* col, cons
             const int fo = (Fout - o0 < colgrp) ? Fout - o0 : colgrp;
             const int nb16 = (fo + 15) / 16;
             const int NB = nb16 <= 1 ? 1 : (nb16 <= 2 ? 2 : (nb16 <= 4 ? 4 : 8));
-            GmlFwdParams p;
+            GmlFwdParams p = {};
             p.rowptr = rowptr; p.col = col; p.ginfo = ginfo; p.epos = epos;
             p.val = val; p.x = x; p.ldx = ldx;
             p.w = w + (int64_t)o0 * w_so; p.w_ss = w_ss; p.w_si = w_si; p.w_so = w_so;
