@@ -11,6 +11,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 #define GML_WAVE 64
 // group record of gml_csr_group_info: {first edge, #edges, first column, window width}; 128-row groups (bf16x3 backward)

@@ -1,5 +1,5 @@
-// Fused backward, bf16x3, third layout (default for S in {2,4,6,8}, Fin <= 32, 16 < Fout <= 32): same outputs as
-// gml_k_spectconv_bwd / gml_k_spectconv_bwd2
+// Fused backward, bf16x3, third layout (default for S in {2,4,6,8}, Fin <= 32, 16 < Fout <= 32, and -- NOB = 1 -- for
+// counting.py's S = 12, Fout <= 16): same outputs as gml_k_spectconv_bwd / gml_k_spectconv_bwd2
 //
 //   dX = sum_s A_s (G W_s^T),   dval[e,s] = < X[src] W_s, G[dst] >,   dW_s = X^T (A_s G)
 //
@@ -16,7 +16,12 @@
 //   * NW = 8 waves / 128-row groups (one workgroup per CU) or NW = 4 waves / 64-row groups (78 KB of LDS: two
 //     independent workgroups per CU, whose matrix / LDS phases overlap each other's VALU edge phases).
 // All XOR keys of the LDS images are chosen with tools/lds_sim.py (conflict-free for every access kind that touches them).
+//
+// NOB = 1 (Fout <= 16; 12 supports fit the registers: 2 x 12 x 4 accumulators per lane): the lane (row, kq) owns outputs
+// 4 kq .. 4 kq + 3; W image [s][16 o][32 f], G window, edge loop and P image work on 16 columns.  The dX projection keeps its
+// K = 32 MFMAs: k slot 8 kq + j is output 4 kq + j for j < 4, the slots j >= 4 are zero in the P fragment.
 #pragma once
+#include <type_traits>
 #include "gml_common.h"
 #include "gml_spectconv_bwd_impl.h"
 
@@ -27,22 +32,23 @@ __host__ __device__ __forceinline__ int gml_wkey3(int o) { return ((o >> 3) & 1)
 // and conflict-free transposing reads of 8 consecutive positions per lane group
 __host__ __device__ __forceinline__ int gml_tkey3(int pos) { return ((pos >> 2) & 1) | ((((pos >> 1) ^ (pos >> 2) ^ (pos >> 3)) & 1) << 1); }
 
-template <int S, int NFB, int NW>
+template <int S, int NFB, int NW, int NOB = 2>
 struct GmlBwd3Cfg {
     static constexpr int ROWS = 16 * NW, NT = 64 * NW;
-    static constexpr int ECAP_MAX = 8 * ROWS;               // register-batched staging bounds (per group)
+    static constexpr int ECAP_MAX = (S > 8 ? 12 : 8) * ROWS; // register-batched staging bounds (per group)
     static constexpr int XCAP_MAX = NW == 8 ? 224 : 160;
-    static constexpr int LDG = 36;                           // G window rows (floats, b128 aligned)
-    static constexpr int W_HALF = S * 32 * 32;               // bf16 elements of one (hi or lo) W image
+    static constexpr int LDG = 16 * NOB + 4;                 // G window rows (floats, b128 aligned)
+    static constexpr int W_HALF = S * 16 * NOB * 32;         // bf16 elements of one (hi or lo) W image [s][o][32 f]
     static constexpr int W_BYTES = 2 * W_HALF * 2;
     static constexpr int SS = (S % 4 == 0) ? 4 : ((S % 3 == 0) ? 3 : S);   // supports per dW slab
     static constexpr int NSLAB = S / SS;
-    static constexpr int NBLK = SS * NFB * 2;                // 16 x 16 output blocks of a slab: (se, fb, ob)
+    static constexpr int NBLK = SS * NFB * NOB;              // 16 x 16 output blocks of a slab: (se, fb, ob)
     static constexpr int BPW = (NBLK + NW - 1) / NW;         // blocks per wave
     static constexpr int XT_BYTES = 2 * ROWS * 64;           // X hi, lo   [position][32 f]
     static constexpr int PT_BYTES = 2 * SS * ROWS * 64;      // P hi, lo   [se][position][32 o]
     static constexpr int GREC = 4 + ROWS / 4;                // ints per group record (ranked)
-    static constexpr bool OK = (S % SS == 0) && (NFB == 1 || NFB == 2) && (NW == 4 || NW == 8);
+    static constexpr bool OK = (S % SS == 0) && (NFB == 1 || NFB == 2) && (NW == 4 || NW == 8) && (NOB == 1 || NOB == 2) &&
+                               NW % (NOB * NFB) == 0;
     __host__ __device__ static size_t stage_bytes(int ecap, int xcap) { return (size_t)ecap * S * 4 + (size_t)xcap * LDG * 4; }
     __host__ __device__ static size_t r_bytes(int ecap, int xcap) {          // staged values + G window, later the P slab
         const size_t a = stage_bytes(ecap, xcap);
@@ -69,9 +75,11 @@ struct GmlBwd3Cfg {
 #endif
 
 // DZ: dx starts from dz[row] . wmix (see GmlBwdParams) instead of zero / the old dx values
-template <int S, int NFB, int NW, bool XV, bool DZ = false>
+template <int S, int NFB, int NW, bool XV, bool DZ = false, int NOB = 2>
 __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdParams p) {
-    using C = GmlBwd3Cfg<S, NFB, NW>;
+    using C = GmlBwd3Cfg<S, NFB, NW, NOB>;
+    constexpr int NH = 2 * NOB, GC = 4 * NOB;                // f32x2 accumulators per support and lane; float4 chunks of a G row
+    static_assert(!DZ || NOB == 2, "the dz hand-over is compiled for the ZINC shape class");
     constexpr int LDG = C::LDG, ROWS = C::ROWS, NT = C::NT, SS = C::SS, BPW = C::BPW;
     constexpr int VAL_ALIGN = (S % 4 == 0) ? 4 : ((S % 2 == 0) ? 2 : 1);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -97,12 +105,13 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
         if (tid < 128) wm_l[tid] = ((tid >> 5) < p.nmix && (tid & 31) < p.Fin) ? p.wmix[(tid >> 5) * p.Fin + (tid & 31)] : 0.f;
     }
     // W -> bf16 (hi, lo) image, zero padded to 32 x 32
-    for (int e = tid; e < S * 32 * 32; e += NT) {
-        const int f = e & 31, o = (e >> 5) & 31, s = e >> 10;
+    constexpr int WO = 16 * NOB;                             // output rows of one support's image
+    for (int e = tid; e < S * WO * 32; e += NT) {
+        const int f = e & 31, o = (e >> 5) % WO, s = (e >> 5) / WO;
         const float v = (f < p.Fin && o < p.Fout) ? p.w[((int64_t)s * p.Fin + f) * p.Fout + o] : 0.f;
         const __bf16 h = (__bf16)v;
         const __bf16 l = (__bf16)(v - (float)h);
-        const int i = (s * 32 + o) * 32 + ((((f >> 3) ^ gml_wkey3(o)) & 3) << 3) + (f & 7);
+        const int i = (s * WO + o) * 32 + ((((f >> 3) ^ gml_wkey3(o)) & 3) << 3) + (f & 7);
         W_h[i] = h; W_l[i] = l;
     }
 
@@ -120,7 +129,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
     //      before its stores) and committed to LDS at the top of the group; all unconditional with clamped indices so that
     //      the compiler can count them (see gml_spectconv_bwd2_impl.h)
     constexpr int NC = C::ECAP_MAX / NT, NE4 = (S % 4 == 0) ? C::ECAP_MAX * (S / 4) / NT : 1;
-    constexpr int NG4 = (C::XCAP_MAX * 8 + NT - 1) / NT;
+    constexpr int NG4 = (C::XCAP_MAX * GC + NT - 1) / NT;
     const int etot = p.rowptr[p.nrows];
     const int* colb = etot > 0 ? p.col : p.ginfo;
     const f32x4* valb = etot > 0 ? reinterpret_cast<const f32x4*>(p.val) : reinterpret_cast<const f32x4*>(p.ginfo);
@@ -161,8 +170,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
 #pragma unroll
         for (int t = 0; t < NG4; ++t) {
             const int i = tid + NT * t;
-            const int64_t rr = min((int64_t)lo + min(i >> 3, nw1), p.nrows - 1);
-            gv4[t] = *reinterpret_cast<const f32x4*>(p.g + rr * p.ldg + min((i & 7) * 4, o4max));
+            const int64_t rr = min((int64_t)lo + min(i / GC, nw1), p.nrows - 1);
+            gv4[t] = *reinterpret_cast<const f32x4*>(p.g + rr * p.ldg + min((i % GC) * 4, o4max));
         }
     };
     auto load_rows = [&](int g) {                            // ranked record: {kb, ne, lo, nwin}, then the row of every position
@@ -200,14 +209,14 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
 #pragma unroll
             for (int t = 0; t < NG4; ++t) {
                 const int i = tid + NT * t;
-                if (i < nwin * 8)
-                    *reinterpret_cast<f32x4*>(gs + (i >> 3) * LDG + (i & 7) * 4) = ((i & 7) * 4 < p.Fout) ? gv4[t] : f32x4{0.f, 0.f, 0.f, 0.f};
+                if (i < nwin * GC)
+                    *reinterpret_cast<f32x4*>(gs + (i / GC) * LDG + (i % GC) * 4) = ((i % GC) * 4 < p.Fout) ? gv4[t] : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         } else {
             for (int i = tid; i < ne; i += NT) col_l[i] = p.col[kb + i] - lo;
             for (int i = tid; i < ne * S; i += NT) ea_l[i] = p.val[(int64_t)kb * S + i];
-            for (int i = tid; i < nwin * 32; i += NT) {
-                const int rr = i >> 5, o = i & 31;
+            for (int i = tid; i < nwin * 16 * NOB; i += NT) {
+                const int rr = i / (16 * NOB), o = i % (16 * NOB);
                 gs[rr * LDG + o] = (o < p.Fout) ? p.g[(int64_t)(lo + rr) * p.ldg + o] : 0.f;
             }
         }
@@ -249,15 +258,15 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
 
         // ---- Z^T = W^T X^T: MFMA row i of block ob carries o = 8*(i>>2) + 4*ob + (i&3), so lane kq receives its 8
         //      consecutive outputs o = 8*kq + 4*ob + reg.  Fragments of support s + 1 are requested before the MFMAs of s.
-        f32x2 Z[S][4], P[S][4];
+        f32x2 Z[S][NH], P[S][NH];
         {
-            const int oa0 = 8 * (r16 >> 2) + (r16 & 3);
-            bf16x8 wh[2][2], wl[2][2];
+            const int oa0 = NOB == 2 ? 8 * (r16 >> 2) + (r16 & 3) : r16;   // (NOB = 1: MFMA row i = output i, lane kq receives 4 kq + reg)
+            bf16x8 wh[2][NOB], wl[2][NOB];
             auto frag = [&](int s, int st) {
 #pragma unroll
-                for (int ob = 0; ob < 2; ++ob) {
+                for (int ob = 0; ob < NOB; ++ob) {
                     const int oa = oa0 + 4 * ob;
-                    const int off = (s * 32 + oa) * 32 + (((kq ^ gml_wkey3(oa)) & 3) << 3);
+                    const int off = (s * WO + oa) * 32 + (((kq ^ gml_wkey3(oa)) & 3) << 3);
                     wh[st][ob] = *reinterpret_cast<const bf16x8*>(W_h + off);
                     wl[st][ob] = *reinterpret_cast<const bf16x8*>(W_l + off);
                 }
@@ -268,27 +277,29 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
                 const int st = s & 1;
                 if (GML_ABL & 16) {
 #pragma unroll
-                    for (int h = 0; h < 4; ++h) { Z[s][h] = f32x2{xb[h], xb[h + 4]}; P[s][h] = f32x2{0.f, 0.f}; }
+                    for (int h = 0; h < NH; ++h) { Z[s][h] = f32x2{xb[h], xb[h + 4]}; P[s][h] = f32x2{0.f, 0.f}; }
                     continue;
                 }
                 if (s + 1 < S) frag(s + 1, st ^ 1);
-                f32x4 d0 = f32x4{0.f, 0.f, 0.f, 0.f}, d1 = f32x4{0.f, 0.f, 0.f, 0.f};
-                d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[st][0], xh, d0, 0, 0, 0);
-                d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[st][1], xh, d1, 0, 0, 0);
-                d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[st][0], xl, d0, 0, 0, 0);
-                d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[st][1], xl, d1, 0, 0, 0);
-                d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[st][0], xh, d0, 0, 0, 0);
-                d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[st][1], xh, d1, 0, 0, 0);
-                Z[s][0] = f32x2{d0[0], d0[1]}; Z[s][1] = f32x2{d0[2], d0[3]};
-                Z[s][2] = f32x2{d1[0], d1[1]}; Z[s][3] = f32x2{d1[2], d1[3]};
+                f32x4 dd[NOB];
 #pragma unroll
-                for (int h = 0; h < 4; ++h) P[s][h] = f32x2{0.f, 0.f};
+                for (int ob = 0; ob < NOB; ++ob) dd[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ob = 0; ob < NOB; ++ob) dd[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[st][ob], xh, dd[ob], 0, 0, 0);
+#pragma unroll
+                for (int ob = 0; ob < NOB; ++ob) dd[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[st][ob], xl, dd[ob], 0, 0, 0);
+#pragma unroll
+                for (int ob = 0; ob < NOB; ++ob) dd[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[st][ob], xh, dd[ob], 0, 0, 0);
+#pragma unroll
+                for (int ob = 0; ob < NOB; ++ob) { Z[s][2 * ob] = f32x2{dd[ob][0], dd[ob][1]}; Z[s][2 * ob + 1] = f32x2{dd[ob][2], dd[ob][3]}; }
+#pragma unroll
+                for (int h = 0; h < NH; ++h) P[s][h] = f32x2{0.f, 0.f};
             }
-            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * NOB, 0);
 #pragma unroll
             for (int s = 0; s < S; ++s) {
-                if (s + 1 < S) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                if (s + 1 < S) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NOB, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3 * NOB, 0);
             }
         }
 
@@ -300,12 +311,11 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
             const int dstl = col_l[k];
             float ev[S];
             gml_load_row<S, VAL_ALIGN>(ea_l + k * S, ev);
-            f32x2 gv[4];
-            {
-                const f32x4 t0 = *reinterpret_cast<const f32x4*>(gs + dstl * LDG + 8 * kq);
-                const f32x4 t1 = *reinterpret_cast<const f32x4*>(gs + dstl * LDG + 8 * kq + 4);
-                gv[0] = f32x2{t0.x, t0.y}; gv[1] = f32x2{t0.z, t0.w};
-                gv[2] = f32x2{t1.x, t1.y}; gv[3] = f32x2{t1.z, t1.w};
+            f32x2 gv[NH];
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob) {               // the lane's 4 NOB columns of the destination's G row
+                const f32x4 t0 = *reinterpret_cast<const f32x4*>(gs + dstl * LDG + 4 * NOB * kq + 4 * ob);
+                gv[2 * ob] = f32x2{t0.x, t0.y}; gv[2 * ob + 1] = f32x2{t0.z, t0.w};
             }
             float d[S];
 #pragma unroll
@@ -313,7 +323,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
                 f32x2 a2 = f32x2{0.f, 0.f};
                 const f32x2 e2 = f32x2{ev[s], ev[s]};
 #pragma unroll
-                for (int h = 0; h < 4; ++h) {
+                for (int h = 0; h < NH; ++h) {
                     P[s][h] = e2 * gv[h] + P[s][h];
                     a2 = Z[s][h] * gv[h] + a2;
                 }
@@ -343,11 +353,20 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
         const int r16o = tid_o & 15, kqo = (tid_o >> 4) & 3, waveo = __builtin_amdgcn_readfirstlane(tid_o >> 6);
         // P -> bf16 (hi, lo) once: B fragments of dX^T (k = o = 8*kq + j) and the rows of the P image.  Before the next
         // group's loads are issued: P and its split are both live here, the prefetch registers are not yet.
-        bf16x8 PH[S], PL[S];
+        typedef typename std::conditional<NOB == 2, bf16x8, bf16x4>::type PFrag;   // (NOB = 1: the 4 live k slots; the rest is zero)
+        PFrag PH[S], PL[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            const float pv[8] = {P[s][0].x, P[s][0].y, P[s][1].x, P[s][1].y, P[s][2].x, P[s][2].y, P[s][3].x, P[s][3].y};
-            gml_split8(pv, PH[s], PL[s]);
+            float pv[8];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const f32x2 t = h < NH ? P[s][h < NH ? h : 0] : f32x2{0.f, 0.f};
+                pv[2 * h] = t.x; pv[2 * h + 1] = t.y;
+            }
+            bf16x8 th, tl;
+            gml_split8(pv, th, tl);                          // (NOB = 1: k slots 8 kq + 4 .. + 7 are zero, like their W rows)
+            if constexpr (NOB == 2) { PH[s] = th; PL[s] = tl; }
+            else { PH[s] = bf16x4{th[0], th[1], th[2], th[3]}; PL[s] = bf16x4{tl[0], tl[1], tl[2], tl[3]}; }
         }
         GML_T3(10);
         latch();
@@ -385,7 +404,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int fb = 0; fb < NFB; ++fb) {
-                    const int o = 8 * kqo + 4 * h + tj, cidx = 4 * fb + tc;
+                    // (NOB = 1: k slots 8 kq + j, j < 4, are outputs 4 kq + j; the slots j >= 4 meet zeros in P -- any finite A will do)
+                    const int o = NOB == 2 ? 8 * kqo + 4 * h + tj : 4 * kqo + tj, cidx = 4 * fb + tc;
                     aoff[h][fb] = o * 64 + ((((cidx >> 1) ^ gml_wkey3(o)) & 3) << 4) + ((cidx & 1) << 3);
                 }
             const unsigned char* Wh8 = reinterpret_cast<const unsigned char*>(W_h);
@@ -394,8 +414,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
             auto fragx = [&](int s, int st) {
 #pragma unroll
                 for (int fb = 0; fb < NFB; ++fb) {
-                    vh[st][fb] = gml_tr_frag(Wh8 + s * 2048 + aoff[0][fb], Wh8 + s * 2048 + aoff[1][fb]);
-                    vl[st][fb] = gml_tr_frag(Wl8 + s * 2048 + aoff[0][fb], Wl8 + s * 2048 + aoff[1][fb]);
+                    vh[st][fb] = gml_tr_frag(Wh8 + s * (WO * 64) + aoff[0][fb], Wh8 + s * (WO * 64) + aoff[1][fb]);
+                    vl[st][fb] = gml_tr_frag(Wl8 + s * (WO * 64) + aoff[0][fb], Wl8 + s * (WO * 64) + aoff[1][fb]);
                 }
             };
             fragx(0, 0);
@@ -403,7 +423,13 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
             for (int s = 0; s < S; ++s) {
                 const int st = s & 1;
                 if (s + 1 < S) fragx(s + 1, st ^ 1);
-                const bf16x8 ph = PH[s], pl = PL[s];
+                bf16x8 ph, pl;
+                if constexpr (NOB == 2) { ph = PH[s]; pl = PL[s]; }
+                else {
+                    const __bf16 z = (__bf16)0.f;
+                    ph = bf16x8{PH[s][0], PH[s][1], PH[s][2], PH[s][3], z, z, z, z};
+                    pl = bf16x8{PL[s][0], PL[s][1], PL[s][2], PL[s][3], z, z, z, z};
+                }
 #pragma unroll
                 for (int fb = 0; fb < NFB; ++fb) dxa[fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl[st][fb], ph, dxa[fb], 0, 0, 0);
 #pragma unroll
@@ -459,15 +485,21 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
 #pragma unroll
                 for (int se = 0; se < SS; ++se) {
                     const int s = sl * SS + se;
-                    *reinterpret_cast<bf16x8*>(pT + se * ROWS * 64 + woff) = PH[s];
-                    *reinterpret_cast<bf16x8*>(pT + (SS + se) * ROWS * 64 + woff) = PL[s];
+                    if constexpr (NOB == 2) {
+                        *reinterpret_cast<bf16x8*>(pT + se * ROWS * 64 + woff) = PH[s];
+                        *reinterpret_cast<bf16x8*>(pT + (SS + se) * ROWS * 64 + woff) = PL[s];
+                    } else {                                 // compact: channel = output 4 kq + j = 8-byte piece kq of the row
+                        const int woff1 = pos * 64 + ((((kqo >> 1) ^ gml_tkey3(pos)) & 3) << 4) + ((kqo & 1) << 3);
+                        *reinterpret_cast<bf16x4*>(pT + se * ROWS * 64 + woff1) = PH[s];
+                        *reinterpret_cast<bf16x4*>(pT + (SS + se) * ROWS * 64 + woff1) = PL[s];
+                    }
                 }
                 __syncthreads();
                 GML_T3(11);
-                // wave's blocks b = wave + NW i: ob = b & 1, fb = (b >> 1) % NFB (the same for every i), se = (b >> 1) / NFB.
+                // wave's blocks b = wave + NW i: ob = b % NOB, fb = (b / NOB) % NFB (the same for every i), se = (b / NOB) / NFB.
                 // The fragments of K step st + 1 are requested before the MFMAs of step st, and the blocks' accumulator
                 // chains are interleaved (one chain of dependent MFMAs behind its own reads is pure latency).
-                const int ob = wave & 1, fb = (wave >> 1) % NFB;
+                const int ob = wave % NOB, fb = (wave / NOB) % NFB;
                 constexpr int NB_ = (C::NBLK >= NW) ? BPW : 1;     // (fewer blocks than waves: one block on the first waves)
                 if (wave < C::NBLK) {
                     bf16x8 fah[2], fal[2], fbh[2][NB_], fbl[2][NB_];
@@ -478,7 +510,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
 #pragma unroll
                         for (int i = 0; i < NB_; ++i) {
                             const int b = min(wave + NW * i, C::NBLK - 1);       // (a wave without an i-th block re-reads its last one)
-                            const int se = (b >> 1) / NFB;
+                            const int se = (b / NOB) / NFB;
                             const unsigned char* pa = pT + se * ROWS * 64 + st * 2048;
                             fbh[sg][i] = gml_tr_frag(pa + roff[0][ob], pa + roff[1][ob]);
                             fbl[sg][i] = gml_tr_frag(pa + SS * ROWS * 64 + roff[0][ob], pa + SS * ROWS * 64 + roff[1][ob]);
@@ -530,7 +562,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
             for (int i = 0; i < BPW; ++i) {
                 const int b = wave + NW * i;
                 if (b < C::NBLK) {
-                    const int ob = b & 1, fb = (b >> 1) % NFB, s = sl * SS + (b >> 1) / NFB;
+                    const int ob = b % NOB, fb = (b / NOB) % NFB, s = sl * SS + (b / NOB) / NFB;
                     const int o = ob * 16 + r16;
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
@@ -542,7 +574,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
     }
 }
 
-template <int S, int NFB, int NW>
+template <int S, int NFB, int NW, int NOB = 2>
 int gml_launch_bwd3(const GmlBwdParams& p, dim3 grid, size_t lds, hipStream_t st);
 
 // the DZ form (dx = conv part + dz . wmix) is compiled for the shape class that uses it: ZINC's layers (S = 8, Fin <= 32,
@@ -574,5 +606,20 @@ struct GmlBwd3Dz<S, NFB, NW, true> {
         if (rc0 != hipSuccess) return (int)rc0;                                                              \
         if (p.xvec) hipLaunchKernelGGL((gml_k_spectconv_bwd3<SV, NFBV, NWV, true>), grid, dim3(64 * NWV), lds, st, p);  \
         else hipLaunchKernelGGL((gml_k_spectconv_bwd3<SV, NFBV, NWV, false>), grid, dim3(64 * NWV), lds, st, p);        \
+        return gml_launch_status();                                                                          \
+    }
+
+// NOB = 1 (Fout <= 16): no dz hand-over form
+#define GML_DEFINE_BWD3_N1(SV, NFBV, NWV)                                                                    \
+    template <>                                                                                              \
+    int gml_launch_bwd3<SV, NFBV, NWV, 1>(const GmlBwdParams& p, dim3 grid, size_t lds, hipStream_t st) {    \
+        static_assert(GmlBwd3Cfg<SV, NFBV, NWV, 1>::OK, "unsupported shape");                                \
+        if (p.dz != nullptr) return GML_E_UNSUPPORTED;                                                       \
+        GML_ALLOW_BIG_LDS(rc1, (&gml_k_spectconv_bwd3<SV, NFBV, NWV, true, false, 1>), 160 * 1024)           \
+        GML_ALLOW_BIG_LDS(rc0, (&gml_k_spectconv_bwd3<SV, NFBV, NWV, false, false, 1>), 160 * 1024)          \
+        if (rc1 != hipSuccess) return (int)rc1;                                                              \
+        if (rc0 != hipSuccess) return (int)rc0;                                                              \
+        if (p.xvec) hipLaunchKernelGGL((gml_k_spectconv_bwd3<SV, NFBV, NWV, true, false, 1>), grid, dim3(64 * NWV), lds, st, p);  \
+        else hipLaunchKernelGGL((gml_k_spectconv_bwd3<SV, NFBV, NWV, false, false, 1>), grid, dim3(64 * NWV), lds, st, p);        \
         return gml_launch_status();                                                                          \
     }

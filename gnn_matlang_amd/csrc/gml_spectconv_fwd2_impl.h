@@ -38,7 +38,7 @@ struct GmlFwd2Cfg {
     // NW = 8 waves / 128-row groups (one workgroup per CU) or NW = 4 waves / 64-row groups (two independent workgroups
     // per CU: each one's per-group latency chain -- record, data, commit, barrier -- overlaps the other's arithmetic)
     static constexpr int rows(int nw) { return 16 * nw; }
-    static constexpr int ecap(int nw) { return 8 * rows(nw); }
+    static constexpr int ecap(int nw) { return (S > 8 ? 12 : 8) * rows(nw); }   // staged edges per group (S = 12, counting.py: 7 edges per row)
     static constexpr int xcap(int nw) { return nw == 8 ? GML_FWD2_XCAP : 144; }   // 64 rows + 2 x the largest graph
     static constexpr size_t lds_bytes(int nw = 8) {
         return (size_t)W_BYTES + (rows(nw) + 8) * 4 + (size_t)ecap(nw) * 4 + (size_t)ecap(nw) * S * 4 +

@@ -196,11 +196,13 @@ def test_fused_forward_and_grads_vs_oracle(dev, S, fin, fout):
 
 
 @pytest.mark.parametrize('S,fin,fout,deg', [(8, 32, 30, 5), (8, 25, 30, 24), (4, 32, 16, 24), (8, 32, 32, 40),
-                                             (12, 32, 32, 5), (12, 32, 30, 7), (12, 20, 9, 24)])
+                                             (12, 32, 32, 5), (12, 32, 30, 7), (12, 20, 9, 24), (12, 32, 16, 10), (12, 32, 16, 11)])
 def test_eight_wave_forward_staged_and_global_paths(dev, S, fin, fout, deg):
     """the 128-row forward kernel on groups inside its LDS capacities (deg 5) and far outside (deg >= 24: > 1024 edges
     per group -> global-gather path), aligned and unaligned x rows, against the oracle; backward rides along.  S = 12
-    (counting.py) stays on the register-staged 8-wave kernel."""
+    (counting.py) stays on the register-staged 8-wave kernel, which stages up to 1,536 edges per group there (deg 10, 11:
+    groups between the old bound of 1,024 and the new one); its backward is the 12-support / 16-column instantiation of the
+    8-wave backward."""
     from gnn_matlang_amd import SpectConv
     from oracle import spect_conv_oracle as O
     rng = np.random.default_rng(S * 100 + deg)
@@ -495,7 +497,7 @@ def test_ml3layer_golden(dev, golden, arith):
 
 @pytest.mark.parametrize('ne,neo,Fin,n1,n2', [(5, 3, 9, 24, 6), (3, 8, 9, 24, 6), (4, 12, 9, 24, 6),
                                               (4, 4, 80, 64, 16), (3, 3, 21, 16, 40),
-                                              (12, 12, 32, 30, 2), (12, 12, 32, 29, 3), (12, 12, 28, 12, 4)])
+                                              (12, 12, 32, 30, 2), (12, 12, 32, 29, 3), (12, 12, 28, 12, 4), (12, 12, 32, 16, 16)])
 def test_ml3layer_wide_shapes(dev, ne, neo, Fin, n1, n2):
     """Shapes off the fused kernels' main road, against the oracle in fp64: nedgeoutput != nedgeinput (allowed by
     spect_conv.py:66-71, unused by the scripts), ninp = 80 (ptc.py:331-338) and a wide Hadamard branch; the last three
