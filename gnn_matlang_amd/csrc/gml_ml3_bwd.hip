@@ -8,6 +8,10 @@
 //   dx             = dz1 w11 + dz2 w12                          (WRITTEN; the conv backward then accumulates into it)
 //   dw11, dw12, db11, db12 = dz^T [x | 1]
 //
+// Pre-masked form (y = G = NULL): gy[:, :nout1] already IS G -- the consumer layer's conv backward applied this layer's relu
+// mask where it produced the gradient (gml_spectconv_bwd_mix_relu) -- so the saved output is not read and no G is written;
+// the pass keeps the bias sums and the Hadamard branch.
+//
 // Replaces three passes (relu mask, Hadamard-branch backward with a strided read-modify-write of dx, bias
 // column sums) by one whose global accesses are all coalesced: SB_ROWS-row tiles, the x / dx tile goes through LDS
 // (row-per-lane compute in between), the weight gradients are contracted on the matrix cores as in
@@ -47,6 +51,7 @@ __global__ __launch_bounds__(SB_ROWS, (FINP <= 32 ? 2 : 1)) void gml_k_ml3_split
     constexpr int LDX = FINP + 1;                              // odd: row-per-lane accesses are conflict free
     constexpr int NFB = FINP / 16;
     const int F2 = p.F2, Fin = p.Fin, nout1 = p.nout1;
+    const bool premasked = p.y == nullptr;                     // (uniform) gy's conv columns are G already
     const int C2 = 2 * F2, C2P = (C2 + 15) / 16 * 16, LDZ = C2P + 1, ncb = C2P / 16, LDI = F2 | 1;
     float* xs = lds;                                           // [SB_ROWS][LDX]   x tile, later the dx tile
     float* wc = xs + SB_ROWS * LDX;                            // [C2][FINP]   w11 rows then w12 rows, zero padded
@@ -125,12 +130,12 @@ __global__ __launch_bounds__(SB_ROWS, (FINP <= 32 ? 2 : 1)) void gml_k_ml3_split
                     const int og = (p.gyseg ? p.gyseg[r0 + rr] * ldgy : __umul24(rr, ldgy)) + fa_y, oy = __umul24(rr, ldy) + fa_o;
                     if constexpr (VEC == 4) {
                         const f32x4 a4 = *reinterpret_cast<const f32x4*>(gyb + og);
-                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(yb + oy);
+                        const f32x4 b4 = premasked ? f32x4{1.f, 1.f, 1.f, 1.f} : *reinterpret_cast<const f32x4*>(yb + oy);
                         vg[j][0] = a4.x; vg[j][1] = a4.y; vg[j][2] = a4.z; vg[j][3] = a4.w;
                         vo[j][0] = b4.x; vo[j][1] = b4.y; vo[j][2] = b4.z; vo[j][3] = b4.w;
                     } else {
                         vg[j][0] = gyb[og];
-                        vo[j][0] = yb[oy];
+                        vo[j][0] = premasked ? 1.f : yb[oy];
                     }
                 }
             }
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(SB_ROWS, (FINP <= 32 ? 2 : 1)) void gml_k_ml3_split
                         if constexpr (FINP > 0)
                             if (fa + k >= nout1 && fa + k < Cy) gi[rr * LDI + (fa + k - nout1)] = rv ? vg[j][k] : 0.f;
                     }
-                    if (rv && fa < ldg) {
+                    if (rv && fa < ldg && !premasked) {
                         const int off = __umul24(rr, ldg) + fa;
                         if constexpr (VEC == 4) *reinterpret_cast<f32x4*>(Gb + off) = f32x4{gm[0], gm[1], gm[2], gm[3]};
                         else Gb[off] = gm[0];
@@ -334,7 +339,7 @@ static int split_bwd_impl(const float* gy, int64_t ldgy, const int32_t* gy_seg, 
                           float* db12, int64_t num_rows, int32_t Fin, int32_t nout1, int32_t F2, void* ws,
                           size_t ws_bytes, gml_stream_t stream) {
     if (dz != nullptr && (dx != nullptr || F2 < 1 || 2 * F2 > 4 || (((uintptr_t)dz) & 15) != 0)) return GML_E_BADARG;
-    if (num_rows < 0 || nout1 <= 0 || F2 < 0 || ldgy < nout1 + F2 || ldy < nout1 || ldg < nout1) return GML_E_BADARG;
+    if (num_rows < 0 || nout1 <= 0 || F2 < 0 || ldgy < nout1 + F2 || (y && ldy < nout1) || (G && ldg < nout1)) return GML_E_BADARG;
     if (F2 > 0 && (Fin <= 0 || ldx < Fin || (dx && lddx < Fin) || !w11 || !w12 || !dw11 || !dw12)) return GML_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     if (F2 == 0) Fin = 0;
@@ -348,7 +353,9 @@ static int split_bwd_impl(const float* gy, int64_t ldgy, const int32_t* gy_seg, 
         }
         return gml_launch_status();
     }
-    if (!gy || !y || !G || (F2 > 0 && !x)) return GML_E_BADARG;
+    if (!gy || (y == nullptr) != (G == nullptr) || (F2 > 0 && !x)) return GML_E_BADARG;   /* y = G = NULL: pre-masked gy */
+    if (!y && gy_seg) return GML_E_BADARG;
+    if (!y) { ldy = ldgy; ldg = ldgy; }
     const int FINP = sb_finp(Fin, F2), CP = sb_cp(ldg > nout1 + F2 ? ldg : nout1 + F2);
     if (FINP < 0 || CP == 0 || 2 * F2 > 16 * SB_MAXCB) return GML_E_UNSUPPORTED;
     const size_t need = gml_ml3_split_bwd_workspace_bytes(num_rows, Fin, nout1, F2);

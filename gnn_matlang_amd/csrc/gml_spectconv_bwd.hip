@@ -155,7 +155,8 @@ static int spectconv_bwd_impl(const int32_t* rowptr, const int32_t* col, const i
                               float* dx, int64_t lddx, float* dval, float* dw,
                               int64_t num_rows, int32_t S, int32_t Fin, int32_t Fout,
                               int32_t max_group_edges, int32_t max_group_window, uint32_t flags,
-                              void* ws, size_t ws_bytes, gml_stream_t stream, const float* dz, const float* wmix, int32_t nmix) {
+                              void* ws, size_t ws_bytes, gml_stream_t stream, const float* dz, const float* wmix, int32_t nmix,
+                              int32_t relu_cols = 0) {
     if (num_rows < 0 || S <= 0 || Fin <= 0 || Fout <= 0 || ldx < Fin || ldg < Fout) return GML_E_BADARG;
     if (dx && lddx < Fin) return GML_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
@@ -174,7 +175,7 @@ static int spectconv_bwd_impl(const int32_t* rowptr, const int32_t* col, const i
     p.rowptr = rowptr; p.col = col; p.ginfo = ginfo; p.val = val; p.x = x; p.ldx = ldx; p.g = g; p.ldg = ldg;
     p.w = w; p.dx = dx; p.lddx = lddx; p.dval = dval; p.dw_partial = dw ? (float*)ws : nullptr;
     p.nrows = num_rows; p.S = S; p.Fin = Fin; p.Fout = Fout; p.flags = flags;
-    p.dz = dz; p.wmix = wmix; p.nmix = nmix;
+    p.dz = dz; p.wmix = wmix; p.nmix = nmix; p.relu_cols = relu_cols;
     if (dz != nullptr && (pl.layout != 3 || (flags & GML_ACCUM) || (((uintptr_t)dz) & 15) != 0))
         return GML_E_UNSUPPORTED;
 #ifdef GML_BWD2_TIMING
@@ -255,6 +256,23 @@ extern "C" int gml_spectconv_bwd_mix(const int32_t* rowptr, const int32_t* col, 
     if (!dz || !wmix || !dx || !gml_spectconv_bwd_mix_supported(S, Fin, Fout, nmix, flags)) return GML_E_UNSUPPORTED;
     return spectconv_bwd_impl(rowptr, col, ginfo, val, x, ldx, g, ldg, w, dx, lddx, dval, dw, num_rows, S, Fin, Fout,
                               max_group_edges, max_group_window, flags, ws, ws_bytes, stream, dz, wmix, nmix);
+}
+
+// gml_spectconv_bwd_mix for an ML3Layer whose input x is the output of another ML3Layer ([relu(conv) | Hadamard columns],
+// libs/spect_conv.py:209-212, stacked as in Zinc12k.py:338-341): dx[:, f] for f < relu_cols is written multiplied by
+// (x[:, f] > 0) -- the relu of the layer below applied where its gradient is produced (the kernel holds those x rows anyway).
+// The layer below then runs gml_ml3_split_bwd_ex in its pre-masked form (y = G = NULL): no saved output read, no G written.
+extern "C" int gml_spectconv_bwd_mix_relu(const int32_t* rowptr, const int32_t* col, const int32_t* ginfo, const float* val,
+                                          const float* x, int64_t ldx, const float* g, int64_t ldg, const float* w,
+                                          float* dx, int64_t lddx, float* dval, float* dw, const float* dz, const float* wmix,
+                                          int32_t nmix, int32_t relu_cols, int64_t num_rows, int32_t S, int32_t Fin, int32_t Fout,
+                                          int32_t max_group_edges, int32_t max_group_window, uint32_t flags,
+                                          void* ws, size_t ws_bytes, gml_stream_t stream) {
+    if (relu_cols < 0 || relu_cols > Fin) return GML_E_BADARG;
+    if (!dz || !wmix || !dx || !gml_spectconv_bwd_mix_supported(S, Fin, Fout, nmix, flags)) return GML_E_UNSUPPORTED;
+    if (relu_cols > 0 && (bwd4_env() || (flags & GML_DMA_RING))) return GML_E_UNSUPPORTED;   /* (the ring form has no mask) */
+    return spectconv_bwd_impl(rowptr, col, ginfo, val, x, ldx, g, ldg, w, dx, lddx, dval, dw, num_rows, S, Fin, Fout,
+                              max_group_edges, max_group_window, flags, ws, ws_bytes, stream, dz, wmix, nmix, relu_cols);
 }
 
 #ifdef GML_BWD2_TIMING

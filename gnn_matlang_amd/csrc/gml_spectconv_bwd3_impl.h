@@ -255,6 +255,11 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
                 if (!(rvalid && 8 * kq + j < p.Fin)) xb[j] = 0.f;
         }
         gml_split8(xb, xh, xl);
+        unsigned xpos = 0;                                   // DZ, relu_cols > 0: bit j = (x[row][8 kq + j] > 0), the relu mask of the layer below
+        if constexpr (DZ) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xpos |= (xb[j] > 0.f ? 1u : 0u) << j;
+        }
 
         // ---- Z^T = W^T X^T: MFMA row i of block ob carries o = 8*(i>>2) + 4*ob + (i&3), so lane kq receives its 8
         //      consecutive outputs o = 8*kq + 4*ob + reg.  Fragments of support s + 1 are requested before the MFMAs of s.
@@ -442,6 +447,17 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
             for (int s = 0; s < S; ++s) {
                 if (s + 1 < S) __builtin_amdgcn_sched_group_barrier(0x100, 4 * NFB, 1);
                 __builtin_amdgcn_sched_group_barrier(0x008, 3 * NFB, 1);
+            }
+            if constexpr (DZ) {
+                if (p.relu_cols > 0) {                       // features 16 fb + 4 kq + reg of the own row: their mask bits sit in the lane
+#pragma unroll                                               // (r16, 2 fb + (kq >> 1)), nibble kq & 1
+                    for (int fb = 0; fb < NFB; ++fb) {
+                        const unsigned mm = (unsigned)__shfl((int)xpos, r16o + 16 * (2 * fb + (kqo >> 1))) >> (4 * (kqo & 1));
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg)
+                            if (16 * fb + 4 * kqo + reg < p.relu_cols && !((mm >> reg) & 1u)) dxa[fb][reg] = 0.f;
+                    }
+                }
             }
             float* dr = p.dx + (r0 + row) * p.lddx + 4 * kqo;
             if (GML_ABL & 8) {

@@ -49,6 +49,10 @@ struct GmlBwdParams {
     const float* dz;
     const float* wmix;
     int32_t nmix;
+    // bwd3 DZ form, optional: the first relu_cols features of x are relu outputs of the layer below (x = [relu(conv) | ...], an
+    // ML3Layer feeding an ML3Layer): dx[:, f < relu_cols] is written already multiplied by (x[:, f] > 0) -- it IS the gradient at
+    // that layer's conv output, so its output-stage backward needs neither its saved output nor a second [N, C] array
+    int32_t relu_cols;
 #ifdef GML_BWD2_TIMING
     unsigned long long* prof;    // debug build: per-phase cycle sums
 #endif

@@ -304,12 +304,14 @@ def node_mix_native(Fin, F2):
 
 
 def ml3_split_bwd(gy, y, nout1, x=None, w11=None, b11=None, w12=None, b12=None, need_dx=False, need_dcb=False, dz_out=False,
-                  gy_seg=None):
+                  gy_seg=None, premasked=False):
     """One pass over the rows for the backward of  cat[relu(conv), tanh(fc11 x) * tanh(fc12 x)]  (or of a plain
     relu(conv) when w11 is None): returns G [N, nout1] (view of a zero-padded buffer), dx (Hadamard-branch part
     only, or None), dcb, dw11, db11, dw12, db12.  dz_out (2 nout2 <= 4): the second result is dz [N, 4] = (dz11 | dz12)
     instead of dx = dz [w11; w12] (the operand of fused_conv_bwd(..., mix=)).  gy_seg (int32 [N]): gy has one row per
-    segment and row r reads gy[gy_seg[r]] (the un-expanded gradient of a global add pool that follows the layer)."""
+    segment and row r reads gy[gy_seg[r]] (the un-expanded gradient of a global add pool that follows the layer).
+    premasked: gy[:, :nout1] already carries this layer's relu mask (the consumer layer's conv backward applied it,
+    fused_conv_bwd(..., relu_cols=)): y is not read, no G is written -- the returned G is a view of gy."""
     N = y.size(0)
     F2 = 0 if w11 is None else int(w11.size(0))
     Fin = int(x.size(1)) if F2 else 0
@@ -318,7 +320,8 @@ def ml3_split_bwd(gy, y, nout1, x=None, w11=None, b11=None, w12=None, b12=None, 
     if nbytes == 0 and N > 0:
         return None
     ld = (nout1 + 3) // 4 * 4                                # zero padded: float4-readable rows
-    G = torch.empty(N, ld, dtype=torch.float32, device=dev)
+    premasked = bool(premasked and gy_seg is None and gy.stride(0) % 4 == 0 and gy.stride(0) >= ld and gy.data_ptr() % 16 == 0)
+    G = gy if premasked else torch.empty(N, ld, dtype=torch.float32, device=dev)
     ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=dev)
     dx = torch.empty(N, Fin, dtype=torch.float32, device=dev) if (need_dx and F2 and not dz_out) else None
     dz = torch.empty(N, 4, dtype=torch.float32, device=dev) if (dz_out and F2) else None
@@ -327,10 +330,10 @@ def ml3_split_bwd(gy, y, nout1, x=None, w11=None, b11=None, w12=None, b12=None, 
     dw12 = torch.empty_like(w12) if F2 else None
     db11 = torch.empty_like(b11) if (F2 and b11 is not None) else None
     db12 = torch.empty_like(b12) if (F2 and b12 is not None) else None
-    with _Timed('ml3_split_bwd', 4 * N * (3 * (nout1 + F2) + (2 * Fin if dx is not None else Fin) + (4 if dz is not None else 0))):
-        if dz is not None or gy_seg is not None:
-            _lib.call('gml_ml3_split_bwd_ex', _ptr(gy), int(gy.stride(0)), _ptr(gy_seg), _ptr(y), int(y.stride(0)), _ptr(x),
-                      int(x.stride(0)) if F2 else 0, _ptr(w11), _ptr(b11), _ptr(w12), _ptr(b12), _ptr(G), ld, _ptr(dx), Fin,
+    with _Timed('ml3_split_bwd', 4 * N * ((1 if premasked else 3) * (nout1 + F2) + (2 * Fin if dx is not None else Fin) + (4 if dz is not None else 0))):
+        if dz is not None or gy_seg is not None or premasked:
+            _lib.call('gml_ml3_split_bwd_ex', _ptr(gy), int(gy.stride(0)), _ptr(gy_seg), _ptr(None if premasked else y), int(y.stride(0)), _ptr(x),
+                      int(x.stride(0)) if F2 else 0, _ptr(w11), _ptr(b11), _ptr(w12), _ptr(b12), _ptr(None if premasked else G), ld, _ptr(dx), Fin,
                       _ptr(dz), _ptr(dcb), _ptr(dw11), _ptr(db11), _ptr(dw12), _ptr(db12), int(N), Fin, int(nout1), F2,
                       _ptr(ws), ws.numel(), _stream(dev))
         else:
@@ -464,9 +467,10 @@ def conv_bwd_takes_dz(csr, S, Fin, Fout, nmix):
 BWD_DMA = _os.environ.get('GML_BWD_DMA') == '1'     # fused backward on the LDS-DMA ring kernel (bwd4) where it applies; A/B switch
 
 
-def fused_conv_bwd(csr, val_t, x, G, weight, need_x, need_val, need_w, dx_accum_into=None, mix=None):
+def fused_conv_bwd(csr, val_t, x, G, weight, need_x, need_val, need_w, dx_accum_into=None, mix=None, relu_cols=0):
     """one launch: dX, dval (source order), dW.  val_t: supports in source order.  mix = (dz [N, 4], wmix [nmix, Fin]):
-    dX = conv part + dz wmix (instead of accumulating into a dx another kernel wrote)."""
+    dX = conv part + dz wmix (instead of accumulating into a dx another kernel wrote).  relu_cols (with mix): dX[:, f] for
+    f < relu_cols is written multiplied by (x[:, f] > 0) (gml_spectconv_bwd_mix_relu: the relu of the ML3Layer below)."""
     S, Fin, Fout = weight.shape
     dev = x.device
     flags, ginfo, gmax, nbytes, _ = _bwd_plan(csr, S, Fin, Fout)
@@ -489,11 +493,12 @@ def fused_conv_bwd(csr, val_t, x, G, weight, need_x, need_val, need_w, dx_accum_
     with _Timed('spectconv_bwd', q, f):
         if mix is not None:
             dz, wmix = mix
-            _lib.call('gml_spectconv_bwd_mix', _ptr(csr.rowptr_t), _ptr(csr.col_t), _ptr(ginfo), _ptr(val_t),
+            _lib.call('gml_spectconv_bwd_mix_relu', _ptr(csr.rowptr_t), _ptr(csr.col_t), _ptr(ginfo), _ptr(val_t),
                       _ptr(x), int(x.stride(0)), _ptr(G), int(G.stride(0)), _ptr(weight), _ptr(dx), Fin, _ptr(dval_t),
-                      _ptr(dw), _ptr(dz), _ptr(wmix), int(wmix.size(0)), csr.N, S, Fin, Fout, gmax[0], gmax[1], flags, _ptr(ws),
-                      ws.numel() if ws is not None else 0, _stream(dev))
+                      _ptr(dw), _ptr(dz), _ptr(wmix), int(wmix.size(0)), int(relu_cols), csr.N, S, Fin, Fout, gmax[0], gmax[1], flags,
+                      _ptr(ws), ws.numel() if ws is not None else 0, _stream(dev))
         else:
+            assert relu_cols == 0, 'the relu hand-over rides on the dz form of the backward'
             _lib.call('gml_spectconv_bwd', _ptr(csr.rowptr_t), _ptr(csr.col_t), _ptr(ginfo), _ptr(val_t),
                       _ptr(x), int(x.stride(0)), _ptr(G), int(G.stride(0)), _ptr(weight), _ptr(dx), Fin, _ptr(dval_t),
                       _ptr(dw), csr.N, S, Fin, Fout, gmax[0], gmax[1], flags, _ptr(ws),
@@ -503,7 +508,7 @@ def fused_conv_bwd(csr, val_t, x, G, weight, need_x, need_val, need_w, dx_accum_
 
 # ---------------------------------------------------------------------------- shared backward pieces
 def _conv_backward(csr, x, val, weight, G, need_x, need_val, need_w, val_t=None, want_source_order=False,
-                   dx_accum_into=None, mix=None):
+                   dx_accum_into=None, mix=None, relu_cols=0):
     """G [N,Fout] contiguous = gradient at the (pre-activation) conv output.
     Returns dx, dval, dw; dval is in source order when want_source_order (and the fused kernel ran).
     dx_accum_into: [N,Fin] buffer that already holds a partial dx; the conv contribution is added to it."""
@@ -517,7 +522,7 @@ def _conv_backward(csr, x, val, weight, G, need_x, need_val, need_w, val_t=None,
         if val_t is None:
             with _Timed('val_to_source_order'):
                 val_t = csr.to_source_order(val)
-        dx, dval_t, dw = fused_conv_bwd(csr, val_t, x, G, weight, need_x, need_val, need_w, dx_accum_into, mix)
+        dx, dval_t, dw = fused_conv_bwd(csr, val_t, x, G, weight, need_x, need_val, need_w, dx_accum_into, mix, relu_cols)
         if need_val and not want_source_order:
             with _Timed('dval_from_source_order'):
                 dval_t = csr.from_source_order(dval_t)
@@ -591,6 +596,21 @@ class SpectConvFunction(torch.autograd.Function):
         return dx, dval, dw, db, None, None
 
 
+class ChainToken(object):
+    """Hand-over between two stacked ML3Layers (Zinc12k.py:338-341: x = conv2(conv1(x, ...), ...)): the upper layer's conv
+    backward holds the rows of x = [relu(conv) | Hadamard columns] of the lower layer anyway, so it writes dx already
+    multiplied by that relu's mask (`premasked`), and the lower layer's output-stage backward then neither reads its saved
+    output nor writes a second [N, C] array.  Valid only when the upper layer is the ONLY consumer of that tensor --
+    ML3Layer.chain_after() is how a model says so.  cols: relu columns of the lower layer's output (nout1)."""
+    __slots__ = ('cols', 'premasked')
+
+    def __init__(self, cols):
+        self.cols, self.premasked = int(cols), False
+
+
+CHAIN = not _os.environ.get('GML_NO_CHAIN')      # A/B switch for the relu hand-over between stacked ML3Layers
+
+
 class ML3LayerFunction(torch.autograd.Function):
     """Whole ML3Layer.forward (libs/spect_conv.py:204-212) with the concat written in place:
          ea' = edge-MLP(val)                      (learnedge)
@@ -600,7 +620,9 @@ class ML3LayerFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, val, w1, w2, w3, w4, cw, cb, w11, b11, w12, b12, csr, learnedge, nout2, val_is_source=False,
-                pool_ptr=None, pool_seg=None, pool_mean=False):
+                pool_ptr=None, pool_seg=None, pool_mean=False, chain_in=None, chain_out=None):
+        # chain_in / chain_out (ChainToken): x is the output of the ML3Layer that owns chain_in and has no other consumer /
+        # this layer's own token, which the consumer of its output sets (see ChainToken)
         # pool_ptr / pool_seg (int32 [B+1] / [N]): the layer is directly followed by global_add_pool / global_mean_pool
         # (Zinc12k.py:343): the pooled [B, C] tensor is returned and the pool's gradient is never expanded to [N, C]
         # val_is_source: val holds the raw supports in SOURCE order (the caller checked ml3_edge_in_source_order and that they
@@ -663,6 +685,8 @@ class ML3LayerFunction(torch.autograd.Function):
         ctx.src_order = epos is not None
         ctx.val_is_source = bool(val_is_source)
         ctx.pool = (pool_ptr, pool_seg, bool(pool_mean)) if pool_ptr is not None else None
+        ctx.chain_in = chain_in if (CHAIN and chain_in is not None and chain_in.cols <= Fin) else None
+        ctx.chain_out = chain_out if (CHAIN and ctx.pool is None) else None
         ctx.save_for_backward(x, val, (ea if learnedge and epos is None else None), w1, w2, w3, w4, cw, w11, b11, w12, b12, out, ea_t)
         if ctx.pool is not None:
             return segment_sum(out, pool_ptr, pool_mean)
@@ -678,7 +702,7 @@ class ML3LayerFunction(torch.autograd.Function):
         gy = _f32c(gy, 'grad_out')
         if not learnedge:
             ea = val
-        g = [None] * 19
+        g = [None] * 21
         gy_seg = None
         if ctx.pool is not None:                               # gy is the POOLED gradient [B, C]
             pptr, pseg, pmean = ctx.pool
@@ -700,15 +724,24 @@ class ML3LayerFunction(torch.autograd.Function):
             # 2 nout2 <= 4 (Zinc12k.py's 30+2 layers): the Hadamard branch hands its share of dx to the conv backward as 4 numbers
             # per row (dz) instead of writing a [N, Fin] array the conv kernel reads back
             use_dz = bool(mixk and need[0] and conv_bwd_takes_dz(csr, S, Fin, nout1, 2 * nout2))
-            r = ml3_split_bwd(gy, out, nout1, x, w11, b11, w12, b12, need_dx=need[0], need_dcb=want_cb, dz_out=use_dz, gy_seg=gy_seg) \
-                if mixk else ml3_split_bwd(gy, out, nout1, need_dcb=want_cb, gy_seg=gy_seg)
+            # the consumer of this layer's output already applied the relu mask to gy (ChainToken); read once, then cleared
+            pre = ctx.chain_out is not None and ctx.chain_out.premasked and gy_seg is None
+            if ctx.chain_out is not None:
+                ctx.chain_out.premasked = False
+            r = ml3_split_bwd(gy, out, nout1, x, w11, b11, w12, b12, need_dx=need[0], need_dcb=want_cb, dz_out=use_dz, gy_seg=gy_seg,
+                              premasked=pre) \
+                if mixk else ml3_split_bwd(gy, out, nout1, need_dcb=want_cb, gy_seg=gy_seg, premasked=pre)
             if r is not None:
                 # one pass: relu mask, conv1.bias gradient, Hadamard branch (its dx written, conv adds to it)
                 G, dx0, g[7], g[8], g[9], g[10], g[11] = r
                 mix = (dx0, torch.cat([w11, w12], 0).contiguous()) if use_dz else None
+                # x is the lower ML3Layer's output and only this layer consumes it: hand its relu mask back inside dx
+                rc = ctx.chain_in.cols if (use_dz and ctx.chain_in is not None and not BWD_DMA) else 0
                 dx, dea, dcw, dea_src = _conv_backward(csr, x, ea, cw, G, need[0], need_val, need[6], val_t=ea_t,
                                                        want_source_order=learnedge,
-                                                       dx_accum_into=None if use_dz else dx0, mix=mix)
+                                                       dx_accum_into=None if use_dz else dx0, mix=mix, relu_cols=rc)
+                if rc:
+                    ctx.chain_in.premasked = True
                 g[6] = dcw
             else:
                 assert gy_seg is None, 'pooled gradient without the one-pass output-stage kernel'

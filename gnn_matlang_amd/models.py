@@ -78,6 +78,11 @@ class GNNML3(torch.nn.Module):
             fin = widths[i] + nout2
             if bn:
                 setattr(self, 'bn%d' % (i + 1), torch.nn.BatchNorm1d(fin))
+        if not bn and not self.dense_n:
+            # x = conv2(conv1(x, ...), ...) with nothing else reading the intermediate outputs (Zinc12k.py:338-341,
+            # counting.py:361-366, sr25.py:266-270): the relu hand-over between stacked layers applies
+            for i in range(1, nlayers):
+                getattr(self, 'conv%d' % (i + 1)).chain_after(getattr(self, 'conv%d' % i))
         nin = fin
         if readout_bn:                       # TF ReadoutLayer: batch_normalization of the pooled vector
             # tf.layers.batch_normalization defaults (libs/layers_tf.py:349): epsilon 1e-3, momentum 0.99 (= 0.01 in torch's convention)

@@ -13,6 +13,8 @@ required (only ``aggr='add'``, ``flow='source_to_target'``, ``node_dim=0`` exist
 """
 import math
 
+import weakref
+
 import torch
 from torch.nn import Parameter
 
@@ -253,6 +255,10 @@ class _EpilogueFn(torch.autograd.Function):
         return (None, None, None) + tuple(grads)
 
 
+# per ML3Layer instance: (weakref to the output tensor of its latest forward, that forward's functional.ChainToken)
+_CHAIN_STATE = weakref.WeakKeyDictionary()
+
+
 class ML3Layer(torch.nn.Module):
     """One GNNML3 layer: optional per-edge MLP on the supports, relu(SpectConv) || tanh(fc11 x)*tanh(fc12 x)."""
 
@@ -271,6 +277,23 @@ class ML3Layer(torch.nn.Module):
         if nout2 > 0:
             self.fc11 = torch.nn.Linear(ninp, nout2)
             self.fc12 = torch.nn.Linear(ninp, nout2)
+        self._chain_prev = ()        # (the ML3Layer whose output tensor IS this layer's x,) -- see chain_after
+
+    def chain_after(self, prev):
+        """Declare that this layer's input x is `prev`'s output tensor itself and that NOTHING else consumes that tensor
+        (Zinc12k.py:338-341: x = conv2(conv1(x, ...), ...)).  The backward then applies prev's relu where this layer produces
+        dL/dx and prev's output-stage backward skips its saved output (functional.ChainToken).  Checked per call: only taken
+        when x is that very tensor object; with a skip connection or a second reader of prev's output, do not declare it."""
+        self._chain_prev = (prev,) if prev is not None else ()      # (a tuple: not registered as a submodule)
+        return self
+
+    def _chain_args(self, x):
+        cin = None
+        if self._chain_prev and torch.is_grad_enabled() and x.requires_grad:
+            ref, token = _CHAIN_STATE.get(self._chain_prev[0], (None, None))
+            if ref is not None and ref() is x:
+                cin = token
+        return cin, Fn.ChainToken(self.conv1.weight.size(2))
 
     def forward_pooled(self, x, edge_index, edge_attr, ptr, batch, mean=False):
         """global_add_pool / global_mean_pool (mean=True) of forward(...) in one autograd node: [B, nout1 + nout2].  Same
@@ -294,7 +317,7 @@ class ML3Layer(torch.nn.Module):
             return ML3LayerFunction.apply(x, val, None, None, None, None, self.conv1.weight, self.conv1.bias,
                                           self.fc11.weight if n2 > 0 else None, self.fc11.bias if n2 > 0 else None,
                                           self.fc12.weight if n2 > 0 else None, self.fc12.bias if n2 > 0 else None,
-                                          csr, False, n2, False, *(_pool if _pool is not None else (None, None, False)))
+                                          csr, False, n2, False, *(_pool if _pool is not None else (None, None, False)))   # (no hand-over on this road)
         # learnedge: fc1_1..3 are Linear(nedgeinput, .) -- the width must match, as in the reference; otherwise conv1
         # reads the first K columns only
         # Training with the edge branch: the branch runs in SOURCE order (functional.ML3LayerFunction).  SpectralDesign emits
@@ -308,14 +331,20 @@ class ML3Layer(torch.nn.Module):
             val = edge_attr.detach()
         else:
             val = _sorted_values(csr, edge_index, edge_attr, None if le else self.conv1.weight.size(0))
-        return ML3LayerFunction.apply(
+        cin, cout = self._chain_args(x)
+        out = ML3LayerFunction.apply(
             x, val,
             self.fc1_1.weight if le else None, self.fc1_2.weight if le else None,
             self.fc1_3.weight if le else None, self.fc1_4.weight if le else None,
             self.conv1.weight, self.conv1.bias,
             self.fc11.weight if n2 > 0 else None, self.fc11.bias if n2 > 0 else None,
             self.fc12.weight if n2 > 0 else None, self.fc12.bias if n2 > 0 else None,
-            csr, le, n2, bool(raw_src), *(_pool if _pool is not None else (None, None, False)))
+            csr, le, n2, bool(raw_src), *(_pool if _pool is not None else (None, None, False)), cin, cout)
+        if _pool is None and torch.is_grad_enabled():
+            _CHAIN_STATE[self] = (weakref.ref(out), cout)       # the output tensor of this forward and its hand-over token
+        else:
+            _CHAIN_STATE.pop(self, None)
+        return out
 
 
 __all__ = ['SpectConv', 'SpectConCatConv', 'ML3Layer', 'GraphCSR', 'glorot', 'zeros']

@@ -178,6 +178,18 @@ int gml_spectconv_bwd_mix(const int32_t* rowptr, const int32_t* col, const int32
                           int32_t max_group_edges, int32_t max_group_window, uint32_t flags,
                           void* ws, size_t ws_bytes, gml_stream_t stream);
 
+/* gml_spectconv_bwd_mix for a layer whose input x is itself an ML3Layer output [relu(conv) | Hadamard columns] with nothing
+ * else consuming it (libs/spect_conv.py:209-212 stacked as in Zinc12k.py:338-341): dx[:, f] for f < relu_cols is written
+ * multiplied by (x[:, f] > 0), i.e. dx[:, :relu_cols] IS the gradient at the conv output of the layer below.  That layer then
+ * calls gml_ml3_split_bwd_ex in its pre-masked form (y = G = NULL) and passes dx itself as g to its own conv backward
+ * (columns >= its Fout are ignored there).  relu_cols = 0: gml_spectconv_bwd_mix.  Same support test. */
+int gml_spectconv_bwd_mix_relu(const int32_t* rowptr, const int32_t* col, const int32_t* ginfo, const float* val,
+                               const float* x, int64_t ldx, const float* g, int64_t ldg, const float* w,
+                               float* dx, int64_t lddx, float* dval, float* dw, const float* dz, const float* wmix, int32_t nmix,
+                               int32_t relu_cols, int64_t num_rows, int32_t S, int32_t Fin, int32_t Fout,
+                               int32_t max_group_edges, int32_t max_group_window, uint32_t flags,
+                               void* ws, size_t ws_bytes, gml_stream_t stream);
+
 /* H[r, s, :] = sum_{k in row r} val[pos(k), s] * x[col[k], :]     H is [N, S, Fin] contiguous.
  * ginfo128 (optional): 128-row group records of this CSR -> the LDS-DMA ring kernel (gml_spmm3_impl.h): any S, any Fin % 4 == 0,
  * float4-addressable x rows, epos NULL, groups of up to ~2048 staged edges (larger ones gather from global memory, same
@@ -265,7 +277,9 @@ int gml_ml3_split_bwd(const float* gy, int64_t ldgy, const float* y, int64_t ldy
 
 /* general form.  dz != NULL (then dx == NULL; 2 F2 <= 4): dz [num_rows, 4] = (dz11 | dz12) is written instead of dx (columns
  * beyond 2 F2 zero): the operand of gml_spectconv_bwd_mix.  gy_seg != NULL: gy holds one row per SEGMENT and row r reads
- * gy[gy_seg[r]] -- the gradient of a global add pool that directly follows the layer (Zinc12k.py:343), never expanded. */
+ * gy[gy_seg[r]] -- the gradient of a global add pool that directly follows the layer (Zinc12k.py:343), never expanded.
+ * y == NULL and G == NULL (pre-masked form; gy_seg NULL): gy[:, :nout1] already carries the relu mask
+ * (gml_spectconv_bwd_mix_relu wrote it): the saved output is not read and no G is written -- gy is G. */
 int gml_ml3_split_bwd_ex(const float* gy, int64_t ldgy, const int32_t* gy_seg, const float* y, int64_t ldy,
                          const float* x, int64_t ldx, const float* w11, const float* b11, const float* w12, const float* b12,
                          float* G, int64_t ldg, float* dx, int64_t lddx, float* dz, float* dcb,

@@ -911,6 +911,54 @@ def test_ml3_hadamard_dx_handover_matches_accumulate(dev, monkeypatch):
         close(a, b, tol=2e-5, what='dz hand-over vs accumulate')
 
 
+def test_stacked_ml3_relu_handover_matches_unchained(dev, monkeypatch):
+    """Two / three stacked ML3Layers declared with chain_after (Zinc12k.py:338-341): the upper layer's conv backward writes dx
+    already multiplied by the lower layer's relu mask (gml_spectconv_bwd_mix_relu), the lower layer's output stage runs
+    pre-masked (no saved-output read, no G array).  Same gradients as the unchained stack -- every tensor, including the
+    lower layers' conv bias (column sums of the masked gradient) -- and the hand-over is dropped, not mis-applied, when the
+    intermediate tensor is not the declared one (a clone in between)."""
+    from gnn_matlang_amd import ML3Layer, functional as Fn
+    rng = np.random.default_rng(41)
+    torch.manual_seed(41)
+    N, S = 900, 8
+    ei = _random_graph(rng, N, 6)
+    ei = ei[:, np.lexsort((ei[1], ei[0]))]                   # source-sorted, as SpectralDesign emits
+    eit = T(ei).to(dev)
+    layers = [ML3Layer(True, S, S, 25, 30, 2).to(dev), ML3Layer(True, S, S, 32, 30, 2).to(dev), ML3Layer(True, S, S, 32, 30, 2).to(dev)]
+    x0, ea = torch.randn(N, 25, device=dev), torch.randn(ei.shape[1], S, device=dev)
+    gout = torch.randn(N, 32, device=dev)
+
+    def run(chained, clone_between=False):
+        for i, l in enumerate(layers):
+            l.zero_grad()
+            l.chain_after(layers[i - 1] if (chained and i > 0) else None)
+        x = x0.clone().requires_grad_(True)
+        h = x
+        Fn.PATHS.clear()
+        for i, l in enumerate(layers):
+            h = l(h, eit, ea)
+            if clone_between and i == 0:
+                h = h.clone()                                # a different tensor object: the declaration does not apply to it
+        (h * gout).sum().backward()
+        return [x.grad.clone()] + [p.grad.clone() for l in layers for p in l.parameters()]
+
+    calls = []
+    real = Fn.ml3_split_bwd
+    monkeypatch.setattr(Fn, 'ml3_split_bwd', lambda *a, **k: (calls.append(bool(k.get('premasked'))), real(*a, **k))[1])
+    ref = run(False)
+    assert calls == [False, False, False]
+    del calls[:]
+    got = run(True)
+    assert calls == [False, True, True], calls               # (backward order: top layer first; the two below ran pre-masked)
+    for a, b in zip(got, ref):
+        close(a, b, tol=1e-6, what='relu hand-over vs unchained')
+    del calls[:]
+    got = run(True, clone_between=True)
+    assert calls == [False, True, False], calls
+    for a, b in zip(got, ref):
+        close(a, b, tol=1e-6, what='relu hand-over with a foreign tensor in between')
+
+
 @pytest.mark.parametrize('mean', [False, True])
 def test_ml3_forward_pooled_matches_layer_then_pool(dev, mean):
     """ML3Layer.forward_pooled (the layer and the global add / mean pool that follows it as one autograd node: the pool's
