@@ -281,6 +281,11 @@ def main():
     # EXACTLY K steps per block, bracketed by barrier + synchronize; the block is repeated until min-seconds of GPU time
     # have passed (so that a sampler sees the GPU busy) and the MEDIAN block is reported.  Kernel events: last block.
     # (all ranks take the same number of blocks: the decision is made on rank 0's clock and broadcast)
+    # (the cyclic garbage collector is parked for the timed blocks, as timeit does: a generation-2 pass is a ~65 ms host stall,
+    #  which in the block that records two HIP events per launch shows up as GPU idle time inside one event pair)
+    import gc
+    gc.collect()
+    gc.disable()
     blocks, total = [], 0.0
     while True:
         last = total + (blocks[-1] if blocks else 0) >= args.min_seconds or len(blocks) >= 63
@@ -295,7 +300,15 @@ def main():
         total += dt
         if last:
             break
+    gc.enable()
     prof, Fn.PROFILE = Fn.PROFILE, None
+    if os.environ.get('GML_BENCH_DUMP') and prof:            # debugging aid: per-launch HIP-event times of the profiled block
+        for tag, recs in prof.items():
+            ms = [a.elapsed_time(b) for a, b, _, _ in recs]
+            n = max(len(ms) // args.steps, 1)
+            log('launches of %s: %s' % (tag, [round(sum(ms[i::n]) / args.steps, 3) for i in range(n)]))
+            log('   first launch of every step: %s' % [round(v, 2) for v in ms[0::n]])
+        log('blocks: %s' % [round(b, 4) for b in blocks])
     dt = float(np.median(blocks))
     log('timed region: %d blocks of %d steps, median %.3f s (min %.3f, max %.3f)' % (len(blocks), args.steps, dt, min(blocks), max(blocks)))
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)

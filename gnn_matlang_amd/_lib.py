@@ -37,6 +37,7 @@ SIGNATURES = {
     'gml_spectconv_bwd_mix_supported': (ctypes.c_int, [_i32, _i32, _i32, _i32, _u32]),
     'gml_spectconv_bwd_mix': (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _i32,
                                              _i64, _i32, _i32, _i32, _i32, _i32, _u32, _p, _sz, _p]),
+    'gml_edge_mlp_fwd_stack': (ctypes.c_int, [_p, _i32, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
     'gml_spectconv_bwd_mix_relu': (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _i32, _i32,
                                                   _i64, _i32, _i32, _i32, _i32, _i32, _u32, _p, _sz, _p]),
     'gml_spectconv_fwd_epi': (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _p, _p, _i64, _i64, _i32, _i32, _i32,

@@ -330,6 +330,91 @@ __global__ __launch_bounds__(256, 2) void gml_k_edge_chain_fwd(const float* __re
     }
 }
 
+// ------------------------------------------------------------------------------------------ forward of a layer stack
+// Every ML3Layer of a stack applies ITS edge branch to the SAME raw supports (Zinc12k.py:338-341 passes data.edge_attr2 to
+// conv1 .. conv4): the kernel above is HBM-bound reading them (32 B per edge in, 32 B out), so L launches read them L times.
+// Here one pass reads a tile pair's pre-split operand once and runs the L chains on it, each with its own weight registers
+// (20 VGPRs per layer) and its own output array: (1 + L) x 32 B per edge instead of 2 L x 32 B.
+template <int L>
+struct GmlChainStack {
+    const float* w1[L]; const float* w2[L]; const float* w3[L]; const float* w4[L];
+    float* out[L];
+};
+
+template <int S, int L>
+__global__ __launch_bounds__(256, 2) void gml_k_edge_chain_fwd_stack(const uint32_t* __restrict__ es, const GmlChainStack<L> a,
+                                                                    int64_t E, int64_t ntiles) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c16 = lane & 15, g = lane >> 4;
+    GmlChainW<S> W[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) gml_chain_load_fwd_weights<S>(W[l], a.w1[l], a.w2[l], a.w3[l], a.w4[l], c16, g);
+    const int q0 = 4 * (g & 1);
+    const int64_t stride = (int64_t)gridDim.x * 8;
+    int64_t t = ((int64_t)blockIdx.x * 4 + wave) * 2;
+    u32x4 b1n[2], b1[2];
+    auto fetch = [&](int64_t tt) {                             // unconditional, clamped: the loads stay countable
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t e = min((tt + u) * 16 + c16, E - 1);
+            b1n[u] = *reinterpret_cast<const u32x4*>(es + e * 8 + 4 * (g & 1));
+        }
+    };
+    fetch(t);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        asm volatile("" : "+v"(b1n[u]));
+        b1[u] = b1n[u];
+    }
+    for (; t < ntiles; t += stride) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if ((t + u) * 16 + c16 >= E) b1[u] = u32x4{0u, 0u, 0u, 0u};
+        fetch(t + stride);                                     // next pair in flight during this pair's chains
+        __builtin_amdgcn_sched_barrier(0);
+        const int64_t tb = t * (16 * S * 4);                   // wave-uniform byte offset of the pair in every output
+        const uint32_t tlo = __builtin_amdgcn_readfirstlane((uint32_t)tb), thi = __builtin_amdgcn_readfirstlane((uint32_t)(tb >> 32));
+        const int64_t left = E - t * 16;
+        const int nrec = __builtin_amdgcn_readfirstlane((int)(left < 32 ? left : 32)) * (S * 4);
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            GmlChainT T[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) gml_chain_forward<S, false>(W[l], T[u], __builtin_bit_cast(bf16x8, b1[u]), g);
+            // lane groups 0,1 hold q = 0..3 / 4..7; the range check of the descriptor drops edges past E
+            const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.out[l]) + (((uint64_t)thi << 32) | tlo), 0, nrec, 0x00020000);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int off_o = (g < 2 && q0 < S) ? ((u * 16 + c16) * S + q0) * 4 : (int)0xffffff00;
+                if constexpr (S % 4 == 0) {
+                    const f32x4 v = f32x4{fmaxf(T[u].out[0], 0.f), fmaxf(T[u].out[1], 0.f), fmaxf(T[u].out[2], 0.f), fmaxf(T[u].out[3], 0.f)};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_o, off_o, 0, 2);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fmaxf(T[u].out[r], 0.f)), rs_o,
+                                                              (g < 2 && q0 + r < S) ? off_o + 4 * r : (int)0xffffff00, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            asm volatile("" : "+v"(b1n[u]));                   // the wait for the prefetch belongs HERE (exact count)
+            b1[u] = b1n[u];
+        }
+    }
+}
+
+template <int S, int L>
+int gml_launch_edge_chain_fwd_stack(const uint32_t* es, const GmlChainStack<L>& a, int64_t E, hipStream_t st) {
+    const int64_t ntiles = gml_cdiv(E, 16);
+    int64_t grid = gml_cdiv(ntiles, 8);
+    if (grid > 4 * GML_NUM_CU) grid = 4 * GML_NUM_CU;
+    hipLaunchKernelGGL((gml_k_edge_chain_fwd_stack<S, L>), dim3((unsigned)grid), dim3(256), 0, st, es, a, E, ntiles);
+    return gml_launch_status();
+}
+
 // ------------------------------------------------------------------------------------------ backward kernel
 template <int S, bool GIN>
 struct GmlChainWB {

@@ -278,6 +278,28 @@ def edge_mlp_fwd(ea, w1, w2, w3, w4, tpos=None, ea_split=None):
     return out, out_t
 
 
+EDGE_STACK = not _os.environ.get('GML_NO_EDGE_STACK')     # A/B switch: edge branches of stacked layers in one launch
+
+
+def edge_mlp_fwd_stack(ea, ea_split, weights):
+    """The edge branches of several layers on the SAME supports in one pass (gml_edge_mlp_fwd_stack): weights = [(w1, w2, w3, w4)]
+    per layer; returns the list of outputs [E, S] (edge order of ea), or None when the library has no stacked kernel for the shape."""
+    import ctypes
+    E, S = ea.shape
+    L = len(weights)
+    if ea_split is None or not (2 <= L <= 4) or any(w[3].size(0) != S or w[0].size(1) != S for w in weights):
+        return None
+    outs = [torch.empty(E, S, dtype=torch.float32, device=ea.device) for _ in range(L)]
+    arr = lambda ts: (ctypes.c_void_p * L)(*[t.data_ptr() for t in ts])
+    rc = _lib.lib().gml_edge_mlp_fwd_stack(_ptr(ea_split), L, arr([w[0] for w in weights]), arr([w[1] for w in weights]),
+                                           arr([w[2] for w in weights]), arr([w[3] for w in weights]), arr(outs), int(E), int(S),
+                                           int(S), _stream(ea.device))
+    if rc == _lib.GML_E_UNSUPPORTED:
+        return None
+    _lib.check(rc)
+    return outs
+
+
 def edge_mlp_bwd(ea, w1, w2, w3, w4, gout, need_gin, ea_split=None):
     E, S = ea.shape
     So = w4.size(0)
@@ -620,7 +642,10 @@ class ML3LayerFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, val, w1, w2, w3, w4, cw, cb, w11, b11, w12, b12, csr, learnedge, nout2, val_is_source=False,
-                pool_ptr=None, pool_seg=None, pool_mean=False, chain_in=None, chain_out=None):
+                pool_ptr=None, pool_seg=None, pool_mean=False, chain_in=None, chain_out=None, ea_pre=None, stack=None):
+        # ea_pre: this layer's edge-branch output in source order, already computed by the first layer of its stack; stack =
+        # (weights of the layers stacked on this one [(w1, w2, w3, w4)], list that receives their edge-branch outputs): the
+        # layers all read the same raw supports, one pass serves them (edge_mlp_fwd_stack)
         # chain_in / chain_out (ChainToken): x is the output of the ML3Layer that owns chain_in and has no other consumer /
         # this layer's own token, which the consumer of its output sets (see ChainToken)
         # pool_ptr / pool_seg (int32 [B+1] / [N]): the layer is directly followed by global_add_pool / global_mean_pool
@@ -652,8 +677,18 @@ class ML3LayerFunction(torch.autograd.Function):
                 _path('edge', 'matrix-core chain' if max(val.size(1), w4.size(0)) <= 8 else ('matrix-core chain16' if max(val.size(1), w4.size(0)) <= 16 and not EDGE_VALU else 'VALU kernels'), val.size(1), '-', w4.size(0))
                 if src_order:
                     val_s = val if val_is_source else csr.to_source_order(val, cache=not val.requires_grad)
-                    with _Timed('edge_mlp_fwd', 4 * val.numel() * 2, 20 * val.size(0) * val.size(1) ** 2):
-                        ea_t, _ = edge_mlp_fwd(val_s, w1, w2, w3, w4, None, csr.presplit(val_s))
+                    ea_t = ea_pre if val_is_source else None
+                    if ea_t is None and stack is not None and val_is_source:
+                        ws_ = [(w1, w2, w3, w4)] + [tuple(_f32c(t, 'edge branch weight') for t in w) for w in stack[0]]
+                        with _Timed('edge_mlp_fwd', 4 * val.numel() * (1 + len(ws_)), 20 * val.size(0) * val.size(1) ** 2 * len(ws_)):
+                            outs = edge_mlp_fwd_stack(val_s, csr.presplit(val_s), ws_)
+                        if outs is not None:
+                            _path('edge', 'stack of %d layers in one pass' % len(ws_), val.size(1), '-', w4.size(0))
+                            ea_t = outs[0]
+                            stack[1].extend(outs[1:])
+                    if ea_t is None:
+                        with _Timed('edge_mlp_fwd', 4 * val.numel() * 2, 20 * val.size(0) * val.size(1) ** 2):
+                            ea_t, _ = edge_mlp_fwd(val_s, w1, w2, w3, w4, None, csr.presplit(val_s))
                     ea, epos = ea_t, csr.tpos
                 else:
                     with _Timed('edge_mlp_fwd', 4 * val.numel() * (3 if dual else 2), 20 * val.size(0) * val.size(1) ** 2):
@@ -702,7 +737,7 @@ class ML3LayerFunction(torch.autograd.Function):
         gy = _f32c(gy, 'grad_out')
         if not learnedge:
             ea = val
-        g = [None] * 21
+        g = [None] * 23
         gy_seg = None
         if ctx.pool is not None:                               # gy is the POOLED gradient [B, C]
             pptr, pseg, pmean = ctx.pool

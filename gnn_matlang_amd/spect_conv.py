@@ -257,6 +257,8 @@ class _EpilogueFn(torch.autograd.Function):
 
 # per ML3Layer instance: (weakref to the output tensor of its latest forward, that forward's functional.ChainToken)
 _CHAIN_STATE = weakref.WeakKeyDictionary()
+# per ML3Layer instance: (key of supports + weight versions, edge-branch output the head of its stack computed for it)
+_EDGE_STASH = weakref.WeakKeyDictionary()
 
 
 class ML3Layer(torch.nn.Module):
@@ -278,14 +280,45 @@ class ML3Layer(torch.nn.Module):
             self.fc11 = torch.nn.Linear(ninp, nout2)
             self.fc12 = torch.nn.Linear(ninp, nout2)
         self._chain_prev = ()        # (the ML3Layer whose output tensor IS this layer's x,) -- see chain_after
+        self._chain_next = ()        # (the ML3Layer stacked on this one,)
 
     def chain_after(self, prev):
         """Declare that this layer's input x is `prev`'s output tensor itself and that NOTHING else consumes that tensor
         (Zinc12k.py:338-341: x = conv2(conv1(x, ...), ...)).  The backward then applies prev's relu where this layer produces
         dL/dx and prev's output-stage backward skips its saved output (functional.ChainToken).  Checked per call: only taken
         when x is that very tensor object; with a skip connection or a second reader of prev's output, do not declare it."""
+        old = self._chain_prev[0] if self._chain_prev else None
+        if old is not None and old._chain_next and old._chain_next[0] is self:
+            old._chain_next = ()
         self._chain_prev = (prev,) if prev is not None else ()      # (a tuple: not registered as a submodule)
+        if prev is not None:
+            prev._chain_next = (self,)
         return self
+
+    def _edge_key(self, val, csr):
+        w = (self.fc1_1.weight, self.fc1_2.weight, self.fc1_3.weight, self.fc1_4.weight)
+        return (val.data_ptr(), tuple(val.shape), id(csr)) + tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in w)
+
+    def _edge_stack(self, val, csr):
+        """(ea_pre, stack) for ML3LayerFunction: this layer's edge-branch output if the head of its stack already computed it
+        for exactly these supports and these weight versions; otherwise, for a layer with layers stacked on it that read the
+        same supports (chain_after), the request to compute theirs in the same pass."""
+        hit = _EDGE_STASH.pop(self, None)
+        if hit is not None and hit[0] == self._edge_key(val, csr):
+            return hit[1], None
+        if not Fn.EDGE_STACK:
+            return None, None
+        succ, cur = [], self
+        while cur._chain_next and len(succ) < 3:
+            nxt = cur._chain_next[0]
+            if not (nxt.learnedge and all(getattr(nxt, n).weight.shape == getattr(self, n).weight.shape and
+                                          getattr(nxt, n).weight.device == val.device for n in ('fc1_1', 'fc1_2', 'fc1_3', 'fc1_4'))):
+                break
+            succ.append(nxt)
+            cur = nxt
+        if not succ:
+            return None, None
+        return None, ([tuple(getattr(m, n).weight.detach() for n in ('fc1_1', 'fc1_2', 'fc1_3', 'fc1_4')) for m in succ], [], succ)
 
     def _chain_args(self, x):
         cin = None
@@ -332,6 +365,7 @@ class ML3Layer(torch.nn.Module):
         else:
             val = _sorted_values(csr, edge_index, edge_attr, None if le else self.conv1.weight.size(0))
         cin, cout = self._chain_args(x)
+        ea_pre, stack = self._edge_stack(val, csr) if raw_src else (None, None)
         out = ML3LayerFunction.apply(
             x, val,
             self.fc1_1.weight if le else None, self.fc1_2.weight if le else None,
@@ -339,7 +373,12 @@ class ML3Layer(torch.nn.Module):
             self.conv1.weight, self.conv1.bias,
             self.fc11.weight if n2 > 0 else None, self.fc11.bias if n2 > 0 else None,
             self.fc12.weight if n2 > 0 else None, self.fc12.bias if n2 > 0 else None,
-            csr, le, n2, bool(raw_src), *(_pool if _pool is not None else (None, None, False)), cin, cout)
+            csr, le, n2, bool(raw_src), *(_pool if _pool is not None else (None, None, False)), cin, cout, ea_pre,
+            stack[:2] if stack is not None else None)
+        if stack is not None and len(stack[1]) == len(stack[2]):
+            # the layers stacked on this one find their edge-branch outputs here (same supports, same weight versions: checked)
+            for m, t in zip(stack[2], stack[1]):
+                _EDGE_STASH[m] = (m._edge_key(val, csr), t)
         if _pool is None and torch.is_grad_enabled():
             _CHAIN_STATE[self] = (weakref.ref(out), cout)       # the output tensor of this forward and its hand-over token
         else:

@@ -223,6 +223,15 @@ int gml_edge_presplit(const float* ea, void* ea_split, int64_t num_edges, int32_
 int gml_edge_mlp_fwd(const float* ea, const void* ea_split, const float* w1, const float* w2, const float* w3,
                      const float* w4, float* out, const int32_t* tpos, float* out_t,
                      int64_t num_edges, int32_t S, int32_t Sout, gml_stream_t stream);
+
+/* The edge branches of a STACK of ML3Layers in one pass: every layer of Zinc12k.py:338-341 / counting.py:361-366 receives the
+ * same raw supports (data.edge_attr2), so L launches of gml_edge_mlp_fwd read them L times.  out[l] [num_edges, Sout] =
+ * the branch of layer l (weights w1[l] .. w4[l]) applied to the rows whose split image is ea_split (gml_edge_presplit), same
+ * edge order.  The five pointer arrays (nlayers entries each) live on the HOST.  GML_E_UNSUPPORTED outside S = Sout in {4, 8},
+ * 2 <= nlayers <= 4 (or under GML_EDGE_VALU=1): call gml_edge_mlp_fwd per layer -- same results either way. */
+int gml_edge_mlp_fwd_stack(const void* ea_split, int32_t nlayers, const float* const* w1, const float* const* w2,
+                           const float* const* w3, const float* const* w4, float* const* out,
+                           int64_t num_edges, int32_t S, int32_t Sout, gml_stream_t stream);
 size_t gml_edge_mlp_bwd_workspace_bytes(int64_t num_edges, int32_t S, int32_t Sout);
 /* gout: dL/dout [E, Sout].  Writes dw1..dw4 (same shapes as the weights) and, if gin != NULL,
  * dL/dea [E, S].  Intermediates are recomputed from ea. */

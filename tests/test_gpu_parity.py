@@ -959,6 +959,56 @@ def test_stacked_ml3_relu_handover_matches_unchained(dev, monkeypatch):
         close(a, b, tol=1e-6, what='relu hand-over with a foreign tensor in between')
 
 
+@pytest.mark.parametrize('S,nl', [(8, 4), (8, 2), (4, 3)])
+def test_stacked_edge_branches_in_one_pass(dev, monkeypatch, S, nl):
+    """Layers declared with chain_after read the same raw supports (Zinc12k.py:338-341): the first layer's forward computes the
+    edge branches of the whole stack in one pass (gml_edge_mlp_fwd_stack) and the others pick theirs up.  Outputs and every
+    gradient are bit-identical to the per-layer launches (same arithmetic, same order); a weight update between two forwards
+    invalidates what was stashed (version check)."""
+    from gnn_matlang_amd import ML3Layer, functional as Fn
+    rng = np.random.default_rng(43)
+    torch.manual_seed(43)
+    N = 700
+    ei = _random_graph(rng, N, 5)
+    ei = ei[:, np.lexsort((ei[1], ei[0]))]                   # source-sorted, as SpectralDesign emits
+    eit = T(ei).to(dev)
+    layers = [ML3Layer(True, S, S, 32, 30, 2).to(dev) for _ in range(nl)]
+    for i in range(1, nl):
+        layers[i].chain_after(layers[i - 1])
+    x0, ea = torch.randn(N, 32, device=dev), torch.randn(ei.shape[1], S, device=dev)
+    gout = torch.randn(N, 32, device=dev)
+
+    monkeypatch.setattr(Fn, 'VERBOSE', True)                 # (Fn.PATHS is filled)
+
+    def run(stack):
+        monkeypatch.setattr(Fn, 'EDGE_STACK', stack)
+        for l in layers:
+            l.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        Fn.PATHS.clear()
+        h = x
+        for l in layers:
+            h = l(h, eit, ea)
+        (h * gout).sum().backward()
+        return [h.detach().clone(), x.grad.clone()] + [p.grad.clone() for l in layers for p in l.parameters()], dict(Fn.PATHS)
+
+    ref, paths0 = run(False)
+    got, paths1 = run(True)
+    assert not any('stack of' in k for k in paths0)
+    assert any('stack of %d layers' % nl in k for k in paths1), paths1
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    # stale stash: forward the first layer only (stashes for the others), change a weight of layer 2, then run the stack
+    monkeypatch.setattr(Fn, 'EDGE_STACK', True)
+    layers[0](x0.clone().requires_grad_(True), eit, ea)
+    with torch.no_grad():
+        layers[1].fc1_4.weight.mul_(1.25)
+    got2, _ = run(True)
+    ref2, _ = run(False)
+    for a, b in zip(got2, ref2):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('mean', [False, True])
 def test_ml3_forward_pooled_matches_layer_then_pool(dev, mean):
     """ML3Layer.forward_pooled (the layer and the global add / mean pool that follows it as one autograd node: the pool's
