@@ -17,6 +17,7 @@
 // (row-per-lane compute in between), the weight gradients are contracted on the matrix cores as in
 // gml_k_node_mix, every sum is formed in a fixed order (per-workgroup partials + fold).
 #include "gml_common.h"
+#include <stdlib.h>
 
 #ifndef SB_ROWS
 #define SB_ROWS 128      /* rows per tile = threads per workgroup: small groups, several per CU, overlap phases */
@@ -315,7 +316,8 @@ static int sb_finp(int Fin, int F2) {
 static int sb_cp(int64_t ldg) { return ldg <= 32 ? 32 : (ldg <= 64 ? 64 : (ldg <= 128 ? 128 : ((ldg <= 256 && SB_ROWS >= 256) ? 256 : 0))); }
 static int sb_grid(int64_t num_rows) {
     const int64_t nt = gml_cdiv(num_rows, SB_ROWS);
-    return (int)(nt < GML_NUM_CU * SB_WGS_PER_CU ? nt : GML_NUM_CU * SB_WGS_PER_CU);
+    static const int wgs = [] { const char* e = getenv("GML_SPLIT_WGS"); const int n = e ? atoi(e) : SB_WGS_PER_CU; return n < 1 ? 1 : n; }();
+    return (int)(nt < GML_NUM_CU * wgs ? nt : GML_NUM_CU * wgs);
 }
 static int sb_npart(int Fin, int nout1, int F2) { return 2 * F2 * Fin + 2 * F2 + nout1; }
 static size_t sb_lds(int FINP, int F2) {
