@@ -41,13 +41,16 @@ struct GmlSplitBwdParams {
     float* part;
     int64_t nrows;
     int Fin, nout1, F2, ntiles, CP, npart;      // CP: power of two >= ldg (<= 256); npart: floats per partial
+    int nopipe;                                 // GML_SPLIT_PIPE=0: the unpipelined loop (A/B)
 };
 
 // FINP = 0: no Hadamard branch (plain SpectConv + relu): mask and bias sums only
 // VEC / VX = 4: the leading dimensions of gy, y, G / of x, dx are multiples of 4 floats and the bases 16-byte
 // aligned (float4 accesses); 1 otherwise
-template <int FINP, int VEC, int VX>
+// DZO: the dz hand-over form (dz out, no dx; 2 F2 <= 4: one block of Hadamard columns) -- the ZINC path; only this form is pipelined
+template <int FINP, int VEC, int VX, bool DZO = false>
 __global__ __launch_bounds__(SB_ROWS, (FINP <= 32 ? 2 : 1)) void gml_k_ml3_split_bwd(const GmlSplitBwdParams p) {
+    constexpr int MAXCB = DZO ? 1 : SB_MAXCB;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int LDX = FINP + 1;                              // odd: row-per-lane accesses are conflict free
     constexpr int NFB = FINP / 16;
@@ -78,11 +81,43 @@ __global__ __launch_bounds__(SB_ROWS, (FINP <= 32 ? 2 : 1)) void gml_k_ml3_split
     float bacc[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) bacc[k] = 0.f;
-    f32x4 acc[SB_MAXCB][NFB + 1];
+    f32x4 acc[MAXCB][NFB + 1];
 #pragma unroll
-    for (int a = 0; a < SB_MAXCB; ++a)
+    for (int a = 0; a < MAXCB; ++a)
 #pragma unroll
         for (int b = 0; b <= NFB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // Pipelined form (the ZINC / counting shape class: Fin <= 32 with the Hadamard branch, float4-addressable rows of <= 32
+    // columns, no segment map): the NEXT tile's x, gy and y rows are requested before pass B of the current one and committed at
+    // the top of the next trip -- with 2 waves per workgroup and 4 workgroups per CU the two exposed load latencies per tile
+    // were most of the kernel's time (the arithmetic of a tile is ~1.5 us of a measured 8.7 us per trip).
+    constexpr bool PIPE_OK = DZO && FINP > 0 && FINP <= 32 && VEC == 4 && VX == 4;
+    constexpr int PNX = PIPE_OK ? FINP / 4 : 1;                // x loads per thread and tile (= NIX below)
+    constexpr bool pipe = PIPE_OK;                             // (the dispatcher sends only CP = 32 launches to the DZO instantiation)
+    f32x4 px[PNX], pg[PIPE_OK ? 8 : 1], py[PIPE_OK ? 8 : 1];
+    auto issue = [&](int tn) {                                 // (clamped, unconditional: 8 + 16 loads in flight)
+        if constexpr (PIPE_OK) {
+            const int64_t r0n = (int64_t)tn * SB_ROWS;
+            const int nrn = (int)min((int64_t)SB_ROWS, p.nrows - r0n);
+            constexpr int FV = FINP / 4, RPX = SB_ROWS / FV;
+            const float* xb = p.x + r0n * p.ldx;
+            const int fc = min((tid % FV) * 4, (Fin - 1) / 4 * 4), rb = tid / FV;
+#pragma unroll
+            for (int j = 0; j < PNX; ++j) px[j] = *reinterpret_cast<const f32x4*>(xb + __umul24(min(rb + j * RPX, nrn - 1), ldx) + fc);
+            const float* gyb = p.gyseg ? p.gy : p.gy + r0n * p.ldgy;
+            const float* yb = p.y + r0n * p.ldy;
+            int sg[8];                                         // segment map: the row's graph first, then that graph's gradient row
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sg[j] = p.gyseg ? p.gyseg[r0n + min(ra + j * RPS, nrn - 1)] : min(ra + j * RPS, nrn - 1);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int rr = min(ra + j * RPS, nrn - 1);
+                pg[j] = *reinterpret_cast<const f32x4*>(gyb + __umul24(sg[j], ldgy) + fa_y);
+                if (!premasked) py[j] = *reinterpret_cast<const f32x4*>(yb + __umul24(rr, ldy) + fa_o);
+            }
+        }
+    };
+    if constexpr (pipe) { if ((int)blockIdx.x < p.ntiles) issue(blockIdx.x); }
 
     for (int t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
         const int64_t r0 = (int64_t)t * SB_ROWS;
@@ -92,6 +127,31 @@ __global__ __launch_bounds__(SB_ROWS, (FINP <= 32 ? 2 : 1)) void gml_k_ml3_split
         const float* gyb = p.gyseg ? p.gy : p.gy + r0 * p.ldgy;
         const float* yb = p.y + r0 * p.ldy;
         float* Gb = p.G + r0 * p.ldg;
+        if constexpr (pipe) {
+            {                                                  // commit what was requested one trip ago
+                constexpr int FV = FINP / 4, RPX = SB_ROWS / FV;
+                const int f = (tid % FV) * 4, rb = tid / FV;
+#pragma unroll
+                for (int j = 0; j < PNX; ++j) {
+                    const int rr = rb + j * RPX;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) xs[rr * LDX + f + k] = (rr < nr && f + k < Fin) ? px[j][k] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int rr = ra + j * RPS;
+                    const bool rv = rr < nr;
+                    f32x4 gm;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        gm[k] = (rv && fa + k < nout1 && (premasked || py[j][k] > 0.f)) ? pg[j][k] : 0.f;
+                        bacc[k] += gm[k];
+                        if (fa + k >= nout1 && fa + k < Cy) gi[rr * LDI + (fa + k - nout1)] = rv ? pg[j][k] : 0.f;
+                    }
+                    if (rv && fa < ldg && !premasked) *reinterpret_cast<f32x4*>(Gb + __umul24(rr, ldg) + fa) = gm;
+                }
+            }
+        } else {
         if constexpr (FINP > 0) {                              // x tile: lane <-> VX features, 8 / 16 loads in flight
             constexpr int FV = FINP / VX, RPX = SB_ROWS / FV, NIX = (SB_ROWS + RPX - 1) / RPX;
             constexpr int XCH = 8;
@@ -161,12 +221,14 @@ __global__ __launch_bounds__(SB_ROWS, (FINP <= 32 ? 2 : 1)) void gml_k_ml3_split
                 }
             }
         }
+        }   // (!pipe)
         if constexpr (FINP > 0) {
             __syncthreads();
+            if constexpr (pipe) { if (t + (int)gridDim.x < p.ntiles) issue(t + gridDim.x); }   // the next tile's rows travel during pass B
             // ---- pass B: one row per lane
-            float xr[FINP], dxr[FINP];
+            float xr[FINP], dxr[DZO ? 1 : FINP];
 #pragma unroll
-            for (int f = 0; f < FINP; ++f) { xr[f] = xs[tid * LDX + f]; dxr[f] = 0.f; }
+            for (int f = 0; f < FINP; ++f) { xr[f] = xs[tid * LDX + f]; if constexpr (!DZO) dxr[f] = 0.f; }
             for (int c = C2; c < C2P; ++c) gz[tid * LDZ + c] = 0.f;
             for (int o = 0; o < F2; ++o) {
                 float a = bc[o], b = bc[F2 + o];
@@ -187,12 +249,14 @@ __global__ __launch_bounds__(SB_ROWS, (FINP <= 32 ? 2 : 1)) void gml_k_ml3_split
                 const float g1 = g * tb * (1.f - ta * ta), g2 = g * ta * (1.f - tb * tb);
                 gz[tid * LDZ + o] = g1;
                 gz[tid * LDZ + F2 + o] = g2;
+                if constexpr (!DZO) {
 #pragma unroll
-                for (int f4 = 0; f4 < FINP / 4; ++f4) {
-                    const f32x4 va = *reinterpret_cast<const f32x4*>(wa + 4 * f4);
-                    const f32x4 vb = *reinterpret_cast<const f32x4*>(wb + 4 * f4);
+                    for (int f4 = 0; f4 < FINP / 4; ++f4) {
+                        const f32x4 va = *reinterpret_cast<const f32x4*>(wa + 4 * f4);
+                        const f32x4 vb = *reinterpret_cast<const f32x4*>(wb + 4 * f4);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) dxr[4 * f4 + i] = fmaf(g1, va[i], fmaf(g2, vb[i], dxr[4 * f4 + i]));
+                        for (int i = 0; i < 4; ++i) dxr[4 * f4 + i] = fmaf(g1, va[i], fmaf(g2, vb[i], dxr[4 * f4 + i]));
+                    }
                 }
             }
             // weight / bias gradients of this wave's 64 rows: D[c][f] += sum_rows dz[row][c] * [x | 1][row][f]
@@ -202,7 +266,7 @@ __global__ __launch_bounds__(SB_ROWS, (FINP <= 32 ? 2 : 1)) void gml_k_ml3_split
             for (int t16 = 0; t16 < 16; ++t16) {
                 const int rr = rb + 4 * t16 + kq;
 #pragma unroll
-                for (int cb = 0; cb < SB_MAXCB; ++cb) {
+                for (int cb = 0; cb < MAXCB; ++cb) {
                     if (cb < ncb) {
                         const float a = gz[rr * LDZ + cb * 16 + r16];
 #pragma unroll
@@ -218,9 +282,9 @@ __global__ __launch_bounds__(SB_ROWS, (FINP <= 32 ? 2 : 1)) void gml_k_ml3_split
                 for (int c = 0; c < 4; ++c) if (c < C2) v[c] = gz[tid * LDZ + c];
                 if (tid < nr) *reinterpret_cast<f32x4*>(p.dz + (r0 + tid) * 4) = v;
             }
-            if (p.dx != nullptr) {                             // dx tile through LDS: row-per-lane in, coalesced out
+            if (!DZO && p.dx != nullptr) {                     // dx tile through LDS: row-per-lane in, coalesced out
 #pragma unroll
-                for (int f = 0; f < FINP; ++f) xs[tid * LDX + f] = dxr[f];
+                for (int f = 0; f < FINP; ++f) xs[tid * LDX + f] = dxr[DZO ? 0 : f];
                 __syncthreads();
                 constexpr int FV = FINP / VX, RPX = SB_ROWS / FV, NIX = (SB_ROWS + RPX - 1) / RPX;
                 float* dxb = p.dx + r0 * p.lddx;
@@ -244,10 +308,10 @@ __global__ __launch_bounds__(SB_ROWS, (FINP <= 32 ? 2 : 1)) void gml_k_ml3_split
     float* P = p.part + (int64_t)blockIdx.x * p.npart;
     if constexpr (FINP > 0) {
         // D layout: lane (col j = r16, rows i = 4*kq + reg): i = c index, j = f index;  4 waves folded through xs
-        constexpr int NA = SB_MAXCB * (NFB + 1) * 4;
+        constexpr int NA = MAXCB * (NFB + 1) * 4;
         float* wred = xs;                                      // [SB_WAVES][NA][64]
 #pragma unroll
-        for (int cb = 0; cb < SB_MAXCB; ++cb)
+        for (int cb = 0; cb < MAXCB; ++cb)
 #pragma unroll
             for (int fb = 0; fb <= NFB; ++fb)
 #pragma unroll
@@ -368,6 +432,7 @@ static int split_bwd_impl(const float* gy, int64_t ldgy, const int32_t* gy_seg, 
     p.G = G; p.ldg = ldg; p.dx = dx; p.lddx = lddx; p.dz = dz; p.part = (float*)ws; p.nrows = num_rows;
     p.Fin = Fin; p.nout1 = nout1; p.F2 = F2; p.ntiles = (int)gml_cdiv(num_rows, SB_ROWS); p.CP = CP;
     p.npart = sb_npart(Fin, nout1, F2);
+    { static const int np = [] { const char* e = getenv("GML_SPLIT_PIPE"); return (e && e[0] == '0') ? 1 : 0; }(); p.nopipe = np; }
     const int grid = sb_grid(num_rows);
     const size_t lds = sb_lds(FINP, F2);
     const int va = (((ldgy | ldy | ldg) & 3) == 0 && (((uintptr_t)gy | (uintptr_t)y | (uintptr_t)G) & 15) == 0) ? 4 : 1;
@@ -379,7 +444,18 @@ static int split_bwd_impl(const float* gy, int64_t ldgy, const int32_t* gy_seg, 
         hipLaunchKernelGGL((gml_k_ml3_split_bwd<FP, VA, VXX>), dim3(grid), dim3(SB_ROWS), lds, st, p);           \
     }
 #define SB_GO4(FP) SB_GO(FP, 1, 1) SB_GO(FP, 1, 4) SB_GO(FP, 4, 1) SB_GO(FP, 4, 4)
+    /* the dz hand-over form on float4-addressable rows (Zinc12k.py's layers): its own, pipelined instantiation */
+    const bool dzo = dz != nullptr && dx == nullptr && 2 * F2 <= 4 && va == 4 && vx == 4 && (FINP == 16 || FINP == 32) && CP == 32 && !p.nopipe;
+#define SB_GO_DZ(FP)                                                                                             \
+    if (dzo && FINP == FP) {                                                                                     \
+        GML_ALLOW_BIG_LDS(arc, (&gml_k_ml3_split_bwd<FP, 4, 4, true>), 160 * 1024)                               \
+        if (arc != hipSuccess) return (int)arc;                                                                  \
+        hipLaunchKernelGGL((gml_k_ml3_split_bwd<FP, 4, 4, true>), dim3(grid), dim3(SB_ROWS), lds, st, p);        \
+    }
+    SB_GO_DZ(16) SB_GO_DZ(32)
+    if (!dzo) {
     SB_GO(0, 1, 4) SB_GO(0, 4, 4) SB_GO4(16) SB_GO4(32) SB_GO4(48) SB_GO4(64)
+    }
     int rc = gml_launch_status();
     if (rc != GML_OK) return rc;
     hipLaunchKernelGGL(gml_k_split_fold, dim3((unsigned)gml_cdiv(p.npart, 16)), dim3(256), 0, st, (const float*)ws,
