@@ -116,8 +116,9 @@ class SpectralDesign(object):
             sizes = (ptr32[1:] - ptr32[:-1])
             nmax = int(sizes.max().item()) if B else 0
             if nmax > self.MAX_DEVICE_NODES or self.nfreq > 16:
-                raise NotImplementedError('graphs with more than %d nodes (or nfreq > 16): use the host path'
-                                          % self.MAX_DEVICE_NODES)
+                # graphs beyond the LDS-resident Jacobi kernel (proteins: up to 620 nodes, filtering.py: 900): those go through
+                # the device's dense libraries graph by graph, the others through the kernels; merged in graph order
+                return self._design_device_mixed(x, ei, ptr32, sizes)
             # edges per graph: graph id of each edge's source, counted
             gid = torch.bucketize(ei[0], ptr32[1:].to(torch.int64), right=True) if e else ei.new_zeros(0)
             eptr = torch.zeros(B + 1, dtype=torch.int32, device=dev)
@@ -144,6 +145,99 @@ class SpectralDesign(object):
                     key = torch.unique(ei[0] * x.size(0) + ei[1])
                     deg.index_add_(0, key % x.size(0), torch.ones_like(key, dtype=torch.float32))
                 xo = torch.cat([x.float(), deg[:, None]], 1)
+        return dict(x=xo, edge_index2=ei2, edge_attr2=ea2, lmax=lmax)
+
+    def _design_large(self, n, src, dst, dev):
+        """one graph of n nodes on the device with library calls (float64 eigh = rocSOLVER, GEMMs): the arithmetic of
+        _design_group / libs/utils.py:546-610.  src, dst: local node ids.  Returns (rows, cols) of the mask in row-major
+        order, the [m, S] supports and lmax."""
+        A = torch.zeros(n, n, dtype=torch.float32, device=dev)
+        if src.numel():
+            A[src, dst] = 1
+        eye = torch.eye(n, dtype=torch.float64, device=dev)
+        if self.recfield == 0:
+            M = A.double()
+        else:
+            M = A.double() + eye
+            for _ in range(1, self.recfield):
+                M = (M @ M > 0).double()                               # (the count itself is never used: only > 0; keeps it finite)
+        M = M > 0
+        d = A.sum(0)                                                   # column sums, float32
+        dis = torch.where(d > 0, 1 / torch.sqrt(d), torch.zeros_like(d))
+        t1 = A * dis[None, :]
+        t2 = t1.t() * dis[None, :]
+        nL = eye - t2.double()
+        V, U = torch.linalg.eigh(nL)
+        V = V.clamp(min=0)
+        lmax = V.max().float()
+        if not self.laplacien:
+            Vf, Uf = torch.linalg.eigh(A)                              # float32, like the reference
+            V, U = Vf.double(), Uf.double()
+        top = V.max() if self.vmax is None else torch.tensor(float(self.vmax), dtype=torch.float64, device=dev)
+        lo = V.min()
+        r, c = M.nonzero(as_tuple=True)                                # row-major
+        SP = torch.empty(r.numel(), self.nsup, dtype=torch.float32, device=dev)
+        for i in range(self.nfreq):
+            ctr = lo + (top - lo) * (i / (self.nfreq - 1)) if self.nfreq > 1 else lo
+            wgt = torch.exp(-(self.dv * (V - ctr) ** 2))
+            SP[:, i] = ((U * wgt[None, :]) @ U.t())[r, c].float()
+        SP[:, self.nfreq] = (r == c).float()
+        if self.addadj:
+            SP[:, self.nfreq + 1] = A[r, c]
+        return r, c, SP, lmax
+
+    def _design_device_mixed(self, x, ei, ptr32, sizes):
+        dev = x.device
+        B = int(sizes.numel())
+        ptr = ptr32.to(torch.int64)
+        N = int(ptr[-1].item())
+        small = (sizes <= self.MAX_DEVICE_NODES) if self.nfreq <= 16 else torch.zeros_like(sizes, dtype=torch.bool)
+        node_g = torch.repeat_interleave(torch.arange(B, device=dev), sizes.to(torch.int64))       # graph of every node
+        edge_g = node_g[ei[0]] if ei.size(1) else ei.new_zeros(0)
+        nnz = torch.zeros(B, dtype=torch.int64, device=dev)
+        lmax = torch.zeros(B, dtype=torch.float32, device=dev)
+        S = self.nsup
+        parts = []                                                     # (graph ids of the entries, rank inside the graph, ei2 [2, m], ea2 [m, S])
+        sm_ids = small.nonzero().flatten()
+        if sm_ids.numel():
+            keep = small[node_g]
+            old = keep.nonzero().flatten()                             # compact node id -> original node id
+            new = torch.cumsum(keep.to(torch.int64), 0) - 1            # original -> compact (valid where keep)
+            ek = small[edge_g] if ei.size(1) else torch.zeros(0, dtype=torch.bool, device=dev)
+            cptr = torch.zeros(sm_ids.numel() + 1, dtype=torch.int64, device=dev)
+            cptr[1:] = sizes[sm_ids].to(torch.int64).cumsum(0)
+            d = SpectralDesign(recfield=self.recfield, dv=self.dv, nfreq=self.nfreq, adddegree=False, laplacien=self.laplacien,
+                               addadj=self.addadj, vmax=self.vmax).design_device(x[old], new[ei[:, ek]], cptr.to(torch.int32))
+            cg = torch.bucketize(d['edge_index2'][0], cptr[1:], right=True)          # compact graph of every entry
+            cnt = torch.bincount(cg, minlength=sm_ids.numel())
+            nnz[sm_ids] = cnt
+            lmax[sm_ids] = d['lmax']
+            start = torch.cumsum(cnt, 0) - cnt
+            parts.append((sm_ids[cg], torch.arange(cg.numel(), device=dev) - start[cg], old[d['edge_index2']], d['edge_attr2']))
+        for b in (~small).nonzero().flatten().tolist():
+            n, lo = int(sizes[b].item()), int(ptr[b].item())
+            sel = (edge_g == b) if ei.size(1) else torch.zeros(0, dtype=torch.bool, device=dev)
+            r, c, SP, lm = self._design_large(n, ei[0, sel] - lo, ei[1, sel] - lo, dev)
+            nnz[b] = r.numel()
+            lmax[b] = lm
+            parts.append((torch.full((r.numel(),), b, dtype=torch.int64, device=dev), torch.arange(r.numel(), device=dev),
+                          torch.stack([r + lo, c + lo]), SP))
+        out_ptr = torch.zeros(B + 1, dtype=torch.int64, device=dev)
+        out_ptr[1:] = nnz.cumsum(0)
+        m = int(out_ptr[-1].item())
+        ei2 = torch.empty(2, m, dtype=torch.int64, device=dev)
+        ea2 = torch.empty(m, S, dtype=torch.float32, device=dev)
+        for g, rank, e2, a2 in parts:
+            pos = out_ptr[g] + rank
+            ei2[:, pos] = e2
+            ea2[pos] = a2
+        xo = x
+        if self.adddegree:
+            deg = torch.zeros(N, dtype=torch.float32, device=dev)
+            if ei.size(1):
+                key = torch.unique(ei[0] * N + ei[1])
+                deg.index_add_(0, key % N, torch.ones_like(key, dtype=torch.float32))
+            xo = torch.cat([x.float(), deg[:, None]], 1)
         return dict(x=xo, edge_index2=ei2, edge_attr2=ea2, lmax=lmax)
 
     # ------------------------------------------------------------------ reference call convention

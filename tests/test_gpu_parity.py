@@ -474,6 +474,36 @@ def test_spectral_design_on_device(dev, golden):
     assert np.array_equal(d['x'].cpu().numpy(), np.concatenate([h['x'] for h in host]))
 
 
+@pytest.mark.parametrize('kw', [dict(recfield=2, dv=2, nfreq=7, adddegree=True), dict(recfield=1, dv=5, nfreq=5, addadj=True),
+                                dict(recfield=1, dv=3, nfreq=4, laplacien=False, vmax=2.5)])
+def test_spectral_design_on_device_large_graphs(dev, kw):
+    """Graphs beyond the LDS-resident eigen-solver (more than 80 nodes: proteins has up to 620, libs/utils.py:546-610 is
+    size-agnostic): design_device sends those through the device's dense libraries (float64 eigh + GEMMs), the small ones of the
+    same batch through the kernels, and merges in graph order -- same mask, same order, same supports as the host path."""
+    from gnn_matlang_amd import SpectralDesign
+    rng = np.random.default_rng(5)
+    raw = []
+    for n, deg in ((12, 3), (130, 4), (7, 2), (97, 3), (81, 5), (40, 4), (200, 3), (3, 0)):
+        src = np.repeat(np.arange(n), deg)
+        dst = rng.integers(0, n, src.size)
+        keep = src != dst
+        ei = np.unique(np.concatenate([np.stack([src[keep], dst[keep]]), np.stack([dst[keep], src[keep]])], 1), axis=1).astype(np.int64)
+        raw.append((np.ones((n, 1), np.float32), ei.reshape(2, -1), 0.0))
+    sd = SpectralDesign(**kw)
+    host = sd.design_many(raw)
+    sizes = np.array([x.shape[0] for x, _, _ in raw])
+    ptr = np.concatenate([[0], np.cumsum(sizes)])
+    X = np.concatenate([x for x, _, _ in raw])
+    EI = np.concatenate([ei + ptr[i] for i, (_, ei, _) in enumerate(raw)], 1)
+    d = sd.design_device(T(X).to(dev), T(EI).to(dev), torch.tensor(ptr, dtype=torch.int32, device=dev))
+    ei2 = np.concatenate([h['edge_index2'] + ptr[i] for i, h in enumerate(host)], 1)
+    ea2 = np.concatenate([h['edge_attr2'] for h in host])
+    assert np.array_equal(d['edge_index2'].cpu().numpy(), ei2)
+    np.testing.assert_allclose(d['edge_attr2'].cpu().numpy(), ea2, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(d['lmax'].cpu().numpy(), np.array([h['lmax'] for h in host]), rtol=2e-6, atol=1e-6)
+    assert np.array_equal(d['x'].cpu().numpy(), np.concatenate([h['x'] for h in host]))
+
+
 # ------------------------------------------------------------------------------------------ ML3Layer
 def test_ml3layer_golden(dev, golden, arith):
     from gnn_matlang_amd import ML3Layer
