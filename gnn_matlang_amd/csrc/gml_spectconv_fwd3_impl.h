@@ -136,7 +136,11 @@ __global__ __launch_bounds__(GmlFwd3Cfg<S>::NT, 1) void gml_k_spectconv_fwd3(con
         Wof_h[iof] = h;
         Wof_l[iof] = l;
     }
-    float* ds_l = reinterpret_cast<float*>(lds_raw + 8192);   // depthwise: [S + 1][32] scales behind the single W image (4 KB hi + lo)
+    // depthwise: [S + 1][32] scales right behind the single hi W image (bytes [0, 2048)); the lo image keeps its place at byte
+    // W_HALF * 2 = S * 2048 (>= 8192), so [2048, 2048 + 128 (S + 1)) is free for S in {4, 8} (r03: it sat at byte 8192 -- ON the
+    // lo image when S = 4; found by the randomised sweep, tools/fuzz_parity.py)
+    float* ds_l = reinterpret_cast<float*>(lds_raw + 2048);
+    static_assert(EPL != 2 || (2048 + 128 * (S + 1) <= S * 2048), "depthwise scales overlap the lo W image");
     if constexpr (EPL == 2) {
         for (int e = tid; e < (S + 1) * 32; e += C::NT) {
             const int f = e & 31, s = e >> 5;

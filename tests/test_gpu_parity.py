@@ -225,6 +225,47 @@ def test_eight_wave_forward_staged_and_global_paths(dev, S, fin, fout, deg):
     close(m.weight.grad, wo.grad, what='g_weight')
 
 
+@pytest.mark.parametrize('S,fin,fout,selfconn,depthwise', [(4, 1, 4, False, True), (4, 21, 30, False, True), (4, 3, 4, True, True),
+                                                           (8, 32, 30, True, True), (8, 7, 16, False, True),
+                                                           (4, 20, 30, True, False), (8, 32, 16, False, False)])
+def test_ring_kernel_epilogues_vs_oracle(dev, S, fin, fout, selfconn, depthwise):
+    """The ring kernel's epilogues (gml_spectconv_fwd_epi) at both of its support counts: depthwise SpectConv
+    (libs/spect_conv.py:81-91; depthwise=True) with and without the self term, and SpectConCatConv (:137-158; depthwise=False here)
+    -- forward and every gradient against the oracle modules.  (S = 4 depthwise once put its scales on the lo image of W:
+    the randomised sweep found it, these cases pin it.)"""
+    from gnn_matlang_amd import SpectConv, SpectConCatConv
+    from oracle.spect_conv_oracle import OracleSpectConv, OracleSpectConCatConv
+    rng = np.random.default_rng(S * 10 + fin)
+    torch.manual_seed(S + fout)
+    N = 300
+    ei = _random_graph(rng, N, 4)
+    x, ea = torch.randn(N, fin), torch.randn(ei.shape[1], S)
+    if depthwise:
+        ref = OracleSpectConv(fin, fout, S, selfconn=selfconn, depthwise=True).double()
+        m = SpectConv(fin, fout, S, selfconn=selfconn, depthwise=True).to(dev)
+        with torch.no_grad():
+            ref.DSweight.normal_(0, 0.5)
+    else:
+        ref = OracleSpectConCatConv(fin, fout, S, selfconn=selfconn).double()
+        m = SpectConCatConv(fin, fout, S, selfconn=selfconn).to(dev)
+    with torch.no_grad():
+        ref.bias.uniform_(-0.5, 0.5)
+    m.load_state_dict({n: p.detach().float() for n, p in ref.state_dict().items()})
+    xr, er = x.double().requires_grad_(True), ea.double().requires_grad_(True)
+    yr = ref(xr, T(ei), er)
+    go = torch.randn_like(yr)
+    (yr * go).sum().backward()
+    xg, eg = x.to(dev).requires_grad_(True), ea.to(dev).requires_grad_(True)
+    y = m(xg, T(ei).to(dev), eg)
+    close(y, yr, what='out')
+    (y * go.float().to(dev)).sum().backward()
+    close(xg.grad, xr.grad, what='g_x')
+    close(eg.grad, er.grad, what='g_edge_attr')
+    gp = dict(m.named_parameters())
+    for n, p in ref.named_parameters():
+        close(gp[n].grad, p.grad, what=n)
+
+
 def test_exact_fp32_mode_is_closer_to_the_oracle(dev):
     """GML_F32_MFMA (f32-input MFMA: exact fp32 products) must agree with the oracle at fp32-roundoff level, an
     order of magnitude tighter than the default bf16 hi/lo split is asked to."""
