@@ -170,6 +170,74 @@ def conv_sweep(a, dev):
     return fails
 
 
+def stack_sweep(a, dev):
+    """Stacks of 2-4 ML3Layers declared with chain_after (one pass for the edge branches of the stack, relu hand-over between the
+    layers) against the SAME layers run undeclared: every output and gradient must agree to fp32 roundoff (the two roads differ
+    only in where a relu mask is applied and in which launch computed an edge branch).  Shapes around the kernels' classes:
+    ZINC's (S = 8, 30 + 2), counting's (S = 12, 16 + 16), odd widths, wide Hadamard branches, learnedge off."""
+    from gnn_matlang_amd import ML3Layer, functional as Fn
+    rng = np.random.default_rng(a.seed + 277)
+    worst, fails = 0.0, 0
+    used = dict(premasked_output_stages=0, stacked_edge_passes=0)      # how often the two hand-overs actually ran
+    real_split, real_stack = Fn.ml3_split_bwd, Fn.edge_mlp_fwd_stack
+
+    def split(*aa, **kk):
+        used['premasked_output_stages'] += 1 if kk.get('premasked') else 0
+        return real_split(*aa, **kk)
+
+    def stack(*aa, **kk):
+        r = real_stack(*aa, **kk)
+        used['stacked_edge_passes'] += 1 if r is not None else 0
+        return r
+    Fn.ml3_split_bwd, Fn.edge_mlp_fwd_stack = split, stack
+    for k in range(a.cases):
+        kind = ['molecule', 'hubs', 'dense', 'sparse'][k % 4]
+        N = int(rng.choice([1, 7, 64, 129, 300, 777, 2048, 5000]))
+        ei = random_graph(rng, N, kind)
+        S = int(rng.choice([2, 4, 4, 6, 8, 8, 8, 12]))
+        cls = int(rng.integers(0, 4))
+        n1, n2 = [(30, 2), (16, 16), (int(rng.integers(1, 33)), int(rng.integers(1, 9))), (int(rng.integers(4, 31)), 2)][cls]
+        if cls in (0, 3) and rng.random() < 0.7:
+            S = 8                                   # (the shape class of the relu hand-over: 8 supports, 2 Hadamard columns)
+        learn = bool(rng.integers(0, 5) > 0)
+        nl = int(rng.integers(2, 5))
+        fin0 = int(rng.choice([1, 3, 21, 25, 32]))
+        torch.manual_seed(a.seed * 1000 + k)
+        layers, fin = [], fin0
+        for _ in range(nl):
+            layers.append(ML3Layer(learn, S, S, fin, n1, n2).to(dev))
+            fin = n1 + n2
+        x0 = torch.randn(N, fin0, device=dev)
+        ea = torch.randn(ei.shape[1], S, device=dev) * 0.5
+        gout = torch.randn(N, n1 + n2, device=dev)
+        eit = torch.from_numpy(ei).to(dev)
+        tag = dict(case=k, kind=kind, N=N, E=int(ei.shape[1]), S=S, n1=n1, n2=n2, learn=learn, layers=nl, fin0=fin0)
+
+        def run(chained):
+            for i, l in enumerate(layers):
+                l.zero_grad()
+                l.chain_after(layers[i - 1] if (chained and i > 0) else None)
+            x = x0.clone().requires_grad_(True)
+            h = x
+            for l in layers:
+                h = l(h, eit, ea)
+            (h * gout).sum().backward()
+            torch.cuda.synchronize()
+            return [h.detach().double().cpu(), x.grad.double().cpu()] + [q.grad.double().cpu() for l in layers for q in l.parameters()]
+
+        ref, got = run(False), run(True)
+        e = max(rel_err(g, r) for g, r in zip(got, ref))
+        worst = max(worst, e)
+        if a.verbose:
+            print(json.dumps(tag), '%.2e' % e, flush=True)
+        if not np.isfinite(e) or e > 2e-5:
+            fails += 1
+            print('FAIL', json.dumps(tag), '%.2e' % e, flush=True)
+    Fn.ml3_split_bwd, Fn.edge_mlp_fwd_stack = real_split, real_stack
+    print(json.dumps(dict({'sweep': 'stack', 'cases': a.cases, 'seed': a.seed, 'worst_rel_err': worst, 'failures': fails, 'tol': 2e-5}, **used)))
+    return fails
+
+
 def special_graph(rng, n):
     """edge list [2,e] of one small graph: structured families with degenerate spectra among random ones."""
     kind = rng.integers(0, 8)
@@ -238,7 +306,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--cases', type=int, default=80)
     ap.add_argument('--seed', type=int, default=0)
-    ap.add_argument('--sweep', choices=['ml3', 'conv', 'spectral'], default='ml3')
+    ap.add_argument('--sweep', choices=['ml3', 'conv', 'spectral', 'stack'], default='ml3')
     ap.add_argument('--only', type=int, default=-1, help='ml3 sweep: run just this case of the sequence')
     ap.add_argument('--verbose', action='store_true')
     a = ap.parse_args()
@@ -246,6 +314,8 @@ def main():
         sys.exit(1 if conv_sweep(a, torch.device('cuda:0')) else 0)
     if a.sweep == 'spectral':
         sys.exit(1 if spectral_sweep(a, torch.device('cuda:0')) else 0)
+    if a.sweep == 'stack':
+        sys.exit(1 if stack_sweep(a, torch.device('cuda:0')) else 0)
     sys.exit(1 if ml3_sweep(a) else 0)
 
 
