@@ -133,6 +133,16 @@ __device__ __forceinline__ float gml_tanh(float x) {
     return fmaf(-2.f, __builtin_amdgcn_rcpf(e + 1.f), 1.f);
 }
 
+// tanh(x) and its derivative 1 - tanh(x)^2 without the cancellation of 1 - t * t near saturation (t = 1 - 1.7e-6 already loses
+// 4 % there in fp32): with e = exp(2x), r = 1 / (e + 1):  t = 1 - 2 r,  1 - t^2 = 4 e r^2.  |x| is clamped to 40 (tanh = +-1 to the
+// last bit far earlier; keeps e finite).
+__device__ __forceinline__ void gml_tanh_d(float x, float& t, float& d) {
+    const float e = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(x, -40.f, 40.f) * 2.8853900817779268f);
+    const float r = __builtin_amdgcn_rcpf(e + 1.f);
+    t = fmaf(-2.f, r, 1.f);
+    d = 4.f * (e * r) * r;
+}
+
 // fp32 -> (hi, lo) bf16 pair with hi + lo = x to ~2^-17 relative (round-to-nearest both times).  Products of
 // two such splits, a_hi b_hi + a_hi b_lo + a_lo b_hi accumulated in fp32 by the bf16 matrix cores, carry a
 // relative error of ~2^-16 per term (the dropped a_lo b_lo and the lo roundings): fp32-class for the

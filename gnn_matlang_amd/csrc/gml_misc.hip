@@ -114,12 +114,14 @@ __global__ __launch_bounds__(256) void gml_k_node_mix(const float* __restrict__ 
                     b = fmaf(xr[4 * f4 + i], vb[i], b);
                 }
             }
-            const float ta = gml_tanh(a), tb = gml_tanh(b);
+            float ta, tb, da, db;
+            gml_tanh_d(a, ta, da);
+            gml_tanh_d(b, tb, db);
             if constexpr (!BWD) {
                 if (rv) out[(r0 + tid) * ldo + o] = ta * tb;
             } else {
                 const float g = rv ? gout[(r0 + tid) * ldg + o] : 0.f;
-                const float g1 = g * tb * (1.f - ta * ta), g2 = g * ta * (1.f - tb * tb);
+                const float g1 = g * tb * da, g2 = g * ta * db;
                 gz[tid * LDZ + o] = g1;
                 gz[tid * LDZ + F2 + o] = g2;
 #pragma unroll

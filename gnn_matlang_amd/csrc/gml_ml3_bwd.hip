@@ -244,9 +244,11 @@ __global__ __launch_bounds__(SB_ROWS, (FINP <= 32 ? 2 : 1)) void gml_k_ml3_split
                         b = fmaf(xr[4 * f4 + i], vb[i], b);
                     }
                 }
-                const float ta = gml_tanh(a), tb = gml_tanh(b);
+                float ta, tb, da, db;                          // (tanh and its derivative without the cancellation of 1 - t * t)
+                gml_tanh_d(a, ta, da);
+                gml_tanh_d(b, tb, db);
                 const float g = gi[tid * LDI + o];
-                const float g1 = g * tb * (1.f - ta * ta), g2 = g * ta * (1.f - tb * tb);
+                const float g1 = g * tb * da, g2 = g * ta * db;
                 gz[tid * LDZ + o] = g1;
                 gz[tid * LDZ + F2 + o] = g2;
                 if constexpr (!DZO) {
