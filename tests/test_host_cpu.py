@@ -217,3 +217,42 @@ def test_dense_block_row_slabs():
         assert 1 <= p <= 64 and rows % p == 0
         assert p == 1 or rows // p >= 1024
     assert _splits(76800) == 64 and _splits(75) == 1
+
+
+def test_chain_after_bookkeeping():
+    """ML3Layer.chain_after (host logic of the relu hand-over and the stacked edge branch): the hand-over token of the layer
+    below is offered only for the very tensor object that layer returned, under grad mode, to a tensor that requires grad; the
+    declaration does not register submodules, survives deepcopy, can be withdrawn; the stash key of the stacked edge branch
+    follows the weights' versions."""
+    import copy
+    import weakref
+    from gnn_matlang_amd import models, functional as Fn
+    from gnn_matlang_amd import spect_conv as SC
+    net = models.GNNML3(32, 8, 30, 2, 3)
+    c1, c2, c3 = net.conv1, net.conv2, net.conv3
+    assert c2._chain_prev[0] is c1 and c3._chain_prev[0] is c2 and c1._chain_next[0] is c2 and not c1._chain_prev
+    assert len([n for n, _ in net.named_modules() if n.startswith('conv2.')]) == len([n for n, _ in net.named_modules() if n.startswith('conv1.')])
+    twin = copy.deepcopy(net)
+    assert twin.conv2._chain_prev[0] is twin.conv1 and twin.conv2._chain_prev[0] is not c1
+    assert not models.GNNML3(32, 8, 30, 2, 3, bn=True).conv2._chain_prev       # BatchNorm in between: another tensor, not declared
+    # the token is offered for the declared layer's own output tensor only
+    out = torch.zeros(5, 32, requires_grad=True)
+    tok = Fn.ChainToken(30)
+    SC._CHAIN_STATE[c1] = (weakref.ref(out), tok)
+    cin, cout = c2._chain_args(out)
+    assert cin is tok and cout is not tok and cout.cols == 30 and not cout.premasked
+    assert c2._chain_args(out.clone())[0] is None                          # a different tensor object
+    assert c2._chain_args(out.detach())[0] is None                         # no gradient wanted
+    with torch.no_grad():
+        assert c2._chain_args(out)[0] is None
+    assert c1._chain_args(out)[0] is None                                  # nothing declared below conv1
+    c2.chain_after(None)
+    assert c2._chain_args(out)[0] is None and not c1._chain_next
+    c2.chain_after(c1)
+    # stash key of the stacked edge branch: supports' identity + the four weights' versions
+    val = torch.zeros(7, 8)
+    k0 = c2._edge_key(val, 'csr')
+    assert k0 == c2._edge_key(val, 'csr') and k0 != c2._edge_key(val.clone(), 'csr') and k0 != c2._edge_key(val, 'other')
+    with torch.no_grad():
+        c2.fc1_3.weight.add_(1.0)
+    assert c2._edge_key(val, 'csr') != k0
