@@ -1030,6 +1030,39 @@ def test_stacked_ml3_relu_handover_matches_unchained(dev, monkeypatch):
         close(a, b, tol=1e-6, what='relu hand-over with a foreign tensor in between')
 
 
+def test_relu_handover_below_a_layer_without_hadamard_branch(dev, monkeypatch):
+    """The lower layer of a declared pair has no Hadamard branch (nout2 = 0: its output is all relu(conv) columns, 32 of them):
+    its output stage then runs the mask-and-bias-sums kernel in its pre-masked form.  Same gradients as undeclared."""
+    from gnn_matlang_amd import ML3Layer, functional as Fn
+    rng = np.random.default_rng(47)
+    torch.manual_seed(47)
+    N, S = 500, 8
+    ei = _random_graph(rng, N, 5)
+    ei = ei[:, np.lexsort((ei[1], ei[0]))]
+    eit = T(ei).to(dev)
+    lower, upper = ML3Layer(True, S, S, 20, 32, 0).to(dev), ML3Layer(True, S, S, 32, 30, 2).to(dev)
+    x0, ea = torch.randn(N, 20, device=dev), torch.randn(ei.shape[1], S, device=dev)
+    gout = torch.randn(N, 32, device=dev)
+    calls = []
+    real = Fn.ml3_split_bwd
+    monkeypatch.setattr(Fn, 'ml3_split_bwd', lambda *a, **k: (calls.append(bool(k.get('premasked'))), real(*a, **k))[1])
+
+    def run(chained):
+        upper.chain_after(lower if chained else None)
+        for l in (lower, upper):
+            l.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        (upper(lower(x, eit, ea), eit, ea) * gout).sum().backward()
+        return [x.grad.clone()] + [p.grad.clone() for l in (lower, upper) for p in l.parameters()]
+
+    ref = run(False)
+    del calls[:]
+    got = run(True)
+    assert calls == [False, True], calls
+    for a, b in zip(got, ref):
+        close(a, b, tol=1e-6, what='relu hand-over below a plain relu(conv) layer')
+
+
 @pytest.mark.parametrize('S,nl', [(8, 4), (8, 2), (4, 3)])
 def test_stacked_edge_branches_in_one_pass(dev, monkeypatch, S, nl):
     """Layers declared with chain_after read the same raw supports (Zinc12k.py:338-341): the first layer's forward computes the
