@@ -171,8 +171,7 @@ class SpectralDesign(object):
         V = V.clamp(min=0)
         lmax = V.max().float()
         if not self.laplacien:
-            Vf, Uf = torch.linalg.eigh(A)                              # float32, like the reference
-            V, U = Vf.double(), Uf.double()
+            V, U = torch.linalg.eigh(A.double())                       # (float64 like the device kernels; the reference: float32)
         top = V.max() if self.vmax is None else torch.tensor(float(self.vmax), dtype=torch.float64, device=dev)
         lo = V.min()
         r, c = M.nonzero(as_tuple=True)                                # row-major

@@ -160,6 +160,14 @@ def conv_sweep(a, dev):
         worst_ew = max(worst_ew, ew)
         if gout.numel() <= 4:                   # a 1 x 1 (<= 4 element) output is a few cancelling sums: the max-norm bar
             errs['out'] = ew                    # degenerates to 1e-4 of the cancelled value; hold it to its term sums instead
+        if x.numel() <= 4 and 'g_x' in errs:    # likewise d loss / d x of a 1-node, <= 4-feature input (hundreds of cancelling terms):
+            xa = x.double().abs().requires_grad_(True)      # its term sums = the gradient of the absolute-value module (multilinear)
+            (abs_copy(ref)(xa, eit, ea.double().abs()) * gout.double().abs()).sum().backward()
+            xd = x.to(dev).requires_grad_(True)
+            (m(xd, eit.to(dev), ea.to(dev)) * gout.to(dev)).sum().backward()
+            xr2 = x.double().requires_grad_(True)
+            (ref(xr2, eit, ea.double()) * gout.double()).sum().backward()
+            errs['g_x'] = elementwise_err(xd.grad.cpu().double(), xr2.grad, xa.grad)
         e = max(errs.values())
         worst = max(worst, e)
         if not np.isfinite(e) or e > TOL:
@@ -292,7 +300,7 @@ def spectral_sweep(a, dev):
                   adddegree=bool(rng.integers(0, 2)), laplacien=bool(rng.integers(0, 4) > 0), addadj=bool(rng.integers(0, 2)),
                   vmax=None if rng.integers(0, 3) else 2.5)
         B = int(rng.integers(1, 40))
-        nmax = int(rng.choice([1, 2, 5, 12, 30, 80]))
+        nmax = int(rng.choice([1, 2, 5, 12, 30, 80, 80, 130]))      # (130: some graphs beyond the LDS-resident solver -> the mixed road)
         raw = []
         for _ in range(B):
             n = int(rng.integers(1, nmax + 1))
@@ -307,7 +315,9 @@ def spectral_sweep(a, dev):
                              torch.tensor(ptr, dtype=torch.int32, device=dev))
         ei2 = np.concatenate([h['edge_index2'] + ptr[i] for i, h in enumerate(host)], 1)
         ea2 = np.concatenate([h['edge_attr2'] for h in host])
-        tol = 5e-6 if kw['laplacien'] else 5e-5
+        # laplacien=False: the reference (and the host path) decompose A in float32, the device in float64: the bar is the host's own
+        # float32 error, which grows with n and with the filters' sharpness dv (exp(-dv (l - c)^2): d/dl = -2 dv (l - c) f)
+        tol = 5e-6 if kw['laplacien'] else (5e-5 if nmax <= 80 else 5e-4)
         ok = np.array_equal(d['edge_index2'].cpu().numpy(), ei2)
         err = float(np.abs(d['edge_attr2'].cpu().numpy() - ea2).max()) if ok and ea2.size else 0.0
         lerr = float(np.abs(d['lmax'].cpu().numpy() - np.array([h['lmax'] for h in host])).max())
