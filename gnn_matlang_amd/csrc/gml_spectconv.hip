@@ -215,7 +215,8 @@ extern "C" int gml_spectconv_fwd(const int32_t* rowptr, const int32_t* col, cons
             p.flags = (first ? (flags & GML_ACCUM) : GML_ACCUM) | (last ? (flags & GML_RELU) : 0u) | (flags & 0xff00u);
             const size_t wblk = (size_t)SC * FPL * NB * 64 * sizeof(float);
             const size_t all = wblk * p.npass * nchunks;
-            const size_t stage = (size_t)(76 + GML_ECAP + GML_ECAP * SC + GML_XCAP * (4 * FPL + 4)) * sizeof(float);
+            const int ecap = SC == 6 ? 2 * GML_ECAP : GML_ECAP;                  /* = GmlStage<SC, FPL>::ECAP */
+            const size_t stage = (size_t)(76 + ecap + ecap * SC + GML_XCAP * (4 * FPL + 4)) * sizeof(float);
             p.allw = all + stage <= 80 * 1024;           // two workgroups per CU
             const int va = (SC % 4 == 0) ? 4 : ((SC % 2 == 0) ? 2 : 1);
             p.val_vec = (S % va == 0) && (p.s0 % va == 0);

@@ -68,11 +68,14 @@ struct GmlFwdParams {
 template <int SC, int FPL>
 struct GmlStage {
     static constexpr int CH = 4 * FPL;
+    // staged edges per 64-row group: 8 per row; 16 for the 6-support chunk -- sr25.py's supports (S = 6) have 13 entries per row
+    // and every one of its groups used to fall back to global gathers
+    static constexpr int ECAP = SC == 6 ? 2 * GML_ECAP : GML_ECAP;
     static constexpr int LDX = CH + 4;                       // +16 B: spreads rows over LDS banks, keeps b128 alignment
     static constexpr int RP = 76;                            // rowptr slice [0..64], min scratch [66..69], max scratch [70..73]
     static constexpr int OFF_COL = RP;
-    static constexpr int OFF_EA = OFF_COL + GML_ECAP;
-    static constexpr int OFF_X = OFF_EA + GML_ECAP * SC;
+    static constexpr int OFF_EA = OFF_COL + ECAP;
+    static constexpr int OFF_X = OFF_EA + ECAP * SC;
     static constexpr int FLOATS = OFF_X + GML_XCAP * LDX;
 };
 
@@ -126,8 +129,8 @@ template <int SC, int FPL>
 struct GmlPrefetch {
     using ST = GmlStage<SC, FPL>;
     static constexpr int CH = ST::CH;
-    static constexpr int CL = GML_ECAP / 256;
-    static constexpr int EN = GML_ECAP * SC / 256;                               // floats of value rows per thread
+    static constexpr int CL = ST::ECAP / 256;
+    static constexpr int EN = ST::ECAP * SC / 256;                               // floats of value rows per thread
     static constexpr int XN4 = (GML_XCAP * (CH / 4) + 255) / 256;                // float4 of X window per thread
     static constexpr int XN = (GML_XCAP * CH + 255) / 256 > 4 * XN4 ? (GML_XCAP * CH + 255) / 256 : 4 * XN4;
     int kb, ne, lo, nwin, nr;
@@ -147,7 +150,7 @@ __device__ __forceinline__ void gml_prefetch_issue(GmlPrefetch<SC, FPL>& q, cons
     const int32_t* rec = p.ginfo + (int64_t)g * GML_GREC_INTS(GML_GROUP);
     const int4 gi = *reinterpret_cast<const int4*>(rec);                         // {kb, ne, lo, nwin}
     q.kb = gi.x; q.ne = gi.y; q.lo = gi.z; q.nwin = gi.w;
-    q.staged = (q.ne <= GML_ECAP) && (q.nwin <= GML_XCAP) && (p.epos == nullptr);
+    q.staged = (q.ne <= PF::ST::ECAP) && (q.nwin <= GML_XCAP) && (p.epos == nullptr);
     q.rp = (tid <= q.nr) ? p.rowptr[r0 + tid] : 0;
     if (!q.staged) return;
 #pragma unroll
