@@ -345,8 +345,12 @@ class ML3Layer(torch.nn.Module):
             Fn._path('edge', 'library GEMMs (more than 16 supports)', self.fc1_1.weight.size(1), '-', self.fc1_4.weight.size(0))
             _require_cuda(edge_attr, 'edge_attr')
             ea = edge_attr.to(torch.float32)
-            tmp = torch.cat([torch.relu(self.fc1_1(ea)), torch.tanh(self.fc1_2(ea)) * torch.tanh(self.fc1_3(ea))], 1)
-            val = _sorted_values(csr, edge_index, torch.relu(self.fc1_4(tmp)), self.conv1.weight.size(0))
+            # fc1_4 applied to the two halves of its input separately: the concatenation of libs/spect_conv.py:205 is never
+            # materialised (at S = 48 it is a 2.5e9-element tensor: torch.cat alone took 83 ms of the layer's 90 on 13 M edges)
+            h1, h23 = torch.relu(self.fc1_1(ea)), torch.tanh(self.fc1_2(ea)) * torch.tanh(self.fc1_3(ea))
+            w4 = self.fc1_4.weight
+            out4 = torch.addmm(h1 @ w4[:, :h1.size(1)].t(), h23, w4[:, h1.size(1):].t())
+            val = _sorted_values(csr, edge_index, torch.relu(out4), self.conv1.weight.size(0))
             return ML3LayerFunction.apply(x, val, None, None, None, None, self.conv1.weight, self.conv1.bias,
                                           self.fc11.weight if n2 > 0 else None, self.fc11.bias if n2 > 0 else None,
                                           self.fc12.weight if n2 > 0 else None, self.fc12.bias if n2 > 0 else None,

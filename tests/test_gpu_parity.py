@@ -568,7 +568,8 @@ def test_ml3layer_golden(dev, golden, arith):
 
 @pytest.mark.parametrize('ne,neo,Fin,n1,n2', [(5, 3, 9, 24, 6), (3, 8, 9, 24, 6), (4, 12, 9, 24, 6),
                                               (4, 4, 80, 64, 16), (3, 3, 21, 16, 40),
-                                              (12, 12, 32, 30, 2), (12, 12, 32, 29, 3), (12, 12, 28, 12, 4), (12, 12, 32, 16, 16)])
+                                              (12, 12, 32, 30, 2), (12, 12, 32, 29, 3), (12, 12, 28, 12, 4), (12, 12, 32, 16, 16),
+                                              (24, 24, 20, 16, 2)])                     # (> 16 supports: the edge branch as library GEMMs)
 def test_ml3layer_wide_shapes(dev, ne, neo, Fin, n1, n2):
     """Shapes off the fused kernels' main road, against the oracle in fp64: nedgeoutput != nedgeinput (allowed by
     spect_conv.py:66-71, unused by the scripts), ninp = 80 (ptc.py:331-338) and a wide Hadamard branch; the last three
