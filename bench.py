@@ -286,21 +286,23 @@ def main():
     import gc
     gc.collect()
     gc.disable()
-    blocks, total = [], 0.0
-    while True:
-        last = total + (blocks[-1] if blocks else 0) >= args.min_seconds or len(blocks) >= 63
-        if world > 1:
-            flag = torch.tensor([1 if last else 0], device=dev)
-            dist.broadcast(flag, 0)
-            last = bool(flag.item())
-        if last and not args.no_profile:
-            Fn.PROFILE = {}
-        dt, loss = timed_block(step, args.steps)
-        blocks.append(dt)
-        total += dt
-        if last:
-            break
-    gc.enable()
+    try:
+        blocks, total = [], 0.0
+        while True:
+            last = total + (blocks[-1] if blocks else 0) >= args.min_seconds or len(blocks) >= 63
+            if world > 1:
+                flag = torch.tensor([1 if last else 0], device=dev)
+                dist.broadcast(flag, 0)
+                last = bool(flag.item())
+            if last and not args.no_profile:
+                Fn.PROFILE = {}
+            dt, loss = timed_block(step, args.steps)
+            blocks.append(dt)
+            total += dt
+            if last:
+                break
+    finally:
+        gc.enable()
     prof, Fn.PROFILE = Fn.PROFILE, None
     if os.environ.get('GML_BENCH_DUMP') and prof:            # debugging aid: per-launch HIP-event times of the profiled block
         for tag, recs in prof.items():

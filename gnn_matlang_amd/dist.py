@@ -71,9 +71,10 @@ class _SyncBNFunction(torch.autograd.Function):
         rstd = torch.rsqrt(var + eps)
         xhat = (x - mean) * rstd
         ctx.save_for_backward(xhat, weight, rstd, n)
-        ctx.group = group
+        ctx.group, ctx.has_bias = group, bias is not None
         ctx.mark_non_differentiable(mean, var, n)
-        return xhat * weight + bias, mean, var, n
+        y = xhat if weight is None else xhat * weight            # affine=False: weight and bias are None
+        return (y if bias is None else y + bias), mean, var, n
 
     @staticmethod
     def backward(ctx, dy, _dm, _dv, _dn):
@@ -82,8 +83,8 @@ class _SyncBNFunction(torch.autograd.Function):
         sums = torch.cat([dy.sum(0), (dy * xhat).sum(0)])            # local sums = the parameter gradients of this shard
         g = sums.clone()
         dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
-        dx = (dy - g[:C] / n - xhat * (g[C:] / n)) * (weight * rstd)
-        return dx, sums[C:], sums[:C], None, None
+        dx = (dy - g[:C] / n - xhat * (g[C:] / n)) * (rstd if weight is None else weight * rstd)
+        return dx, (sums[C:] if weight is not None else None), (sums[:C] if ctx.has_bias else None), None, None
 
 
 class SyncBatchNorm1d(torch.nn.BatchNorm1d):
@@ -92,9 +93,15 @@ class SyncBatchNorm1d(torch.nn.BatchNorm1d):
 
     def forward(self, x):
         world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
-        if not self.training or world == 1 or not self.track_running_stats or x.dim() != 2:
+        # batch statistics are used in training mode AND whenever no running statistics exist (track_running_stats=False):
+        # both take the synchronised road, so that the R-rank step equals the 1-rank step.  Every rank must run
+        # the layer in the same mode -- the all-reduces are collective.
+        use_batch_stats = self.training or self.running_mean is None
+        if not use_batch_stats or world == 1 or x.dim() != 2:
             return super().forward(x)
         y, mean, var, n = _SyncBNFunction.apply(x, self.weight, self.bias, self.eps, None)
+        if not self.training or self.running_mean is None:
+            return y
         with torch.no_grad():
             self.num_batches_tracked += 1
             m = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked)

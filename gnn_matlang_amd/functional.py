@@ -1,9 +1,10 @@
 """Autograd functions over the C ABI of libgml_hip.so.
 
-Forward of one SpectConv (libs/spect_conv.py:64-96) is ONE fused launch; backward is
-  dX   = the same fused kernel on the source-keyed CSR with W transposed (a strided view),
-  dW   = H^T G   with H = gml_spmm_fwd(X) (plain GEMM through torch.mm),
-  dval = gml_sddmm(X, G W^T),   dbias = colsum(G).
+Forward of one SpectConv (libs/spect_conv.py:64-96) is ONE fused launch (gml_spectconv_fwd / gml_ml3_fwd); backward is ONE
+fused launch organised by source rows (gml_spectconv_bwd*: dX = sum_s A_s (G W_s^T), dval[e, s] = <X[src] W_s, G[dst]>,
+dW_s = X^T (A_s G), no atomics) plus the one-pass output stage (gml_ml3_split_bwd*: relu mask, bias sums, Hadamard branch).
+Only shapes outside every compiled kernel class take the unfused composition (_conv_backward: transposed forward + SpMM +
+SDDMM + two GEMMs; GML_VERBOSE=1 shows which road a call took).
 Every tensor handed to the library is fp32, contiguous and on the current CUDA(HIP) device; the
 launches go to torch's current stream, so they order with the surrounding torch ops and are
 captured by torch.cuda.graphs like any other kernel.
@@ -118,8 +119,12 @@ _ROWS4_CACHE = _collections.OrderedDict()
 def rows4(x):
     if x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0:
         return x
+    # While a HIP graph is being captured the copy must be RECORDED: a cache hit would leave it out of the graph, and every
+    # replay after `static_x.copy_(new)` would read the padded copy of the warm-up data; the cached buffer could
+    # also be evicted and freed while the graph still holds its address.  So: no lookup, no insert under capture.
+    capturing = x.is_cuda and torch.cuda.is_current_stream_capturing()
     key = id(x)
-    ent = _ROWS4_CACHE.get(key)
+    ent = None if capturing else _ROWS4_CACHE.get(key)
     if ent is not None and ent[0]() is x and ent[1] == x._version:
         _ROWS4_CACHE.move_to_end(key)
         return ent[2]
@@ -127,7 +132,7 @@ def rows4(x):
     buf = torch.zeros(x.size(0), (F + 3) // 4 * 4, dtype=x.dtype, device=x.device)
     buf[:, :F] = x
     v = buf[:, :F]
-    if not x.requires_grad:
+    if not x.requires_grad and not capturing:
         _ROWS4_CACHE[key] = (_weakref.ref(x), x._version, v)
         while len(_ROWS4_CACHE) > 4:
             _ROWS4_CACHE.popitem(last=False)

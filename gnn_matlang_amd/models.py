@@ -61,8 +61,12 @@ class GNNML3(torch.nn.Module):
     """head 'mlp32': fc2(relu(fc1 x)), fc1: nin->32, fc2: 32->nclass;  'tanh10': tanh(fc1 x), fc1: nin->10."""
 
     def __init__(self, ninp, ne, nout1, nout2, nlayers, learnedge=True, bn=False, pool='add', head='mlp32',
-                 nclass=1, readout_bn=False, dense_n=0):
+                 nclass=1, readout_bn=False, dense_n=0, chain=True):
         super().__init__()
+        # chain=False: do not declare the relu hand-over between stacked layers (ML3Layer.chain_after).  The hand-over is
+        # valid only while convN+1 is the SOLE consumer of convN's output tensor: a forward hook, an auxiliary loss or a
+        # feature tap on an intermediate output adds a second gradient the lower layer would then leave unmasked -- pass
+        # chain=False for such models (GML_NO_CHAIN=1 switches it off process-wide).
         # dense_n > 0: equal-size graphs of dense_n nodes with near-dense masks (MNIST-75) are evaluated as dense
         # blocks (dense_block.py: HIP batched support product + one tall GEMM per layer); same parameters, same values
         if dense_n and (learnedge or nout2):
@@ -78,7 +82,7 @@ class GNNML3(torch.nn.Module):
             fin = widths[i] + nout2
             if bn:
                 setattr(self, 'bn%d' % (i + 1), torch.nn.BatchNorm1d(fin))
-        if not bn and not self.dense_n:
+        if chain and not bn and not self.dense_n:
             # x = conv2(conv1(x, ...), ...) with nothing else reading the intermediate outputs (Zinc12k.py:338-341,
             # counting.py:361-366, sr25.py:266-270): the relu hand-over between stacked layers applies
             for i in range(1, nlayers):

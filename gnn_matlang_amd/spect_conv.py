@@ -297,7 +297,9 @@ class ML3Layer(torch.nn.Module):
 
     def _edge_key(self, val, csr):
         w = (self.fc1_1.weight, self.fc1_2.weight, self.fc1_3.weight, self.fc1_4.weight)
-        return (val.data_ptr(), tuple(val.shape), id(csr)) + tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in w)
+        # val._version: supports rewritten IN PLACE in the same buffer (a static batch buffer) must not be served the branch
+        # output of the old ones
+        return (val.data_ptr(), val._version, tuple(val.shape), id(csr)) + tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in w)
 
     def _edge_stack(self, val, csr):
         """(ea_pre, stack) for ML3LayerFunction: this layer's edge-branch output if the head of its stack already computed it
@@ -318,6 +320,8 @@ class ML3Layer(torch.nn.Module):
             cur = nxt
         if not succ:
             return None, None
+        for m in succ:                                        # whatever an interrupted / partial forward left behind
+            _EDGE_STASH.pop(m, None)
         return None, ([tuple(getattr(m, n).weight.detach() for n in ('fc1_1', 'fc1_2', 'fc1_3', 'fc1_4')) for m in succ], [], succ)
 
     def _chain_args(self, x):

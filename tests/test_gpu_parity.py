@@ -1277,3 +1277,56 @@ def test_static_caps_csr_deferred_check(dev):
     oob = GraphCSR.from_edge_index(torch.tensor([[0, 1, 2], [0, 7, 2]], device=dev), 3, static_caps=(8, 8))
     with pytest.raises(IndexError):
         oob.check()
+
+
+def test_captured_layer_with_unpadded_rows_reads_fresh_data_on_replay(dev):
+    """functional.rows4 keeps a zero-padded copy of a first-layer input whose rows are not float4-addressable
+    (Zinc12k.py's 25 features).  Under HIP-graph capture the copy must be RECORDED in the graph, not served from that cache:
+    capture a layer on a static x, copy new data into it, replay, compare with eager on the new data."""
+    from gnn_matlang_amd import ML3Layer
+    rng = np.random.default_rng(5)
+    torch.manual_seed(5)
+    N = 300
+    ei = _random_graph(rng, N, 5)
+    eit = T(ei).to(dev)
+    layer = ML3Layer(True, 8, 8, 25, 30, 2).to(dev)
+    ea = torch.randn(ei.shape[1], 8, device=dev)
+    static_x = torch.randn(N, 25, device=dev)
+    with torch.no_grad():
+        for _ in range(2):
+            layer(static_x, eit, ea)                          # warm-up: fills the cache for this tensor object
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = layer(static_x, eit, ea)
+        new = torch.randn(N, 25, device=dev)
+        static_x.copy_(new)
+        g.replay()
+        torch.cuda.synchronize()
+        ref = layer(new.clone(), eit, ea)
+    assert torch.equal(out, ref)
+
+
+def test_stacked_edge_branch_not_served_after_inplace_edit_of_the_supports(dev, monkeypatch):
+    """the edge-branch outputs the head of a stack computes for the layers stacked on it are keyed by the
+    supports' buffer AND version: an in-place edit of edge_attr between two layers of a declared stack must not be answered with
+    the branch output of the old supports."""
+    from gnn_matlang_amd import ML3Layer, functional as Fn
+    rng = np.random.default_rng(44)
+    torch.manual_seed(44)
+    N = 400
+    ei = _random_graph(rng, N, 5)
+    ei = ei[:, np.lexsort((ei[1], ei[0]))]
+    eit = T(ei).to(dev)
+    l1, l2 = ML3Layer(True, 8, 8, 32, 30, 2).to(dev), ML3Layer(True, 8, 8, 32, 30, 2).to(dev)
+    l2.chain_after(l1)
+    monkeypatch.setattr(Fn, 'EDGE_STACK', True)
+    x0 = torch.randn(N, 32, device=dev)
+    ea = torch.randn(ei.shape[1], 8, device=dev)
+    h = l1(x0.clone().requires_grad_(True), eit, ea)          # stashes l2's branch output for THESE supports
+    with torch.no_grad():
+        ea.mul_(0.5)                                          # same buffer, new contents
+    got = l2(h, eit, ea)
+    monkeypatch.setattr(Fn, 'EDGE_STACK', False)
+    ref = l2(h.detach().clone().requires_grad_(True), eit, ea.clone())
+    assert torch.equal(got.detach(), ref.detach())
