@@ -26,6 +26,7 @@ SIGNATURES = {
     'gml_gather_rows_presplit': (ctypes.c_int, [_p, _p, _p, _p, _i64, _i32, _p]),
     'gml_scatter_rows': (ctypes.c_int, [_p, _p, _p, _i64, _i32, _p]),
     'gml_spectconv_fwd_group_rows': (ctypes.c_int32, [_i32, _i32, _i32, ctypes.c_uint32]),
+    'gml_spectconv_fwd_stage_edges': (ctypes.c_int32, [_i32, _i32, _i32, ctypes.c_uint32]),
     'gml_spectconv_fwd': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _p, _p, _i64,
                                          _i64, _i32, _i32, _i32, _u32, _p]),
     'gml_ml3_fwd': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _i64,
@@ -79,7 +80,7 @@ SIGNATURES = {
 }
 
 GML_OK, GML_E_BADARG, GML_E_UNSUPPORTED, GML_E_WORKSPACE = 0, -1, -2, -3
-GML_RELU, GML_ACCUM, GML_F32_MFMA, GML_GROUPS128, GML_GROUPS64R, GML_DMA_RING = 1, 2, 4, 8, 16, 32
+GML_RELU, GML_ACCUM, GML_F32_MFMA, GML_GROUPS128, GML_GROUPS64R, GML_DMA_RING, GML_FWD_CHUNKED = 1, 2, 4, 8, 16, 32, 64
 GML_GROUPS64_RANKED = 1064      # group kind of gml_csr_group_info: 64-row groups with rank bytes
 
 _lib = None

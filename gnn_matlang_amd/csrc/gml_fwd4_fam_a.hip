@@ -1,0 +1,4 @@
+// chunked ring forward (gml_spectconv_fwd4_impl.h), S = 4: Fin <= 32 and Fin <= 48
+#include "gml_spectconv_fwd4_impl.h"
+GML_DEFINE_FWD4(4, 0, 2)
+GML_DEFINE_FWD4(4, 1, 2)

@@ -2,6 +2,7 @@
 #include "gml_spectconv_impl.h"
 #include "gml_spectconv_fwd2_impl.h"
 #include "gml_spectconv_fwd3_impl.h"
+#include "gml_spectconv_fwd4_impl.h"
 #include "gml_spmm3_impl.h"
 
 #define GML_DECL_FWD2(S, B) template <> int gml_launch_fwd2<S, B>(const GmlFwdParams&, dim3, hipStream_t, bool, bool);
@@ -12,15 +13,28 @@ GML_DECL_FWD2(12, 2) GML_DECL_FWD2(12, 1) GML_DECL_FWD2(12, 0)  /* counting.py's
 #define GML_DECL_FWD3(S, B) template <> int gml_launch_fwd3<S, B>(const GmlFwdParams&, dim3, hipStream_t, bool);
 GML_DECL_FWD3(8, 2) GML_DECL_FWD3(8, 1) GML_DECL_FWD3(4, 2) GML_DECL_FWD3(4, 1)
 
+#define GML_DECL_FWD4(S, FB, B) template <> int gml_launch_fwd4<S, FB, B>(const GmlFwdParams&, dim3, hipStream_t);
+GML_DECL_FWD4(4, 0, 2) GML_DECL_FWD4(4, 1, 2) GML_DECL_FWD4(6, 0, 2) GML_DECL_FWD4(6, 1, 2) GML_DECL_FWD4(8, 0, 2) GML_DECL_FWD4(8, 1, 2)
+
 // GML_FWD_DMA=0: the register-staged 8-wave kernel (fwd2) instead of the LDS-DMA ring (fwd3), for A/B runs
 static bool fwd3_env() { static const bool v = [] { const char* e = getenv("GML_FWD_DMA"); return !(e && e[0] == '0'); }(); return v; }
+
+// shapes only the chunked ring kernel (fwd4) serves on 128-row records: 6 supports (sr25.py) and / or 33 .. 48 input features
+// (the hidden layers of sr25.py:252-262 and mutag.py:272-288); x must be float4-addressable there
+static bool fwd4_only_shape(int S, int Fin, int Fout, uint32_t flags) {
+    static const bool off = [] { const char* e = getenv("GML_FWD4"); return e && e[0] == '0'; }();   // A/B: the r03 roads
+    if (off || (flags & GML_F32_MFMA) || Fout > 32) return false;
+    return (S == 6 && Fin <= 48) || ((S == 4 || S == 8) && Fin > 32 && Fin <= 48);
+}
+// GML_FWD4=1: every shape of the ring kernels on the chunked one (A/B against fwd3)
+static bool fwd4_all_env() { static const bool v = [] { const char* e = getenv("GML_FWD4"); return e && e[0] == '1'; }(); return v; }
 
 static bool fwd2_shape(int S, int Fin, int Fout, uint32_t flags) {
 #ifdef GML_NO_FWD2
     return false;
 #endif
     // S % 4 == 0: the register-staged value rows are float4 (other S keep the 64-row kernel, which stages any S)
-    return (flags & GML_F32_MFMA) == 0 && (S == 4 || S == 8 || S == 12) && Fin <= 32 && Fout <= 32;
+    return ((flags & GML_F32_MFMA) == 0 && (S == 4 || S == 8 || S == 12) && Fin <= 32 && Fout <= 32) || fwd4_only_shape(S, Fin, Fout, flags);
 }
 
 // GML_FWD_NW=4: the 8-wave kernel family in its 4-wave / 64-row geometry (two workgroups per CU)
@@ -28,6 +42,13 @@ static int fwd2_nw_env() { static const int v = [] { const char* e = getenv("GML
 extern "C" int32_t gml_spectconv_fwd_group_rows(int32_t S, int32_t Fin, int32_t Fout, uint32_t flags) {
     if (!fwd2_shape(S, Fin, Fout, flags)) return 64;
     return fwd2_nw_env() == 4 ? GML_GROUPS64_RANKED : 128;
+}
+
+// edges of one 128-row group the ring kernel (fwd3) keeps in LDS at once for this shape; 0: the shape is not on fwd3.  A caller
+// that knows a larger group exists passes GML_FWD_CHUNKED and gets the chunked ring kernel instead of global gathers.
+extern "C" int32_t gml_spectconv_fwd_stage_edges(int32_t S, int32_t Fin, int32_t Fout, uint32_t flags) {
+    if (!fwd2_shape(S, Fin, Fout, flags) || fwd4_only_shape(S, Fin, Fout, flags) || !fwd3_env()) return 0;
+    return S == 8 ? GmlFwd3Cfg<8>::ECAP - 3 : (S == 4 ? GmlFwd3Cfg<4>::ECAP - 3 : 0);
 }
 
 // ---- families defined in gml_fwd_fam_*.hip ---------------------------------------------------
@@ -90,6 +111,19 @@ static int launch_fwd2(const int32_t* rowptr, const int32_t* col, const int32_t*
     grid = (int)gml_cdiv(p.ngroups, p.groups_per_wg);
     const int nob = Fout > 16 ? 2 : 1;
     const bool mix = F2 > 0;
+    // chunked ring kernel (fwd4): the shapes only it serves, groups with more edges than fwd3 stages (GML_FWD_CHUNKED: the caller
+    // knows the largest group), or everything (GML_FWD4=1)
+    const bool only4 = fwd4_only_shape(S, Fin, Fout, flags);
+    if (only4 || ((flags & GML_FWD_CHUNKED) || fwd4_all_env())) {
+        const bool ok4 = p.nw == 8 && xv && !mix && !(flags & GML_ACCUM) && (num_rows + 16) * ldx * 4 < (int64_t)INT32_MAX &&
+                         (S == 4 || S == 6 || S == 8) && Fin <= 48;
+        if (ok4) {
+            const int fb = Fin > 32 ? 1 : 0;
+#define GML_FWD4_GO(SV, FBV) if (S == SV && fb == FBV) return gml_launch_fwd4<SV, FBV, 2>(p, dim3(grid), st);
+            GML_FWD4_GO(4, 0) GML_FWD4_GO(4, 1) GML_FWD4_GO(6, 0) GML_FWD4_GO(6, 1) GML_FWD4_GO(8, 0) GML_FWD4_GO(8, 1)
+        }
+        if (only4) return GML_E_UNSUPPORTED;             /* (unaligned x rows, accumulate mode: the caller takes the 64-row family) */
+    }
     // LDS-DMA landing ring: float4-addressable x, no accumulate mode, 32-bit buffer offsets
     // (value rows beyond 4 GB are handled inside the kernel: it reads the edge count itself)
     if (p.nw == 8 && xv && fwd3_env() && (S == 8 || S == 4) && !(flags & GML_ACCUM) &&
@@ -153,7 +187,7 @@ extern "C" int gml_spectconv_fwd(const int32_t* rowptr, const int32_t* col, cons
 
     if (flags & (GML_GROUPS128 | GML_GROUPS64R)) {
         // 128-row / 8-wave kernel (or its 64-row / 4-wave geometry): the caller passes 128-row group records (gml_spectconv_fwd_group_rows said 128)
-        if (!fwd2_shape(S, Fin, Fout, flags) || (((uintptr_t)val & 15) != 0)) return GML_E_BADARG;
+        if (!fwd2_shape(S, Fin, Fout, flags) || (((uintptr_t)val & (S % 4 == 0 ? 15 : 7)) != 0)) return GML_E_BADARG;
         return launch_fwd2(rowptr, col, ginfo, epos, val, x, ldx, w, w_ss, w_si, w_so, bias, nullptr, nullptr, nullptr, nullptr,
                            out, ldo, num_rows, S, Fin, Fout, 0, flags, st);
     }
@@ -239,6 +273,7 @@ extern "C" int gml_ml3_fwd(const int32_t* rowptr, const int32_t* col, const int3
     if (F2 < 0 || ldo < nout1 + F2 || (F2 > 0 && (!w11 || !w12))) return GML_E_BADARG;
 #ifndef GML_NO_MIXFUSE
     if (num_rows > 0 && F2 > 0 && F2 <= 8 && (flags & (GML_GROUPS128 | GML_GROUPS64R)) && fwd2_shape(S, Fin, nout1, flags) &&
+        !fwd4_only_shape(S, Fin, nout1, flags) && !(flags & GML_FWD_CHUNKED) && !fwd4_all_env() &&
         (((uintptr_t)val & 15) == 0) && !(flags & GML_ACCUM)) {
         if (!rowptr || !ginfo || !x || !w || !out) return GML_E_BADARG;
         return launch_fwd2(rowptr, col, ginfo, epos, val, x, ldx, w, w_ss, w_si, w_so, bias, w11, b11, w12, b12, out, ldo,

@@ -187,7 +187,16 @@ def fwd_groups(csr, x, S, Fin, Fout):
     if _os.environ.get('GML_FWD64'):                         # experiments: force the 4-wave / 64-row kernel family
         return csr.ginfo, 0
     rows = int(_lib.lib().gml_spectconv_fwd_group_rows(int(S), int(Fin), int(Fout), flags))
+    if rows == 128 and not (x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0) and (S == 6 or Fin > 32):
+        rows = 64                                            # (6 supports / 48 features exist only on the ring kernel: float4 rows)
     if rows == 128:
+        # the largest 128-row group (of the source view: SpectralDesign's masks are symmetric, so of this view too -- a hint only,
+        # results never depend on it) beyond what the ring kernel stages: its chunked form instead of global gathers
+        cap = int(_lib.lib().gml_spectconv_fwd_stage_edges(int(S), int(Fin), int(Fout), flags))
+        gm = csr.gmax_t128[0] if getattr(csr, 'gmax_t128', None) is not None else 0
+        if cap > 0 and gm > cap:
+            _path('conv_fwd', 'fused 8-wave bf16x3, edge chunks', S, Fin, Fout)
+            return csr.ginfo128, _lib.GML_GROUPS128 | _lib.GML_FWD_CHUNKED
         _path('conv_fwd', 'fused 8-wave bf16x3', S, Fin, Fout)
         return csr.ginfo128, _lib.GML_GROUPS128
     if rows == _lib.GML_GROUPS64_RANKED:

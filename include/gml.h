@@ -54,6 +54,9 @@ enum {
                          the 8-wave forward kernel                                                            */
     GML_GROUPS64R = 16, /* gml_spectconv_fwd: `ginfo` holds ranked 64-row records (gml_spectconv_fwd_group_rows() =
                          GML_GROUPS64_RANKED): the same kernel in its 4-wave geometry, two workgroups per CU     */
+    GML_FWD_CHUNKED = 64, /* gml_spectconv_fwd / gml_ml3_fwd with GML_GROUPS128: some 128-row group holds more edges than the ring
+                         kernel stages at once (the caller knows the maximum from its group records): take the chunked ring kernel
+                         (gml_k_spectconv_fwd4), which walks such groups in edge chunks instead of gathering from global memory */
     GML_DMA_RING = 32   /* gml_spectconv_bwd / _bwd_mix: take the LDS-DMA landing-ring kernel (bwd4) where it applies; the
                          forward uses its ring kernel (fwd3) by default (GML_FWD_DMA=0 in the environment turns it off)   */
 };
@@ -118,6 +121,10 @@ int gml_scatter_rows(const float* in, const int32_t* perm, float* out, int64_t r
 /* group size (64 | 128) whose records the forward wants for this shape and arithmetic; 128 additionally needs
  * epos == NULL -- the caller then passes those records and GML_GROUPS128 */
 int32_t gml_spectconv_fwd_group_rows(int32_t S, int32_t Fin, int32_t Fout, uint32_t flags);
+/* edges of one 128-row group the default ring kernel keeps in LDS at once for this shape (0: not applicable).  When the largest
+ * group of the batch (int 1 of its records) exceeds it, pass GML_FWD_CHUNKED: the chunked ring kernel walks such groups in
+ * edge chunks (sr25.py: 13 entries per row) instead of gathering them from global memory. */
+int32_t gml_spectconv_fwd_stage_edges(int32_t S, int32_t Fin, int32_t Fout, uint32_t flags);
 int gml_spectconv_fwd(const int32_t* rowptr, const int32_t* col, const int32_t* ginfo, const int32_t* epos,
                       const float* val, const float* x, int64_t ldx,
                       const float* w, int64_t w_ss, int64_t w_si, int64_t w_so,

@@ -1330,3 +1330,97 @@ def test_stacked_edge_branch_not_served_after_inplace_edit_of_the_supports(dev, 
     monkeypatch.setattr(Fn, 'EDGE_STACK', False)
     ref = l2(h.detach().clone().requires_grad_(True), eit, ea.clone())
     assert torch.equal(got.detach(), ref.detach())
+
+
+def _banded_graph(rng, N, deg, spread):
+    """every node draws `deg` neighbours within +-spread (duplicates removed): up to min(deg, 2 spread + 1) entries per row and
+    a column window of 128 + 2 spread rows per 128-row group; source-sorted like SpectralDesign's output"""
+    src = np.repeat(np.arange(N), deg)
+    dst = np.clip(src + rng.integers(-spread, spread + 1, size=src.shape), 0, N - 1)
+    return np.unique(np.vstack((src, dst)), axis=1).astype(np.int64)
+
+
+@pytest.mark.parametrize('S,fin,fout,deg,spread', [
+    (6, 48, 32, 13, 12),     # sr25.py:252-262 hidden layers: 6 supports, 48 features, 13 entries per row -> 3 edge chunks per group
+    (6, 2, 32, 13, 12),      # sr25's first layer (2 features, rows padded to float4)
+    (6, 32, 32, 40, 30),     # ~ 30 entries per row: 5-6 chunks, window 188 rows
+    (6, 48, 24, 40, 30),
+    (4, 48, 24, 5, 6),       # mutag.py:272-288 hidden layers: 4 supports, 48 features
+    (4, 40, 24, 40, 30),
+    (8, 48, 32, 13, 12),
+    (8, 32, 30, 40, 30),     # a ZINC-shaped layer on high-degree groups: the caller's hint routes it to the chunked kernel
+    (4, 32, 16, 40, 30),
+    (6, 48, 32, 40, 100),    # window of 328 rows: beyond the staged window -> the kernel's global-gather road
+    (8, 20, 30, 30, 100),
+])
+def test_chunked_ring_forward_any_degree(dev, S, fin, fout, deg, spread):
+    """gml_k_spectconv_fwd4: groups with more edges than one LDS edge buffer are walked in chunks with the
+    accumulators kept across them; 6 supports (24-byte value rows) and 48 input features (third 16-wide feature block); against
+    the oracle, forward and every gradient (the backward rides along on whatever kernel serves the shape)."""
+    from gnn_matlang_amd import SpectConv, functional as Fn
+    from oracle import spect_conv_oracle as O
+    rng = np.random.default_rng(S * 100 + deg + fin)
+    torch.manual_seed(deg + fin)
+    N = 700                                               # 5.5 groups: the ring runs over several items per workgroup
+    ei = _banded_graph(rng, N, deg, spread)
+    ei = ei[:, ei[1] != 130]                              # an empty target row inside the second group
+    ea, x = torch.randn(ei.shape[1], S), torch.randn(N, fin)
+    m = SpectConv(fin, fout, S, selfconn=False).to(dev)
+    with torch.no_grad():
+        m.bias.uniform_(-0.5, 0.5)
+    w, b = m.weight.detach().cpu(), m.bias.detach().cpu()
+    xo, eo, wo = (t.clone().requires_grad_(True) for t in (x, ea, w))
+    yo = O.spectconv_forward(xo, T(ei), eo, wo, b, False)
+    gout = torch.randn_like(yo)
+    (yo * gout).sum().backward()
+    old = Fn.VERBOSE
+    Fn.VERBOSE = True
+    Fn.PATHS.clear()
+    try:
+        xg, eg = x.to(dev).requires_grad_(True), ea.to(dev).requires_grad_(True)
+        y = m(xg, T(ei).to(dev), eg)
+        paths = dict(Fn.PATHS)
+    finally:
+        Fn.VERBOSE = old
+    assert any('8-wave' in k for k in paths), paths        # (not the 4-wave / 64-row family)
+    close(y, yo, what='out')
+    (y * gout.to(dev)).sum().backward()
+    close(xg.grad, xo.grad, what='g_x')
+    close(eg.grad, eo.grad, what='g_edge_attr')
+    close(m.weight.grad, wo.grad, what='g_weight')
+
+
+@pytest.mark.parametrize('ne,Fin,n1,n2,deg', [(6, 48, 32, 16, 13), (6, 2, 32, 16, 13), (6, 48, 32, 16, 3), (8, 48, 32, 16, 13), (4, 48, 24, 24, 4)])
+def test_ml3layer_sr25_shapes_with_learned_supports(dev, ne, Fin, n1, n2, deg):
+    """ML3Layer at sr25.py:252-262's shapes (6 supports, 2 -> 48 -> 48, 32 + 16) and mutag.py's (24 + 24), training with the edge
+    branch: the branch runs in source order and the chunked ring forward gathers its 24-byte value rows through the position
+    map (two lanes per row, 12 bytes each); against the oracle in fp64."""
+    from gnn_matlang_amd import ML3Layer
+    from oracle.spect_conv_oracle import OracleML3Layer
+    from oracle.relu_margin import make_safe
+    torch.manual_seed(ne * 19 + Fin)
+    N = 400
+    rng = np.random.default_rng(Fin + deg)
+    ei = torch.from_numpy(_banded_graph(rng, N, deg, 12))
+    ref = OracleML3Layer(True, ne, ne, Fin, n1, n2).double()
+    m = ML3Layer(True, ne, ne, Fin, n1, n2).to(dev)
+    m.load_state_dict({n: p.detach().float() for n, p in ref.state_dict().items()})
+    x, ea, go = torch.randn(N, Fin), torch.randn(ei.size(1), ne) * 0.5, torch.randn(N, n1 + n2)
+    ea, mask = make_safe(x, ei, ea, ref.state_dict(), True)
+    go[:, :n1] *= mask.float()
+    xr, er = x.double().requires_grad_(True), ea.double().requires_grad_(True)
+    yr = ref(xr, ei, er)
+    (yr * go.double()).sum().backward()
+    for raw in (False, True):                              # supports with / without their own gradient (raw: the source-order fast road)
+        m.zero_grad()
+        xg = x.to(dev).requires_grad_(True)
+        eg = ea.to(dev).requires_grad_(not raw)
+        y = m(xg, ei.to(dev), eg)
+        (y * go.to(dev)).sum().backward()
+        close(y, yr, what='out')
+        close(xg.grad, xr.grad, what='g_x')
+        if not raw:
+            close(eg.grad, er.grad, what='g_edge_attr')
+        gp = dict(m.named_parameters())
+        for n, p in ref.named_parameters():
+            close(gp[n].grad, p.grad, what=n)
