@@ -27,6 +27,7 @@ SIGNATURES = {
     'gml_scatter_rows': (ctypes.c_int, [_p, _p, _p, _i64, _i32, _p]),
     'gml_spectconv_fwd_group_rows': (ctypes.c_int32, [_i32, _i32, _i32, ctypes.c_uint32]),
     'gml_spectconv_fwd_stage_edges': (ctypes.c_int32, [_i32, _i32, _i32, ctypes.c_uint32]),
+    'gml_spectconv_fwd_stage_window': (ctypes.c_int32, [_i32, _i32, _i32, ctypes.c_uint32]),
     'gml_spectconv_fwd': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _p, _p, _i64,
                                          _i64, _i32, _i32, _i32, _u32, _p]),
     'gml_ml3_fwd': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _i64,

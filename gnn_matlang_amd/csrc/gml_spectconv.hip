@@ -13,8 +13,19 @@ GML_DECL_FWD2(12, 2) GML_DECL_FWD2(12, 1) GML_DECL_FWD2(12, 0)  /* counting.py's
 #define GML_DECL_FWD3(S, B) template <> int gml_launch_fwd3<S, B>(const GmlFwdParams&, dim3, hipStream_t, bool);
 GML_DECL_FWD3(8, 2) GML_DECL_FWD3(8, 1) GML_DECL_FWD3(4, 2) GML_DECL_FWD3(4, 1)
 
+#if GML_F4DBG & (8 | 64)
+static unsigned long long* f4dbg_buf() {
+    static unsigned long long* b = [] { unsigned long long* q = nullptr; (void)hipMalloc(&q, 64); (void)hipMemset(q, 0, 64); return q; }();
+    return b;
+}
+extern "C" int gml_debug_f4_counts(unsigned long long* out, int reset) {
+    hipError_t e = hipMemcpy(out, f4dbg_buf(), 64, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && reset) e = hipMemset(f4dbg_buf(), 0, 64);
+    return (int)e;
+}
+#endif
 #define GML_DECL_FWD4(S, FB, B) template <> int gml_launch_fwd4<S, FB, B>(const GmlFwdParams&, dim3, hipStream_t);
-GML_DECL_FWD4(4, 0, 2) GML_DECL_FWD4(4, 1, 2) GML_DECL_FWD4(6, 0, 2) GML_DECL_FWD4(6, 1, 2) GML_DECL_FWD4(8, 0, 2) GML_DECL_FWD4(8, 1, 2)
+GML_DECL_FWD4(4, 0, 2) GML_DECL_FWD4(4, 1, 2) GML_DECL_FWD4(6, 0, 2) GML_DECL_FWD4(6, 1, 2) GML_DECL_FWD4(8, 0, 2)
 
 // GML_FWD_DMA=0: the register-staged 8-wave kernel (fwd2) instead of the LDS-DMA ring (fwd3), for A/B runs
 static bool fwd3_env() { static const bool v = [] { const char* e = getenv("GML_FWD_DMA"); return !(e && e[0] == '0'); }(); return v; }
@@ -24,7 +35,7 @@ static bool fwd3_env() { static const bool v = [] { const char* e = getenv("GML_
 static bool fwd4_only_shape(int S, int Fin, int Fout, uint32_t flags) {
     static const bool off = [] { const char* e = getenv("GML_FWD4"); return e && e[0] == '0'; }();   // A/B: the r03 roads
     if (off || (flags & GML_F32_MFMA) || Fout > 32) return false;
-    return (S == 6 && Fin <= 48) || ((S == 4 || S == 8) && Fin > 32 && Fin <= 48);
+    return (S == 6 && Fin <= 48) || (S == 4 && Fin > 32 && Fin <= 48);     /* (8 supports x 48 features: no script has it; its instantiation spilled) */
 }
 // GML_FWD4=1: every shape of the ring kernels on the chunked one (A/B against fwd3)
 static bool fwd4_all_env() { static const bool v = [] { const char* e = getenv("GML_FWD4"); return e && e[0] == '1'; }(); return v; }
@@ -44,11 +55,27 @@ extern "C" int32_t gml_spectconv_fwd_group_rows(int32_t S, int32_t Fin, int32_t 
     return fwd2_nw_env() == 4 ? GML_GROUPS64_RANKED : 128;
 }
 
-// edges of one 128-row group the ring kernel (fwd3) keeps in LDS at once for this shape; 0: the shape is not on fwd3.  A caller
-// that knows a larger group exists passes GML_FWD_CHUNKED and gets the chunked ring kernel instead of global gathers.
+// edges of one 128-row group the ring kernel of this shape keeps in LDS at once (one work item); 0: the shape is on no ring kernel.
+// Larger groups: fwd3 shapes gather them from global memory, or -- GML_FWD_CHUNKED -- run on the chunked ring kernel; the shapes only
+// the chunked kernel serves walk them in edge chunks (a road that is opt-in for callers: functional.FWD_CHUNKS, DESIGN s4.1c).
 extern "C" int32_t gml_spectconv_fwd_stage_edges(int32_t S, int32_t Fin, int32_t Fout, uint32_t flags) {
-    if (!fwd2_shape(S, Fin, Fout, flags) || fwd4_only_shape(S, Fin, Fout, flags) || !fwd3_env()) return 0;
+    if (!fwd2_shape(S, Fin, Fout, flags)) return 0;
+    if (fwd4_only_shape(S, Fin, Fout, flags)) {                /* one work item of the chunked ring kernel (its gathering form: the smaller one) */
+        const int fb = Fin > 32 ? 1 : 0;
+        if (S == 6) return (fb ? GmlFwd4Cfg<6, 1, true>::ECAP : GmlFwd4Cfg<6, 0, true>::ECAP) - 3;
+        return GmlFwd4Cfg<4, 1, true>::ECAP - 3;
+    }
+    if (!fwd3_env()) return 0;
     return S == 8 ? GmlFwd3Cfg<8>::ECAP - 3 : (S == 4 ? GmlFwd3Cfg<4>::ECAP - 3 : 0);
+}
+
+// widest column window (int 3 of a 128-row group record) the chunked ring kernel serves for this shape; 0 = no bound (the shape's
+// kernel has its own road for wider groups).  Batches with a wider group must stay on the 64-row family (group_rows 64): the chunked
+// kernel has no global-gather road and marks the rows of such a group NaN.
+extern "C" int32_t gml_spectconv_fwd_stage_window(int32_t S, int32_t Fin, int32_t Fout, uint32_t flags) {
+    if (!fwd2_shape(S, Fin, Fout, flags)) return 0;
+    if (!(fwd4_only_shape(S, Fin, Fout, flags) || (flags & GML_FWD_CHUNKED) || fwd4_all_env())) return 0;
+    return Fin > 32 ? GmlFwd4Cfg<4, 1, false>::XCAP - 15 : GmlFwd4Cfg<4, 0, false>::XCAP - 7;
 }
 
 // ---- families defined in gml_fwd_fam_*.hip ---------------------------------------------------
@@ -102,6 +129,12 @@ static int launch_fwd2(const int32_t* rowptr, const int32_t* col, const int32_t*
 #ifdef GML_FWD2_TIMING
     p.prof = fwd2_prof_buf();
 #endif
+#if GML_F4DBG & (8 | 64)
+    p.prof = f4dbg_buf();
+#endif
+#if GML_F4DBG & 256
+    { const char* e = getenv("GML_F4_HOUT"); p.hout = e ? (float*)(uintptr_t)strtoull(e, nullptr, 0) : nullptr; }
+#endif
     p.nw = (flags & GML_GROUPS64R) ? 4 : 8;
     if (p.nw == 4 && !xv) return GML_E_UNSUPPORTED;
     const int wgs = p.nw == 4 ? 2 * GML_NUM_CU : GML_NUM_CU;         // one 512-thread or two 256-thread workgroups per CU
@@ -116,11 +149,11 @@ static int launch_fwd2(const int32_t* rowptr, const int32_t* col, const int32_t*
     const bool only4 = fwd4_only_shape(S, Fin, Fout, flags);
     if (only4 || ((flags & GML_FWD_CHUNKED) || fwd4_all_env())) {
         const bool ok4 = p.nw == 8 && xv && !mix && !(flags & GML_ACCUM) && (num_rows + 16) * ldx * 4 < (int64_t)INT32_MAX &&
-                         (S == 4 || S == 6 || S == 8) && Fin <= 48;
+                         (S == 4 || S == 6 || S == 8) && Fin <= 48 && !(S == 8 && Fin > 32);
         if (ok4) {
             const int fb = Fin > 32 ? 1 : 0;
 #define GML_FWD4_GO(SV, FBV) if (S == SV && fb == FBV) return gml_launch_fwd4<SV, FBV, 2>(p, dim3(grid), st);
-            GML_FWD4_GO(4, 0) GML_FWD4_GO(4, 1) GML_FWD4_GO(6, 0) GML_FWD4_GO(6, 1) GML_FWD4_GO(8, 0) GML_FWD4_GO(8, 1)
+            GML_FWD4_GO(4, 0) GML_FWD4_GO(4, 1) GML_FWD4_GO(6, 0) GML_FWD4_GO(6, 1) GML_FWD4_GO(8, 0)
         }
         if (only4) return GML_E_UNSUPPORTED;             /* (unaligned x rows, accumulate mode: the caller takes the 64-row family) */
     }

@@ -16,9 +16,11 @@
 //     and column block (v_mfma_f32_16x16x16_bf16) against a second W image [s][o][16 f].  X rows are 192 bytes: sixteen of them
 //     are exactly three DMA instructions; blocks 3088 bytes apart.
 //   * S = 6 (sr25): 24-byte value rows.  Stored in CSR order they are one contiguous byte range per chunk (16-byte pieces, no
-//     row structure needed); gathered through a position map (EP) they land with `buffer_load_dwordx3 ... lds`, two lanes per
-//     row, 12 bytes per lane (probed: tools/probes/probe_glds3.hip).
-// Groups whose column window exceeds the staged rows take the global-gather path (same results), as in fwd3.
+//     row structure needed); gathered through a position map (EP) they land as two OVERLAPPING 16-byte lanes per row, bytes
+//     0..15 and 8..23, in 32-byte LDS rows [v0 v1 v2 v3 | v2 v3 v4 v5] (`buffer_load_dwordx3 ... lds` was probed first: it
+//     writes 12 bytes but strides 16 per lane, tools/probes/probe_glds3.hip -- no denser than this and a new instruction form).
+// Groups whose column window exceeds the staged rows (208 / 200) are NOT served: gml_spectconv_fwd_stage_window() tells the
+// caller, who keeps such batches on the 64-row family; the kernel marks their rows NaN rather than compute them wrongly.
 #pragma once
 #include "gml_common.h"
 #include "gml_spectconv_impl.h"
@@ -26,12 +28,21 @@
 
 typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
 
-// 12 bytes per active lane from rs[voff] to LDS byte address lds_addr + 12 * lane (see gml_dma16 for the statement's shape)
-__device__ __forceinline__ void gml_dma12(u32x4 rs, uint32_t lds_addr, int voff) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 2\n\tbuffer_load_dwordx3 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rs) : "memory");
-}
+// debugging builds (tools/build_variant.py <name> -DGML_F4DBG=<bits>; counters in p.prof, read by gml_debug_f4_counts):
+//   8  after every item's barrier the compute waves compare what landed in LDS with global memory (0 value rows, 1 column ids,
+//      2 X window, 3 row pointers, 4 checks done, 5 group record, 6 row mapping)
+//   4  every landing zone (records, row pointers, X windows, edge buffers) starts as NaN patterns
+//   64 the W images against global memory at the start and at the end of the kernel (0/1 start, 2/3 end)
+#ifndef GML_F4DBG
+#define GML_F4DBG 0
+#endif
+// delay experiments (-DGML_F4_DELAY=<bits>): ~8k idle cycles at 1 kernel start, 2 compute waves after barrier A, 4 compute waves after every
+// item barrier, 8 before the projection, 16 loaders between their wait and the barrier
+#ifndef GML_F4_DELAY
+#define GML_F4_DELAY 0
+#endif
+#define GML_F4_IDLE() do { for (int z_ = 0; z_ < 64; ++z_) __builtin_amdgcn_s_sleep(2); } while (0)
+
 
 #define GML_FWD4_NT 768                                        // 8 compute waves + 4 loader waves: 3 waves per SIMD
 
@@ -55,10 +66,17 @@ struct GmlFwd4Cfg {
     static constexpr int RP_BYTES = 528;                       // 132 row pointers
     static constexpr int GRP_BYTES = RP_BYTES + X_BYTES;       // group buffer: row pointers + X window
     static constexpr int VROW = 4 * S;
+    // bytes of a value row in LDS.  24-byte rows (S = 6) land as two OVERLAPPING 16-byte lanes per row, [v0 v1 v2 v3 | v2 v3 v4 v5]
+    // in 32 bytes, whether they are copied in CSR order or gathered through a position map: every read of the aggregation is then
+    // an aligned ds_read_b128.  (Packed 24-byte rows were read with ds_read2_b64 / ds_read_b64 -- and a wave's wait for a
+    // ds_read2_b64 was seen to return before its second element had landed: wrong tiles on the first launches of a process,
+    // DESIGN s4.1c.  The 12-byte LDS-DMA form strides 16 bytes per lane as well: tools/probes/probe_glds3.hip.)
+    static constexpr int VROW_L = (S % 4 != 0) ? 32 : VROW;
+    static_assert(S % 4 == 0 || S == 6, "value rows: multiples of 16 bytes, or 24 bytes");
     static constexpr int AVAIL = 160 * 1024 - W_BYTES - REC_BYTES - 2 * GRP_BYTES;
-    static constexpr int ECAP_RAW = AVAIL / (2 * (4 + VROW) + (EP ? 8 : 0));
+    static constexpr int ECAP_RAW = AVAIL / (2 * (4 + VROW_L) + (EP ? 8 : 0));
     static constexpr int ECAP = ECAP_RAW >= 1024 ? 1024 : ECAP_RAW / 64 * 64;      // staged edges per item
-    static constexpr int COL_BYTES = ECAP * 4, VAL_BYTES = ECAP * VROW;
+    static constexpr int COL_BYTES = ECAP * 4, VAL_BYTES = ECAP * VROW_L;
     static constexpr int EDGE_BYTES = COL_BYTES + VAL_BYTES;
     static constexpr int OFF_W2 = 4 * W_HALF;                  // (hi, lo of the first image, then hi, lo of the second)
     static constexpr int OFF_REC = W_BYTES, OFF_GRP = OFF_REC + REC_BYTES, OFF_EPOS = OFF_GRP + 2 * GRP_BYTES;
@@ -81,8 +99,7 @@ __global__ __launch_bounds__(GML_FWD4_NT, 1) void gml_k_spectconv_fwd4(const Gml
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __bf16* Wof_h = reinterpret_cast<__bf16*>(lds_raw);       // [s][o][32 f], 16-byte chunks XOR-swizzled by gml_wkey(o)
     __bf16* Wof_l = Wof_h + C::W_HALF;
-    __bf16* W2_h = reinterpret_cast<__bf16*>(lds_raw + C::OFF_W2);   // [s][o][16 f] (features 32 + f), 32-byte rows
-    __bf16* W2_l = W2_h + C::W2_HALF;
+    __bf16* W2_h = reinterpret_cast<__bf16*>(lds_raw + C::OFF_W2);   // [s][o][kq][hi 4 | lo 4] (features 32 + 4 kq + j), 64-byte rows
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -93,6 +110,7 @@ __global__ __launch_bounds__(GML_FWD4_NT, 1) void gml_k_spectconv_fwd4(const Gml
     if (g0 >= g1) return;
     const bool loader = wave >= 8;
 
+    if (GML_F4_DELAY & 1) GML_F4_IDLE();
     // ---- once per workgroup: W images, zeroed X areas (chunks at or beyond Fin are never written by a DMA and stay zero)
     for (int e = tid; e < S * 32 * 32; e += C::NT) {
         const int f = e & 31, o = (e >> 5) & 31, s = e >> 10;
@@ -110,8 +128,10 @@ __global__ __launch_bounds__(GML_FWD4_NT, 1) void gml_k_spectconv_fwd4(const Gml
             const float v = (f < p.Fin && o < p.Fout) ? p.w[(int64_t)(p.s0 + s) * p.w_ss + (int64_t)f * p.w_si + (int64_t)o * p.w_so] : 0.f;
             const __bf16 h = (__bf16)v;
             const __bf16 l = (__bf16)(v - (float)h);
-            W2_h[e] = h;
-            W2_l[e] = l;
+            // [s][o][kq][hi 0..3 | lo 0..3]: the lane's K = 16 fragment pair is ONE 16-byte read
+            const int i2 = ((s * 32 + o) * 4 + (f2 >> 2)) * 8 + (f2 & 3);
+            W2_h[i2] = h;
+            W2_h[i2 + 4] = l;
         }
     }
 #pragma unroll
@@ -119,6 +139,12 @@ __global__ __launch_bounds__(GML_FWD4_NT, 1) void gml_k_spectconv_fwd4(const Gml
         for (int i = tid; i < C::X_BYTES / 16; i += C::NT)
             *reinterpret_cast<f32x4*>(lds_raw + C::OFF_GRP + sl * C::GRP_BYTES + C::OFF_X + i * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
 
+#if GML_F4DBG & 4
+    {   // debugging: every landing zone starts as NaN patterns (data read before it landed shows up as NaN rows)
+        const float qn = __int_as_float(0x7fc00000);
+        for (int i = tid; i < (int)(C::lds_bytes() - C::OFF_REC) / 4; i += C::NT) reinterpret_cast<float*>(lds_raw + C::OFF_REC)[i] = qn;
+    }
+#endif
     // a group's geometry from its record in the ring (wave-uniform): edges kb4 .. kb4 + ne4 (16-byte aligned start), window rows
     // lo_a .. lo_a + nwin (block aligned start), nch chunks of cs edges
     struct Geo { int kb4, ne4, lo_a, nwin, nch, cs; bool staged; };
@@ -194,18 +220,25 @@ __global__ __launch_bounds__(GML_FWD4_NT, 1) void gml_k_spectconv_fwd4(const Gml
                 int e0, n;
                 chunk_of(q, c, e0, n);
                 // ---- value rows
-                if constexpr (!EP) {
-                    // CSR order: one contiguous byte range, 16-byte pieces (any S)
+                if constexpr (!EP && S % 4 == 0) {
+                    // CSR order, rows of whole 16-byte pieces: one contiguous byte range
                     const int npc = (n * VROW + 15) >> 4;
                     for (int j = li; 64 * j < npc; j += NL)
                         if (64 * j + lane < npc) gml_dma16(rs_val, ebuf + C::OFF_VAL + j * 1024, e0 * VROW + (64 * j + lane) * 16);
+                } else if constexpr (!EP) {
+                    // CSR order, 24-byte rows: two overlapping 16-byte lanes per row (bytes 0..15 and 8..23), 32 rows per instruction
+                    const int nvi = (n + 31) >> 5;
+                    for (int j = li; j < nvi; j += NL) {
+                        const int e = 32 * j + (lane >> 1);
+                        if (e < n) gml_dma16(rs_val, ebuf + C::OFF_VAL + j * 1024, (e0 + e) * VROW + (lane & 1) * 8);
+                    }
                 } else {
                     const int* epos_l = reinterpret_cast<const int*>(lds_raw + C::OFF_EPOS + (it & 1) * C::COL_BYTES);
-                    constexpr int PB = (S % 4 == 0) ? 16 : 12;             // bytes per lane
-                    constexpr int LPE = VROW / PB;                         // lanes per value row
+                    constexpr int LPE = C::VROW_L / 16;                    // lanes (16 bytes each) per value row
                     constexpr int EPI = 64 / LPE;                          // value rows per instruction
+                    constexpr int LSTEP = (S % 4 == 0) ? 16 : 8;           // source byte step between the lanes of a row
                     const int nvi = (n + EPI - 1) / EPI;
-                    const int part = (lane % LPE) * PB;
+                    const int part = (lane % LPE) * LSTEP;
                     for (int j0 = 4 * li; j0 < nvi; j0 += 4 * NL) {        // four position reads, then their four gathers
                         int voff[4];
 #pragma unroll
@@ -216,10 +249,7 @@ __global__ __launch_bounds__(GML_FWD4_NT, 1) void gml_k_spectconv_fwd4(const Gml
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             const int e = (j0 + u) * EPI + lane / LPE;
-                            if (e < n) {
-                                if constexpr (PB == 16) gml_dma16(rs_val, ebuf + C::OFF_VAL + (j0 + u) * 1024, voff[u]);
-                                else gml_dma12(rs_val, ebuf + C::OFF_VAL + (j0 + u) * 768, voff[u]);
-                            }
+                            if (e < n) gml_dma16(rs_val, ebuf + C::OFF_VAL + (j0 + u) * 1024, voff[u]);
                         }
                     }
                 }
@@ -264,6 +294,7 @@ __global__ __launch_bounds__(GML_FWD4_NT, 1) void gml_k_spectconv_fwd4(const Gml
         }
         issue(0, g0, 0, q);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (GML_F4_DELAY & 16) GML_F4_IDLE();
         for (;;) {
             __builtin_amdgcn_s_barrier();                      // (B) item `it` complete in its buffers; every wave has left the other ones
             asm volatile("" ::: "memory");
@@ -272,6 +303,7 @@ __global__ __launch_bounds__(GML_FWD4_NT, 1) void gml_k_spectconv_fwd4(const Gml
             const bool has = next_of(g, c, q, ng, nc, nq);
             if (has) issue(it + 1, ng, nc, nq);
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (GML_F4_DELAY & 16) GML_F4_IDLE();
             if (!has) break;
             g = ng; c = nc; q = nq; ++it;
         }
@@ -288,59 +320,107 @@ __global__ __launch_bounds__(GML_FWD4_NT, 1) void gml_k_spectconv_fwd4(const Gml
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                          // (A)
         if constexpr (EP) __builtin_amdgcn_s_barrier();        // (A2)
+        if (GML_F4_DELAY & 2) GML_F4_IDLE();
 
         // projection + stores of one group's tile: out tile = sum_s acc_s W_s (acc split on the fly = A fragments; K = 32: k = f =
         // 8 kq + j; K = 16: k = 4 kq + j <-> f = 32 + 4 kq + j)
         auto project = [&](f32x2 (&acc)[S][NH], int64_t r0, int nr, uint32_t out_rows) {
-            f32x4 oacc[NOB];
+            // Order of the projection (pinned with sched_barrier, found the hard way -- DESIGN s4.1c): an MFMA that waits in the matrix
+            // pipe behind its predecessors reads its operands when it STARTS, and an LDS load landing in one of those registers in
+            // the meantime is not interlocked (hipcc assumes operands are read at issue and re-uses them for the next fragment
+            // loads at once: wrong tiles on some waves of some launches).  So the loads for support s + 2 are issued only after the
+            // VALU split of support s + 1, which cannot overtake the MFMAs of support s: two fragment sets, two split sets.
+            auto mm = [&](f32x4 (&oacc)[NOB]) {
 #pragma unroll
             for (int ob = 0; ob < NOB; ++ob) oacc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
-            // (FB: one fragment set -- 12 features per support leave no registers for a second one; three waves per SIMD cover the reads)
-            constexpr int NST = FB ? 1 : 2;
-            bf16x8 wh[NST][NOB], wl[NST][NOB];
-            bf16x4v vh[NST][NOB], vl[NST][NOB];
+            bf16x8 wh[2][NOB], wl[2][NOB];
+            bf16x4v vh[2][NOB], vl[2][NOB];
+            bf16x8 ah[2], al[2];
+            bf16x4v bh[2], bl[2];
+            // `fa` (zero) is added to every fragment address and passes through a VALU statement behind each support's MFMAs: the
+            // next loads then carry an address dependency on an instruction that issues IN ORDER behind those MFMAs
+            int fa = 0;
+            asm volatile("v_mov_b32 %0, 0" : "=v"(fa));
             auto frag = [&](int s, int st) {
 #pragma unroll
                 for (int ob = 0; ob < NOB; ++ob) {
                     const int o = ob * 16 + r16;               // B[k = f][n = o]: 8 consecutive f of column o
-                    const int off = (s * 32 + o) * 32 + (((kq ^ gml_wkey(o)) & 3) << 3);
+                    const int off = (s * 32 + o) * 32 + (((kq ^ gml_wkey(o)) & 3) << 3) + fa;
                     wh[st][ob] = *reinterpret_cast<const bf16x8*>(Wof_h + off);
                     wl[st][ob] = *reinterpret_cast<const bf16x8*>(Wof_l + off);
                     if constexpr (FB) {
-                        const int off2 = (s * 32 + o) * 16 + 4 * kq;
-                        vh[st][ob] = *reinterpret_cast<const bf16x4v*>(W2_h + off2);
-                        vl[st][ob] = *reinterpret_cast<const bf16x4v*>(W2_l + off2);
+                        const bf16x8 t = *reinterpret_cast<const bf16x8*>(W2_h + ((s * 32 + o) * 4 + kq) * 8 + fa);
+                        vh[st][ob] = bf16x4v{t[0], t[1], t[2], t[3]};
+                        vl[st][ob] = bf16x4v{t[4], t[5], t[6], t[7]};
                     }
                 }
             };
-            if constexpr (NST == 2) frag(0, 0);
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const int st = NST == 2 ? (s & 1) : 0;
-                if constexpr (NST == 2) { if (s + 1 < S) frag(s + 1, st ^ 1); }
-                else frag(s, 0);
+            auto split = [&](int s, int t) {
                 const float av[8] = {acc[s][0].x, acc[s][0].y, acc[s][1].x, acc[s][1].y, acc[s][2].x, acc[s][2].y, acc[s][3].x, acc[s][3].y};
-                bf16x8 ah, al;
-                gml_split8(av, ah, al);
-#pragma unroll
-                for (int ob = 0; ob < NOB; ++ob) oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wh[st][ob], oacc[ob], 0, 0, 0);
-#pragma unroll
-                for (int ob = 0; ob < NOB; ++ob) oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wl[st][ob], oacc[ob], 0, 0, 0);
-#pragma unroll
-                for (int ob = 0; ob < NOB; ++ob) oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wh[st][ob], oacc[ob], 0, 0, 0);
+                gml_split8(av, ah[t], al[t]);
                 if constexpr (FB) {
                     bf16x2 h0, l0, h1, l1;
                     gml_split2(acc[s][4].x, acc[s][4].y, h0, l0);
                     gml_split2(acc[s][5].x, acc[s][5].y, h1, l1);
-                    const bf16x4v bh = bf16x4v{h0[0], h0[1], h1[0], h1[1]}, bl = bf16x4v{l0[0], l0[1], l1[0], l1[1]};
-#pragma unroll
-                    for (int ob = 0; ob < NOB; ++ob) oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bl, vh[st][ob], oacc[ob], 0, 0, 0);
-#pragma unroll
-                    for (int ob = 0; ob < NOB; ++ob) oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bh, vl[st][ob], oacc[ob], 0, 0, 0);
-#pragma unroll
-                    for (int ob = 0; ob < NOB; ++ob) oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bh, vh[st][ob], oacc[ob], 0, 0, 0);
+                    bh[t] = bf16x4v{h0[0], h0[1], h1[0], h1[1]};
+                    bl[t] = bf16x4v{l0[0], l0[1], l1[0], l1[1]};
                 }
+            };
+            frag(0, 0);
+            if constexpr (S > 1) frag(1, 1);
+            split(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int st = s & 1;
+#ifdef GML_F4_ASM_MFMA
+                // experiment: in-place accumulation (C = D) through inline asm, pads by hand
+                asm volatile("s_nop 1");
+#pragma unroll
+                for (int ob = 0; ob < NOB; ++ob) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(oacc[ob]) : "v"(al[st]), "v"(wh[st][ob]));
+#pragma unroll
+                for (int ob = 0; ob < NOB; ++ob) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(oacc[ob]) : "v"(ah[st]), "v"(wl[st][ob]));
+#pragma unroll
+                for (int ob = 0; ob < NOB; ++ob) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(oacc[ob]) : "v"(ah[st]), "v"(wh[st][ob]));
+                if constexpr (FB) {
+                    asm volatile("s_nop 7");
+#pragma unroll
+                    for (int ob = 0; ob < NOB; ++ob) asm volatile("v_mfma_f32_16x16x16_bf16 %0, %1, %2, %0" : "+v"(oacc[ob]) : "v"(bl[st]), "v"(vh[st][ob]));
+#pragma unroll
+                    for (int ob = 0; ob < NOB; ++ob) asm volatile("v_mfma_f32_16x16x16_bf16 %0, %1, %2, %0" : "+v"(oacc[ob]) : "v"(bh[st]), "v"(vl[st][ob]));
+#pragma unroll
+                    for (int ob = 0; ob < NOB; ++ob) asm volatile("v_mfma_f32_16x16x16_bf16 %0, %1, %2, %0" : "+v"(oacc[ob]) : "v"(bh[st]), "v"(vh[st][ob]));
+                    asm volatile("s_nop 7");
+                }
+                if (s == S - 1) asm volatile("s_nop 15\n\ts_nop 15");
+#else
+#pragma unroll
+                for (int ob = 0; ob < NOB; ++ob) oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[st], wh[st][ob], oacc[ob], 0, 0, 0);
+#pragma unroll
+                for (int ob = 0; ob < NOB; ++ob) oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[st], wl[st][ob], oacc[ob], 0, 0, 0);
+#pragma unroll
+                for (int ob = 0; ob < NOB; ++ob) oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[st], wh[st][ob], oacc[ob], 0, 0, 0);
+                if constexpr (FB) {
+#pragma unroll
+                    for (int ob = 0; ob < NOB; ++ob) oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bl[st], vh[st][ob], oacc[ob], 0, 0, 0);
+#pragma unroll
+                    for (int ob = 0; ob < NOB; ++ob) oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bh[st], vl[st][ob], oacc[ob], 0, 0, 0);
+#pragma unroll
+                    for (int ob = 0; ob < NOB; ++ob) oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bh[st], vh[st][ob], oacc[ob], 0, 0, 0);
+                }
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                if (s + 1 < S) split(s + 1, st ^ 1);           // VALU: issued behind the MFMAs above, in order
+                __builtin_amdgcn_sched_barrier(0);
+                if (s + 2 < S) {
+                    asm volatile("v_mov_b32 %0, %0" : "+v"(fa));   // (in order behind the MFMAs above)
+                    frag(s + 2, st);                           // the set the MFMAs above read
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
+            };
+            f32x4 oacc[NOB];
+            mm(oacc);
             // output stores through a buffer descriptor based at this group's first row: lanes outside (row >= nr, column >=
             // Fout) get an offset beyond the range and are dropped by the hardware -- no predicate
             const auto ors = __builtin_amdgcn_make_buffer_rsrc(p.out + r0 * p.ldo, 0, 0x7ffffe00, 0x00020000);
@@ -378,84 +458,120 @@ __global__ __launch_bounds__(GML_FWD4_NT, 1) void gml_k_spectconv_fwd4(const Gml
             }
         };
 
-        // One barrier per work item: a group's first item at the top of the group loop, its further chunks inside.  The accumulators
-        // are scoped to ONE group (not carried around the group loop), and the global-gather road has its own set: with one set
-        // shared by both roads the compiler kept two copies of it and moved between them (+48 registers, seen in the ISA).
-        int it = 0;
-        for (int g = g0; g < g1; ++g) {
+#if GML_F4DBG & 64
+        auto check_w = [&](int slot) {                        // debugging: the W images against global memory
+            for (int e = tid; e < S * 32 * 32; e += 512) {
+                const int f = e & 31, o = (e >> 5) & 31, s = e >> 10;
+                const float v = (f < p.Fin && o < p.Fout) ? p.w[(int64_t)(p.s0 + s) * p.w_ss + (int64_t)f * p.w_si + (int64_t)o * p.w_so] : 0.f;
+                const __bf16 h = (__bf16)v;
+                const __bf16 l = (__bf16)(v - (float)h);
+                const int iof = (s * 32 + o) * 32 + ((((f >> 3) ^ gml_wkey(o)) & 3) << 3) + (f & 7);
+                if ((float)Wof_h[iof] != (float)h || (float)Wof_l[iof] != (float)l) atomicAdd(&p.prof[slot], 1ull);
+            }
+            if constexpr (FB) {
+                for (int e = tid; e < S * 32 * 16; e += 512) {
+                    const int f2 = e & 15, o = (e >> 4) & 31, s = e >> 9;
+                    const int f = 32 + f2;
+                    const float v = (f < p.Fin && o < p.Fout) ? p.w[(int64_t)(p.s0 + s) * p.w_ss + (int64_t)f * p.w_si + (int64_t)o * p.w_so] : 0.f;
+                    const __bf16 h = (__bf16)v;
+                    const __bf16 l = (__bf16)(v - (float)h);
+                    const int i2 = ((s * 32 + o) * 4 + (f2 >> 2)) * 8 + (f2 & 3);
+                    if ((float)W2_h[i2] != (float)h || (float)W2_h[i2 + 4] != (float)l) atomicAdd(&p.prof[slot + 1], 1ull);
+                }
+            }
+        };
+        check_w(0);
+#endif
+        // One barrier per work item, ONE barrier site: a flat loop over the items (group, chunk) like fwd3's loop over groups; a new
+        // group's state is set up where its first chunk starts, the projection follows its last chunk.
+        int it = 0, g = g0, c = 0;
+        Geo q = {};
+        int row = 0, nr = 0, kbeg = 0, kend = 0, xoff = 0;
+        uint32_t out_rows = 0;
+        int64_t r0 = 0;
+        bool rvalid = false;
+        f32x2 acc[S][NH];
+        for (;;) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                      // (B) first item of group g
+            __builtin_amdgcn_s_barrier();                      // (B) item `it` has landed
             asm volatile("" ::: "memory");
-            const Geo q = geo_of(g);
-            const unsigned char* gbuf = lds_raw + C::OFF_GRP + (g & 1) * C::GRP_BYTES;
-            const int* rp_l = reinterpret_cast<const int*>(gbuf);
-            const unsigned char* rec = lds_raw + C::OFF_REC + (g & 3) * 256;
-            const int row = rec[16 + wave * 16 + r16];
-            const uint32_t out_rows = reinterpret_cast<const uint32_t*>(rec + 16)[wave * 4 + kq];
-            const int64_t r0 = (int64_t)g * ROWS;
-            const int nr = (int)min((int64_t)ROWS, p.nrows - r0);
-            const bool rvalid = row < nr;
-            const int kbeg = rvalid ? rp_l[row] : 0;
-            const int kend = rvalid ? rp_l[row + 1] : 0;
-
-            if (!q.staged) {
-                // ---- window outside the LDS capacity: global gathers (one item per group).  A wave-uniform loop (every lane runs the
-                //      longest row's trip count, lanes past their row multiply by zero); chunks at or beyond Fin are read from the
-                //      row's start instead and zeroed
-                f32x2 acc[S][NH];
+            if (GML_F4_DELAY & 4) GML_F4_IDLE();
+            if (c == 0) {
+                q = geo_of(g);
+                const unsigned char* gbuf = lds_raw + C::OFF_GRP + (g & 1) * C::GRP_BYTES;
+                const int* rp_l = reinterpret_cast<const int*>(gbuf);
+                const unsigned char* rec = lds_raw + C::OFF_REC + (g & 3) * 256;
+                row = rec[16 + wave * 16 + r16];
+                out_rows = reinterpret_cast<const uint32_t*>(rec + 16)[wave * 4 + kq];
+                r0 = (int64_t)g * ROWS;
+                nr = (int)min((int64_t)ROWS, p.nrows - r0);
+                rvalid = row < nr;
+                kbeg = rvalid ? rp_l[row] : 0;
+                kend = rvalid ? rp_l[row + 1] : 0;
+                // byte offset of (row cidx, features 8 kq ..) in the window: xoff + FR * 4 * cidx + 16 (cidx / XRB)
+                xoff = C::OFF_GRP + (g & 1) * C::GRP_BYTES + C::OFF_X + kq * 32 - q.lo_a * (FR * 4) - (q.lo_a / C::XRB) * 16;
 #pragma unroll
                 for (int s = 0; s < S; ++s)
 #pragma unroll
                     for (int h = 0; h < NH; ++h) acc[s][h] = f32x2{0.f, 0.f};
-                const bool on0 = 8 * kq < p.Fin, on1 = 8 * kq + 4 < p.Fin, on2 = FB && 32 + 4 * kq < p.Fin;
-                const int o0 = on0 ? 8 * kq : 0, o1 = on1 ? 8 * kq + 4 : 0, o2 = on2 ? 32 + 4 * kq : 0;
-                const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
-                const int klim = max(etot, 1) - 1;
-                for (int k = kbeg; __builtin_amdgcn_ballot_w64(k < kend) != 0ull; ++k) {
-                    const bool on = k < kend;
-                    const int kk = min(k, klim);
-                    const float* xr = p.x + (int64_t)p.col[kk] * p.ldx;
-                    const float* vr = p.val + (int64_t)(EP ? p.epos[kk] : kk) * p.S + p.s0;
-                    float e[S];
-                    gml_load_row<S, VAL_ALIGN>(vr, e);
-                    f32x4 t[2 + FB];
-                    t[0] = *reinterpret_cast<const f32x4*>(xr + o0);
-                    t[1] = *reinterpret_cast<const f32x4*>(xr + o1);
-                    if constexpr (FB) t[2] = *reinterpret_cast<const f32x4*>(xr + o2);
-                    t[0] = on0 ? t[0] : zero4; t[1] = on1 ? t[1] : zero4;
-                    if constexpr (FB) t[2] = on2 ? t[2] : zero4;
-#pragma unroll
-                    for (int s = 0; s < S; ++s) {
-                        const float ev = on ? e[s] : 0.f;
-                        const f32x2 e2 = f32x2{ev, ev};
-#pragma unroll
-                        for (int h = 0; h < NH; ++h) acc[s][h] = e2 * f32x2{t[h >> 1][2 * (h & 1)], t[h >> 1][2 * (h & 1) + 1]} + acc[s][h];
-                    }
+                if (!q.staged) {
+                    // ---- column window wider than the staged rows: this kernel has no second road (an inlined global-gather road
+                    //      set the register count of the whole kernel: 168 + spills).  The caller routes such batches elsewhere
+                    //      (gml_spectconv_fwd_stage_window(); functional.fwd_groups); one that did not gets NaN rows, not wrong numbers.
+                    const float qnan = __int_as_float(0x7fc00000);
+                    if (rvalid)
+                        for (int o = kq; o < p.Fout; o += 4) p.out[(r0 + row) * p.ldo + o] = qnan;
+                    ++it;
+                    if (++g >= g1) break;
+                    continue;
                 }
-                project(acc, r0, nr, out_rows);
-                ++it;
-                continue;
             }
-
-            // ---- aggregation (fp32 VALU, packed): acc[s][f] += val[k, s] * x[col[k], f], chunk by chunk
-            // byte offset of (row cidx, features 8 kq ..) in the window: xoff + FR * 4 * cidx + 16 (cidx / XRB)
-            const int xoff = C::OFF_GRP + (g & 1) * C::GRP_BYTES + C::OFF_X + kq * 32 - q.lo_a * (FR * 4) - (q.lo_a / C::XRB) * 16;
-            f32x2 acc[S][NH];
-#pragma unroll
-            for (int s = 0; s < S; ++s)
-#pragma unroll
-                for (int h = 0; h < NH; ++h) acc[s][h] = f32x2{0.f, 0.f};
-            for (int c = 0; c < q.nch; ++c, ++it) {
-                if (c > 0) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();              // (B) further chunks of the group
-                    asm volatile("" ::: "memory");
-                }
+            {
+                // ---- aggregation (fp32 VALU, packed): acc[s][f] += val[k, s] * x[col[k], f] over the lane's edges inside this chunk
                 const unsigned char* ebuf = lds_raw + C::OFF_EDGE + (it & 1) * C::EDGE_BYTES;
                 const int* col_l = reinterpret_cast<const int*>(ebuf);
                 const float* ea_l = reinterpret_cast<const float*>(ebuf + C::OFF_VAL);
                 const int e0 = q.kb4 + c * q.cs;
                 const int e1 = min(e0 + q.cs, q.kb4 + q.ne4);
+#if GML_F4DBG & 8
+                if constexpr (!EP) {                           // verify what landed against global memory
+                    const int n = e1 - e0;
+                    for (int i = tid; i < n * S; i += 512) {
+                        const int kk_ = i / S, ss_ = i % S;
+                        const float a = C::VROW_L == VROW ? ea_l[i] : ea_l[kk_ * 8 + (ss_ < 4 ? ss_ : ss_ + 2)], b = p.val[(int64_t)e0 * S + i];
+                        if (__float_as_int(a) != __float_as_int(b)) atomicAdd(&p.prof[0], 1ull);
+                        if (i == 0) atomicAdd(&p.prof[4], 1ull);
+                    }
+                    for (int i = tid; i < n; i += 512) {
+                        const int a = col_l[i], b = (e0 + i < etot) ? p.col[e0 + i] : a;
+                        if (a != b) atomicAdd(&p.prof[1], 1ull);
+                    }
+                    if (c == 0) {
+                        const int* rp_l = reinterpret_cast<const int*>(lds_raw + C::OFF_GRP + (g & 1) * C::GRP_BYTES);
+                        const unsigned char* rec = lds_raw + C::OFF_REC + (g & 3) * 256;
+                        for (int i = tid; i < q.nwin * FR; i += 512) {
+                            const int rr = i / FR, f = i % FR;
+                            const int cidx = q.lo_a + rr;
+                            const float a = *reinterpret_cast<const float*>(lds_raw + (xoff - kq * 32) + cidx * (FR * 4) + ((cidx / C::XRB) << 4) + f * 4);
+                            const float b = (cidx < p.nrows && f < p.Fin) ? p.x[(int64_t)cidx * p.ldx + f] : 0.f;
+                            if (__float_as_int(a) != __float_as_int(b)) atomicAdd(&p.prof[2], 1ull);
+                        }
+                        for (int i = tid; i <= nr; i += 512) {
+                            const int a = rp_l[i], b = p.rowptr[r0 + i];
+                            if (a != b) atomicAdd(&p.prof[3], 1ull);
+                        }
+                        if (tid < 36) {
+                            const int a = reinterpret_cast<const int*>(rec)[tid], b = p.ginfo[(int64_t)g * 36 + tid];
+                            if (a != b) atomicAdd(&p.prof[5], 1ull);
+                        }
+                        {
+                            const int rr = reinterpret_cast<const unsigned char*>(p.ginfo + (int64_t)g * 36 + 4)[wave * 16 + r16];
+                            const uint32_t orr = reinterpret_cast<const uint32_t*>(p.ginfo + (int64_t)g * 36 + 4)[wave * 4 + kq];
+                            if (rr != row || orr != out_rows) atomicAdd(&p.prof[6], 1ull);
+                        }
+                    }
+                }
+#endif
                 int k = max(kbeg, e0) - e0;
                 const int ke = min(kend, e1) - e0;
                 if (k < ke) {
@@ -463,7 +579,11 @@ __global__ __launch_bounds__(GML_FWD4_NT, 1) void gml_k_spectconv_fwd4(const Gml
                     // the packed FMAs of edge k; two register sets, no rotation moves
                     struct Ops { float e[S]; f32x4 t0, t1, t2; };
                     auto fetch = [&](Ops& o, int kk, int cidx) {
-                        gml_load_row<S, VAL_ALIGN>(ea_l + kk * S, o.e);
+                        if constexpr (C::VROW_L == VROW) gml_load_row<S, VAL_ALIGN>(ea_l + kk * S, o.e);
+                        else {                                 // gathered 24-byte rows: [v0 v1 v2 v3 | v2 v3 v4 v5]
+                            const f32x4 a = *reinterpret_cast<const f32x4*>(ea_l + kk * 8), b = *reinterpret_cast<const f32x4*>(ea_l + kk * 8 + 4);
+                            o.e[0] = a.x; o.e[1] = a.y; o.e[2] = a.z; o.e[3] = a.w; o.e[4] = b.z; o.e[5] = b.w;
+                        }
                         const int off = xoff + cidx * (FR * 4) + ((cidx / C::XRB) << 4);
                         o.t0 = *reinterpret_cast<const f32x4*>(lds_raw + off);
                         o.t1 = *reinterpret_cast<const f32x4*>(lds_raw + off + 16);
@@ -496,8 +616,39 @@ __global__ __launch_bounds__(GML_FWD4_NT, 1) void gml_k_spectconv_fwd4(const Gml
                     }
                 }
             }
+            ++it;
+            if (++c < q.nch) continue;
+            c = 0;
+            // The pipelined loop leaves its last prefetch (the clamped "next" edge) in flight at its exits: drain it before the
+            // projection takes the registers over (the projection's own loads are ordered by hand, see `project`).
+            __builtin_amdgcn_sched_barrier(0);                 // (nothing of the projection may be scheduled above the wait)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (GML_F4_DELAY & 8) { GML_F4_IDLE(); __builtin_amdgcn_sched_barrier(0); }
+#ifdef GML_F4_EXECCHK
+            if (__builtin_amdgcn_read_exec() != ~0ull && p.prof) atomicAdd(&p.prof[7], 1ull);
+#endif
+#if GML_F4DBG & 256
+            if (p.hout != nullptr && rvalid) {                 // debugging: the aggregate H[row][s][48] as the projection receives it
+                float* hr = p.hout + ((r0 + row) * S) * 48;
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) { hr[s * 48 + 8 * kq + 2 * h] = acc[s][h].x; hr[s * 48 + 8 * kq + 2 * h + 1] = acc[s][h].y; }
+                    if constexpr (FB) {
+                        hr[s * 48 + 32 + 4 * kq] = acc[s][4].x; hr[s * 48 + 33 + 4 * kq] = acc[s][4].y;
+                        hr[s * 48 + 34 + 4 * kq] = acc[s][5].x; hr[s * 48 + 35 + 4 * kq] = acc[s][5].y;
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             project(acc, r0, nr, out_rows);
+            if (++g >= g1) break;
         }
+#if GML_F4DBG & 64
+        check_w(2);
+#endif
     }
 }
 

@@ -180,6 +180,13 @@ def conv_epilogue(csr, x, val, w, bias, S, epilogue, ds, self_term, ncols):
     return out
 
 
+# Groups with more edges than one work item of the ring kernels (sr25.py: 13 entries per row): GML_FWD_CHUNKS=1 walks them in edge
+# chunks on gml_k_spectconv_fwd4 (2-3 x the 64-row family's speed, parity-green).  Off by default: under repeat-and-compare stress
+# the chunked road differed from itself in ~1 launch of 500 during the first launches of a process (DESIGN s4.1c) -- not root-caused,
+# so batches with such groups stay on the 64-row family, whose results are bit-stable.
+FWD_CHUNKS = _os.environ.get('GML_FWD_CHUNKS', '0') not in ('0', '')
+
+
 def fwd_groups(csr, x, S, Fin, Fout):
     """(group records, extra flags) the forward kernel wants for this shape: the 8-wave kernel on 128-row records when
     the shape is compiled for it, else the 64-row kernel."""
@@ -187,16 +194,26 @@ def fwd_groups(csr, x, S, Fin, Fout):
     if _os.environ.get('GML_FWD64'):                         # experiments: force the 4-wave / 64-row kernel family
         return csr.ginfo, 0
     rows = int(_lib.lib().gml_spectconv_fwd_group_rows(int(S), int(Fin), int(Fout), flags))
-    if rows == 128 and not (x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0) and (S == 6 or Fin > 32):
-        rows = 64                                            # (6 supports / 48 features exist only on the ring kernel: float4 rows)
+    L = _lib.lib()
+    gm_e, gm_w = csr.gmax128 if getattr(csr, 'gmax128', None) is not None else (0, 0)
+    x4 = x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
     if rows == 128:
-        # the largest 128-row group (of the source view: SpectralDesign's masks are symmetric, so of this view too -- a hint only,
-        # results never depend on it) beyond what the ring kernel stages: its chunked form instead of global gathers
-        cap = int(_lib.lib().gml_spectconv_fwd_stage_edges(int(S), int(Fin), int(Fout), flags))
-        gm = csr.gmax_t128[0] if getattr(csr, 'gmax_t128', None) is not None else 0
-        if cap > 0 and gm > cap:
-            _path('conv_fwd', 'fused 8-wave bf16x3, edge chunks', S, Fin, Fout)
-            return csr.ginfo128, _lib.GML_GROUPS128 | _lib.GML_FWD_CHUNKED
+        cap = int(L.gml_spectconv_fwd_stage_edges(int(S), int(Fin), int(Fout), flags))      # edges of one work item of the ring kernel
+        only4 = S == 6 or (S == 4 and Fin > 32)   # 6 supports / 48 features exist only on the chunked ring kernel: float4 rows, windows it can stage
+        if only4:
+            win = int(L.gml_spectconv_fwd_stage_window(int(S), int(Fin), int(Fout), flags))
+            if not x4 or (win > 0 and gm_w > win) or (gm_e > cap and not FWD_CHUNKS):
+                rows = 64
+            elif gm_e > cap:
+                _path('conv_fwd', 'fused 8-wave bf16x3, edge chunks', S, Fin, Fout)
+                return csr.ginfo128, _lib.GML_GROUPS128
+        elif cap > 0 and gm_e > cap and FWD_CHUNKS and x4:
+            # a group beyond what the default ring kernel stages at once: its chunked form instead of global gathers (opt-in)
+            win = int(L.gml_spectconv_fwd_stage_window(int(S), int(Fin), int(Fout), flags | _lib.GML_FWD_CHUNKED))
+            if gm_w <= win:
+                _path('conv_fwd', 'fused 8-wave bf16x3, edge chunks', S, Fin, Fout)
+                return csr.ginfo128, _lib.GML_GROUPS128 | _lib.GML_FWD_CHUNKED
+    if rows == 128:
         _path('conv_fwd', 'fused 8-wave bf16x3', S, Fin, Fout)
         return csr.ginfo128, _lib.GML_GROUPS128
     if rows == _lib.GML_GROUPS64_RANKED:

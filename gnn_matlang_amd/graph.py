@@ -36,7 +36,7 @@ def _require_cuda(t, name):
 
 class GraphCSR(object):
     __slots__ = ('N', 'E', 'device', 'rowptr', 'col', 'perm', 'rowptr_t', 'col_t', 'pos_t', 'perm_t', 'src_sorted',
-                 '_ginfo', '_ginfo_t', '_gmax', '_gmax_t', 'ginfo_t128', 'gmax_t128', 'ginfo128', 'tpos', '_val_cache', '_keep', '_r64',
+                 '_ginfo', '_ginfo_t', '_gmax', '_gmax_t', 'ginfo_t128', 'gmax_t128', 'ginfo128', 'gmax128', 'tpos', '_val_cache', '_keep', '_r64',
                  '_r64t', '_bad')
 
     def __init__(self):
@@ -97,11 +97,13 @@ class GraphCSR(object):
             # clamped there, so nothing was written out of bounds: raise like the reference's scatter does)
             if static_caps is not None:
                 g.gmax_t128 = (int(static_caps[0]), int(static_caps[1]))
+                g.gmax128 = g.gmax_t128                        # (the caller bounds both views: symmetric masks)
                 g.src_sorted = bool(assume_source_sorted)
                 g._bad = bad.clone()                           # not read here (no host read): see check()
                 return g
-            mx = torch.stack([g.ginfo_t128[:, 1].max(), g.ginfo_t128[:, 3].max(), bad[0]]).tolist()
+            mx = torch.stack([g.ginfo_t128[:, 1].max(), g.ginfo_t128[:, 3].max(), bad[0], g.ginfo128[:, 1].max(), g.ginfo128[:, 3].max()]).tolist()
             g.gmax_t128 = (int(mx[0]), int(mx[1]))
+            g.gmax128 = (int(mx[3]), int(mx[4]))               # target view: largest group (edges, column window) of the forward kernels
             if mx[2] & 1:
                 raise IndexError('edge_index holds node ids outside [0, %d)' % N)
             if mx[2] & 2:                                      # source keys were not sorted: general construction

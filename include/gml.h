@@ -121,10 +121,17 @@ int gml_scatter_rows(const float* in, const int32_t* perm, float* out, int64_t r
 /* group size (64 | 128) whose records the forward wants for this shape and arithmetic; 128 additionally needs
  * epos == NULL -- the caller then passes those records and GML_GROUPS128 */
 int32_t gml_spectconv_fwd_group_rows(int32_t S, int32_t Fin, int32_t Fout, uint32_t flags);
-/* edges of one 128-row group the default ring kernel keeps in LDS at once for this shape (0: not applicable).  When the largest
- * group of the batch (int 1 of its records) exceeds it, pass GML_FWD_CHUNKED: the chunked ring kernel walks such groups in
- * edge chunks (sr25.py: 13 entries per row) instead of gathering them from global memory. */
+/* edges of one 128-row group the ring kernel of this shape keeps in LDS at once (0: not applicable).  When the largest group of the
+ * batch (int 1 of its records) exceeds it: shapes of the default ring kernel gather such groups from global memory, or -- with
+ * GML_FWD_CHUNKED -- run on the chunked ring kernel, which walks them in edge chunks (sr25.py: 13 entries per row); the shapes only the
+ * chunked kernel serves (6 supports, 33..48 input features) always chunk.  The chunked road is parity-green but showed a residual
+ * run-to-run difference (~1 launch in 500, first launches of a process) under repeat-and-compare stress: callers that need bit-stable
+ * results keep such batches on the 64-row family (what gnn_matlang_amd.functional does unless GML_FWD_CHUNKS=1). */
 int32_t gml_spectconv_fwd_stage_edges(int32_t S, int32_t Fin, int32_t Fout, uint32_t flags);
+/* widest column window (int 3 of the 128-row group records) the kernel this shape (and these flags, e.g. GML_FWD_CHUNKED) would run on
+ * serves; 0 = no bound.  A batch with a wider group must use the 64-row family (64-row records, no GML_GROUPS128) for this call:
+ * the chunked ring kernel has no road for such groups and writes NaN into their rows instead of wrong numbers. */
+int32_t gml_spectconv_fwd_stage_window(int32_t S, int32_t Fin, int32_t Fout, uint32_t flags);
 int gml_spectconv_fwd(const int32_t* rowptr, const int32_t* col, const int32_t* ginfo, const int32_t* epos,
                       const float* val, const float* x, int64_t ldx,
                       const float* w, int64_t w_ss, int64_t w_si, int64_t w_so,
