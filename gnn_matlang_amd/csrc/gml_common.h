@@ -113,13 +113,9 @@ __device__ __forceinline__ void gml_load_row(const float* __restrict__ p, float 
             v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
         }
     } else if constexpr (ALIGN_FLOATS >= 2 && N % 2 == 0) {
-        // volatile: the 8-byte loads stay single ds_read_b64 / global_load_dwordx2.  Merged into ds_read2_b64 (what hipcc does with
-        // two adjacent ones) a counted lgkmcnt wait was seen to release before the pair's SECOND element had been written back on
-        // gfx950 -- wrong tiles on the first launches of a process (round 4, DESIGN s4.1c); 6-support value rows are the only
-        // 8-byte-aligned rows of this library.
 #pragma unroll
         for (int i = 0; i < N / 2; ++i) {
-            const f32x2 t = *reinterpret_cast<const volatile f32x2*>(p + 2 * i);
+            const f32x2 t = *reinterpret_cast<const f32x2*>(p + 2 * i);
             v[2 * i] = t.x; v[2 * i + 1] = t.y;
         }
     } else {

@@ -225,8 +225,8 @@ __global__ __launch_bounds__(GmlSpmm3Cfg::NT, 1) void gml_k_spmm3(const GmlSpmm3
                                 o.e0 = *reinterpret_cast<const f32x4*>(er);
                                 o.e1 = *reinterpret_cast<const f32x4*>(er + 4);
                             } else if constexpr (VA == 2) {
-                                const f32x2 a0 = *reinterpret_cast<const volatile f32x2*>(er), a1 = *reinterpret_cast<const volatile f32x2*>(er + 2);   /* volatile: single 8-byte reads, never ds_read2_b64 (gml_load_row) */
-                                const f32x2 a2 = *reinterpret_cast<const volatile f32x2*>(er + 4), a3 = *reinterpret_cast<const volatile f32x2*>(er + 6);
+                                const f32x2 a0 = *reinterpret_cast<const f32x2*>(er), a1 = *reinterpret_cast<const f32x2*>(er + 2);
+                                const f32x2 a2 = *reinterpret_cast<const f32x2*>(er + 4), a3 = *reinterpret_cast<const f32x2*>(er + 6);
                                 o.e0 = f32x4{a0.x, a0.y, a1.x, a1.y}; o.e1 = f32x4{a2.x, a2.y, a3.x, a3.y};
                             } else {
                                 o.e0 = f32x4{er[0], er[1], er[2], er[3]}; o.e1 = f32x4{er[4], er[5], er[6], er[7]};
