@@ -417,6 +417,14 @@ def main():
             res['roofline'] = cands[0]
             res['roofline_other'] = cands[1:]
             res['kernels_ms_per_step'] = kms
+            # the whole step by the same accounting: sum of the SURVEY s8(d) algorithmic bytes of every tagged launch of a step / step time
+            summ_ = Fn.profile_summary(prof)
+            qstep = sum(v['bytes'] * v['launches'] for v in summ_.values()) / args.steps
+            res['roofline_step'] = dict(bound='hbm', algorithmic_bytes_per_step=qstep, ms_per_step=ms,
+                                        achieved=qstep / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s',
+                                        frac=qstep / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
+            log('roofline: dominant kernel %s at %.3f of the HBM roof (%.3f ms/launch); whole step %.3f' % (
+                cands[0]['kernel'].split(' ')[0], cands[0]['frac'], cands[0]['avg_launch_ms'], res['roofline_step']['frac']))
         if world == 1 and not args.no_profile:
             # calibration: what torch's device-to-device copy reaches on THIS box (read + write bytes / time) -- a
             # reference point, not a ceiling (MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy kernel); the
@@ -457,6 +465,8 @@ def main():
                            'avg_launch_ms': t_s * 1e3, 'algorithmic_bytes_per_launch': q_s, 'S': S_, 'Fin': Fin_,
                            'frac_of_copy_rate': q_s / t_s / 1e9 / res['hbm_copy_GBps'],
                            'blocks': len(tblk), 'launches_per_block': nrep, 'block_ms': [round(t * 1e3, 4) for t in tblk]}
+            log('spmm (S = %d, Fin = %d, %d nodes): %.3f ms/launch = %.0f GB/s = %.3f of the HBM roof' % (
+                S_, Fin_, csr.N, t_s * 1e3, q_s / t_s / 1e9, q_s / t_s / 1e9 / HBM_PEAK_GBS))
             del xs, vals
         if world == 1 and not args.no_profile and not args.no_extras:
             # ---- the same step with exact fp32 products (f32-input MFMA; bit-identical to an fmaf chain)

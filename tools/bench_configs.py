@@ -20,17 +20,52 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0
 
 
+def _mutag_like(count, seed):
+    """ZINC-like molecular graphs with mutag's node features: one-hot over 7 atom types (libs/utils.py:192-209 reads 7 columns
+    from mutag.mat); SpectralDesign(adddegree) appends the degree -> 8 input features like mutag.py:14,272-288"""
+    import numpy as np
+    from gnn_matlang_amd import synthetic
+    rng = np.random.default_rng(seed)
+    out = []
+    for x, ei, y in synthetic.make_graphs('zinc', count, seed=seed):
+        x7 = np.zeros((x.shape[0], 7), dtype=np.float32)
+        x7[np.arange(x.shape[0]), rng.integers(7, size=x.shape[0])] = 1
+        out.append((x7, ei, np.float32(rng.integers(2))))
+    return out
+
+
+def _sr25_real():
+    from gnn_matlang_amd import readers
+    return readers.load_sr(os.path.join(ROOT, 'tests', 'golden', 'raw', 'sr251256.g6'))
+
+
 def _configs():
-    from gnn_matlang_amd import models
-    # (name, synthetic kind, pool graphs, repeats (full, quick), SpectralDesign kwargs, model, loss, input features, reference)
+    from gnn_matlang_amd import models, synthetic
+    # (name, graph pool, nodes wanted (full, quick), SpectralDesign kwargs of the reference script, model, loss, reference)
     return [
-        ('counting', 'counting', 256, (64, 16), dict(recfield=1, dv=1, nfreq=10, addadj=True), lambda: models.counting_gnnml3(1, 12),
-         models.counting_loss, 1, 'counting.py:335-372 (GNNML3, S = 12, 5 layers 16+16)'),
-        ('sr25', 'regular', 64, (32, 32), dict(recfield=1, dv=1, nfreq=5), lambda: models.sr25_gnnml3(1, 6), None, 1,
-         'sr25.py:248-280 (GNNML3, S = 6, 3 layers 32+16; synthetic 12-regular 25-node graphs)'),
-        ('mutag_gnnml3', 'zinc', 512, (32, 16), dict(recfield=1, dv=1, nfreq=3), lambda: models.mutag_gnnml3(21, 4), models.mutag_loss, 21,
-         'mutag.py:272-288 (GNNML3, S = 4, 3 layers 24+24, learnedge=False)'),
+        ('counting', lambda: synthetic.make_graphs('counting', 512, seed=2), (600000, 150000),
+         dict(recfield=1, dv=1, nfreq=10, adddegree=True, laplacien=False, addadj=True), lambda: models.counting_gnnml3(2, 12),
+         models.counting_loss, 'counting.py:16,335-372 (GNNML3, S = 12, input [1, degree], 5 layers 16+16)'),
+        ('sr25', _sr25_real, (600000, 150000), dict(recfield=1, dv=2, nfreq=5, adddegree=True), lambda: models.sr25_gnnml3(2, 6), None,
+         'sr25.py:16,248-280 (GNNML3, S = 6, input [1, degree], 3 layers 32+16; the 15 REAL sr25 graphs, tiled)'),
+        ('mutag_gnnml3', lambda: _mutag_like(512, 2), (600000, 150000), dict(recfield=1, dv=4, nfreq=3, adddegree=True), lambda: models.mutag_gnnml3(8, 4),
+         models.mutag_loss, 'mutag.py:14,272-288 (GNNML3, S = 4, 7 atom types + degree, 3 layers 24+24 + BatchNorm, learnedge=False; ZINC-like synthetic graphs)'),
     ]
+
+
+def _tile(base, reps, dev):
+    """the collated pool `base` (on the device) repeated reps times as one block-diagonal batch"""
+    from gnn_matlang_amd.graph import Batch
+    n, B = base.x.size(0), base.num_graphs
+    offs = torch.arange(reps, device=dev) * n
+    return Batch(x=base.x.repeat(reps, 1),
+                 edge_index=(base.edge_index.unsqueeze(1) + offs.view(1, -1, 1)).reshape(2, -1),
+                 edge_index2=(base.edge_index2.unsqueeze(1) + offs.view(1, -1, 1)).reshape(2, -1),
+                 edge_attr2=base.edge_attr2.repeat(reps, 1),
+                 batch=(base.batch.unsqueeze(0) + (torch.arange(reps, device=dev) * B).view(-1, 1)).reshape(-1),
+                 ptr=torch.cat([(base.ptr[:-1].long().view(1, -1) + offs.view(-1, 1)).reshape(-1),
+                                torch.tensor([n * reps], device=dev)]).int(),
+                 y=torch.zeros(B * reps, device=dev))
 
 
 def _roofline(summ, nsteps):
@@ -52,20 +87,18 @@ def _roofline(summ, nsteps):
 
 
 def run(dev, quick=False, only=None):
-    from gnn_matlang_amd import SpectralDesign, collate, synthetic, functional as Fn
+    from gnn_matlang_amd import SpectralDesign, collate, functional as Fn
     out = []
     old_verbose = Fn.VERBOSE
     Fn.VERBOSE = True            # record the kernel family of every layer call (functional.PATHS)
     try:
-        for name, kind, pool_n, reps, kw, ctor, loss, fdim, ref in _configs():
+        for name, make_pool, nodes, kw, ctor, loss, ref in _configs():
             if only and name not in only:
                 continue
-            raw = synthetic.make_graphs(kind, pool_n, seed=2)
-            pool = SpectralDesign(**kw).design_many(raw)
-            host = collate(pool * reps[1 if quick else 0])
-            if host.x.shape[1] != fdim:
-                host.x = host.x[:, :fdim].contiguous() if host.x.shape[1] > fdim else torch.ones(host.x.shape[0], fdim)
-            data = host.to(dev)
+            pool = SpectralDesign(**kw).design_many(make_pool())
+            base = collate(pool).to(dev)
+            want = nodes[1 if quick else 0]
+            data = _tile(base, max((want + base.x.size(0) - 1) // base.x.size(0), 1), dev)
             B = data.num_graphs
             data.y = torch.rand(B, device=dev)
             torch.manual_seed(0)
@@ -96,6 +129,7 @@ def run(dev, quick=False, only=None):
             out.append(dict(config=name, reference=ref, graphs=B, nodes=int(data.x.size(0)), support_edges=int(data.edge_index2.size(1)),
                             S=int(data.edge_attr2.size(1)), ms_per_step=round(dt * 1e3, 3), graphs_per_s=round(B / dt),
                             roofline=_roofline(summ, n),
+                            roofline_step=sum(v['bytes'] * v['launches'] for v in summ.values()) / n / dt / 1e9 / HBM_PEAK_GBS,
                             kernels_ms_per_step={k: round(v['ms'] * v['launches'] / n, 3) for k, v in summ.items()},
                             kernel_GBps={k: round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1) for k, v in summ.items() if v['bytes'] > 0},
                             kernel_paths_per_step=paths,
