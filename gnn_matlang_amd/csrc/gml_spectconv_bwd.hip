@@ -194,6 +194,10 @@ static int spectconv_bwd_impl(const int32_t* rowptr, const int32_t* col, const i
        kernel's staging capacities (+3 edges / +7 window rows of alignment slack), 32-bit row offsets */
     bool dma = pl.layout == 3 && pl.nw == 8 && (bwd4_env() || (flags & GML_DMA_RING)) && (S == 8 || S == 4) && p.xvec && p.gvec && !(flags & GML_ACCUM) &&
                (!dx || p.dxvec || dz == nullptr) && (num_rows + 16) * (ldg > ldx ? ldg : ldx) * 4 < (int64_t)INT32_MAX;
+    if (flags & GML_DVAL_ACCUM) {                            /* dval += : the 8-wave bf16x3 kernel's copy-out only */
+        if (pl.layout != 3) return GML_E_UNSUPPORTED;
+        dma = false;
+    }
     if (dma) {
         const int ecap4 = S == 8 ? (pl.nfb == 2 ? GmlBwd4Cfg<8, 2>::ECAP : GmlBwd4Cfg<8, 1>::ECAP) : (pl.nfb == 2 ? GmlBwd4Cfg<4, 2>::ECAP : GmlBwd4Cfg<4, 1>::ECAP);
         dma = max_group_edges + 3 <= ecap4 && max_group_window + 7 <= GmlBwd4Cfg<8, 2>::XCAP;

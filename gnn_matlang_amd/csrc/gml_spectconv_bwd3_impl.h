@@ -35,7 +35,9 @@ __host__ __device__ __forceinline__ int gml_tkey3(int pos) { return ((pos >> 2) 
 template <int S, int NFB, int NW, int NOB = 2>
 struct GmlBwd3Cfg {
     static constexpr int ROWS = 16 * NW, NT = 64 * NW;
-    static constexpr int ECAP_MAX = (S > 8 ? 12 : 8) * ROWS; // register-batched staging bounds (per group)
+    // register-batched staging bounds (per group): 8 edges per row; 12 for counting.py's S = 12; 16 for S = 6 -- sr25.py's supports
+    // have 13 entries per row (1,664 per 128 rows), and 6 supports leave the registers for it
+    static constexpr int ECAP_MAX = (S > 8 ? 12 : (S == 6 ? 16 : 8)) * ROWS;
     static constexpr int XCAP_MAX = NW == 8 ? 224 : 160;
     static constexpr int LDG = 16 * NOB + 4;                 // G window rows (floats, b128 aligned)
     static constexpr int W_HALF = S * 16 * NOB * 32;         // bf16 elements of one (hi or lo) W image [s][o][32 f]
@@ -128,19 +130,24 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
     // ---- staging registers: a group's global loads are issued one phase early (after the previous group's edge phase,
     //      before its stores) and committed to LDS at the top of the group; all unconditional with clamped indices so that
     //      the compiler can count them (see gml_spectconv_bwd2_impl.h)
-    constexpr int NC = C::ECAP_MAX / NT, NE4 = (S % 4 == 0) ? C::ECAP_MAX * (S / 4) / NT : 1;
+    // staged value rows move as float4 (S % 4 == 0) or float2 (S = 6, 2: 8-byte aligned rows) -- round 4: before, only float4 rows were
+    // prefetched and a 6-support group staged with plain global -> LDS copies at its top (sr25: the whole load latency exposed per group)
+    constexpr int VW = (S % 4 == 0) ? 4 : ((S % 2 == 0) ? 2 : 1);
+    typedef typename std::conditional<VW == 4, f32x4, f32x2>::type EV;
+    constexpr int NC = C::ECAP_MAX / NT, NE4 = (VW > 1) ? C::ECAP_MAX * (S / VW) / NT : 1;
     constexpr int NG4 = (C::XCAP_MAX * GC + NT - 1) / NT;
     const int etot = p.rowptr[p.nrows];
     const int* colb = etot > 0 ? p.col : p.ginfo;
-    const f32x4* valb = etot > 0 ? reinterpret_cast<const f32x4*>(p.val) : reinterpret_cast<const f32x4*>(p.ginfo);
+    const EV* valb = etot > 0 ? reinterpret_cast<const EV*>(p.val) : reinterpret_cast<const EV*>(p.ginfo);
     const int emax = max(etot, 1) - 1;
-    const int64_t emax4 = (S % 4 == 0) ? max((int64_t)etot * (S / 4), (int64_t)1) - 1 : 0;
+    const int64_t emax4 = (VW > 1) ? max((int64_t)etot * (S / VW), (int64_t)1) - 1 : 0;
     const int o4max = p.gvec ? ((p.Fout + 3) / 4 * 4 - 4) : 0;
     int cv[NC], rpv = 0, row_n = 0;
-    f32x4 ev4[NE4], gv4[NG4];
+    EV ev4[NE4];
+    f32x4 gv4[NG4];
     float xb[8];
     auto vec_group = [&](const int4 gi) {
-        return (S % 4 == 0) && p.gvec && gi.y <= C::ECAP_MAX && gi.w <= C::XCAP_MAX;
+        return (VW > 1) && p.gvec && gi.y <= C::ECAP_MAX && gi.w <= C::XCAP_MAX;
     };
     int4 gi_nv = int4{0, 0, 0, 0};
     int4 gi_c = int4{0, 0, 0, 0};
@@ -162,11 +169,11 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
             }
         }
         rpv = p.rowptr[min(r0 + tid, p.nrows)];
-        const int ne1 = max(ne, 1) - 1, ne41 = max(ne * (S / 4), 1) - 1, nw1 = max(nwin, 1) - 1;
+        const int ne1 = max(ne, 1) - 1, ne41 = max(ne * (S / (VW > 1 ? VW : 1)), 1) - 1, nw1 = max(nwin, 1) - 1;
 #pragma unroll
         for (int t = 0; t < NC; ++t) cv[t] = colb[min(kb + min(tid + NT * t, ne1), emax)];
 #pragma unroll
-        for (int t = 0; t < NE4; ++t) ev4[t] = valb[min((int64_t)kb * (S / 4) + min(tid + NT * t, ne41), emax4)];
+        for (int t = 0; t < NE4; ++t) ev4[t] = valb[min((int64_t)kb * (S / (VW > 1 ? VW : 1)) + min(tid + NT * t, ne41), emax4)];
 #pragma unroll
         for (int t = 0; t < NG4; ++t) {
             const int i = tid + NT * t;
@@ -204,7 +211,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
 #pragma unroll
             for (int t = 0; t < NE4; ++t) {
                 const int i = tid + NT * t;
-                if (i < ne * (S / 4)) reinterpret_cast<f32x4*>(ea_l)[i] = ev4[t];
+                if (i < ne * (S / (VW > 1 ? VW : 1))) reinterpret_cast<EV*>(ea_l)[i] = ev4[t];
             }
 #pragma unroll
             for (int t = 0; t < NG4; ++t) {
@@ -379,9 +386,11 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
         GML_T3(8);
 
         if (p.dval && !(GML_ABL & 8)) {
-            if constexpr (S % 4 == 0) {
-                f32x4* dst = reinterpret_cast<f32x4*>(p.dval + (int64_t)kb * S);
-                for (int i = tid_o; i < ne * (S / 4); i += NT) dst[i] = reinterpret_cast<const f32x4*>(ea_l)[i];
+            if (p.flags & GML_DVAL_ACCUM) {                  // dval += (a second launch over another slice of the input features)
+                for (int i = tid_o; i < ne * S; i += NT) p.dval[(int64_t)kb * S + i] += ea_l[i];
+            } else if constexpr (VW > 1) {
+                EV* dst = reinterpret_cast<EV*>(p.dval + (int64_t)kb * S);
+                for (int i = tid_o; i < ne * (S / VW); i += NT) dst[i] = reinterpret_cast<const EV*>(ea_l)[i];
             } else {
                 for (int i = tid_o; i < ne * S; i += NT) p.dval[(int64_t)kb * S + i] = ea_l[i];
             }

@@ -559,6 +559,50 @@ def fused_conv_bwd(csr, val_t, x, G, weight, need_x, need_val, need_w, dx_accum_
     return dx, dval_t, dw
 
 
+def split48_plan(csr, S, Fin, Fout):
+    """48-wide layers (sr25.py:252-262, mutag.py:272-288: hidden width 32 + 16 / 24 + 24) on the 8-wave bf16x3 backward, which is
+    compiled for Fin <= 32: two launches over the feature slices [0, 32) and [32, Fin).  dX and dW split by input feature; dval is
+    linear in x, so the second launch adds its share (GML_DVAL_ACCUM).  The edge loop runs twice -- still ~2 x faster than the
+    64-row f32-MFMA kernel these layers ran on (tools/bench_configs.py).  Returns the two plans or None."""
+    if F32_MFMA or _os.environ.get('GML_NO_SPLIT48') or not (32 < Fin <= 48) or (Fin - 32) % 4 != 0:
+        return None
+    pa, pb = _bwd_plan(csr, S, 32, Fout), _bwd_plan(csr, S, Fin - 32, Fout)
+    if pa is None or pb is None or pa[4] != 128 or pb[4] != 128 or (pa[0] | pb[0]) & _lib.GML_F32_MFMA:
+        return None
+    return pa, pb
+
+
+def fused_conv_bwd_split48(csr, val_t, x, G, weight, need_x, need_val, need_w, dx_accum_into, plans):
+    S, Fin, Fout = weight.shape
+    dev = x.device
+    ld4 = (Fout + 3) // 4 * 4
+    if G.stride(0) % 4 != 0 or G.stride(0) < ld4 or G.data_ptr() % 16 != 0:
+        Gp = torch.zeros(csr.N, ld4, dtype=torch.float32, device=dev)
+        Gp[:, :Fout] = G
+        G = Gp[:, :Fout]
+    dx = dx_accum_into if (need_x and dx_accum_into is not None) else (torch.empty(csr.N, Fin, dtype=torch.float32, device=dev) if need_x else None)
+    dval_t = torch.empty(csr.E, S, dtype=torch.float32, device=dev) if need_val else None
+    dws = []
+    q, f = conv_cost_bwd(csr.N, csr.E, S, Fin, Fout, need_x, need_val) if PROFILE is not None else (0, 0)
+    with _Timed('spectconv_bwd', q, f):
+        for part, (f0, f1) in enumerate(((0, 32), (32, Fin))):
+            flags, ginfo, gmax, nbytes, _ = plans[part]
+            if need_x and dx_accum_into is not None:
+                flags |= _lib.GML_ACCUM
+            if part == 1 and need_val:
+                flags |= _lib.GML_DVAL_ACCUM
+            w_p = weight[:, f0:f1, :].contiguous()
+            dw_p = torch.empty(S, f1 - f0, Fout, dtype=torch.float32, device=dev) if need_w else None
+            ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=dev) if need_w else None
+            _lib.call('gml_spectconv_bwd', _ptr(csr.rowptr_t), _ptr(csr.col_t), _ptr(ginfo), _ptr(val_t),
+                      _off(x, f0), int(x.stride(0)), _ptr(G), int(G.stride(0)), _ptr(w_p), _off(dx, f0) if dx is not None else _ptr(None), Fin,
+                      _ptr(dval_t), _ptr(dw_p), csr.N, S, f1 - f0, Fout, gmax[0], gmax[1], flags, _ptr(ws),
+                      ws.numel() if ws is not None else 0, _stream(dev))
+            dws.append(dw_p)
+    dw = torch.cat(dws, 1) if need_w else None
+    return dx, dval_t, dw
+
+
 # ---------------------------------------------------------------------------- shared backward pieces
 def _conv_backward(csr, x, val, weight, G, need_x, need_val, need_w, val_t=None, want_source_order=False,
                    dx_accum_into=None, mix=None, relu_cols=0):
@@ -570,12 +614,17 @@ def _conv_backward(csr, x, val, weight, G, need_x, need_val, need_w, val_t=None,
     dx = dval = dw = None
     if G.stride(1) != 1:
         G = G.contiguous()
-    if fused_bwd_available(csr, S, Fin, Fout):
-        _path('conv_bwd', 'fused (group kind %d)' % _bwd_plan(csr, S, Fin, Fout)[4], S, Fin, Fout)
+    sp48 = split48_plan(csr, S, Fin, Fout) if (mix is None and relu_cols == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0) else None
+    if sp48 is not None or fused_bwd_available(csr, S, Fin, Fout):
         if val_t is None:
             with _Timed('val_to_source_order'):
                 val_t = csr.to_source_order(val)
-        dx, dval_t, dw = fused_conv_bwd(csr, val_t, x, G, weight, need_x, need_val, need_w, dx_accum_into, mix, relu_cols)
+        if sp48 is not None:
+            _path('conv_bwd', 'fused (group kind 128), two launches over the feature slices [0, 32) and [32, %d)' % Fin, S, Fin, Fout)
+            dx, dval_t, dw = fused_conv_bwd_split48(csr, val_t, x, G, weight, need_x, need_val, need_w, dx_accum_into, sp48)
+        else:
+            _path('conv_bwd', 'fused (group kind %d)' % _bwd_plan(csr, S, Fin, Fout)[4], S, Fin, Fout)
+            dx, dval_t, dw = fused_conv_bwd(csr, val_t, x, G, weight, need_x, need_val, need_w, dx_accum_into, mix, relu_cols)
         if need_val and not want_source_order:
             with _Timed('dval_from_source_order'):
                 dval_t = csr.from_source_order(dval_t)

@@ -57,6 +57,8 @@ enum {
     GML_FWD_CHUNKED = 64, /* gml_spectconv_fwd / gml_ml3_fwd with GML_GROUPS128: some 128-row group holds more edges than the ring
                          kernel stages at once (the caller knows the maximum from its group records): take the chunked ring kernel
                          (gml_k_spectconv_fwd4), which walks such groups in edge chunks instead of gathering from global memory */
+    GML_DVAL_ACCUM = 128, /* gml_spectconv_bwd (8-wave bf16x3 kernel): dval += instead of dval = -- the second of two launches over
+                         slices of the input features (48-wide layers: features 0..31, then 32..47; dval is linear in x) */
     GML_DMA_RING = 32   /* gml_spectconv_bwd / _bwd_mix: take the LDS-DMA landing-ring kernel (bwd4) where it applies; the
                          forward uses its ring kernel (fwd3) by default (GML_FWD_DMA=0 in the environment turns it off)   */
 };
