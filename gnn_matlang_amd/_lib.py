@@ -22,6 +22,7 @@ SIGNATURES = {
     'gml_csr_link_transpose': (ctypes.c_int, [_p, _p, _i64, _p, _p, _p]),
     'gml_csr_group_record_ints': (ctypes.c_int32, [_i32]),
     'gml_csr_group_info': (ctypes.c_int, [_p, _p, _i64, _i32, _p, _p]),
+    'gml_batch_assemble': (ctypes.c_int, [_p, _p]),
     'gml_gather_rows': (ctypes.c_int, [_p, _p, _p, _i64, _i32, _p]),
     'gml_gather_rows_presplit': (ctypes.c_int, [_p, _p, _p, _p, _i64, _i32, _p]),
     'gml_scatter_rows': (ctypes.c_int, [_p, _p, _p, _i64, _i32, _p]),
@@ -80,8 +81,19 @@ SIGNATURES = {
                                          _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _sz, _p]),
 }
 
+
+
+class BatchDesc(ctypes.Structure):
+    """gml_batch_desc of include/gml.h"""
+    _fields_ = [(n, _p) for n in ('node_ptr', 'edge_ptr2', 'x', 'edge_index2', 'edge_attr2', 'es', 'tperm', 'tinv', 'rp_src', 'rp_dst', 'y')] + \
+               [('G', _i64), ('E2all', _i64), ('F', _i32), ('S', _i32), ('ids', _p), ('B', _i32), ('n_pad', _i32), ('e2_pad', _i32), ('dmax', _i32)] + \
+               [(n, _p) for n in ('x_out', 'ea_out', 'es_out', 'y_out', 'valid_out', 'ptr_out', 'batch_out', 'rowptr', 'col', 'perm', 'rowptr_t',
+                                  'col_t', 'pos_t')]
+
+
 GML_OK, GML_E_BADARG, GML_E_UNSUPPORTED, GML_E_WORKSPACE = 0, -1, -2, -3
 GML_RELU, GML_ACCUM, GML_F32_MFMA, GML_GROUPS128, GML_GROUPS64R, GML_DMA_RING, GML_FWD_CHUNKED, GML_DVAL_ACCUM = 1, 2, 4, 8, 16, 32, 64, 128
+GML_POOL_SKIP_LAST = 2
 GML_GROUPS64_RANKED = 1064      # group kind of gml_csr_group_info: 64-row groups with rank bytes
 
 _lib = None

@@ -315,6 +315,7 @@ __global__ void gml_k_segment_sum(const float* __restrict__ x, int64_t ldx, cons
     if (i >= nseg * F) return;
     const int64_t g = i / F;
     const int c = (int)(i % F);
+    if ((mean & GML_POOL_SKIP_LAST) && g == nseg - 1) { out[g * ldo + c] = 0.f; return; }   // the padding graph of a static batch
     const int r0 = ptr[g], r1 = ptr[g + 1];
     float a = 0.f;
     // same ascending order; 32 clamped loads in flight per trip (8 before: a 1,700-row segment -- the padding graph of a static
@@ -328,7 +329,7 @@ __global__ void gml_k_segment_sum(const float* __restrict__ x, int64_t ldx, cons
         for (int u = 0; u < U; ++u)
             if (r + u < r1) a += v[u];
     }
-    if (mean) a = a / (float)max(r1 - r0, 1);
+    if (mean & 1) a = a / (float)max(r1 - r0, 1);
     out[g * ldo + c] = a;
 }
 

@@ -75,10 +75,10 @@ class DeviceDataset(object):
 
     # ------------------------------------------------------------------ static shapes: one captured step for every batch
     def bounds(self, batch_size):
-        """dict(n_pad, e2_pad, dmax, caps) that hold for EVERY batch of batch_size graphs of this data set -- what a
+        """dict(n_pad, e2_pad, dmax, deal, caps) that hold for EVERY batch of batch_size graphs of this data set -- what a
         HIP-graph-captured step is sized with (one host read per data set, not per batch).  caps = (edges, column window)
-        per 128 source rows; n_pad leaves room for e2_pad / dmax padding nodes, so that the padding edges can be dealt dmax
-        per node and the caps also hold on the padding."""
+        per 128 source rows; n_pad leaves room for e2_pad / deal padding nodes, so that the padding edges can be dealt `deal`
+        (<= dmax) per node and the caps also hold on the padding."""
         n = (self.node_ptr[1:] - self.node_ptr[:-1])
         e = (self.edge_ptr2[1:] - self.edge_ptr2[:-1])
         gid = torch.repeat_interleave(torch.arange(len(self), device=n.device), e)
@@ -88,16 +88,20 @@ class DeviceDataset(object):
             deg.max()]).tolist()]
         dmax = max(dmax, 1)
         e2_pad = (e_top + 63) // 64 * 64
-        n_pad = (n_top + (e2_pad + dmax - 1) // dmax + 127) // 128 * 128
-        return dict(n_pad=n_pad, e2_pad=e2_pad, dmax=dmax, caps=(128 * dmax, 128 + 2 * nmax))
+        # padding edges are dealt `deal` per padding node = the data set's mean degree, rounded up: a 128-row group of padding then
+        # carries the edge count of a group of real rows (dealt dmax per node -- rounds 2-3 -- the padding groups held 2.2 x the edges
+        # of a real group and a one-group-per-workgroup launch waited for them: ZINC batch 64, conv forward 52 -> 23 us)
+        deal = max(1, min(dmax, -(-int(self.edge_index2.size(1)) // max(int(self.x.size(0)), 1))))
+        n_pad = (n_top + (e2_pad + deal - 1) // deal + 127) // 128 * 128
+        return dict(n_pad=n_pad, e2_pad=e2_pad, dmax=dmax, deal=deal, caps=(128 * dmax, 128 + 2 * nmax))
 
     def batch_padded(self, ids, bounds):
         """The batch of graphs ``ids`` (entries equal to len(self) = no graph) padded to bounds['n_pad'] nodes and
         bounds['e2_pad'] support edges with torch ops of STATIC shapes only (no host read): padding nodes carry zero
-        features and form one extra graph (index B) at the end; padding edges are zero-valued self loops dealt dmax per
+        features and form one extra graph (index B) at the end; padding edges are zero-valued self loops dealt bounds['deal'] per
         padding node (sorted by source like the rest; a zero support stays zero through the bias-free edge MLP and moves
         no gradient).  Returns a Batch with ptr [B + 2], y [B + 1] and ``graph_valid`` [B] (0 for absent graphs)."""
-        n_pad, e2_pad, dmax = bounds['n_pad'], bounds['e2_pad'], bounds['dmax']
+        n_pad, e2_pad, dmax = bounds['n_pad'], bounds['e2_pad'], bounds.get('deal', bounds['dmax'])
         dev = ids.device
         B = int(ids.numel())
         G = len(self)
@@ -126,6 +130,96 @@ class DeviceDataset(object):
         #  K = 1 raw-adjacency conv, must fail loudly on a padded batch instead of computing on the support edges)
         b = Batch(x=x, edge_index2=ei2, edge_attr2=ea2, batch=nseg, ptr=ptr, y=y, graph_valid=has.to(self.x.dtype))
         b.static_caps = bounds['caps']
+        b.pad_graph = True                                 # the last graph is padding: pooling skips it (its pooled row is zero)
+        return b
+
+    # ------------------------------------------------------------------ precomputed per-graph structure: a batch in ONE launch
+    def prepare(self):
+        """Once per data set: every graph's own index structure -- the stable target sort of its (source-sorted) support edges,
+        its inverse, both local row-pointer prefixes -- and the bf16 pre-split of all supports.  A batch is the block-diagonal
+        union of graphs whose structure never changes, so ``batch_assembled`` only adds offsets (csrc/gml_csr.hip
+        gml_batch_assemble).  Returns self."""
+        if getattr(self, '_prep', None) is not None:
+            return self
+        from . import functional as Fn
+        dev = self.x.device
+        E2, Nall, G = int(self.edge_index2.size(1)), int(self.x.size(0)), len(self)
+        if self.y.dtype != torch.float32 or self.x.dtype != torch.float32:
+            raise TypeError('prepare(): float32 features and targets')
+        e = self.edge_ptr2[1:] - self.edge_ptr2[:-1]
+        gid = torch.repeat_interleave(torch.arange(G, device=dev), e, output_size=E2)
+        nbase, ebase = self.node_ptr[gid], self.edge_ptr2[gid]
+        src, dst = self.edge_index2[0] + nbase, self.edge_index2[1] + nbase
+        if E2 > 1 and not bool((src[1:] >= src[:-1]).all()):
+            raise ValueError('prepare(): the support edges of every graph must be sorted by source (SpectralDesign emits them so)')
+        order = torch.sort(dst, stable=True)[1]                           # global stable target sort = per-graph stable target sort
+        k = torch.arange(E2, device=dev)
+        tperm = (order - ebase[order]).int()                              # [position in target order] -> local source-order position
+        tinv = torch.empty(E2, dtype=torch.int32, device=dev)
+        tinv[order] = (k - ebase[order]).int()                            # [source-order position] -> local position in target order
+        first = self.edge_ptr2[torch.repeat_interleave(torch.arange(G, device=dev), self.node_ptr[1:] - self.node_ptr[:-1], output_size=Nall)]
+
+        def local_rows(keys):
+            cnt = torch.bincount(keys, minlength=Nall)
+            return (torch.cumsum(cnt, 0) - cnt - first).int()
+        S = int(self.edge_attr2.size(1))
+        es = Fn.edge_presplit(self.edge_attr2.contiguous()) if S <= 8 else None
+        self._prep = dict(tperm=tperm.contiguous(), tinv=tinv, rp_src=local_rows(src), rp_dst=local_rows(dst), es=es,
+                          x=self.x.contiguous(), ea=self.edge_attr2.contiguous(), ei2=self.edge_index2.contiguous(), y=self.y.contiguous())
+        return self
+
+    def batch_assembled(self, ids, bounds):
+        """``batch_padded(ids, bounds)`` AND its index structure (Batch.csr('edge_index2')) in one kernel launch plus the two
+        group-record passes, from the per-graph structure ``prepare()`` computed once: bit-identical tensors and CSR arrays
+        (tests/test_gpu_parity.py), no host read, capturable."""
+        from . import _lib
+        from .graph import GraphCSR, _ptr, _stream
+        self.prepare()
+        P = self._prep
+        n_pad, e2_pad, dmax = bounds['n_pad'], bounds['e2_pad'], bounds.get('deal', bounds['dmax'])
+        dev = ids.device
+        B, F, S = int(ids.numel()), int(self.x.size(1)), int(self.edge_attr2.size(1))
+        if ids.dtype != torch.int64 or not ids.is_contiguous():
+            raise ValueError('ids: contiguous int64')
+        f32, i32 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.int32, device=dev)
+        x, ea = torch.empty(n_pad, F, **f32), torch.empty(e2_pad, S, **f32)
+        es = torch.empty(e2_pad, 8, **i32) if P['es'] is not None else None
+        y, valid = torch.empty(B + 1, **f32), torch.empty(B, **f32)
+        ptr, batch = torch.empty(B + 2, **i32), torch.empty(n_pad, **i32)
+        g = GraphCSR()
+        g.N, g.E, g.device = n_pad, e2_pad, dev
+        g.rowptr, g.col, g.perm = torch.empty(n_pad + 1, **i32), torch.empty(e2_pad, **i32), torch.empty(e2_pad, **i32)
+        g.rowptr_t, g.col_t, g.pos_t = torch.empty(n_pad + 1, **i32), torch.empty(e2_pad, **i32), torch.empty(e2_pad, **i32)
+        ident = P.get('ident')
+        if ident is None or ident.numel() != e2_pad:
+            ident = P['ident'] = torch.arange(e2_pad, **i32)
+        g.perm_t, g.tpos = ident, g.perm
+        d = _lib.BatchDesc()
+        for name, t in (('node_ptr', self.node_ptr), ('edge_ptr2', self.edge_ptr2), ('x', P['x']), ('edge_index2', P['ei2']), ('edge_attr2', P['ea']),
+                        ('es', P['es']), ('tperm', P['tperm']), ('tinv', P['tinv']), ('rp_src', P['rp_src']), ('rp_dst', P['rp_dst']), ('y', P['y']),
+                        ('ids', ids), ('x_out', x), ('ea_out', ea), ('es_out', es), ('y_out', y), ('valid_out', valid), ('ptr_out', ptr),
+                        ('batch_out', batch), ('rowptr', g.rowptr), ('col', g.col), ('perm', g.perm), ('rowptr_t', g.rowptr_t),
+                        ('col_t', g.col_t), ('pos_t', g.pos_t)):
+            setattr(d, name, _ptr(t) if t is not None else None)
+        d.G, d.E2all, d.F, d.S, d.B, d.n_pad, d.e2_pad, d.dmax = len(self), int(self.edge_index2.size(1)), F, S, B, n_pad, e2_pad, dmax
+        with torch.cuda.device(dev):
+            st = _stream(dev)
+            import ctypes
+            _lib.call('gml_batch_assemble', ctypes.addressof(d), st)
+            ng2 = max((n_pad + 127) // 128, 1)
+            rec128 = int(_lib.lib().gml_csr_group_record_ints(128))
+            g.ginfo_t128, g.ginfo128 = torch.zeros(ng2, rec128, **i32), torch.zeros(ng2, rec128, **i32)
+            _lib.call('gml_csr_group_info', _ptr(g.rowptr_t), _ptr(g.col_t), n_pad, 128, _ptr(g.ginfo_t128), st)
+            _lib.call('gml_csr_group_info', _ptr(g.rowptr), _ptr(g.col), n_pad, 128, _ptr(g.ginfo128), st)
+        g.gmax_t128 = g.gmax128 = (int(bounds['caps'][0]), int(bounds['caps'][1]))
+        g.src_sorted = True
+        if es is not None:                                                # the pre-split supports travel with the batch (functional.presplit_of)
+            g._val_cache[('p', ea.data_ptr(), ea._version, tuple(ea.shape))] = (ea, es)
+        b = Batch(x=x, edge_attr2=ea, batch=batch, ptr=ptr, y=y, graph_valid=valid)
+        b.static_caps = bounds['caps']
+        b.pad_graph = True
+        b._csr['edge_index2'] = g
+        b._batch_i32 = batch
         return b
 
     def epoch(self, batch_size, generator=None, shuffle=True):

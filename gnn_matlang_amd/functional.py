@@ -459,11 +459,13 @@ def segment_bcast(g, ptr, nrows, mean=False):
 
 
 def segment_sum(x, ptr, mean=False):
-    """global_add_pool / global_mean_pool over a batch whose nodes are grouped per graph (ptr [B+1] int32)."""
+    """global_add_pool / global_mean_pool over a batch whose nodes are grouped per graph (ptr [B+1] int32).  mean: bool, or the
+    flag word of gml_segment_sum (bit 0 mean, bit 1 = _lib.GML_POOL_SKIP_LAST: the last segment is the padding graph of a
+    static-shape batch, its row is written as zeros)."""
     ptr = _ptr32(ptr)
     B, F = int(ptr.numel() - 1), int(x.size(1))
     out = torch.empty(B, F, dtype=torch.float32, device=x.device)
-    _lib.call('gml_segment_sum', _ptr(x), int(x.stride(0)), _ptr(ptr), _ptr(out), F, B, F, 1 if mean else 0,
+    _lib.call('gml_segment_sum', _ptr(x), int(x.stride(0)), _ptr(ptr), _ptr(out), F, B, F, int(mean),
               _stream(x.device))
     return out
 
@@ -799,7 +801,7 @@ class ML3LayerFunction(torch.autograd.Function):
         ctx.csr, ctx.learnedge, ctx.nout2, ctx.has_cb = csr, learnedge, nout2, cb is not None
         ctx.src_order = epos is not None
         ctx.val_is_source = bool(val_is_source)
-        ctx.pool = (pool_ptr, pool_seg, bool(pool_mean)) if pool_ptr is not None else None
+        ctx.pool = (pool_ptr, pool_seg, int(pool_mean)) if pool_ptr is not None else None     # bit 0 mean, bit 1 GML_POOL_SKIP_LAST
         ctx.chain_in = chain_in if (CHAIN and chain_in is not None and chain_in.cols <= Fin) else None
         ctx.chain_out = chain_out if (CHAIN and ctx.pool is None) else None
         ctx.save_for_backward(x, val, (ea if learnedge and epos is None else None), w1, w2, w3, w4, cw, w11, b11, w12, b12, out, ea_t)
@@ -821,6 +823,7 @@ class ML3LayerFunction(torch.autograd.Function):
         gy_seg = None
         if ctx.pool is not None:                               # gy is the POOLED gradient [B, C]
             pptr, pseg, pmean = ctx.pool
+            pmean &= 1
             mixk_ = nout2 > 0 and node_mix_native(Fin, nout2)
             nb_ = int(_lib.lib().gml_ml3_split_bwd_workspace_bytes(int(N), Fin if mixk_ else 0, int(nout1), int(nout2) if mixk_ else 0))
             if nb_ > 0 and (mixk_ or nout2 == 0) and not _os.environ.get('GML_NO_POOL_FUSE'):

@@ -26,7 +26,7 @@ class _SegmentPool(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         ptr, batch = ctx.saved_tensors
-        return segment_bcast(g.contiguous(), ptr, batch.numel(), ctx.mean), None, None, None
+        return segment_bcast(g.contiguous(), ptr, batch.numel(), bool(int(ctx.mean) & 1)), None, None, None
 
 
 class _SegmentMax(torch.autograd.Function):
@@ -49,12 +49,16 @@ def global_max_pool(x, data):
     return _SegmentMax.apply(x, data.ptr)
 
 
+def _pad_flag(data):
+    return 2 if getattr(data, 'pad_graph', False) else 0       # GML_POOL_SKIP_LAST: the padding graph of a static-shape batch
+
+
 def global_add_pool(x, data):
-    return _SegmentPool.apply(x, data.ptr, data.batch, False)
+    return _SegmentPool.apply(x, data.ptr, data.batch, _pad_flag(data))
 
 
 def global_mean_pool(x, data):
-    return _SegmentPool.apply(x, data.ptr, data.batch, True)
+    return _SegmentPool.apply(x, data.ptr, data.batch, 1 | _pad_flag(data))
 
 
 class GNNML3(torch.nn.Module):
@@ -115,7 +119,8 @@ class GNNML3(torch.nn.Module):
                 # the pool directly follows the last layer: one autograd node, the pool's gradient is not expanded to [N, C]
                 if getattr(data, '_batch_i32', None) is None:
                     data._batch_i32 = data.batch.to(torch.int32).contiguous()
-                x = layer.forward_pooled(x, csr, data.edge_attr2, _ptr32(data.ptr), data._batch_i32, self.pool == 'mean')
+                x = layer.forward_pooled(x, csr, data.edge_attr2, _ptr32(data.ptr), data._batch_i32,
+                                         int(self.pool == 'mean') | (2 if getattr(data, 'pad_graph', False) else 0))   # 2: GML_POOL_SKIP_LAST
                 pooled = True
             else:
                 x = layer(x, csr, data.edge_attr2)

@@ -336,7 +336,7 @@ class ML3Layer(torch.nn.Module):
         """global_add_pool / global_mean_pool (mean=True) of forward(...) in one autograd node: [B, nout1 + nout2].  Same
         values as pooling the layer's output (Zinc12k.py:338-343); the pool's gradient then reaches the layer's backward
         un-expanded ([B, C] + the node -> graph map instead of [N, C]).  ptr [B+1] / batch [N]: int32, grouped per graph."""
-        return self.forward(x, edge_index, edge_attr, _pool=(ptr, batch, bool(mean)))
+        return self.forward(x, edge_index, edge_attr, _pool=(ptr, batch, int(mean)))   # (int: the flag word of gml_segment_sum)
 
     def forward(self, x, edge_index, edge_attr, _pool=None):
         _require_cuda(x, 'x')

@@ -103,6 +103,25 @@ int gml_csr_link_transpose(const int32_t* perm_fwd, const int32_t* perm_t, int64
 int32_t gml_csr_group_record_ints(int32_t group_rows);
 int gml_csr_group_info(const int32_t* rowptr, const int32_t* col, int64_t num_rows, int32_t group_rows,
                        int32_t* ginfo, gml_stream_t stream);
+/* One launch: a padded static-shape batch (the graphs `ids`, in that order) and its whole index structure from a device-resident data
+ * set whose per-graph structure was computed once.  The reference collates every batch on the host (DataLoader, Zinc12k.py:20-22,359);
+ * here a batch is gathers + offsets, because a batch is the block-diagonal union of graphs whose own structure never changes.
+ * Data set side (per graph g its nodes node_ptr[g]..node_ptr[g+1] and support edges edge_ptr2[g]..edge_ptr2[g+1], graph-LOCAL node ids,
+ * sorted by source inside a graph): tperm[e] = source-order position (inside its graph) of the graph's k-th TARGET-sorted edge (stable),
+ * tinv its inverse, rp_src / rp_dst [node] = number of the graph's edges whose source / target is a smaller node (local row pointers),
+ * es = gml_edge_presplit(edge_attr2) or NULL.  ids entries outside [0, G) = no graph.  Outputs: x_out [n_pad, F], ea_out [e2_pad, S],
+ * es_out [e2_pad, 8], y_out [B + 1], valid_out [B], ptr_out [B + 2], batch_out [n_pad] (padding nodes: graph B), and the CSR arrays of
+ * both views exactly as gml_csr_from_coo / _from_sorted_coo / _link_transpose give them for the assembled batch (perm == tpos;
+ * perm_t is the identity).  Padding: zero-feature nodes forming graph B; zero-valued self loops dealt dmax per padding node. */
+typedef struct gml_batch_desc {
+    const int64_t* node_ptr; const int64_t* edge_ptr2; const float* x; const int64_t* edge_index2; const float* edge_attr2;
+    const int32_t* es; const int32_t* tperm; const int32_t* tinv; const int32_t* rp_src; const int32_t* rp_dst; const float* y;
+    int64_t G, E2all; int32_t F, S;
+    const int64_t* ids; int32_t B, n_pad, e2_pad, dmax;
+    float* x_out; float* ea_out; int32_t* es_out; float* y_out; float* valid_out; int32_t* ptr_out; int32_t* batch_out;
+    int32_t* rowptr; int32_t* col; int32_t* perm; int32_t* rowptr_t; int32_t* col_t; int32_t* pos_t;
+} gml_batch_desc;
+int gml_batch_assemble(const gml_batch_desc* d, gml_stream_t stream);
 /* out[k, :] = in[perm[k], :]   (rows of `width` floats) */
 int gml_gather_rows(const float* in, const int32_t* perm, float* out, int64_t rows, int32_t width,
                     gml_stream_t stream);
@@ -318,7 +337,9 @@ int gml_ml3_split_bwd_ex(const float* gy, int64_t ldgy, const int32_t* gy_seg, c
 int gml_relu_bwd(const float* gy, int64_t ldgy, const float* y, int64_t ldy, float* g, int64_t ldg,
                  int64_t num_rows, int32_t F, gml_stream_t stream);
 /* out[g, :] = sum_{r in [ptr[g], ptr[g+1])} x[r, :]  (global_add_pool over a sorted batch vector;
- * mean != 0 divides by the segment length: global_mean_pool) */
+ * mean bit 0 divides by the segment length: global_mean_pool; bit 1 = GML_POOL_SKIP_LAST: the last segment is the padding graph of a
+ * static-shape batch (gml_batch_assemble) -- its output row is written as zeros without reading its rows) */
+#define GML_POOL_SKIP_LAST 2
 int gml_segment_sum(const float* x, int64_t ldx, const int32_t* ptr, float* out, int64_t ldo,
                     int64_t num_segments, int32_t F, int32_t mean, gml_stream_t stream);
 /* its gradient: out[r, :] = g[seg(r), :] (/ segment length when mean != 0) for r in [ptr[seg], ptr[seg+1]) */

@@ -928,6 +928,50 @@ def test_padded_static_batch_equals_plain_batch(dev):
         close(gp[n], p.grad, tol=2e-5, what='padded vs plain grad ' + n)
 
 
+@pytest.mark.parametrize('ids', [[5, 33, 0, 17, 21, 40, 40, 40], [39, 38, 37, 36, 35, 34, 33, 32], [40] * 8, [7, 40, 7, 7, 40, 3, 3, 7]])
+def test_assembled_batch_is_bit_identical_to_the_padded_batch_and_its_index(dev, ids):
+    """dataset.DeviceDataset.batch_assembled (csrc/gml_csr.hip gml_batch_assemble: one launch from the per-graph structure
+    computed once per data set) against batch_padded + GraphCSR.from_edge_index on the same graph ids: every tensor of the
+    batch and every array of both CSR views bit-identical, the index arrays also against oracle/csr_oracle.py; then the same
+    loss and gradients through the model.  Absent slots, repeated graphs and the all-absent batch included."""
+    from gnn_matlang_amd import SpectralDesign, models, synthetic
+    from gnn_matlang_amd.dataset import DeviceDataset
+    from oracle import csr_oracle
+    raw = synthetic.make_graphs('zinc', 40, seed=8)
+    dsd = DeviceDataset.from_graphs(SpectralDesign(recfield=2, dv=2, nfreq=7).design_many(raw), dev)
+    dsd.y = dsd.y.float()
+    bd = dsd.bounds(8)
+    ids = torch.tensor(ids, device=dev)
+    bp, ba = dsd.batch_padded(ids, bd), dsd.batch_assembled(ids, bd)
+    for name in ('x', 'edge_attr2', 'y', 'graph_valid'):
+        assert torch.equal(getattr(bp, name).float(), getattr(ba, name)), name
+    assert torch.equal(bp.ptr.int(), ba.ptr) and torch.equal(bp.batch.int(), ba.batch)
+    cp, ca = bp.csr('edge_index2'), ba.csr('edge_index2')
+    for name in ('rowptr', 'col', 'perm', 'rowptr_t', 'col_t', 'perm_t', 'pos_t', 'tpos', 'ginfo128', 'ginfo_t128'):
+        assert torch.equal(getattr(cp, name), getattr(ca, name)), name
+    assert ca.gmax128 == cp.gmax128 and ca.gmax_t128 == cp.gmax_t128 and ca.src_sorted and cp.src_sorted and (ca.N, ca.E) == (cp.N, cp.E)
+    ei = bp.edge_index2.cpu().numpy()
+    rp, col, perm = csr_oracle.csr_from_coo(ei[0], ei[1], bd['n_pad'])
+    assert np.array_equal(rp, ca.rowptr.cpu().numpy()) and np.array_equal(col, ca.col.cpu().numpy()) and np.array_equal(perm, ca.perm.cpu().numpy())
+    rpt, colt, post = csr_oracle.transpose_view(ei[0], ei[1], bd['n_pad'], perm)
+    assert np.array_equal(rpt, ca.rowptr_t.cpu().numpy()) and np.array_equal(colt, ca.col_t.cpu().numpy()) and np.array_equal(post, ca.pos_t.cpu().numpy())
+    # the pre-split supports that travel with the assembled batch = the split of its supports
+    from gnn_matlang_amd import functional as Fn
+    assert torch.equal(ca.presplit(ba.edge_attr2), Fn.edge_presplit(bp.edge_attr2.contiguous()))
+    torch.manual_seed(1)
+    m = models.zinc_gnnml3().to(dev)
+    out = []
+    for b in (bp, ba):
+        m.zero_grad()
+        pre = m(b)
+        l = ((pre[:8, 0] - b.y[:8]).abs() * b.graph_valid).sum()
+        l.backward()
+        out.append((l.item(), {n: p.grad.clone() for n, p in m.named_parameters()}))
+    assert out[0][0] == out[1][0]
+    for n in out[0][1]:
+        assert torch.equal(out[0][1][n], out[1][1][n]), n
+
+
 # ------------------------------------------------------------------------------------------ dense-block support product
 @pytest.mark.parametrize('n,S,F', [(75, 6, 2), (75, 6, 64), (75, 6, 128), (16, 1, 30), (33, 3, 7), (96, 2, 20), (5, 4, 48)])
 def test_dense_support_mm_vs_fp64(dev, n, S, F):
