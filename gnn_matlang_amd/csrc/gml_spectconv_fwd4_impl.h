@@ -574,7 +574,53 @@ __global__ __launch_bounds__(GML_FWD4_NT, 1) void gml_k_spectconv_fwd4(const Gml
 #endif
                 int k = max(kbeg, e0) - e0;
                 const int ke = min(kend, e1) - e0;
+#ifdef GML_F4_UNIFORM
+                // experiment: no lane leaves the edge loop before the whole wave is done (EXEC never changes inside it); a lane
+                // past its last edge keeps walking clamped positions with its support values scaled by zero
+                if (__builtin_amdgcn_ballot_w64(k < ke) != 0) {
+                    const int nmax = e1 - e0 - 1;
+                    struct Ops { float e[S]; f32x4 t0, t1, t2; };
+                    auto fetchu = [&](Ops& o, int kk, int cidx) {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(ea_l + kk * 8), b = *reinterpret_cast<const f32x4*>(ea_l + kk * 8 + 4);
+                        o.e[0] = a.x; o.e[1] = a.y; o.e[2] = a.z; o.e[3] = a.w; o.e[4] = b.z; o.e[5] = b.w;
+                        const int off = xoff + cidx * (FR * 4) + ((cidx / C::XRB) << 4);
+                        o.t0 = *reinterpret_cast<const f32x4*>(lds_raw + off);
+                        o.t1 = *reinterpret_cast<const f32x4*>(lds_raw + off + 16);
+                        if constexpr (FB) o.t2 = *reinterpret_cast<const f32x4*>(lds_raw + off + 128 - 16 * kq);
+                    };
+                    auto fmau = [&](const Ops& o, float act) {
+                        f32x2 xv[NH];
+                        xv[0] = f32x2{o.t0.x, o.t0.y}; xv[1] = f32x2{o.t0.z, o.t0.w}; xv[2] = f32x2{o.t1.x, o.t1.y}; xv[3] = f32x2{o.t1.z, o.t1.w};
+                        if constexpr (FB) { xv[4] = f32x2{o.t2.x, o.t2.y}; xv[5] = f32x2{o.t2.z, o.t2.w}; }
+#pragma unroll
+                        for (int s = 0; s < S; ++s) {
+                            const float ev = o.e[s] * act;
+                            const f32x2 e2 = f32x2{ev, ev};
+#pragma unroll
+                            for (int h = 0; h < NH; ++h) acc[s][h] = e2 * xv[h] + acc[s][h];
+                        }
+                    };
+                    auto cl = [&](int i) { return min(max(i, 0), nmax); };
+                    Ops A, B;
+                    fetchu(A, cl(k), col_l[cl(k)]);
+                    int cn = col_l[cl(k + 1)];
+                    for (;;) {
+                        const int c2 = col_l[cl(k + 2)];
+                        fetchu(B, cl(k + 1), cn);
+                        fmau(A, (k >= 0 && k < ke) ? 1.f : 0.f);
+                        ++k;
+                        if (__builtin_amdgcn_ballot_w64(k < ke) == 0) break;
+                        cn = col_l[cl(k + 2)];
+                        fetchu(A, cl(k + 1), c2);
+                        fmau(B, (k >= 0 && k < ke) ? 1.f : 0.f);
+                        ++k;
+                        if (__builtin_amdgcn_ballot_w64(k < ke) == 0) break;
+                    }
+                }
+                if (false) {
+#else
                 if (k < ke) {
+#endif
                     // software pipeline as in fwd3: operands of edge k + 1 and the column id of edge k + 2 are requested before
                     // the packed FMAs of edge k; two register sets, no rotation moves
                     struct Ops { float e[S]; f32x4 t0, t1, t2; };
@@ -595,10 +641,33 @@ __global__ __launch_bounds__(GML_FWD4_NT, 1) void gml_k_spectconv_fwd4(const Gml
                         if constexpr (FB) { xv[4] = f32x2{o.t2.x, o.t2.y}; xv[5] = f32x2{o.t2.z, o.t2.w}; }
 #pragma unroll
                         for (int s = 0; s < S; ++s) {
-                            const f32x2 e2 = f32x2{o.e[s], o.e[s]};
+#ifdef GML_F4_SCALARFMA
+#pragma unroll
+                            for (int h = 0; h < NH; ++h) {
+                                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc[s][h].x) : "v"(o.e[s]), "v"(xv[h].x));
+                                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc[s][h].y) : "v"(o.e[s]), "v"(xv[h].y));
+                            }
+#else
+                            // The support value of an ODD position of its row goes through a v_mov first.  Left alone, hipcc broadcasts it
+                            // straight out of the odd register of the loaded pair -- v_pk_fma_f32 acc, x, v[a:a+1] op_sel:[0,1,0] (the LOW
+                            // product reads the HIGH half of src1) -- and on gfx950 that form lost, about once in 10^8 issues, the low
+                            // product on lanes 48..63 of one wave: a row's last edge missing from ONE (support, feature) aggregate, 3-8 of
+                            // 768 fresh-process launches of the chunked road wrong (the mechanism is not known; found by dumping the
+                            // aggregates of failing launches and matching the difference to single edge terms -- DESIGN s4.1c).  With the
+                            // copy the compiler emits the op_sel_hi form every other kernel uses: 0 of 1536 (GML_F4_OPSEL restores the old
+                            // code for the A/B).
+                            float ev = o.e[s];
+#ifndef GML_F4_OPSEL
+                            if (s & 1) asm volatile("v_mov_b32 %0, %1" : "=v"(ev) : "v"(o.e[s]));
+#endif
+                            const f32x2 e2 = f32x2{ev, ev};
 #pragma unroll
                             for (int h = 0; h < NH; ++h) acc[s][h] = e2 * xv[h] + acc[s][h];
+#endif
                         }
+#ifdef GML_F4_NOPS
+                        asm volatile("s_nop 7\n\ts_nop 7");
+#endif
                     };
                     Ops A, B;
                     const int klast = ke - 1;

@@ -29,6 +29,23 @@ import collections as _collections
 import weakref as _weakref
 _linear = torch.nn.functional.linear
 F32_MFMA = _os.environ.get('GML_F32_MFMA', '0') not in ('0', '')
+
+
+class exact_products(object):
+    """``with exact_products():`` -- the launches inside run with F32_MFMA = True (a layer whose gradients a BatchNorm backward
+    amplifies: models.GNNML3(bn=True) runs its FIRST layer so; the layer's backward re-enters the scope through ctx.exact)."""
+
+    def __init__(self, on=True):
+        self.on = on
+
+    def __enter__(self):
+        global F32_MFMA
+        self.old = F32_MFMA
+        F32_MFMA = F32_MFMA or bool(self.on)
+
+    def __exit__(self, *a):
+        global F32_MFMA
+        F32_MFMA = self.old
 EDGE_VALU = _os.environ.get('GML_EDGE_VALU', '0') == '1'
 
 
@@ -180,11 +197,11 @@ def conv_epilogue(csr, x, val, w, bias, S, epilogue, ds, self_term, ncols):
     return out
 
 
-# Groups with more edges than one work item of the ring kernels (sr25.py: 13 entries per row): GML_FWD_CHUNKS=1 walks them in edge
-# chunks on gml_k_spectconv_fwd4 (2-3 x the 64-row family's speed, parity-green).  Off by default: under repeat-and-compare stress
-# the chunked road differed from itself in ~1 launch of 500 during the first launches of a process (DESIGN s4.1c) -- not root-caused,
-# so batches with such groups stay on the 64-row family, whose results are bit-stable.
-FWD_CHUNKS = _os.environ.get('GML_FWD_CHUNKS', '0') not in ('0', '')
+# Groups with more edges than one work item of the ring kernels stage at once (sr25.py: 13 entries per row) are walked in edge chunks
+# on gml_k_spectconv_fwd4 (2-3 x the 64-row family's speed).  Opt-in through most of round 4 -- the chunked road differed from itself in
+# ~1 launch of 200 in fresh processes -- until the cause was found (one v_pk_fma_f32 operand form, csrc/gml_spectconv_fwd4_impl.h `fma`,
+# DESIGN s4.1c): 0 of 1536 since.  GML_FWD_CHUNKS=0 keeps such batches on the 64-row family.
+FWD_CHUNKS = _os.environ.get('GML_FWD_CHUNKS', '1') not in ('0', '')
 
 
 def fwd_groups(csr, x, S, Fin, Fout):
@@ -676,11 +693,17 @@ class SpectConvFunction(torch.autograd.Function):
             fused_conv(csr.rowptr, csr.col, gi, None, val, x, int(x.stride(0)), weight, (Fin * Fout, Fout, 1), bias, out,
                        Fout, csr.N, S, Fin, Fout, (_lib.GML_RELU if relu else 0) | gflag)
         ctx.csr, ctx.relu, ctx.has_bias = csr, relu, bias is not None
+        ctx.exact = bool(F32_MFMA)
         ctx.save_for_backward(x, val, weight, out if relu else None)
         return out
 
     @staticmethod
     def backward(ctx, gout):
+        with exact_products(ctx.exact):
+            return SpectConvFunction._backward(ctx, gout)
+
+    @staticmethod
+    def _backward(ctx, gout):
         x, val, weight, out = ctx.saved_tensors
         csr = ctx.csr
         gout = _f32c(gout, 'grad_out')
@@ -799,6 +822,7 @@ class ML3LayerFunction(torch.autograd.Function):
                 # ninp > 64 or nout2 > 24 (ptc.py:331-338 has ninp = 80): two plain library GEMMs + elementwise
                 out[:, nout1:] = torch.tanh(_linear(x, w11, b11)) * torch.tanh(_linear(x, w12, b12))
         ctx.csr, ctx.learnedge, ctx.nout2, ctx.has_cb = csr, learnedge, nout2, cb is not None
+        ctx.exact = bool(F32_MFMA)
         ctx.src_order = epos is not None
         ctx.val_is_source = bool(val_is_source)
         ctx.pool = (pool_ptr, pool_seg, int(pool_mean)) if pool_ptr is not None else None     # bit 0 mean, bit 1 GML_POOL_SKIP_LAST
@@ -811,6 +835,11 @@ class ML3LayerFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
+        with exact_products(ctx.exact):
+            return ML3LayerFunction._backward(ctx, gy)
+
+    @staticmethod
+    def _backward(ctx, gy):
         x, val, ea, w1, w2, w3, w4, cw, w11, b11, w12, b12, out, ea_t = ctx.saved_tensors
         csr, learnedge, nout2 = ctx.csr, ctx.learnedge, ctx.nout2
         S, Fin, nout1 = cw.shape

@@ -122,6 +122,13 @@ class GNNML3(torch.nn.Module):
                 x = layer.forward_pooled(x, csr, data.edge_attr2, _ptr32(data.ptr), data._batch_i32,
                                          int(self.pool == 'mean') | (2 if getattr(data, 'pad_graph', False) else 0))   # 2: GML_POOL_SKIP_LAST
                 pooled = True
+            elif self.bn and i == 0:
+                # BatchNorm layers behind the first layer amplify the ~1e-5 relative error of the split bf16 products in ITS weight /
+                # bias gradients past 1e-4 of their scale (mutag.py:272-288: 1.6e-4 measured): that one layer runs on the exact
+                # f32-product kernels, forward and backward (the narrowest layer of the stack: 8 -> 48 features)
+                from . import functional as _Fn
+                with _Fn.exact_products():
+                    x = layer(x, csr, data.edge_attr2)
             else:
                 x = layer(x, csr, data.edge_attr2)
             if self.bn:
