@@ -80,9 +80,9 @@ def run(dev, nodes=1000000, supports=(6, 12, 24, 48), quick=False):
             torch.cuda.synchronize()
             summ = Fn.profile_summary(Fn.PROFILE)
             Fn.PROFILE = None
-        if S <= 8 and not Fn.FWD_CHUNKS:
-            # the same forward with the groups walked in edge chunks on the ring kernel (gml_k_spectconv_fwd4; opt-in, DESIGN s4.1c)
-            Fn.FWD_CHUNKS = True
+        if S <= 8 and Fn.FWD_CHUNKS:
+            # A/B: the same forward with GML_FWD_CHUNKS=0 -- groups beyond one work item on the 64-row kernel family (rounds 1-3)
+            Fn.FWD_CHUNKS = False
             try:
                 with torch.no_grad():
                     ms_c = _median_launch_ms(lambda: m(data), reps=3, blocks=3)
@@ -91,11 +91,11 @@ def run(dev, nodes=1000000, supports=(6, 12, 24, 48), quick=False):
                         m(data)
                     torch.cuda.synchronize()
                     sc = Fn.profile_summary(Fn.PROFILE)
-                rec['forward_edge_chunks'] = dict(ms=ms_c, graphs_per_s=data.num_graphs / (ms_c * 1e-3), note='GML_FWD_CHUNKS=1 (not the default)',
-                                                  kernels={k: dict(ms=round(v['ms'], 4), frac=round(v['bytes'] / (v['ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if v['bytes'] else None)
-                                                           for k, v in sc.items()})
+                rec['forward_64row_family'] = dict(ms=ms_c, graphs_per_s=data.num_graphs / (ms_c * 1e-3), note='GML_FWD_CHUNKS=0 (not the default)',
+                                                   kernels={k: dict(ms=round(v['ms'], 4), frac=round(v['bytes'] / (v['ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if v['bytes'] else None)
+                                                            for k, v in sc.items()})
             finally:
-                Fn.FWD_CHUNKS = False
+                Fn.FWD_CHUNKS = True
                 Fn.PROFILE = None
         rec['forward'] = dict(ms=ms_f, graphs_per_s=data.num_graphs / (ms_f * 1e-3),
                               kernels={k: dict(ms=round(v['ms'], 4), launches_per_forward=v['launches'] / 3,
