@@ -41,6 +41,8 @@ GML_DECL_BWD3(4, 2, 8) GML_DECL_BWD3(4, 1, 8) GML_DECL_BWD3(2, 2, 8) GML_DECL_BW
 GML_DECL_BWD3(8, 2, 4) GML_DECL_BWD3(8, 1, 4)
 template <> int gml_launch_bwd3<12, 2, 8, 1>(const GmlBwdParams&, dim3, size_t, hipStream_t);   /* counting.py: S = 12, Fout <= 16 */
 template <> int gml_launch_bwd3<12, 1, 8, 1>(const GmlBwdParams&, dim3, size_t, hipStream_t);
+template <> int gml_launch_bwd3<8, 2, 8, 1>(const GmlBwdParams&, dim3, size_t, hipStream_t);    /* S = 8, Fout <= 16 (gml_bwd3_fam_f.hip) */
+template <> int gml_launch_bwd3<8, 1, 8, 1>(const GmlBwdParams&, dim3, size_t, hipStream_t);
 
 #define GML_DECL_BWD4(S, A) template <> int gml_launch_bwd4<S, A>(const GmlBwdParams&, dim3, hipStream_t);
 GML_DECL_BWD4(8, 2) GML_DECL_BWD4(8, 1) GML_DECL_BWD4(4, 2) GML_DECL_BWD4(4, 1)
@@ -73,7 +75,7 @@ static bool bwd2_shape(int S, int Fin, int Fout, uint32_t flags) {
 
 /* shapes of the third layout alone: counting.py's 12 supports with Fout <= 16 (gml_k_spectconv_bwd3<12, NFB, 8, XV, false, 1>) */
 static bool bwd3_only_shape(int S, int Fin, int Fout, uint32_t flags) {
-    return !(flags & GML_F32_MFMA) && S == 12 && Fin <= 32 && Fout <= 16;
+    return !(flags & GML_F32_MFMA) && (S == 12 || S == 8) && Fin <= 32 && Fout <= 16;
 }
 
 static BwdPlan plan_bwd(int64_t num_rows, int S, int Fin, int Fout, int max_edges, int max_window, uint32_t flags) {
@@ -86,7 +88,7 @@ static BwdPlan plan_bwd(int64_t num_rows, int S, int Fin, int Fout, int max_edge
     pl.xcap = (max_window + 15) / 16 * 16;
     if (pl.xcap < 64) pl.xcap = 64;
     if ((bwd2_shape(S, Fin, Fout, flags) && bwd_layout_env() != 2) || bwd3_only_shape(S, Fin, Fout, flags)) {   /* bf16x3 kernel, third layout */
-        pl.layout = 3; pl.nw = bwd3_nw(S); pl.rows = 16 * pl.nw;
+        pl.layout = 3; pl.nw = (S == 8 && nob == 1) ? 8 : bwd3_nw(S); pl.rows = 16 * pl.nw;
         pl.nfb = (Fin + 15) / 16;
         const int ng = (int)gml_cdiv(num_rows, pl.rows);
         const int wgs = GML_NUM_CU * (pl.nw == 4 ? 2 : 1);
@@ -100,6 +102,7 @@ static BwdPlan plan_bwd(int64_t num_rows, int S, int Fin, int Fout, int max_edge
         GML_BWD3_LDS(4, 2, 8) GML_BWD3_LDS(4, 1, 8) GML_BWD3_LDS(2, 2, 8) GML_BWD3_LDS(2, 1, 8)
         GML_BWD3_LDS(8, 2, 4) GML_BWD3_LDS(8, 1, 4)
         if (S == 12) pl.lds = pl.nfb == 2 ? GmlBwd3Cfg<12, 2, 8, 1>::lds_bytes(pl.ecap, pl.xcap) : GmlBwd3Cfg<12, 1, 8, 1>::lds_bytes(pl.ecap, pl.xcap);
+        if (S == 8 && nob == 1) { pl.lds = pl.nfb == 2 ? GmlBwd3Cfg<8, 2, 8, 1>::lds_bytes(pl.ecap, pl.xcap) : GmlBwd3Cfg<8, 1, 8, 1>::lds_bytes(pl.ecap, pl.xcap); }
         if (pl.lds > 0) pl.lds += 512;                      /* the DZ instantiation's wmix rows (gml_spectconv_bwd_mix) */
         /* (a group too large for the LDS: not ok -- the caller then asks for the f32-MFMA kernel with ITS group records) */
         pl.ok = pl.lds > 0 && pl.lds <= (pl.nw == 4 ? 80 : 160) * 1024;
@@ -207,9 +210,12 @@ static int spectconv_bwd_impl(const int32_t* rowptr, const int32_t* col, const i
         GML_BWD4_GO(8, 2) GML_BWD4_GO(8, 1) GML_BWD4_GO(4, 2) GML_BWD4_GO(4, 1)
     } else if (pl.layout == 3) {
 #define GML_BWD3_GO(SV, A, W) if (S == SV && nfb == A && pl.nw == W) rc = gml_launch_bwd3<SV, A, W>(p, dim3(pl.grid), pl.lds, st);
+        if (S == 8 && nob == 1) rc = nfb == 2 ? gml_launch_bwd3<8, 2, 8, 1>(p, dim3(pl.grid), pl.lds, st) : gml_launch_bwd3<8, 1, 8, 1>(p, dim3(pl.grid), pl.lds, st);
+        else {
         GML_BWD3_GO(8, 2, 8) GML_BWD3_GO(8, 1, 8) GML_BWD3_GO(6, 2, 8) GML_BWD3_GO(6, 1, 8)
         GML_BWD3_GO(4, 2, 8) GML_BWD3_GO(4, 1, 8) GML_BWD3_GO(2, 2, 8) GML_BWD3_GO(2, 1, 8)
         GML_BWD3_GO(8, 2, 4) GML_BWD3_GO(8, 1, 4)
+        }
         if (S == 12) rc = nfb == 2 ? gml_launch_bwd3<12, 2, 8, 1>(p, dim3(pl.grid), pl.lds, st) : gml_launch_bwd3<12, 1, 8, 1>(p, dim3(pl.grid), pl.lds, st);
     } else if (pl.layout == 2) {
 #define GML_BWD2_GO(SV, A) if (S == SV && nfb == A) rc = gml_launch_bwd2<SV, A>(p, dim3(pl.grid), pl.lds, st);
