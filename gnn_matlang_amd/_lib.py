@@ -94,6 +94,7 @@ class BatchDesc(ctypes.Structure):
 GML_OK, GML_E_BADARG, GML_E_UNSUPPORTED, GML_E_WORKSPACE = 0, -1, -2, -3
 GML_RELU, GML_ACCUM, GML_F32_MFMA, GML_GROUPS128, GML_GROUPS64R, GML_DMA_RING, GML_FWD_CHUNKED, GML_DVAL_ACCUM = 1, 2, 4, 8, 16, 32, 64, 128
 GML_POOL_SKIP_LAST = 2
+GML_FWD_ONEWIN = 256
 GML_GROUPS64_RANKED = 1064      # group kind of gml_csr_group_info: 64-row groups with rank bytes
 
 _lib = None

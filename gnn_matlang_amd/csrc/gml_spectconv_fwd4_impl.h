@@ -46,7 +46,10 @@ typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
 
 #define GML_FWD4_NT 768                                        // 8 compute waves + 4 loader waves: 3 waves per SIMD
 
-template <int S, int FB, bool EP>
+// X1: ONE X window instead of two (FB = 1 launches whose groups need chunks: the 40 KB saved double the edges of a work item -- sr25's
+// 1,664-edge groups are 2 chunks instead of 4).  The next group's window then lands behind the current group's last chunk, beside its
+// projection and stores: one more barrier per group (C), taken by every wave.
+template <int S, int FB, bool EP, bool X1 = false>
 struct GmlFwd4Cfg {
     static constexpr int ROWS = 128;
     static constexpr int NLOAD = 4;
@@ -65,6 +68,7 @@ struct GmlFwd4Cfg {
     static constexpr int REC_BYTES = 4 * 256;                  // ring of 4 group records
     static constexpr int RP_BYTES = 528;                       // 132 row pointers
     static constexpr int GRP_BYTES = RP_BYTES + X_BYTES;       // group buffer: row pointers + X window
+    static constexpr int GRPS_BYTES = X1 ? 2 * RP_BYTES + X_BYTES : 2 * GRP_BYTES;   // all group buffers
     static constexpr int VROW = 4 * S;
     // bytes of a value row in LDS.  24-byte rows (S = 6) land as two OVERLAPPING 16-byte lanes per row, [v0 v1 v2 v3 | v2 v3 v4 v5]
     // in 32 bytes, whether they are copied in CSR order or gathered through a position map: every read of the aggregation is then
@@ -73,15 +77,17 @@ struct GmlFwd4Cfg {
     // DESIGN s4.1c.  The 12-byte LDS-DMA form strides 16 bytes per lane as well: tools/probes/probe_glds3.hip.)
     static constexpr int VROW_L = (S % 4 != 0) ? 32 : VROW;
     static_assert(S % 4 == 0 || S == 6, "value rows: multiples of 16 bytes, or 24 bytes");
-    static constexpr int AVAIL = 160 * 1024 - W_BYTES - REC_BYTES - 2 * GRP_BYTES;
+    static constexpr int AVAIL = 160 * 1024 - W_BYTES - REC_BYTES - GRPS_BYTES;
     static constexpr int ECAP_RAW = AVAIL / (2 * (4 + VROW_L) + (EP ? 8 : 0));
     static constexpr int ECAP = ECAP_RAW >= 1024 ? 1024 : ECAP_RAW / 64 * 64;      // staged edges per item
     static constexpr int COL_BYTES = ECAP * 4, VAL_BYTES = ECAP * VROW_L;
     static constexpr int EDGE_BYTES = COL_BYTES + VAL_BYTES;
     static constexpr int OFF_W2 = 4 * W_HALF;                  // (hi, lo of the first image, then hi, lo of the second)
-    static constexpr int OFF_REC = W_BYTES, OFF_GRP = OFF_REC + REC_BYTES, OFF_EPOS = OFF_GRP + 2 * GRP_BYTES;
+    static constexpr int OFF_REC = W_BYTES, OFF_GRP = OFF_REC + REC_BYTES, OFF_EPOS = OFF_GRP + GRPS_BYTES;
     static constexpr int OFF_EDGE = OFF_EPOS + (EP ? 2 * COL_BYTES : 0);
-    static constexpr int OFF_X = RP_BYTES;                     // inside a group buffer
+    // byte offsets of group g's row pointers / X window (two of each; X1: two row-pointer buffers, then the one window)
+    __host__ __device__ static constexpr int rp_off(int g) { return OFF_GRP + (g & 1) * (X1 ? RP_BYTES : GRP_BYTES); }
+    __host__ __device__ static constexpr int x_off(int g) { return X1 ? OFF_GRP + 2 * RP_BYTES : OFF_GRP + (g & 1) * GRP_BYTES + RP_BYTES; }
     static constexpr int OFF_VAL = COL_BYTES;                  // inside an edge buffer
     static constexpr size_t lds_bytes() { return (size_t)OFF_EDGE + 2 * (size_t)EDGE_BYTES; }
     static_assert(ECAP >= 256, "edge buffers too small");
@@ -89,9 +95,9 @@ struct GmlFwd4Cfg {
     static_assert(OFF_EDGE + 2 * EDGE_BYTES <= 160 * 1024, "LDS budget");
 };
 
-template <int S, int FB, int NOB, bool EP>
+template <int S, int FB, int NOB, bool EP, bool X1 = false>
 __global__ __launch_bounds__(GML_FWD4_NT, 1) void gml_k_spectconv_fwd4(const GmlFwdParams p) {
-    using C = GmlFwd4Cfg<S, FB, EP>;
+    using C = GmlFwd4Cfg<S, FB, EP, X1>;
     static_assert(S % 2 == 0, "value rows are read as float2 / float4");
     constexpr int ROWS = C::ROWS, ECAP = C::ECAP, XCAP = C::XCAP, VROW = C::VROW, FR = C::FR;
     constexpr int VAL_ALIGN = (S % 4 == 0) ? 4 : 2;
@@ -135,9 +141,9 @@ __global__ __launch_bounds__(GML_FWD4_NT, 1) void gml_k_spectconv_fwd4(const Gml
         }
     }
 #pragma unroll
-    for (int sl = 0; sl < 2; ++sl)
+    for (int sl = 0; sl < (X1 ? 1 : 2); ++sl)
         for (int i = tid; i < C::X_BYTES / 16; i += C::NT)
-            *reinterpret_cast<f32x4*>(lds_raw + C::OFF_GRP + sl * C::GRP_BYTES + C::OFF_X + i * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(lds_raw + C::x_off(sl) + i * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #if GML_F4DBG & 4
     {   // debugging: every landing zone starts as NaN patterns (data read before it landed shows up as NaN rows)
@@ -213,9 +219,20 @@ __global__ __launch_bounds__(GML_FWD4_NT, 1) void gml_k_spectconv_fwd4(const Gml
             nq = geo_of(ng);
             return true;
         };
-        auto issue = [&](int it, int g, int c, const Geo& q) {
+        // a group's X window, whole blocks (the loaders with fewer value batches first)
+        auto issue_x = [&](int g, const Geo& q) {
+            if (!q.staged) return;
+            const int nblk = (q.nwin + C::XRB - 1) / C::XRB;
+            for (int b = NL - 1 - li; b < nblk; b += NL) {
+                const int xo = (q.lo_a + C::XRB * b) * ldxb;
+                const uint32_t xd = lds0 + C::x_off(g) + b * C::XBLK;
+#pragma unroll
+                for (int j = 0; j < C::XIB; ++j)
+                    if (xon[j]) gml_dma16(rs_x, xd + j * 1024, xo + xsrc[j]);
+            }
+        };
+        auto issue = [&](int it, int g, int c, const Geo& q, bool with_x) {
             const uint32_t ebuf = lds0 + C::OFF_EDGE + (it & 1) * C::EDGE_BYTES;
-            const uint32_t gbuf = lds0 + C::OFF_GRP + (g & 1) * C::GRP_BYTES;
             if (q.staged) {
                 int e0, n;
                 chunk_of(q, c, e0, n);
@@ -257,19 +274,10 @@ __global__ __launch_bounds__(GML_FWD4_NT, 1) void gml_k_spectconv_fwd4(const Gml
                 const int nci = (n + 255) >> 8;
                 for (int j = (li + 2) % NL; j < nci; j += NL)
                     if (256 * j + 4 * lane < n) gml_dma16(rs_col, ebuf + j * 1024, (e0 + 256 * j + 4 * lane) * 4);
-                // ---- a new group: its X window, whole blocks
-                if (c == 0) {
-                    const int nblk = (q.nwin + C::XRB - 1) / C::XRB;
-                    for (int b = NL - 1 - li; b < nblk; b += NL) {         // (the loaders with fewer value batches first)
-                        const int xo = (q.lo_a + C::XRB * b) * ldxb;
-                        const uint32_t xd = gbuf + C::OFF_X + b * C::XBLK;
-#pragma unroll
-                        for (int j = 0; j < C::XIB; ++j)
-                            if (xon[j]) gml_dma16(rs_x, xd + j * 1024, xo + xsrc[j]);
-                    }
-                }
+                // ---- a new group: its X window
+                if (c == 0 && with_x) issue_x(g, q);
             }
-            if (c == 0 && li == NL - 1 && lane < 33) gml_dma16(rs_rp, gbuf, (g * ROWS + 4 * lane) * 4);
+            if (c == 0 && li == NL - 1 && lane < 33) gml_dma16(rs_rp, lds0 + C::rp_off(g), (g * ROWS + 4 * lane) * 4);
             if constexpr (EP) {                                            // positions of the item after this one
                 int ng, nc; Geo nq;
                 if (next_of(g, c, q, ng, nc, nq) && nq.staged) {
@@ -292,7 +300,7 @@ __global__ __launch_bounds__(GML_FWD4_NT, 1) void gml_k_spectconv_fwd4(const Gml
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                      // (A2) every loader's share of the first positions has landed
         }
-        issue(0, g0, 0, q);
+        issue(0, g0, 0, q, true);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (GML_F4_DELAY & 16) GML_F4_IDLE();
         for (;;) {
@@ -301,7 +309,14 @@ __global__ __launch_bounds__(GML_FWD4_NT, 1) void gml_k_spectconv_fwd4(const Gml
             if (c == 0 && g + 3 < g1) dma_rec(g + 3);          // (entry (g - 1) & 3: group g - 1 is finished)
             int ng, nc; Geo nq;
             const bool has = next_of(g, c, q, ng, nc, nq);
-            if (has) issue(it + 1, ng, nc, nq);
+            if (has) issue(it + 1, ng, nc, nq, !X1);
+            if constexpr (X1) {
+                if (has && nc == 0) {                          // the next item opens a group: its window goes where this group's is read
+                    __builtin_amdgcn_s_barrier();              // (C) every compute wave has finished this group's aggregation
+                    asm volatile("" ::: "memory");
+                    issue_x(ng, nq);
+                }
+            }
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             if (GML_F4_DELAY & 16) GML_F4_IDLE();
             if (!has) break;
@@ -498,8 +513,7 @@ __global__ __launch_bounds__(GML_FWD4_NT, 1) void gml_k_spectconv_fwd4(const Gml
             if (GML_F4_DELAY & 4) GML_F4_IDLE();
             if (c == 0) {
                 q = geo_of(g);
-                const unsigned char* gbuf = lds_raw + C::OFF_GRP + (g & 1) * C::GRP_BYTES;
-                const int* rp_l = reinterpret_cast<const int*>(gbuf);
+                const int* rp_l = reinterpret_cast<const int*>(lds_raw + C::rp_off(g));
                 const unsigned char* rec = lds_raw + C::OFF_REC + (g & 3) * 256;
                 row = rec[16 + wave * 16 + r16];
                 out_rows = reinterpret_cast<const uint32_t*>(rec + 16)[wave * 4 + kq];
@@ -509,7 +523,7 @@ __global__ __launch_bounds__(GML_FWD4_NT, 1) void gml_k_spectconv_fwd4(const Gml
                 kbeg = rvalid ? rp_l[row] : 0;
                 kend = rvalid ? rp_l[row + 1] : 0;
                 // byte offset of (row cidx, features 8 kq ..) in the window: xoff + FR * 4 * cidx + 16 (cidx / XRB)
-                xoff = C::OFF_GRP + (g & 1) * C::GRP_BYTES + C::OFF_X + kq * 32 - q.lo_a * (FR * 4) - (q.lo_a / C::XRB) * 16;
+                xoff = C::x_off(g) + kq * 32 - q.lo_a * (FR * 4) - (q.lo_a / C::XRB) * 16;
 #pragma unroll
                 for (int s = 0; s < S; ++s)
 #pragma unroll
@@ -523,6 +537,7 @@ __global__ __launch_bounds__(GML_FWD4_NT, 1) void gml_k_spectconv_fwd4(const Gml
                         for (int o = kq; o < p.Fout; o += 4) p.out[(r0 + row) * p.ldo + o] = qnan;
                     ++it;
                     if (++g >= g1) break;
+                    if constexpr (X1) __builtin_amdgcn_s_barrier();    // (C) the loaders wait for it before the next group's window
                     continue;
                 }
             }
@@ -547,7 +562,7 @@ __global__ __launch_bounds__(GML_FWD4_NT, 1) void gml_k_spectconv_fwd4(const Gml
                         if (a != b) atomicAdd(&p.prof[1], 1ull);
                     }
                     if (c == 0) {
-                        const int* rp_l = reinterpret_cast<const int*>(lds_raw + C::OFF_GRP + (g & 1) * C::GRP_BYTES);
+                        const int* rp_l = reinterpret_cast<const int*>(lds_raw + C::rp_off(g));
                         const unsigned char* rec = lds_raw + C::OFF_REC + (g & 3) * 256;
                         for (int i = tid; i < q.nwin * FR; i += 512) {
                             const int rr = i / FR, f = i % FR;
@@ -693,6 +708,10 @@ __global__ __launch_bounds__(GML_FWD4_NT, 1) void gml_k_spectconv_fwd4(const Gml
             __builtin_amdgcn_sched_barrier(0);                 // (nothing of the projection may be scheduled above the wait)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (X1) {
+                if (g + 1 < g1) __builtin_amdgcn_s_barrier();  // (C) this group's window is free: the next one lands beside the projection
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if (GML_F4_DELAY & 8) { GML_F4_IDLE(); __builtin_amdgcn_sched_barrier(0); }
 #ifdef GML_F4_EXECCHK
             if (__builtin_amdgcn_read_exec() != ~0ull && p.prof) atomicAdd(&p.prof[7], 1ull);
@@ -724,17 +743,24 @@ __global__ __launch_bounds__(GML_FWD4_NT, 1) void gml_k_spectconv_fwd4(const Gml
 template <int S, int FB, int NOB>
 int gml_launch_fwd4(const GmlFwdParams& p, dim3 grid, hipStream_t st);
 
-#define GML_FWD4_LAUNCH(SV, FBV, NOBV, EPV)                                                                  \
+#define GML_FWD4_LAUNCH(SV, FBV, NOBV, EPV, X1V)                                                             \
     {                                                                                                        \
-        GML_ALLOW_BIG_LDS(rc_, (&gml_k_spectconv_fwd4<SV, FBV, NOBV, EPV>), 160 * 1024)                      \
+        GML_ALLOW_BIG_LDS(rc_, (&gml_k_spectconv_fwd4<SV, FBV, NOBV, EPV, X1V>), 160 * 1024)                 \
         if (rc_ != hipSuccess) return (int)rc_;                                                              \
-        const size_t lds_ = GmlFwd4Cfg<SV, FBV, EPV>::lds_bytes();                                           \
-        hipLaunchKernelGGL((gml_k_spectconv_fwd4<SV, FBV, NOBV, EPV>), grid, dim3(GML_FWD4_NT), lds_, st, p); \
+        const size_t lds_ = GmlFwd4Cfg<SV, FBV, EPV, X1V>::lds_bytes();                                      \
+        hipLaunchKernelGGL((gml_k_spectconv_fwd4<SV, FBV, NOBV, EPV, X1V>), grid, dim3(GML_FWD4_NT), lds_, st, p); \
         return gml_launch_status();                                                                          \
     }
+// GML_FWD_ONEWIN (48-feature shapes only): the single-window form, for batches whose groups need edge chunks
 #define GML_DEFINE_FWD4(SV, FBV, NOBV)                                                                       \
     template <>                                                                                              \
     int gml_launch_fwd4<SV, FBV, NOBV>(const GmlFwdParams& p, dim3 grid, hipStream_t st) {                   \
-        if (p.epos != nullptr) GML_FWD4_LAUNCH(SV, FBV, NOBV, true)                                          \
-        GML_FWD4_LAUNCH(SV, FBV, NOBV, false)                                                                \
+        if constexpr (FBV == 1) {                                                                            \
+            if (p.flags & GML_FWD_ONEWIN) {                                                                  \
+                if (p.epos != nullptr) GML_FWD4_LAUNCH(SV, FBV, NOBV, true, true)                            \
+                GML_FWD4_LAUNCH(SV, FBV, NOBV, false, true)                                                  \
+            }                                                                                                \
+        }                                                                                                    \
+        if (p.epos != nullptr) GML_FWD4_LAUNCH(SV, FBV, NOBV, true, false)                                   \
+        GML_FWD4_LAUNCH(SV, FBV, NOBV, false, false)                                                         \
     }

@@ -222,8 +222,10 @@ def fwd_groups(csr, x, S, Fin, Fout):
             if not x4 or (win > 0 and gm_w > win) or (gm_e > cap and not FWD_CHUNKS):
                 rows = 64
             elif gm_e > cap:
-                _path('conv_fwd', 'fused 8-wave bf16x3, edge chunks', S, Fin, Fout)
-                return csr.ginfo128, _lib.GML_GROUPS128
+                # 48 features: one staged X window instead of two -> twice the edges per chunk (sr25: 2 chunks per group instead of 4)
+                onewin = _lib.GML_FWD_ONEWIN if (Fin > 32 and _os.environ.get('GML_FWD_ONEWIN', '1') != '0') else 0
+                _path('conv_fwd', 'fused 8-wave bf16x3, edge chunks%s' % (', one X window' if onewin else ''), S, Fin, Fout)
+                return csr.ginfo128, _lib.GML_GROUPS128 | onewin
         elif cap > 0 and gm_e > cap and FWD_CHUNKS and x4:
             # a group beyond what the default ring kernel stages at once: its chunked form instead of global gathers (opt-in)
             win = int(L.gml_spectconv_fwd_stage_window(int(S), int(Fin), int(Fout), flags | _lib.GML_FWD_CHUNKED))

@@ -59,6 +59,8 @@ enum {
                          (gml_k_spectconv_fwd4), which walks such groups in edge chunks instead of gathering from global memory */
     GML_DVAL_ACCUM = 128, /* gml_spectconv_bwd (8-wave bf16x3 kernel): dval += instead of dval = -- the second of two launches over
                          slices of the input features (48-wide layers: features 0..31, then 32..47; dval is linear in x) */
+    GML_FWD_ONEWIN = 256, /* gml_spectconv_fwd, 48-feature shapes on the chunked ring kernel: ONE staged X window instead of two, twice the
+                         edges per work item -- for batches whose groups need edge chunks (the caller knows the batch's largest group) */
     GML_DMA_RING = 32   /* gml_spectconv_bwd / _bwd_mix: take the LDS-DMA landing-ring kernel (bwd4) where it applies; the
                          forward uses its ring kernel (fwd3) by default (GML_FWD_DMA=0 in the environment turns it off)   */
 };
