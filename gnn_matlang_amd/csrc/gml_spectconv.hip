@@ -394,11 +394,19 @@ extern "C" int gml_spmm_fwd_ex(const int32_t* rowptr, const int32_t* col, const 
         int grid = q.ngroups < GML_NUM_CU ? q.ngroups : GML_NUM_CU;
         q.groups_per_wg = (int)gml_cdiv(q.ngroups, grid);
         grid = (int)gml_cdiv(q.ngroups, q.groups_per_wg);
-        for (int f0 = 0; f0 < Fin; f0 += 32) {                  // (feature chunks of 32: separate launches, the value rows are read again)
-            q.x = x + f0; q.Fin = (Fin - f0 < 32) ? Fin - f0 : 32; q.hf0 = f0;
-            const int rc = (S % 4 == 0) ? gml_launch_spmm3<4>(q, dim3(grid), st)
-                         : ((S % 2 == 0) ? gml_launch_spmm3<2>(q, dim3(grid), st) : gml_launch_spmm3<1>(q, dim3(grid), st));
+        static const bool w48_on = [] { const char* e = getenv("GML_SPMM3_W48"); return !(e && e[0] == '0'); }();
+        for (int f0 = 0; f0 < Fin;) {                           // feature chunks: separate launches, the value rows are read again
+            const int left = Fin - f0;
+            // a remainder of 36 .. 48 features is ONE launch of the 192-byte-row form (sr25 / mutag hidden width 48); else chunks of 32
+            const bool w48 = w48_on && left > 32 && left <= 48 && (int64_t)S * 4 * 24 <= GmlSpmm3CfgT<true>::VAL_BYTES;
+            q.x = x + f0; q.Fin = w48 ? left : (left < 32 ? left : 32); q.hf0 = f0;
+            int rc;
+            if (w48) rc = (S % 4 == 0) ? gml_launch_spmm3<4, true>(q, dim3(grid), st)
+                          : ((S % 2 == 0) ? gml_launch_spmm3<2, true>(q, dim3(grid), st) : gml_launch_spmm3<1, true>(q, dim3(grid), st));
+            else rc = (S % 4 == 0) ? gml_launch_spmm3<4>(q, dim3(grid), st)
+                      : ((S % 2 == 0) ? gml_launch_spmm3<2>(q, dim3(grid), st) : gml_launch_spmm3<1>(q, dim3(grid), st));
             if (rc != GML_OK) return rc;
+            f0 += q.Fin;
         }
         return GML_OK;
     }

@@ -37,24 +37,31 @@ struct GmlSpmm3Params {
     int32_t ngroups, groups_per_wg;
 };
 
-struct GmlSpmm3Cfg {
+// W48: feature chunks of up to 48 (x rows of 192 bytes, 16 rows per 3,088-byte window block as in gml_k_spectconv_fwd4's FB = 1 form):
+// a 48-feature input is ONE pass over the edges instead of a 32- and a 16-feature launch that each read every value row (round 4).
+template <bool W48>
+struct GmlSpmm3CfgT {
     static constexpr int ROWS = 128, NLOAD = 4, NT = 512 + 64 * NLOAD;
-    static constexpr int XCAP = 200, XBLK = 1040;
+    static constexpr int XRB = W48 ? 16 : 8;                    // rows per window block
+    static constexpr int XROW = W48 ? 192 : 128;                // bytes of a staged x row
+    static constexpr int XBLK = XRB * XROW + 16;                // 1040 / 3088: the 16-byte pad spreads the gathers over the bank groups
+    static constexpr int XCAP = W48 ? 208 : 200;
     static constexpr int ECAP = 2048;                           // staged column ids per group (16 per row on average)
-    static constexpr int VAL_BYTES = 44 * 1024;                 // one value buffer: whole [edge][S] rows of a row block
+    static constexpr int VAL_BYTES = (W48 ? 30 : 44) * 1024;    // one value buffer: whole [edge][S] rows of a row block
     static constexpr int REC_BYTES = 4 * 256, RP_BYTES = 528;
-    static constexpr int COL_BYTES = ECAP * 4, X_BYTES = XCAP / 8 * XBLK;
+    static constexpr int COL_BYTES = ECAP * 4, X_BYTES = XCAP / XRB * XBLK;
     static constexpr int SLOT_BYTES = RP_BYTES + COL_BYTES + X_BYTES;
     static constexpr int OFF_REC = 0, OFF_VAL = REC_BYTES, OFF_SLOT = OFF_VAL + 2 * VAL_BYTES;
     static constexpr int OFF_COL = RP_BYTES, OFF_X = OFF_COL + COL_BYTES;
     static constexpr size_t lds_bytes() { return (size_t)OFF_SLOT + 2 * (size_t)SLOT_BYTES; }
+    static_assert(OFF_SLOT + 2 * SLOT_BYTES <= 160 * 1024 && SLOT_BYTES % 16 == 0, "LDS budget");
 };
-static_assert(GmlSpmm3Cfg::lds_bytes() <= 160 * 1024 && GmlSpmm3Cfg::SLOT_BYTES % 16 == 0, "LDS budget");
+typedef GmlSpmm3CfgT<false> GmlSpmm3Cfg;
 
 // VA: alignment class of the value rows in floats (4: S % 4 == 0 -> one 16-byte read per chunk; 2; 1)
-template <int VA>
+template <int VA, bool W48 = false>
 __global__ __launch_bounds__(GmlSpmm3Cfg::NT, 1) void gml_k_spmm3(const GmlSpmm3Params p) {
-    using C = GmlSpmm3Cfg;
+    using C = GmlSpmm3CfgT<W48>;
     constexpr int ROWS = C::ROWS, ECAP = C::ECAP, XCAP = C::XCAP, NL = C::NLOAD;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int tid = threadIdx.x;
@@ -81,10 +88,10 @@ __global__ __launch_bounds__(GmlSpmm3Cfg::NT, 1) void gml_k_spmm3(const GmlSpmm3
         q.kb = __builtin_amdgcn_readfirstlane(v.x); q.ne = __builtin_amdgcn_readfirstlane(v.y);
         const int lo = __builtin_amdgcn_readfirstlane(v.z), nwin = __builtin_amdgcn_readfirstlane(v.w);
         q.kb4 = q.kb & ~3; q.ne4 = q.ne + (q.kb & 3);
-        q.lo8 = lo & ~7; q.nwin8 = q.ne > 0 ? lo + nwin - q.lo8 : 0;
+        q.lo8 = lo & ~(C::XRB - 1); q.nwin8 = q.ne > 0 ? lo + nwin - q.lo8 : 0;      // (block-aligned window start)
         q.staged = q.ne4 <= ECAP && q.nwin8 <= XCAP;
         int sh = 0;
-        while (sh < 3 && ((q.ne * 5 / 4) >> sh) + 8 > vcap) ++sh;   // 25 % headroom for uneven blocks
+        while (sh < (W48 ? 4 : 3) && ((q.ne * 5 / 4) >> sh) + 8 > vcap) ++sh;   // 25 % headroom for uneven blocks (W48: smaller value buffers, blocks down to 8 rows)
         q.sh = sh;
         return q;
     };
@@ -111,11 +118,23 @@ __global__ __launch_bounds__(GmlSpmm3Cfg::NT, 1) void gml_k_spmm3(const GmlSpmm3
             const uint32_t slot = lds0 + C::OFF_SLOT + (g & 1) * C::SLOT_BYTES;
             if (q.staged) {
                 const u32x4 rs_col = gml_raw_rsrc(p.col + q.kb4, (uint32_t)min((uint64_t)(etot - q.kb4) * 4u, (uint64_t)0xffffff00u));
-                const int nxi = (q.nwin8 + 7) >> 3;
-                const int c4 = (lane & 7) * 4;
-                for (int i = li; i < nxi; i += NL) {
-                    const int rr = q.lo8 + 8 * i + (lane >> 3);
-                    if (c4 < p.Fin) gml_dma16(rs_x, slot + C::OFF_X + i * C::XBLK, rr * ldxb + c4 * 4);
+                if constexpr (!W48) {
+                    const int nxi = (q.nwin8 + 7) >> 3;
+                    const int c4 = (lane & 7) * 4;
+                    for (int i = li; i < nxi; i += NL) {
+                        const int rr = q.lo8 + 8 * i + (lane >> 3);
+                        if (c4 < p.Fin) gml_dma16(rs_x, slot + C::OFF_X + i * C::XBLK, rr * ldxb + c4 * 4);
+                    }
+                } else {                                        // 16 rows x 12 pieces of 16 bytes = three instructions per block
+                    const int nxi = (q.nwin8 + 15) >> 4;
+                    for (int i = li; i < nxi; i += NL) {
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            const int qd = 64 * j + lane;
+                            const int row = (qd * 171) >> 11, ch = qd - row * 12;      // / 12 (exact for qd < 192)
+                            if (ch * 4 < p.Fin) gml_dma16(rs_x, slot + C::OFF_X + i * C::XBLK + j * 1024, (q.lo8 + 16 * i + row) * ldxb + ch * 16);
+                        }
+                    }
                 }
                 const int nci = (q.ne4 + 255) >> 8;
                 for (int j = (li + 1) % NL; j < nci; j += NL)
@@ -178,7 +197,11 @@ __global__ __launch_bounds__(GmlSpmm3Cfg::NT, 1) void gml_k_spmm3(const GmlSpmm3
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                               // (A)
     asm volatile("" ::: "memory");
-    const int r8 = lane >> 3, j4 = (lane & 7) * 4;
+    // lanes <-> (row of the tile, 4 features): 8 rows x 8 feature quads; a feature chunk of <= 16 (the second launch of a 48-feature
+    // input) would leave half the lanes without a feature: 16 rows x 4 quads then (round 4: Fin = 48 SpMM 0.41 -> see DESIGN s5)
+    const bool narrow = !W48 && p.Fin <= 16;
+    const int tr = narrow ? 16 : 8;                            // rows of a tile
+    const int r8 = narrow ? lane >> 2 : lane >> 3, j4 = narrow ? (lane & 3) * 4 : (lane & 7) * 4;
     const bool fok = j4 < p.Fin;
     const int64_t hrow = (int64_t)p.S * p.hs;                  // floats between rows of H
     const int nchunk = (p.S + 7) >> 3;
@@ -201,24 +224,28 @@ __global__ __launch_bounds__(GmlSpmm3Cfg::NT, 1) void gml_k_spmm3(const GmlSpmm3
             block_edges(g, q, b, ks, ke_b);
             const int ks4 = ks & ~3;
             const bool staged = q.staged && (ke_b - ks4) <= vcap + 3;
-            const int rb = ROWS >> q.sh, ntile = rb >> 3;
-            const int xoff = C::OFF_SLOT + (g & 1) * C::SLOT_BYTES + C::OFF_X + j4 * 4 - q.lo8 * 130;
+            const int rb = ROWS >> q.sh, ntile = rb / tr;        // (rb >= tr: 16-row tiles only without W48, whose sh <= 3)
+            // byte offset of (window row c, features j4 ..): xoff + XROW c + 16 (c / XRB)
+            const int xoff = C::OFF_SLOT + (g & 1) * C::SLOT_BYTES + C::OFF_X + j4 * 4 - q.lo8 * C::XROW - (q.lo8 / C::XRB) * 16;
             const auto hrs = __builtin_amdgcn_make_buffer_rsrc(p.h + r0 * hrow, 0, (int)(nr * hrow * 4), 0x00020000);
             // work units (8-row tile, chunk of 8 supports) dealt to the waves
             for (int u = wave; u < ntile * nchunk; u += 8) {
                 const int tile = u % ntile, ch = u / ntile;
-                const int row = b * rb + tile * 8 + r8;
+                const int row = b * rb + tile * tr + r8;
                 const bool rvalid = row < nr;
                 const int kbeg = rvalid ? rp_l[row] : 0;
                 const int kend = rvalid ? rp_l[row + 1] : 0;
-                f32x2 acc[8][2];
+                constexpr int NQ = W48 ? 2 : 1;                 // feature quads per lane: 4 j .. 4 j + 3 and (W48, lanes j < 4) 32 + 4 j .. + 3
+                f32x2 acc[8][2 * NQ];
 #pragma unroll
-                for (int s = 0; s < 8; ++s) { acc[s][0] = f32x2{0.f, 0.f}; acc[s][1] = f32x2{0.f, 0.f}; }
+                for (int s = 0; s < 8; ++s)
+#pragma unroll
+                    for (int h = 0; h < 2 * NQ; ++h) acc[s][h] = f32x2{0.f, 0.f};
                 if (staged) {
                     int k = kbeg;
                     const int ke = kend;
                     if (k < ke) {
-                        struct Ops { f32x4 e0, e1, t; };
+                        struct Ops { f32x4 e0, e1, t, t2; };
                         auto fetch = [&](Ops& o, int kk, int c) {
                             const float* er = ea_l + (kk - ks4) * p.S + 8 * ch;
                             if constexpr (VA == 4) {
@@ -231,7 +258,9 @@ __global__ __launch_bounds__(GmlSpmm3Cfg::NT, 1) void gml_k_spmm3(const GmlSpmm3
                             } else {
                                 o.e0 = f32x4{er[0], er[1], er[2], er[3]}; o.e1 = f32x4{er[4], er[5], er[6], er[7]};
                             }
-                            o.t = *reinterpret_cast<const f32x4*>(lds_raw + xoff + c * 128 + ((c & ~7) << 1));
+                            const int xa = xoff + c * C::XROW + ((c / C::XRB) << 4);
+                            o.t = *reinterpret_cast<const f32x4*>(lds_raw + xa);
+                            if constexpr (W48) o.t2 = *reinterpret_cast<const f32x4*>(lds_raw + xa + 128 - ((lane & 4) << 4));   // (lanes j >= 4: a readable address, result unused)
                         };
                         auto fma = [&](const Ops& o) {
                             const f32x2 x0 = f32x2{o.t.x, o.t.y}, x1 = f32x2{o.t.z, o.t.w};
@@ -241,6 +270,10 @@ __global__ __launch_bounds__(GmlSpmm3Cfg::NT, 1) void gml_k_spmm3(const GmlSpmm3
                                 const f32x2 e2 = f32x2{ev, ev};
                                 acc[s][0] = e2 * x0 + acc[s][0];
                                 acc[s][1] = e2 * x1 + acc[s][1];
+                                if constexpr (W48) {
+                                    acc[s][2] = e2 * f32x2{o.t2.x, o.t2.y} + acc[s][2];
+                                    acc[s][3] = e2 * f32x2{o.t2.z, o.t2.w} + acc[s][3];
+                                }
                             }
                         };
                         Ops A, B;
@@ -272,6 +305,18 @@ __global__ __launch_bounds__(GmlSpmm3Cfg::NT, 1) void gml_k_spmm3(const GmlSpmm3
                             acc[s][0] = e2 * f32x2{xb[0], xb[1]} + acc[s][0];
                             acc[s][1] = e2 * f32x2{xb[2], xb[3]} + acc[s][1];
                         }
+                        if constexpr (W48) {
+                            float xc[4];
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) xc[t] = (32 + j4 + t < p.Fin && j4 < 16) ? xr[32 + t] : 0.f;
+#pragma unroll
+                            for (int s = 0; s < 8; ++s) {
+                                const float e = (8 * ch + s < p.S) ? p.val[(int64_t)k * p.S + 8 * ch + s] : 0.f;
+                                const f32x2 e2 = f32x2{e, e};
+                                acc[s][2] = e2 * f32x2{xc[0], xc[1]} + acc[s][2];
+                                acc[s][3] = e2 * f32x2{xc[2], xc[3]} + acc[s][3];
+                            }
+                        }
                     }
                 }
                 // stores: H[r0 + row][8 ch + s][hf0 + 4 j ..]: 8 lanes = one 128-byte line; lanes without a row / feature /
@@ -282,16 +327,21 @@ __global__ __launch_bounds__(GmlSpmm3Cfg::NT, 1) void gml_k_spmm3(const GmlSpmm3
                     const bool ok = rvalid && fok && 8 * ch + s < p.S;
                     const u32x4 a = u32x4{__float_as_uint(acc[s][0].x), __float_as_uint(acc[s][0].y), __float_as_uint(acc[s][1].x), __float_as_uint(acc[s][1].y)};
                     __builtin_amdgcn_raw_buffer_store_b128(a, hrs, ok ? base + s * p.hs * 4 : 0x7fffff00, 0, /*nt*/ 2);
+                    if constexpr (W48) {
+                        const bool ok2 = rvalid && j4 < 16 && 32 + j4 < p.Fin && 8 * ch + s < p.S;
+                        const u32x4 a2 = u32x4{__float_as_uint(acc[s][2].x), __float_as_uint(acc[s][2].y), __float_as_uint(acc[s][3].x), __float_as_uint(acc[s][3].y)};
+                        __builtin_amdgcn_raw_buffer_store_b128(a2, hrs, ok2 ? base + 128 + s * p.hs * 4 : 0x7fffff00, 0, /*nt*/ 2);
+                    }
                 }
             }
         }
     }
 }
 
-template <int VA>
+template <int VA, bool W48 = false>
 static int gml_launch_spmm3(const GmlSpmm3Params& p, dim3 grid, hipStream_t st) {
-    GML_ALLOW_BIG_LDS(rc_, (&gml_k_spmm3<VA>), 160 * 1024)
+    GML_ALLOW_BIG_LDS(rc_, (&gml_k_spmm3<VA, W48>), 160 * 1024)
     if (rc_ != hipSuccess) return (int)rc_;
-    hipLaunchKernelGGL((gml_k_spmm3<VA>), grid, dim3(GmlSpmm3Cfg::NT), GmlSpmm3Cfg::lds_bytes(), st, p);
+    hipLaunchKernelGGL((gml_k_spmm3<VA, W48>), grid, dim3(GmlSpmm3Cfg::NT), GmlSpmm3CfgT<W48>::lds_bytes(), st, p);
     return gml_launch_status();
 }

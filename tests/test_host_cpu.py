@@ -31,6 +31,27 @@ def test_library_exports_match_header():
     assert b'workspace' in _lib.lib().gml_error_string(-3)
 
 
+def test_batch_descriptor_layout_matches_the_header(tmp_path):
+    """gml_batch_desc (include/gml.h) is passed by pointer from ctypes (_lib.BatchDesc): same size, same field offsets, same flag
+    values as the C compiler gives the header -- checked with gcc on the header itself (the header is plain C)."""
+    import subprocess
+    fields = [f[0] for f in _lib.BatchDesc._fields_]
+    src = tmp_path / 'layout.c'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "gml.h"\nint main(void) {\n'
+                   '  printf("%zu\\n", sizeof(gml_batch_desc));\n' +
+                   ''.join('  printf("%%zu\\n", offsetof(gml_batch_desc, %s));\n' % f for f in fields) +
+                   '  printf("%d %d %d %d %d\\n", (int)GML_FWD_CHUNKED, (int)GML_DVAL_ACCUM, (int)GML_FWD_ONEWIN, (int)GML_POOL_SKIP_LAST, (int)GML_DMA_RING);\n'
+                   '  return 0;\n}\n')
+    exe = tmp_path / 'layout'
+    subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
+    out = subprocess.check_output([str(exe)]).decode().split('\n')
+    assert int(out[0]) == ctypes.sizeof(_lib.BatchDesc)
+    for f, line in zip(fields, out[1:]):
+        assert int(line) == getattr(_lib.BatchDesc, f).offset, f
+    assert [int(v) for v in out[1 + len(fields)].split()] == [_lib.GML_FWD_CHUNKED, _lib.GML_DVAL_ACCUM, _lib.GML_FWD_ONEWIN,
+                                                              _lib.GML_POOL_SKIP_LAST, _lib.GML_DMA_RING]
+
+
 def test_cpu_tensors_fail_loudly():
     m = G.SpectConv(4, 3, 2, selfconn=False)
     with pytest.raises(RuntimeError, match='no CPU fallback'):
