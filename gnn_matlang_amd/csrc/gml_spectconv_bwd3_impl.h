@@ -387,23 +387,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
 
         if (p.dval && !(GML_ABL & 8)) {
             if (p.flags & GML_DVAL_ACCUM) {                  // dval += (a second launch over another slice of the input features)
-                // vector pieces, four loads in flight per thread (a scalar load-add-store chain per element cost sr25's 1,664-edge
-                // groups ~20 dependent round trips each: 0.3 ms of the 48-wide layer's 1.12 ms backward)
-                if constexpr (VW > 1) {
-                    EV* dst = reinterpret_cast<EV*>(p.dval + (int64_t)kb * S);
-                    const EV* add = reinterpret_cast<const EV*>(ea_l);
-                    const int n = ne * (S / VW);
-                    for (int i0 = tid_o; i0 < n; i0 += 4 * NT) {
-                        EV v[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) v[u] = dst[min(i0 + u * NT, n - 1)];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u)
-                            if (i0 + u * NT < n) dst[i0 + u * NT] = v[u] + add[i0 + u * NT];
-                    }
-                } else {
-                    for (int i = tid_o; i < ne * S; i += NT) p.dval[(int64_t)kb * S + i] += ea_l[i];
-                }
+                for (int i = tid_o; i < ne * S; i += NT) p.dval[(int64_t)kb * S + i] += ea_l[i];
             } else if constexpr (VW > 1) {
                 EV* dst = reinterpret_cast<EV*>(p.dval + (int64_t)kb * S);
                 for (int i = tid_o; i < ne * (S / VW); i += NT) dst[i] = reinterpret_cast<const EV*>(ea_l)[i];

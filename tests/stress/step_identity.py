@@ -1,0 +1,30 @@
+"""One process = a few train steps of a config on a seeded batch; prints a hash of the logits and every gradient of every step.
+tests/stress/run_step_identity.sh runs it in many FRESH processes and counts the distinct hashes (expected: one per config)."""
+import sys, os, hashlib
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch
+from gnn_matlang_amd import SpectralDesign, collate, models, synthetic
+dev = torch.device('cuda:0')
+cfg = os.environ.get('CFG', 'zinc')
+if cfg == 'zinc':
+    pool = SpectralDesign(recfield=2, dv=2, nfreq=7).design_many(synthetic.make_graphs('zinc', 4096, seed=11))
+    ctor, loss = models.zinc_gnnml3, models.zinc_loss
+elif cfg == 'counting':
+    pool = SpectralDesign(recfield=1, dv=1, nfreq=10, adddegree=True, laplacien=False, addadj=True).design_many(synthetic.make_graphs('counting', 1024, seed=11))
+    ctor, loss = (lambda: models.counting_gnnml3(2, 12)), models.counting_loss
+data = collate(pool).to(dev)
+data.y = torch.rand(data.num_graphs, *(() if cfg == 'zinc' else (1,)), generator=torch.Generator().manual_seed(3)).to(dev) if cfg == 'zinc' else data.y.to(dev)
+torch.manual_seed(5)
+m = ctor().to(dev).train()
+opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+h = hashlib.sha256()
+for step in range(int(os.environ.get('STEPS', 4))):
+    opt.zero_grad(set_to_none=True)
+    pre = m(data)
+    l = loss(pre, data.y)
+    l.backward()
+    h.update(pre.detach().cpu().numpy().tobytes())
+    for p in m.parameters():
+        h.update(p.grad.detach().cpu().numpy().tobytes())
+    opt.step()
+print(cfg, 'nodes', int(data.x.size(0)), 'hash', h.hexdigest()[:16])
