@@ -198,7 +198,7 @@ static int spectconv_bwd_impl(const int32_t* rowptr, const int32_t* col, const i
     bool dma = pl.layout == 3 && pl.nw == 8 && (bwd4_env() || (flags & GML_DMA_RING)) && (S == 8 || S == 4) && p.xvec && p.gvec && !(flags & GML_ACCUM) &&
                (!dx || p.dxvec || dz == nullptr) && (num_rows + 16) * (ldg > ldx ? ldg : ldx) * 4 < (int64_t)INT32_MAX;
     if (flags & GML_DVAL_ACCUM) {                            /* dval += : the 8-wave bf16x3 kernel's copy-out only */
-        if (pl.layout != 3) return GML_E_UNSUPPORTED;
+        if (pl.layout != 3 || (S == 8 && nob == 2)) return GML_E_UNSUPPORTED;   /* (not compiled into the ZINC shape class) */
         dma = false;
     }
     if (dma) {

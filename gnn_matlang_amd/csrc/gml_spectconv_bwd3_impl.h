@@ -386,7 +386,11 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
         GML_T3(8);
 
         if (p.dval && !(GML_ABL & 8)) {
-            if (p.flags & GML_DVAL_ACCUM) {                  // dval += (a second launch over another slice of the input features)
+            // dval += : a second launch over another slice of the input features (48-wide layers).  Not compiled into the ZINC shape
+            // class (S = 8, 32 output columns: no config has 48-wide layers with 8 supports; the host refuses the flag there) -- the
+            // mere presence of the branch cost that instantiation 1.5 % through its schedule (tools/ab.sh on one box, round 4)
+            constexpr bool ACC = !(S == 8 && NOB == 2);
+            if (ACC && (p.flags & GML_DVAL_ACCUM)) {
                 for (int i = tid_o; i < ne * S; i += NT) p.dval[(int64_t)kb * S + i] += ea_l[i];
             } else if constexpr (VW > 1) {
                 EV* dst = reinterpret_cast<EV*>(p.dval + (int64_t)kb * S);

@@ -585,7 +585,7 @@ def split48_plan(csr, S, Fin, Fout):
     compiled for Fin <= 32: two launches over the feature slices [0, 32) and [32, Fin).  dX and dW split by input feature; dval is
     linear in x, so the second launch adds its share (GML_DVAL_ACCUM).  The edge loop runs twice -- still ~2 x faster than the
     64-row f32-MFMA kernel these layers ran on (tools/bench_configs.py).  Returns the two plans or None."""
-    if F32_MFMA or _os.environ.get('GML_NO_SPLIT48') or not (32 < Fin <= 48) or (Fin - 32) % 4 != 0:
+    if F32_MFMA or _os.environ.get('GML_NO_SPLIT48') or not (32 < Fin <= 48) or (Fin - 32) % 4 != 0 or (S == 8 and Fout > 16):   # (S = 8, 32 columns: no dval += in that kernel)
         return None
     pa, pb = _bwd_plan(csr, S, 32, Fout), _bwd_plan(csr, S, Fin - 32, Fout)
     if pa is None or pb is None or pa[4] != 128 or pb[4] != 128 or (pa[0] | pb[0]) & _lib.GML_F32_MFMA:
