@@ -621,12 +621,37 @@ def main():
                              mode='eager: per batch device-side assembly from the HBM-resident data set (one host read for the '
                                   'sizes), CSR + group records + pre-split built, fwd + loss + bwd + fused Adam')
                 log('epoch at batch %d, eager: %.3f s for %d graphs (%.3f ms/step)' % (args.ref_batch, dt2, len(dsd), dt2 / nb * 1e3))
+                # ---- eager again, over static-shape batches from gml_batch_assemble (no host read per batch, no HIP graph)
+                dsd.y = dsd.y.float()
+                bd_e = dsd.bounds(args.ref_batch)
+
+                def epoch_static():
+                    tot = torch.zeros((), device=dev)
+                    nb = 0
+                    Bq_ = args.ref_batch
+                    for b in dsd.epoch_static(args.ref_batch, generator=gen, bounds=bd_e):
+                        eo.zero_grad(set_to_none=True)
+                        pre = em(b)
+                        l = ((pre[:Bq_, 0] - b.y[:Bq_]).abs() * b.graph_valid).sum()
+                        l.backward()
+                        eo.step()
+                        tot += l.detach()
+                        nb += 1
+                    return tot, nb
+                epoch_static()
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                tot_s, nb_s = epoch_static()
+                torch.cuda.synchronize()
+                dt2s = time.perf_counter() - t2
+                eager['static_batches'] = dict(seconds=dt2s, value=len(dsd) / dt2s, ms_per_step=dt2s / nb_s * 1e3, mean_loss=float(tot_s.item()) / len(dsd),
+                                               mode='eager over DeviceDataset.epoch_static: one gml_batch_assemble launch per batch, no host read, no HIP graph')
+                log('epoch at batch %d, eager over static batches: %.3f ms/step' % (args.ref_batch, dt2s / nb_s * 1e3))
                 # ---- the same epoch as ONE captured HIP graph replayed per batch: static padded shapes (bounds of the data
                 #      set), batch assembly + index build + fwd + loss + bwd + Adam all inside the graph, no host read
                 bd = dsd.bounds(args.ref_batch)
                 G_, Bq = len(dsd), args.ref_batch
                 ids_buf = torch.zeros(Bq, dtype=torch.int64, device=dev)
-                dsd.y = dsd.y.float()
                 dsd.prepare()                                  # once per data set: every graph's own index structure + pre-split supports
 
                 def captured_epoch(assemble):

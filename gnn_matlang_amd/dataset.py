@@ -222,6 +222,18 @@ class DeviceDataset(object):
         b._batch_i32 = batch
         return b
 
+    def epoch_static(self, batch_size, generator=None, shuffle=True, bounds=None):
+        """One shuffled epoch as STATIC-shape batches (``batch_assembled``): no host read per batch, every batch of the same padded
+        shape -- absent slots in the last one.  Use the loss form of a padded batch: ``((pre[:B, 0] - b.y[:B]).abs() * b.graph_valid).sum()``
+        (Zinc12k.py:365's L1 sum over the real graphs)."""
+        G = len(self)
+        dev = self.node_ptr.device
+        bd = bounds if bounds is not None else self.bounds(batch_size)
+        perm = torch.randperm(G, generator=generator).to(dev) if shuffle else torch.arange(G, device=dev)
+        perm = torch.cat([perm, torch.full(((-G) % batch_size,), G, dtype=torch.int64, device=dev)])
+        for i in range(0, perm.numel(), batch_size):
+            yield self.batch_assembled(perm[i:i + batch_size].contiguous(), bd)
+
     def epoch(self, batch_size, generator=None, shuffle=True):
         """yields one shuffled epoch of batches (the DataLoader(shuffle=True) loop of Zinc12k.py:20,359)."""
         G = len(self)

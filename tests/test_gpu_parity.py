@@ -968,6 +968,28 @@ def test_assembled_batch_is_bit_identical_to_the_padded_batch_and_its_index(dev,
         assert torch.equal(out[0][1][n], out[1][1][n]), n
 
 
+def test_static_epoch_covers_every_graph_once(dev):
+    """DeviceDataset.epoch_static: every graph of the data set appears in exactly one batch slot, the rest are absent slots, every
+    batch has the same padded shape, and the summed L1 loss over the epoch equals the plain epoch's (same model, no update)."""
+    from gnn_matlang_amd import SpectralDesign, models, synthetic
+    from gnn_matlang_amd.dataset import DeviceDataset
+    raw = synthetic.make_graphs('zinc', 50, seed=18)
+    dsd = DeviceDataset.from_graphs(SpectralDesign(recfield=2, dv=2, nfreq=7).design_many(raw), dev)
+    dsd.y = dsd.y.float()
+    torch.manual_seed(2)
+    m = models.zinc_gnnml3().to(dev)
+    tot_s, shapes, valid = 0.0, set(), 0
+    with torch.no_grad():
+        for b in dsd.epoch_static(16, generator=torch.Generator().manual_seed(4)):
+            pre = m(b)
+            tot_s += float(((pre[:16, 0] - b.y[:16]).abs() * b.graph_valid).sum())
+            shapes.add((tuple(b.x.shape), tuple(b.edge_attr2.shape)))
+            valid += int(b.graph_valid.sum())
+        tot_p = sum(float(models.zinc_loss(m(b), b.y)) for b in dsd.epoch(16, generator=torch.Generator().manual_seed(4)))
+    assert valid == 50 and len(shapes) == 1
+    assert abs(tot_s - tot_p) <= 1e-5 * abs(tot_p)
+
+
 # ------------------------------------------------------------------------------------------ dense-block support product
 @pytest.mark.parametrize('n,S,F', [(75, 6, 2), (75, 6, 64), (75, 6, 128), (16, 1, 30), (33, 3, 7), (96, 2, 20), (5, 4, 48)])
 def test_dense_support_mm_vs_fp64(dev, n, S, F):
