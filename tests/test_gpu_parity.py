@@ -1555,11 +1555,12 @@ def test_chunked_ring_forward_any_degree(dev, monkeypatch, S, fin, fout, deg, sp
 
 
 @pytest.mark.parametrize('chunks', [False, True])
-@pytest.mark.parametrize('ne,Fin,n1,n2,deg', [(6, 48, 32, 16, 13), (6, 2, 32, 16, 13), (6, 48, 32, 16, 3), (4, 48, 24, 24, 4)])
+@pytest.mark.parametrize('ne,Fin,n1,n2,deg', [(6, 48, 32, 16, 13), (6, 2, 32, 16, 13), (6, 48, 32, 16, 3), (4, 48, 24, 24, 4), (6, 48, 32, 16, 40)])
 def test_ml3layer_sr25_shapes_with_learned_supports(dev, monkeypatch, ne, Fin, n1, n2, deg, chunks):
     """ML3Layer at sr25.py:252-262's shapes (6 supports, 2 -> 48 -> 48, 32 + 16) and mutag.py's (24 + 24), training with the edge
     branch: the branch runs in source order and the chunked ring forward gathers its 24-byte value rows through the position
-    map (two lanes per row, 12 bytes each); against the oracle in fp64."""
+    map (two overlapping 16-byte lanes per row); against the oracle in fp64.  deg 40: five chunks per group forward (one X window),
+    a backward beyond the 8-wave kernel's 16 staged edges per row (the 64-row family)."""
     from gnn_matlang_amd import ML3Layer, functional as Fn
     from oracle.spect_conv_oracle import OracleML3Layer
     from oracle.relu_margin import make_safe
@@ -1595,8 +1596,9 @@ def test_ml3layer_sr25_shapes_with_learned_supports(dev, monkeypatch, ne, Fin, n
 @pytest.mark.parametrize('S,fin,deg', [(6, 48, 5), (6, 48, 13), (6, 32, 13), (6, 32, 5), (4, 48, 5), (4, 48, 13), (8, 32, 13), (8, 32, 5), (6, 2, 5)])
 def test_repeated_launches_are_bit_identical(dev, S, fin, deg):
     """Stress check behind DESIGN s4.1c: the same fused forward launched 16 times, with a cache-thrashing kernel in between,
-    must give the same bits every time (and the oracle's values).  Round 4 found a gfx950 ordering trap this way: an LDS load
-    landing in a register that a still-queued MFMA had not read yet -- wrong tiles on SOME waves of SOME launches, invisible to a
+    must give the same bits every time (and the oracle's values).  Round 4 found a gfx950 trap this way: one operand form of
+    v_pk_fma_f32 (op_sel:[0,1,0]) lost a low product about once in 10^7 issues -- a row's last edge missing from one aggregate on
+    SOME waves of SOME launches (mostly the first ones of a process: tests/stress/ runs this in fresh processes), invisible to a
     single parity run.  deg 13: groups walked in edge chunks; deg 5: one item per workgroup."""
     from gnn_matlang_amd import SpectConv
     from oracle import spect_conv_oracle as O
