@@ -342,6 +342,7 @@ __global__ __launch_bounds__(256) void gml_k_batch_assemble(const gml_batch_desc
         return lo;
     };
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t ldo = d.ldx_out > d.F ? d.ldx_out : d.F;
     // ---- graphs
     if (i <= B + 1) {
         d.ptr_out[i] = i <= B ? (int32_t)(nnew[i] < d.n_pad ? nnew[i] : d.n_pad) : d.n_pad;
@@ -358,12 +359,13 @@ __global__ __launch_bounds__(256) void gml_k_batch_assemble(const gml_batch_desc
         else if (i < n_real) {
             const int g = seg_of(nnew, i);
             const int64_t src = i - nnew[g] + nlo[g];
-            for (int f = 0; f < d.F; ++f) d.x_out[i * d.F + f] = d.x[src * d.F + f];
+            for (int f = 0; f < d.F; ++f) d.x_out[i * ldo + f] = d.x[src * d.F + f];
+            for (int f = d.F; f < ldo; ++f) d.x_out[i * ldo + f] = 0.f;
             d.batch_out[i] = g;
             d.rowptr_t[i] = (int32_t)(enew[g] + d.rp_src[src]);
             d.rowptr[i] = (int32_t)(enew[g] + d.rp_dst[src]);
         } else {
-            for (int f = 0; f < d.F; ++f) d.x_out[i * d.F + f] = 0.f;
+            for (int f = 0; f < ldo; ++f) d.x_out[i * ldo + f] = 0.f;
             d.batch_out[i] = B;
             const int64_t r = e_real + (i - n_real) * (int64_t)d.dmax;
             d.rowptr_t[i] = d.rowptr[i] = (int32_t)(r < d.e2_pad ? r : d.e2_pad);

@@ -182,7 +182,9 @@ class DeviceDataset(object):
         if ids.dtype != torch.int64 or not ids.is_contiguous():
             raise ValueError('ids: contiguous int64')
         f32, i32 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.int32, device=dev)
-        x, ea = torch.empty(n_pad, F, **f32), torch.empty(e2_pad, S, **f32)
+        ldx = (F + 3) // 4 * 4                                         # float4-addressable rows: the first layer reads them without a padding copy
+        xbuf, ea = torch.empty(n_pad, ldx, **f32), torch.empty(e2_pad, S, **f32)
+        x = xbuf[:, :F]
         es = torch.empty(e2_pad, 8, **i32) if P['es'] is not None else None
         y, valid = torch.empty(B + 1, **f32), torch.empty(B, **f32)
         ptr, batch = torch.empty(B + 2, **i32), torch.empty(n_pad, **i32)
@@ -197,18 +199,20 @@ class DeviceDataset(object):
         d = _lib.BatchDesc()
         for name, t in (('node_ptr', self.node_ptr), ('edge_ptr2', self.edge_ptr2), ('x', P['x']), ('edge_index2', P['ei2']), ('edge_attr2', P['ea']),
                         ('es', P['es']), ('tperm', P['tperm']), ('tinv', P['tinv']), ('rp_src', P['rp_src']), ('rp_dst', P['rp_dst']), ('y', P['y']),
-                        ('ids', ids), ('x_out', x), ('ea_out', ea), ('es_out', es), ('y_out', y), ('valid_out', valid), ('ptr_out', ptr),
+                        ('ids', ids), ('x_out', xbuf), ('ea_out', ea), ('es_out', es), ('y_out', y), ('valid_out', valid), ('ptr_out', ptr),
                         ('batch_out', batch), ('rowptr', g.rowptr), ('col', g.col), ('perm', g.perm), ('rowptr_t', g.rowptr_t),
                         ('col_t', g.col_t), ('pos_t', g.pos_t)):
             setattr(d, name, _ptr(t) if t is not None else None)
         d.G, d.E2all, d.F, d.S, d.B, d.n_pad, d.e2_pad, d.dmax = len(self), int(self.edge_index2.size(1)), F, S, B, n_pad, e2_pad, dmax
+        d.ldx_out = ldx
         with torch.cuda.device(dev):
             st = _stream(dev)
             import ctypes
             _lib.call('gml_batch_assemble', ctypes.addressof(d), st)
             ng2 = max((n_pad + 127) // 128, 1)
             rec128 = int(_lib.lib().gml_csr_group_record_ints(128))
-            g.ginfo_t128, g.ginfo128 = torch.zeros(ng2, rec128, **i32), torch.zeros(ng2, rec128, **i32)
+            both = torch.zeros(2, ng2, rec128, **i32)                      # (one fill for the records of both views)
+            g.ginfo_t128, g.ginfo128 = both[0], both[1]
             _lib.call('gml_csr_group_info', _ptr(g.rowptr_t), _ptr(g.col_t), n_pad, 128, _ptr(g.ginfo_t128), st)
             _lib.call('gml_csr_group_info', _ptr(g.rowptr), _ptr(g.col), n_pad, 128, _ptr(g.ginfo128), st)
         g.gmax_t128 = g.gmax128 = (int(bounds['caps'][0]), int(bounds['caps'][1]))

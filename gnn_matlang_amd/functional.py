@@ -125,6 +125,15 @@ def _f32c(t, name):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _f32rows(t, name):
+    """x as the kernels take it: float32 rows with unit column stride -- a row-strided view (a data set that hands out
+    float4-addressable rows: dataset.DeviceDataset.batch_assembled) passes as it is, like the padded copy rows4 makes"""
+    _require_cuda(t, name)
+    if t.dtype != torch.float32:
+        raise TypeError('%s must be float32, got %s' % (name, t.dtype))
+    return t if (t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.size(1)) else t.contiguous()
+
+
 # rows of x as the 8-wave kernels want them: float4-addressable (leading dimension a multiple of 4 floats, 16-byte aligned
 # base), which is what the LDS-DMA landing ring of the forward (csrc/gml_spectconv_fwd3_impl.h) and the vector paths of the
 # backward kernels copy.  Zinc12k.py's 21 + 4 = 25 input features (libs/utils.py:253-259) are not: the first layer's input is
@@ -681,7 +690,7 @@ class SpectConvFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, val, weight, bias, csr, relu):
-        x, val, weight = _f32c(x, 'x'), _f32c(val, 'edge_attr'), _f32c(weight, 'weight')
+        x, val, weight = _f32rows(x, 'x'), _f32c(val, 'edge_attr'), _f32c(weight, 'weight')
         S, Fin, Fout = weight.shape
         if x.size(1) != Fin or val.size(1) < S or val.size(0) != csr.E or x.size(0) != csr.N:
             raise ValueError('shape mismatch: x %s, edge_attr %s, weight %s, graph N=%d E=%d'
@@ -761,7 +770,7 @@ class ML3LayerFunction(torch.autograd.Function):
         # (Zinc12k.py:343): the pooled [B, C] tensor is returned and the pool's gradient is never expanded to [N, C]
         # val_is_source: val holds the raw supports in SOURCE order (the caller checked ml3_edge_in_source_order and that they
         # carry no gradient); otherwise target-sorted order
-        x, val, cw = _f32c(x, 'x'), _f32c(val, 'edge_attr'), _f32c(cw, 'conv1.weight')
+        x, val, cw = _f32rows(x, 'x'), _f32c(val, 'edge_attr'), _f32c(cw, 'conv1.weight')
         S, Fin, nout1 = cw.shape
         N = csr.N
         if x.size(0) != N or x.size(1) != Fin or val.size(0) != csr.E:

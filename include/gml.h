@@ -122,6 +122,7 @@ typedef struct gml_batch_desc {
     const int64_t* ids; int32_t B, n_pad, e2_pad, dmax;
     float* x_out; float* ea_out; int32_t* es_out; float* y_out; float* valid_out; int32_t* ptr_out; int32_t* batch_out;
     int32_t* rowptr; int32_t* col; int32_t* perm; int32_t* rowptr_t; int32_t* col_t; int32_t* pos_t;
+    int32_t ldx_out;   /* floats between rows of x_out (0: F); columns F .. ldx_out - 1 are written as zeros (float4-addressable rows) */
 } gml_batch_desc;
 int gml_batch_assemble(const gml_batch_desc* d, gml_stream_t stream);
 /* out[k, :] = in[perm[k], :]   (rows of `width` floats) */
