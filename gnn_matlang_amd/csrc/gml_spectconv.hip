@@ -57,7 +57,7 @@ extern "C" int32_t gml_spectconv_fwd_group_rows(int32_t S, int32_t Fin, int32_t 
 
 // edges of one 128-row group the ring kernel of this shape keeps in LDS at once (one work item); 0: the shape is on no ring kernel.
 // Larger groups: fwd3 shapes gather them from global memory, or -- GML_FWD_CHUNKED -- run on the chunked ring kernel; the shapes only
-// the chunked kernel serves walk them in edge chunks (a road that is opt-in for callers: functional.FWD_CHUNKS, DESIGN s4.1c).
+// the chunked kernel serves walk them in edge chunks (functional.FWD_CHUNKS: on by default since the fix of DESIGN s4.1c).
 extern "C" int32_t gml_spectconv_fwd_stage_edges(int32_t S, int32_t Fin, int32_t Fout, uint32_t flags) {
     if (!fwd2_shape(S, Fin, Fout, flags)) return 0;
     if (fwd4_only_shape(S, Fin, Fout, flags)) {                /* one work item of the chunked ring kernel (its gathering form: the smaller one) */

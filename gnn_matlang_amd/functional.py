@@ -236,7 +236,7 @@ def fwd_groups(csr, x, S, Fin, Fout):
                 _path('conv_fwd', 'fused 8-wave bf16x3, edge chunks%s' % (', one X window' if onewin else ''), S, Fin, Fout)
                 return csr.ginfo128, _lib.GML_GROUPS128 | onewin
         elif cap > 0 and gm_e > cap and FWD_CHUNKS and x4:
-            # a group beyond what the default ring kernel stages at once: its chunked form instead of global gathers (opt-in)
+            # a group beyond what the default ring kernel stages at once: its chunked form instead of global gathers
             win = int(L.gml_spectconv_fwd_stage_window(int(S), int(Fin), int(Fout), flags | _lib.GML_FWD_CHUNKED))
             if gm_w <= win:
                 _path('conv_fwd', 'fused 8-wave bf16x3, edge chunks', S, Fin, Fout)

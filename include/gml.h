@@ -148,9 +148,9 @@ int32_t gml_spectconv_fwd_group_rows(int32_t S, int32_t Fin, int32_t Fout, uint3
 /* edges of one 128-row group the ring kernel of this shape keeps in LDS at once (0: not applicable).  When the largest group of the
  * batch (int 1 of its records) exceeds it: shapes of the default ring kernel gather such groups from global memory, or -- with
  * GML_FWD_CHUNKED -- run on the chunked ring kernel, which walks them in edge chunks (sr25.py: 13 entries per row); the shapes only the
- * chunked kernel serves (6 supports, 33..48 input features) always chunk.  The chunked road is parity-green but showed a residual
- * run-to-run difference (~1 launch in 500, first launches of a process) under repeat-and-compare stress: callers that need bit-stable
- * results keep such batches on the 64-row family (what gnn_matlang_amd.functional does unless GML_FWD_CHUNKS=1). */
+ * chunked kernel serves (6 supports, 33..48 input features) always chunk (with GML_FWD_ONEWIN at 33..48 features: twice the edges per
+ * chunk).  gnn_matlang_amd.functional takes the chunked road whenever a batch needs it (GML_FWD_CHUNKS=0 in the environment: the 64-row
+ * family instead); its run-to-run stability is covered by tests/stress (DESIGN s4.1c). */
 int32_t gml_spectconv_fwd_stage_edges(int32_t S, int32_t Fin, int32_t Fout, uint32_t flags);
 /* widest column window (int 3 of the 128-row group records) the kernel this shape (and these flags, e.g. GML_FWD_CHUNKED) would run on
  * serves; 0 = no bound.  A batch with a wider group must use the 64-row family (64-row records, no GML_GROUPS128) for this call:
