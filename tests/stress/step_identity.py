@@ -12,8 +12,23 @@ if cfg == 'zinc':
 elif cfg == 'counting':
     pool = SpectralDesign(recfield=1, dv=1, nfreq=10, adddegree=True, laplacien=False, addadj=True).design_many(synthetic.make_graphs('counting', 1024, seed=11))
     ctor, loss = (lambda: models.counting_gnnml3(2, 12)), models.counting_loss
+elif cfg == 'sr25':          # the 15 real strongly-regular graphs tiled: 13 entries per row -> edge chunks forward, two-launch backward
+    from gnn_matlang_amd import readers
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    raw = readers.load_sr(os.path.join(root, 'tests', 'golden', 'raw', 'sr251256.g6')) * 40
+    pool = SpectralDesign(recfield=1, dv=2, nfreq=5, adddegree=True).design_many(raw)
+    ctor, loss = (lambda: models.sr25_gnnml3(2, 6)), (lambda pre, y: pre.square().sum())
+elif cfg == 'mutag':         # 48-wide hidden layers + BatchNorm (first layer on the exact kernels)
+    rng = np.random.default_rng(2)
+    raw = []
+    for x, ei, y in synthetic.make_graphs('zinc', 2048, seed=11):
+        x7 = np.zeros((x.shape[0], 7), dtype=np.float32)
+        x7[np.arange(x.shape[0]), rng.integers(7, size=x.shape[0])] = 1
+        raw.append((x7, ei, np.float32(rng.integers(2))))
+    pool = SpectralDesign(recfield=1, dv=4, nfreq=3, adddegree=True).design_many(raw)
+    ctor, loss = (lambda: models.mutag_gnnml3(8, 4)), models.mutag_loss
 data = collate(pool).to(dev)
-data.y = torch.rand(data.num_graphs, *(() if cfg == 'zinc' else (1,)), generator=torch.Generator().manual_seed(3)).to(dev) if cfg == 'zinc' else data.y.to(dev)
+data.y = torch.rand(data.num_graphs, generator=torch.Generator().manual_seed(3)).to(dev) if cfg in ('zinc', 'sr25') else data.y.to(dev)
 torch.manual_seed(5)
 m = ctor().to(dev).train()
 opt = torch.optim.Adam(m.parameters(), lr=1e-3)
