@@ -23,6 +23,11 @@ SIGNATURES = {
     'gml_csr_group_record_ints': (ctypes.c_int32, [_i32]),
     'gml_csr_group_info': (ctypes.c_int, [_p, _p, _i64, _i32, _p, _p]),
     'gml_batch_assemble': (ctypes.c_int, [_p, _p]),
+    'gml_bn_workspace_bytes': (ctypes.c_size_t, [_i64]),
+    'gml_bn_stats': (ctypes.c_int, [_p, _i64, _i64, _i32, ctypes.c_float, _p, _p, _p, _p, ctypes.c_size_t, _p]),
+    'gml_bn_apply': (ctypes.c_int, [_p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _i64, _p]),
+    'gml_bn_bwd_sums': (ctypes.c_int, [_p, _i64, _p, _i64, _i64, _i32, _p, _p, _p, _p, _p, ctypes.c_size_t, _p]),
+    'gml_bn_bwd_apply': (ctypes.c_int, [_p, _i64, _p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _i64, _p]),
     'gml_gather_rows': (ctypes.c_int, [_p, _p, _p, _i64, _i32, _p]),
     'gml_gather_rows_presplit': (ctypes.c_int, [_p, _p, _p, _p, _i64, _i32, _p]),
     'gml_scatter_rows': (ctypes.c_int, [_p, _p, _p, _i64, _i32, _p]),

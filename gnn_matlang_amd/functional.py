@@ -438,6 +438,51 @@ def xty(a, b):
     return out
 
 
+class BatchNormFunction(torch.autograd.Function):
+    """torch.nn.BatchNorm1d in training mode on the HIP kernels of csrc/gml_bn.hip (mutag.py:272-288: BatchNorm between the layers).
+    Returns (y, batch mean, biased batch variance); raises NotImplementedError for shapes the kernels do not take (the module then
+    uses torch's implementation)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        N, C = int(x.size(0)), int(x.size(1))
+        dev = x.device
+        L = _lib.lib()
+        with torch.cuda.device(dev):
+            st = _stream(dev)
+            stats = torch.empty(3, C, dtype=torch.float32, device=dev)
+            ws = torch.empty(max(int(L.gml_bn_workspace_bytes(N)), 4), dtype=torch.uint8, device=dev)
+            rc = L.gml_bn_stats(_ptr(x), int(x.stride(0)), N, C, float(eps), _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]), _ptr(ws), ws.numel(), st)
+            if rc == _lib.GML_E_UNSUPPORTED:
+                raise NotImplementedError('shape')
+            _lib.check(rc)
+            y = torch.empty(N, C, dtype=torch.float32, device=dev)
+            _lib.call('gml_bn_apply', _ptr(x), int(x.stride(0)), N, C, _ptr(stats[0]), _ptr(stats[2]), _ptr(weight), _ptr(bias), _ptr(y), C, st)
+        ctx.save_for_backward(x, weight, stats)
+        ctx.has_bias = bias is not None
+        ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, _ds):
+        x, weight, stats = ctx.saved_tensors
+        N, C = int(x.size(0)), int(x.size(1))
+        dev = x.device
+        dy = dy if (dy.stride(1) == 1 and dy.stride(0) % 4 == 0 and dy.data_ptr() % 16 == 0) else dy.contiguous()
+        with torch.cuda.device(dev):
+            st = _stream(dev)
+            sums = torch.empty(2, C, dtype=torch.float32, device=dev)
+            ws = torch.empty(max(int(_lib.lib().gml_bn_workspace_bytes(N)), 4), dtype=torch.uint8, device=dev)
+            _lib.call('gml_bn_bwd_sums', _ptr(dy), int(dy.stride(0)), _ptr(x), int(x.stride(0)), N, C, _ptr(stats[0]), _ptr(stats[2]),
+                      _ptr(sums[0]), _ptr(sums[1]), _ptr(ws), ws.numel(), st)
+            dx = None
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty(N, C, dtype=torch.float32, device=dev)
+                _lib.call('gml_bn_bwd_apply', _ptr(dy), int(dy.stride(0)), _ptr(x), int(x.stride(0)), N, C, _ptr(stats[0]), _ptr(stats[2]),
+                          _ptr(weight), _ptr(sums[0]), _ptr(sums[1]), _ptr(dx), C, st)
+        return dx, (sums[1] if weight is not None else None), (sums[0] if ctx.has_bias else None), None
+
+
 class TallLinearFunction(torch.autograd.Function):
     """F.linear for a small layer applied to many rows; only the weight gradient g^T x differs from autograd's
     (a K = rows contraction that a library GEMM runs on a single workgroup)."""

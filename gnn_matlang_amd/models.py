@@ -14,6 +14,29 @@ from .spect_conv import ML3Layer, SpectConv
 from .dist import SyncBatchNorm1d
 
 
+class BatchNorm1d(torch.nn.BatchNorm1d):
+    """torch.nn.BatchNorm1d (same parameters, buffers, state_dict keys: mutag.py:272-288) whose TRAINING pass over a float32 CUDA
+    [N, C] input runs on csrc/gml_bn.hip (C <= 64, C % 4 == 0, float4-addressable rows); eval mode, other shapes and dtypes: the
+    base class.  GML_TORCH_BN=1 in the environment: always the base class (A/B)."""
+
+    def forward(self, x):
+        import os
+        if not (self.training or self.running_mean is None) or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 2 \
+                or x.size(1) > 64 or x.size(1) % 4 or x.stride(1) != 1 or x.stride(0) % 4 or x.data_ptr() % 16 or x.size(0) < 2 \
+                or os.environ.get('GML_TORCH_BN'):
+            return super().forward(x)
+        from .functional import BatchNormFunction
+        y, stats = BatchNormFunction.apply(x, self.weight, self.bias, self.eps)
+        if self.training and self.running_mean is not None:
+            with torch.no_grad():
+                self.num_batches_tracked += 1
+                m = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked)
+                n = x.size(0)
+                self.running_mean.mul_(1 - m).add_(stats[0], alpha=m)
+                self.running_var.mul_(1 - m).add_(stats[1], alpha=m * n / (n - 1))
+        return y
+
+
 class _SegmentPool(torch.autograd.Function):
     """global_add_pool / global_mean_pool (torch_geometric.nn, used at Zinc12k.py:343, mutag.py:307)."""
 
@@ -85,7 +108,7 @@ class GNNML3(torch.nn.Module):
                              ninp=fin, nout1=widths[i], nout2=nout2))
             fin = widths[i] + nout2
             if bn:
-                setattr(self, 'bn%d' % (i + 1), torch.nn.BatchNorm1d(fin))
+                setattr(self, 'bn%d' % (i + 1), BatchNorm1d(fin))
         if chain and not bn and not self.dense_n:
             # x = conv2(conv1(x, ...), ...) with nothing else reading the intermediate outputs (Zinc12k.py:338-341,
             # counting.py:361-366, sr25.py:266-270): the relu hand-over between stacked layers applies
@@ -149,7 +172,7 @@ class GNNML1Mutag(torch.nn.Module):
         super().__init__()
         nin = nout1 + nout2 + nout3
         for i, fin in enumerate([ninp, nin, nin], start=1):
-            setattr(self, 'bn%d' % i, torch.nn.BatchNorm1d(nin))
+            setattr(self, 'bn%d' % i, BatchNorm1d(nin))
             setattr(self, 'conv%d1' % i, SpectConv(fin, nout2, 1, selfconn=False))
             setattr(self, 'fc%d1' % i, torch.nn.Linear(fin, nout1))
             setattr(self, 'fc%d2' % i, torch.nn.Linear(fin, nout3))

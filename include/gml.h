@@ -406,6 +406,21 @@ int gml_spectral_design(const int32_t* node_ptr, const int32_t* edge_ptr, const 
                         int32_t has_vmax, double vmax, int32_t laplacien, int32_t addadj, const int64_t* out_ptr,
                         int64_t m_total, int64_t* edge_index2, float* edge_attr2, float* lmax, gml_stream_t stream);
 
+/* torch.nn.BatchNorm1d in training mode over the rows of x [num_rows, C] (mutag.py:272-288: one between every two layers): batch
+ * statistics (mean, BIASED variance, rstd = 1 / sqrt(var + eps)), y = (x - mean) rstd weight + bias, and the backward: sum_dy = d bias,
+ * sum_dyxhat = d weight, dx = (dy - sum_dy / n - xhat sum_dyxhat / n) rstd weight.  C <= 64, C % 4 == 0, float4-addressable rows; other
+ * shapes: GML_E_UNSUPPORTED.  weight / bias may be NULL (affine=False).  ws: gml_bn_workspace_bytes(num_rows). */
+size_t gml_bn_workspace_bytes(int64_t num_rows);
+int gml_bn_stats(const float* x, int64_t ldx, int64_t num_rows, int32_t C, float eps, float* mean, float* var, float* rstd,
+                 void* ws, size_t ws_bytes, gml_stream_t stream);
+int gml_bn_apply(const float* x, int64_t ldx, int64_t num_rows, int32_t C, const float* mean, const float* rstd, const float* weight,
+                 const float* bias, float* y, int64_t ldy, gml_stream_t stream);
+int gml_bn_bwd_sums(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t num_rows, int32_t C, const float* mean,
+                    const float* rstd, float* sum_dy, float* sum_dyxhat, void* ws, size_t ws_bytes, gml_stream_t stream);
+int gml_bn_bwd_apply(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t num_rows, int32_t C, const float* mean,
+                     const float* rstd, const float* weight, const float* sum_dy, const float* sum_dyxhat, float* dx, int64_t lddx,
+                     gml_stream_t stream);
+
 /* out[i, j] = sum_r A[r, i] * B[r, j]  (a, b <= 64): weight gradient g^T x of a small dense layer over n rows
  * (readout head fc1 / fc2, Zinc12k.py:343-345), rows split over the chip, fixed summation order */
 size_t gml_xty_workspace_bytes(int64_t n, int32_t a, int32_t b);

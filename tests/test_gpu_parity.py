@@ -1651,3 +1651,36 @@ def test_repeated_training_steps_are_bit_identical(dev, ne, Fin, n1, n2, deg):
         else:
             for i, (a, b) in enumerate(zip(got, first)):
                 assert torch.equal(a, b), 'repeat %d: tensor %d differs' % (rep, i)
+
+
+@pytest.mark.parametrize('N,C,affine', [(1000, 48, True), (4097, 32, True), (70000, 48, True), (333, 64, False), (5, 4, True)])
+def test_batchnorm_kernels_vs_torch(dev, N, C, affine):
+    """models.BatchNorm1d (csrc/gml_bn.hip: statistics, normalise, and the backward as four launches) against torch.nn.BatchNorm1d in
+    training mode on the same input: output, running statistics after two steps, d/dx, d/d weight, d/d bias (mutag.py:272-288)."""
+    from gnn_matlang_amd import models
+    torch.manual_seed(N + C)
+    x0 = (torch.randn(N, C) * 1.5 + 0.7).relu()                          # post-relu activations, like a layer output
+    go = torch.randn(N, C)
+    ref = torch.nn.BatchNorm1d(C, affine=affine).double()
+    m = models.BatchNorm1d(C, affine=affine).to(dev)
+    if affine:
+        with torch.no_grad():
+            ref.weight.uniform_(0.5, 1.5); ref.bias.uniform_(-0.5, 0.5)
+            m.weight.copy_(ref.weight.float()); m.bias.copy_(ref.bias.float())
+    for step in range(2):
+        xr = x0.double().requires_grad_(True)
+        xg = x0.to(dev).requires_grad_(True)
+        yr = ref(xr)
+        yg = m(xg)
+        (yr * go.double()).sum().backward()
+        (yg * go.to(dev)).sum().backward()
+        close(yg, yr, tol=2e-5, what='y')
+        close(xg.grad, xr.grad, tol=2e-5, what='dx')
+    close(m.running_mean, ref.running_mean, tol=2e-5, what='running_mean')
+    close(m.running_var, ref.running_var, tol=2e-5, what='running_var')
+    assert int(m.num_batches_tracked) == 2
+    if affine:
+        close(m.weight.grad, ref.weight.grad, tol=2e-5, what='d weight')
+        close(m.bias.grad, ref.bias.grad, tol=2e-5, what='d bias')
+    m.eval()
+    close(m(x0.to(dev)), ref.eval()(x0.double()), tol=2e-5, what='eval')
