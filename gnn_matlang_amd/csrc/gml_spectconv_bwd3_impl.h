@@ -32,6 +32,29 @@ __host__ __device__ __forceinline__ int gml_wkey3(int o) { return ((o >> 3) & 1)
 // and conflict-free transposing reads of 8 consecutive positions per lane group
 __host__ __device__ __forceinline__ int gml_tkey3(int pos) { return ((pos >> 2) & 1) | ((((pos >> 1) ^ (pos >> 2) ^ (pos >> 3)) & 1) << 1); }
 
+// structural variants of the ZINC shape class (A/B builds: tools/build_variant.py <name> -DGML_B3V=<bits>):
+//   1 = dval straight from the edge loop to global memory (one 8-byte store per lane and edge: no d rows in LDS, no copy-out
+//       phase, the P images of slab 0 are written right behind the edge barrier -- one workgroup barrier less per group)
+//   2 = the Z projection runs between the commit's LDS writes and the barrier that publishes them (it needs neither)
+//   4 = the next group's loads as buffer loads from per-group descriptors: the offsets are a per-lane constant plus a scalar,
+//       the hardware range check replaces the clamps (no 64-bit address arithmetic in the vector unit)
+//   8 = the waves of the second half issue the next group's loads AFTER their dX projection (the first half before): the
+//       address-unit-bound issue of one half overlaps the matrix-pipe-bound projection of the other (spills: not usable)
+//  16 = P accumulators cleared with packed moves;  64 = s_setprio 1 for the second half of the waves
+// 512 = (with 256) the NEXT group's commit (column ids, G window, row pointers -- regions dead since this group's edge barrier) sits
+//       in front of the last slab barrier of this group, which publishes it: no commit barrier at the top of a group
+// 1024 = (with 256) the edge loop software-pipelined over two register sets: the G row of edge k + 1 and the column id of edge
+//       k + 2 are requested before the arithmetic of edge k (the loop's two dependent LDS round trips leave the critical path)
+// 2048 = (with 512) the next group's loads are issued BEFORE this group's edge loop (its registers have room for them: the
+//       staging registers of the rolled form are dead there): the address-unit-bound issue overlaps the VALU-bound loop
+// 256 = (with 1) value rows from global memory in the edge loop (two rows in flight per lane, the group's lines touched at its
+//       top): no value rows in the staging registers, in the commit or in the LDS; the freed 28 KB give the images regions of
+//       their own, and with nothing aliased the barrier at the top of a group goes
+// default (round 5): 1 + 4 + 16 + 256 + 512, A/B'd step by step on single boxes (profiles/r05_bwd3_variants_ab.txt)
+#ifndef GML_B3V
+#define GML_B3V 789
+#endif
+
 template <int S, int NFB, int NW, int NOB = 2>
 struct GmlBwd3Cfg {
     static constexpr int ROWS = 16 * NW, NT = 64 * NW;
@@ -56,7 +79,11 @@ struct GmlBwd3Cfg {
         const size_t a = stage_bytes(ecap, xcap);
         return a > (size_t)PT_BYTES ? a : (size_t)PT_BYTES;
     }
+    // VALG (GML_B3V & 256, the ZINC shape class): the value rows are read from global memory inside the edge loop, so the LDS holds
+    // column ids + G window and -- in regions of their own, aliasing nothing -- the X image and one P slab
+    static constexpr bool VALG = (GML_B3V & 256) && S == 8 && NOB == 2 && NW == 8;
     __host__ __device__ static size_t lds_bytes(int ecap, int xcap) {
+        if (VALG) return (size_t)W_BYTES + (ROWS + 8) * 4 + (size_t)ecap * 4 + (size_t)xcap * LDG * 4 + XT_BYTES + PT_BYTES;
         return (size_t)W_BYTES + (ROWS + 8) * 4 + (size_t)ecap * 4 + r_bytes(ecap, xcap) + XT_BYTES;
     }
 };
@@ -84,17 +111,30 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
     static_assert(!DZ || NOB == 2, "the dz hand-over is compiled for the ZINC shape class");
     constexpr int LDG = C::LDG, ROWS = C::ROWS, NT = C::NT, SS = C::SS, BPW = C::BPW;
     constexpr int VAL_ALIGN = (S % 4 == 0) ? 4 : ((S % 2 == 0) ? 2 : 1);
+    constexpr bool DIRECT = (GML_B3V & 1) && S == 8 && NOB == 2;      // (the shape class without the dval += branch)
+    constexpr bool ZEARLY = (GML_B3V & 2) != 0;
+    constexpr bool PINGPONG = (GML_B3V & 8) != 0;
+    constexpr bool BUFLD = (GML_B3V & 4) && S == 8 && NOB == 2 && XV;
+    constexpr bool PKZ = (GML_B3V & 16) != 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __bf16* W_h = reinterpret_cast<__bf16*>(lds_raw);        // [s][o][f], chunks XOR gml_wkey3(o)
     __bf16* W_l = W_h + C::W_HALF;
     int* rp_l = reinterpret_cast<int*>(lds_raw + C::W_BYTES);
     int* col_l = rp_l + ROWS + 8;
+    constexpr bool VALG = C::VALG;
+    constexpr bool LATEC = VALG && (GML_B3V & 512) && C::NSLAB == 2;
+    constexpr bool PIPE = VALG && (GML_B3V & 1024);
+    // (2048 with VALG: dead -- loads return in order, the loop's first value-row wait also waits for the whole prefetch.  4096: the
+    //  same placement WITHOUT value-row loads in the loop: LDS-staged value rows, only the dval stores are in flight there)
+    constexpr bool EARLYI = (LATEC && (GML_B3V & 2048)) || (DIRECT && !VALG && (GML_B3V & 4096));
+    static_assert(!VALG || DIRECT, "VALG needs the direct dval stores (GML_B3V bit 1)");
     unsigned char* rreg = reinterpret_cast<unsigned char*>(col_l + p.ecap);
     float* ea_l = reinterpret_cast<float*>(rreg);
-    float* gs = ea_l + (size_t)p.ecap * S;
-    unsigned char* pT = rreg;                                // [hi, lo][se][position] 64-byte rows (after the dval rows left)
-    unsigned char* xT = rreg + C::r_bytes(p.ecap, p.xcap);   // [hi, lo][position]     64-byte rows (own region)
-    float* wm_l = reinterpret_cast<float*>(xT + C::XT_BYTES);  // DZ: [4][32] rows of wmix, zero padded (the plan's lds includes these 512 bytes)
+    float* gs = VALG ? ea_l : ea_l + (size_t)p.ecap * S;
+    // [hi, lo][position] 64-byte rows (own region);  [hi, lo][se][position] 64-byte rows (after the dval rows left; VALG: own region)
+    unsigned char* xT = VALG ? rreg + (size_t)p.xcap * LDG * 4 : rreg + C::r_bytes(p.ecap, p.xcap);
+    unsigned char* pT = VALG ? xT + C::XT_BYTES : rreg;
+    float* wm_l = reinterpret_cast<float*>(VALG ? pT + C::PT_BYTES : xT + C::XT_BYTES);  // DZ: [4][32] rows of wmix, zero padded (the plan's lds includes these 512 bytes)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -103,6 +143,9 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
     const int g0 = wg * p.groups_per_wg;
     const int g1 = min(g0 + p.groups_per_wg, p.ngroups);
 
+    if constexpr ((GML_B3V & 64) != 0) {
+        if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+    }
     if constexpr (DZ) {
         if (tid < 128) wm_l[tid] = ((tid >> 5) < p.nmix && (tid & 31) < p.Fin) ? p.wmix[(tid >> 5) * p.Fin + (tid & 31)] : 0.f;
     }
@@ -155,10 +198,39 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
         gi_c = int4{__builtin_amdgcn_readfirstlane(gi_nv.x), __builtin_amdgcn_readfirstlane(gi_nv.y),
                     __builtin_amdgcn_readfirstlane(gi_nv.z), __builtin_amdgcn_readfirstlane(gi_nv.w)};
     };
+    const int voff_g = (tid / GC) * (int)p.ldg * 4 + (tid % GC) * 16;   // BUFLD: the lane's offset inside the G window (chunk tid of trip 0)
     auto issue = [&](int g) {
         const int64_t r0 = (int64_t)g * ROWS;
         const int4 gi = gi_c;
         const int kb = gi.x, ne = gi.y, lo = gi.z, nwin = gi.w;
+        if constexpr (BUFLD) {
+            // descriptors based at the group's first row pointer / edge / window row / x row: every offset is small, whatever
+            // the size of the arrays; elements past the arrays read zeros, elements past the group are never committed
+            auto rsrc = [](const void* base, int64_t nbytes) {
+                return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(nbytes < 0 ? 0 : (nbytes > 0x7fffff00 ? 0x7fffff00 : nbytes)), 0x00020000);
+            };
+            const int64_t rem = (int64_t)etot - kb;
+            const auto rs_rp = rsrc(p.rowptr + r0, (p.nrows + 1 - r0) * 4);
+            const auto rs_col = rsrc(p.col + kb, rem * 4);
+            const auto rs_val = rsrc(p.val + (int64_t)kb * S, rem * (S * 4));
+            const auto rs_g = rsrc(p.g + (int64_t)lo * p.ldg, (p.nrows - lo) * p.ldg * 4);
+            const auto rs_x = rsrc(p.x + r0 * p.ldx, (p.nrows - r0) * p.ldx * 4);
+            const int ldxb = (int)p.ldx * 4, ldgb = (int)p.ldg * 4;
+#pragma unroll
+            for (int q4 = 0; q4 < 2; ++q4) {
+                const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_x, row_n * ldxb + 32 * kq + 16 * q4, 0, 0);
+                xb[4 * q4] = __uint_as_float(t.x); xb[4 * q4 + 1] = __uint_as_float(t.y);
+                xb[4 * q4 + 2] = __uint_as_float(t.z); xb[4 * q4 + 3] = __uint_as_float(t.w);
+            }
+            rpv = (int)__builtin_amdgcn_raw_buffer_load_b32(rs_rp, tid * 4, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NC; ++t) cv[t] = (int)__builtin_amdgcn_raw_buffer_load_b32(rs_col, tid * 4, NT * 4 * t, 0);
+#pragma unroll
+            for (int t = 0; t < (VALG ? 0 : NE4); ++t) ev4[t] = __builtin_bit_cast(EV, __builtin_amdgcn_raw_buffer_load_b128(rs_val, tid * 16, NT * 16 * t, 0));
+#pragma unroll
+            for (int t = 0; t < NG4; ++t) gv4[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_g, voff_g, t * (NT / GC) * ldgb, 0));
+            return;
+        }
         if constexpr (XV) {
             const float* xr = p.x + min(r0 + row_n, p.nrows - 1) * p.ldx;
             const int f4max = (p.Fin + 3) / 4 * 4 - 4;
@@ -173,7 +245,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
 #pragma unroll
         for (int t = 0; t < NC; ++t) cv[t] = colb[min(kb + min(tid + NT * t, ne1), emax)];
 #pragma unroll
-        for (int t = 0; t < NE4; ++t) ev4[t] = valb[min((int64_t)kb * (S / (VW > 1 ? VW : 1)) + min(tid + NT * t, ne41), emax4)];
+        for (int t = 0; t < (VALG ? 0 : NE4); ++t) ev4[t] = valb[min((int64_t)kb * (S / (VW > 1 ? VW : 1)) + min(tid + NT * t, ne41), emax4)];
 #pragma unroll
         for (int t = 0; t < NG4; ++t) {
             const int i = tid + NT * t;
@@ -186,30 +258,14 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
         gi_nv = *reinterpret_cast<const int4*>(rec);
         row_n = reinterpret_cast<const unsigned char*>(rec + 4)[wave * 16 + r16];
     };
-    if (g0 < g1) { load_rows(g0); latch(); issue(g0); }
-    for (int g = g0; g < g1; ++g) {
-        const int64_t r0 = (int64_t)g * ROWS;
-        const int nr = (int)min((int64_t)ROWS, p.nrows - r0);
-        const int4 gi = gi_c;
+    auto commit = [&](const int4 gi, const int nr) {
         const int kb = gi.x, ne = gi.y, lo = gi.z, nwin = gi.w;
-        const int row = row_n;
-        load_rows((GML_ABL & 1) ? g0 : min(g + 1, g1 - 1));
-        __syncthreads();                                     // previous group is done with every LDS region
-        GML_T3(0);
-
-        // ---- stage: commit the registers loaded one phase ago
-        const bool rvalid = row < nr;
-        if constexpr (!XV) {
-            const float* xr = p.x + (r0 + row) * p.ldx + 8 * kq;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) xb[t] = (rvalid && 8 * kq + t < p.Fin) ? xr[t] : 0.f;
-        }
         if (tid <= nr) rp_l[tid] = rpv;
         if (vec_group(gi)) {
 #pragma unroll
             for (int t = 0; t < NC; ++t) { const int i = tid + NT * t; if (i < ne) col_l[i] = cv[t] - lo; }
 #pragma unroll
-            for (int t = 0; t < NE4; ++t) {
+            for (int t = 0; t < (VALG ? 0 : NE4); ++t) {
                 const int i = tid + NT * t;
                 if (i < ne * (S / (VW > 1 ? VW : 1))) reinterpret_cast<EV*>(ea_l)[i] = ev4[t];
             }
@@ -221,48 +277,54 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
             }
         } else {
             for (int i = tid; i < ne; i += NT) col_l[i] = p.col[kb + i] - lo;
-            for (int i = tid; i < ne * S; i += NT) ea_l[i] = p.val[(int64_t)kb * S + i];
+            if constexpr (!VALG)
+                for (int i = tid; i < ne * S; i += NT) ea_l[i] = p.val[(int64_t)kb * S + i];
             for (int i = tid; i < nwin * 16 * NOB; i += NT) {
                 const int rr = i / (16 * NOB), o = i % (16 * NOB);
                 gs[rr * LDG + o] = (o < p.Fout) ? p.g[(int64_t)(lo + rr) * p.ldg + o] : 0.f;
             }
         }
+    };
+    if (g0 < g1) { load_rows(g0); latch(); issue(g0); }
+    if constexpr (LATEC) {                                   // the first group's commit (every later one: inside the previous group)
+        if (g0 < g1) commit(gi_c, (int)min((int64_t)ROWS, p.nrows - (int64_t)g0 * ROWS));
         __syncthreads();
-        GML_T3(1);
-        // old dx values (accumulate mode): the lane's own row, features 16 fb + 4 kq .. + 3 (D rows of dX^T);
-        // DZ: the row's 4 Hadamard-branch gradients instead (one 16-byte load; dx then starts from dz . wmix)
-        f32x4 dxa[NFB];
-        f32x4 dzv = f32x4{0.f, 0.f, 0.f, 0.f};
-        const bool dxv = p.dx && p.dxvec;                    // dx rows float4-addressable (Fin % 4 == 0, aligned rows)
-        if constexpr (DZ) {
-            dzv = *reinterpret_cast<const f32x4*>(p.dz + min(r0 + row, p.nrows - 1) * 4);
-        } else {
-            const float* dxb = p.dx ? p.dx : p.x;            // (no dx wanted: any readable rows, the values are dropped)
-            const int64_t ldb = p.dx ? p.lddx : p.ldx;
-            const float* dr = dxb + min(r0 + row, p.nrows - 1) * ldb;
-            if (dxv) {
-                const int f4max = (p.Fin + 3) / 4 * 4 - 4;
+    }
+    for (int g = g0; g < g1; ++g) {
+        const int64_t r0 = (int64_t)g * ROWS;
+        const int nr = (int)min((int64_t)ROWS, p.nrows - r0);
+        const int4 gi = gi_c;
+        const int kb = gi.x, ne = gi.y, lo = gi.z, nwin = gi.w;
+        const int row = row_n;
+        load_rows((GML_ABL & 1) ? g0 : min(g + 1, g1 - 1));
+        // value rows of THIS group (VALG): one descriptor for the edge loop's loads; every 128-byte line of the group is touched now --
+        // a commit and a Z projection ahead of its first use -- so that the loop's loads find it in the L2 / L1
+        const auto vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(VALG ? p.val + (int64_t)kb * S : p.x), 0, VALG ? ne * (S * 4) : 0, 0x00020000);
+        uint32_t vtouch = 0;
+        if constexpr (VALG) vtouch = __builtin_amdgcn_raw_buffer_load_b32(vrs, tid * 128, 0, 0);
+        // (VALG: the images live in regions nothing else uses, and whoever writes them has passed this group's commit barrier, which
+        //  every wave reaches with the previous group's contraction behind it: no barrier here)
+        if constexpr (!VALG) __syncthreads();                // previous group is done with every LDS region
+        GML_T3(0);
+
+        // ---- stage: commit the registers loaded one phase ago
+        const bool rvalid = row < nr;
+        if constexpr (!XV) {
+            const float* xr = p.x + (r0 + row) * p.ldx + 8 * kq;
 #pragma unroll
-                for (int fb = 0; fb < NFB; ++fb) dxa[fb] = *reinterpret_cast<const f32x4*>(dr + min(16 * fb + 4 * kq, f4max));
-            } else {
-#pragma unroll
-                for (int fb = 0; fb < NFB; ++fb)
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) dxa[fb][reg] = dr[min(16 * fb + 4 * kq + reg, p.Fin - 1)];
-            }
+            for (int t = 0; t < 8; ++t) xb[t] = (rvalid && 8 * kq + t < p.Fin) ? xr[t] : 0.f;
         }
-
-        const int kbeg = rvalid ? rp_l[row] - kb : 0;
-        const int kend = rvalid ? rp_l[row + 1] - kb : 0;
-
+        if constexpr (!LATEC) commit(gi, nr);
         bf16x8 xh, xl;                                       // own X row, features 8*kq .. 8*kq+7: B fragment of Z^T, row of the X image
+        unsigned xpos = 0;                                   // DZ, relu_cols > 0: bit j = (x[row][8 kq + j] > 0), the relu mask of the layer below
+        f32x2 Z[S][NH], P[S][NH];
+        auto zproj = [&]() {
         if constexpr (XV) {
 #pragma unroll
             for (int j = 0; j < 8; ++j)
                 if (!(rvalid && 8 * kq + j < p.Fin)) xb[j] = 0.f;
         }
         gml_split8(xb, xh, xl);
-        unsigned xpos = 0;                                   // DZ, relu_cols > 0: bit j = (x[row][8 kq + j] > 0), the relu mask of the layer below
         if constexpr (DZ) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) xpos |= (xb[j] > 0.f ? 1u : 0u) << j;
@@ -270,7 +332,6 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
 
         // ---- Z^T = W^T X^T: MFMA row i of block ob carries o = 8*(i>>2) + 4*ob + (i&3), so lane kq receives its 8
         //      consecutive outputs o = 8*kq + 4*ob + reg.  Fragments of support s + 1 are requested before the MFMAs of s.
-        f32x2 Z[S][NH], P[S][NH];
         {
             const int oa0 = NOB == 2 ? 8 * (r16 >> 2) + (r16 & 3) : r16;   // (NOB = 1: MFMA row i = output i, lane kq receives 4 kq + reg)
             bf16x8 wh[2][NOB], wl[2][NOB];
@@ -305,7 +366,10 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
 #pragma unroll
                 for (int ob = 0; ob < NOB; ++ob) { Z[s][2 * ob] = f32x2{dd[ob][0], dd[ob][1]}; Z[s][2 * ob + 1] = f32x2{dd[ob][2], dd[ob][3]}; }
 #pragma unroll
-                for (int h = 0; h < NH; ++h) P[s][h] = f32x2{0.f, 0.f};
+                for (int h = 0; h < NH; ++h) {
+                    if constexpr (PKZ) asm volatile("v_pk_mov_b32 %0, 0, 0" : "=v"(P[s][h]));
+                    else P[s][h] = f32x2{0.f, 0.f};
+                }
             }
             __builtin_amdgcn_sched_group_barrier(0x100, 2 * NOB, 0);
 #pragma unroll
@@ -314,21 +378,58 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
                 __builtin_amdgcn_sched_group_barrier(0x008, 3 * NOB, 0);
             }
         }
+        };
+        if constexpr (ZEARLY) zproj();                       // (needs the W image and the lane's own x row only: neither is part of the commit)
+        if constexpr (!LATEC) __syncthreads();
+        GML_T3(1);
+        // old dx values (accumulate mode): the lane's own row, features 16 fb + 4 kq .. + 3 (D rows of dX^T);
+        // DZ: the row's 4 Hadamard-branch gradients instead (one 16-byte load; dx then starts from dz . wmix)
+        f32x4 dxa[NFB];
+        f32x4 dzv = f32x4{0.f, 0.f, 0.f, 0.f};
+        const bool dxv = p.dx && p.dxvec;                    // dx rows float4-addressable (Fin % 4 == 0, aligned rows)
+        if constexpr (DZ) {
+            dzv = *reinterpret_cast<const f32x4*>(p.dz + min(r0 + row, p.nrows - 1) * 4);
+        } else {
+            const float* dxb = p.dx ? p.dx : p.x;            // (no dx wanted: any readable rows, the values are dropped)
+            const int64_t ldb = p.dx ? p.lddx : p.ldx;
+            const float* dr = dxb + min(r0 + row, p.nrows - 1) * ldb;
+            if (dxv) {
+                const int f4max = (p.Fin + 3) / 4 * 4 - 4;
+#pragma unroll
+                for (int fb = 0; fb < NFB; ++fb) dxa[fb] = *reinterpret_cast<const f32x4*>(dr + min(16 * fb + 4 * kq, f4max));
+            } else {
+#pragma unroll
+                for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) dxa[fb][reg] = dr[min(16 * fb + 4 * kq + reg, p.Fin - 1)];
+            }
+        }
+
+        const int kbeg = rvalid ? rp_l[row] - kb : 0;
+        const int kend = rvalid ? rp_l[row + 1] - kb : 0;
+
+        if constexpr (!ZEARLY) zproj();
+        if constexpr (EARLYI) {
+            latch();
+            issue((GML_ABL & 1) ? g0 : min(g + 1, g1 - 1));
+        }
 
         GML_T3(2);
         // ---- edge phase (fp32 VALU, packed): P += val * G[dst],  d[s] = <Z[s], G[dst]>
         // (tried and measured slower, r02: requesting edge k + 1's value row / G row and edge k + 2's column before the
         //  arithmetic of edge k -- the rotation costs ~20 moves and two clamps per trip and pushes 16 registers into spills)
-        for (int k = kbeg; k < ((GML_ABL & 4) ? kbeg : kend); ++k) {
-            const int dstl = col_l[k];
-            float ev[S];
-            gml_load_row<S, VAL_ALIGN>(ea_l + k * S, ev);
-            f32x2 gv[NH];
+        // DIRECT: dval[kb + k][2 kq, 2 kq + 1] leaves the loop as one 8-byte store (a buffer based at the group's first value row; no
+        // dval wanted: zero records, the hardware drops the stores)
+        const auto dvrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DIRECT && p.dval ? p.dval + (int64_t)kb * S : p.x), 0,
+                                                            (DIRECT && p.dval && !(GML_ABL & 8)) ? ne * (S * 4) : 0, 0x00020000);
+        auto ldg_row = [&](int dstl, f32x2 (&gv)[NH]) {      // the lane's 4 NOB columns of the destination's G row
 #pragma unroll
-            for (int ob = 0; ob < NOB; ++ob) {               // the lane's 4 NOB columns of the destination's G row
+            for (int ob = 0; ob < NOB; ++ob) {
                 const f32x4 t0 = *reinterpret_cast<const f32x4*>(gs + dstl * LDG + 4 * NOB * kq + 4 * ob);
                 gv[2 * ob] = f32x2{t0.x, t0.y}; gv[2 * ob + 1] = f32x2{t0.z, t0.w};
             }
+        };
+        auto edge_g = [&](int k, const float (&ev)[S], const f32x2 (&gv)[NH]) {
             float d[S];
 #pragma unroll
             for (int s = 0; s < S; ++s) {
@@ -341,6 +442,20 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
                 }
                 d[s] = a2.x + a2.y;
             }
+            if constexpr (DIRECT) {                          // fold slot j of chunk c = support 2 j + c: lane kq ends with supports 2 kq, 2 kq + 1
+                float tot2[2];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const auto a01 = __builtin_amdgcn_permlane16_swap(__float_as_uint(d[c]), __float_as_uint(d[2 + c]), false, false);
+                    const auto a23 = __builtin_amdgcn_permlane16_swap(__float_as_uint(d[4 + c]), __float_as_uint(d[6 + c]), false, false);
+                    const float c01 = __uint_as_float(a01[0]) + __uint_as_float(a01[1]);
+                    const float c23 = __uint_as_float(a23[0]) + __uint_as_float(a23[1]);
+                    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(c01), __float_as_uint(c23), false, false);
+                    tot2[c] = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+                }
+                typedef uint32_t u32x2_ __attribute__((ext_vector_type(2)));
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2_{__float_as_uint(tot2[0]), __float_as_uint(tot2[1])}, dvrs, (k * S + 2 * kq) * 4, 0, 0);
+            } else {
 #pragma unroll
             for (int c = 0; c < (S + 3) / 4; ++c) {
                 const float v0 = d[4 * c], v1 = (4 * c + 1 < S) ? d[4 * c + 1] : 0.f;
@@ -352,6 +467,72 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
                 const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(c01), __float_as_uint(c23), false, false);
                 const float tot = __uint_as_float(b[0]) + __uint_as_float(b[1]);
                 if (4 * c + kq < S) ea_l[k * S + 4 * c + kq] = tot;
+            }
+            }
+        };
+        auto edge = [&](int k, const float (&ev)[S]) {
+            f32x2 gv[NH];
+            ldg_row(col_l[k], gv);
+            edge_g(k, ev, gv);
+        };
+        if constexpr (PIPE) {
+            asm volatile("" :: "v"(vtouch));
+            auto ldval = [&](int k, float (&ev)[S]) {
+                const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(vrs, k * (S * 4), 0, 0);
+                const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(vrs, k * (S * 4) + 16, 0, 0);
+                ev[0] = __uint_as_float(a.x); ev[1] = __uint_as_float(a.y); ev[2] = __uint_as_float(a.z); ev[3] = __uint_as_float(a.w);
+                ev[4] = __uint_as_float(b.x); ev[5] = __uint_as_float(b.y); ev[6] = __uint_as_float(b.z); ev[7] = __uint_as_float(b.w);
+            };
+            int k = kbeg;
+            const int klast = kend - 1;
+            if (k < ((GML_ABL & 4) ? kbeg : kend)) {
+                float eA[S], eB[S];
+                f32x2 gA[NH], gB[NH];
+                ldval(k, eA);
+                ldg_row(col_l[k], gA);
+                int cn = col_l[min(k + 1, klast)];
+                for (;;) {
+                    const int c2 = col_l[min(k + 2, klast)];
+                    ldval(min(k + 1, klast), eB);
+                    ldg_row(cn, gB);
+                    edge_g(k, eA, gA);
+                    if (++k >= kend) break;
+                    cn = col_l[min(k + 2, klast)];
+                    ldval(min(k + 1, klast), eA);
+                    ldg_row(c2, gA);
+                    edge_g(k, eB, gB);
+                    if (++k >= kend) break;
+                }
+            }
+        } else if constexpr (VALG) {
+            // two value rows in flight per lane (two register sets, no rotation): the row of edge k + 1 is requested before the
+            // arithmetic of edge k
+            asm volatile("" :: "v"(vtouch));
+            auto ldval = [&](int k, float (&ev)[S]) {
+                const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(vrs, k * (S * 4), 0, 0);
+                const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(vrs, k * (S * 4) + 16, 0, 0);
+                ev[0] = __uint_as_float(a.x); ev[1] = __uint_as_float(a.y); ev[2] = __uint_as_float(a.z); ev[3] = __uint_as_float(a.w);
+                ev[4] = __uint_as_float(b.x); ev[5] = __uint_as_float(b.y); ev[6] = __uint_as_float(b.z); ev[7] = __uint_as_float(b.w);
+            };
+            int k = kbeg;
+            const int klast = kend - 1;
+            if (k < ((GML_ABL & 4) ? kbeg : kend)) {
+                float eA[S], eB[S];
+                ldval(k, eA);
+                for (;;) {
+                    ldval(min(k + 1, klast), eB);
+                    edge(k, eA);
+                    if (++k >= kend) break;
+                    ldval(min(k + 1, klast), eA);
+                    edge(k, eB);
+                    if (++k >= kend) break;
+                }
+            }
+        } else {
+            for (int k = kbeg; k < ((GML_ABL & 4) ? kbeg : kend); ++k) {
+                float ev[S];
+                gml_load_row<S, VAL_ALIGN>(ea_l + k * S, ev);
+                edge(k, ev);
             }
         }
         GML_T3(3);
@@ -381,11 +562,39 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
             else { PH[s] = bf16x4{th[0], th[1], th[2], th[3]}; PL[s] = bf16x4{tl[0], tl[1], tl[2], tl[3]}; }
         }
         GML_T3(10);
-        latch();
-        issue((GML_ABL & 1) ? g0 : min(g + 1, g1 - 1));
+        // row-major bf16 images [position = wave*16 + r16][32 channels] of X and P for the dW contraction (see below)
+        const int pos = waveo * 16 + r16o;
+        const int woff = pos * 64 + (((kqo ^ gml_tkey3(pos)) & 3) << 4);
+        auto write_x = [&]() {
+            *reinterpret_cast<bf16x8*>(xT + woff) = xh;
+            *reinterpret_cast<bf16x8*>(xT + ROWS * 64 + woff) = xl;
+        };
+        auto write_slab = [&](int sl) {
+#pragma unroll
+            for (int se = 0; se < SS; ++se) {
+                const int s = sl * SS + se;
+                if constexpr (NOB == 2) {
+                    *reinterpret_cast<bf16x8*>(pT + se * ROWS * 64 + woff) = PH[s];
+                    *reinterpret_cast<bf16x8*>(pT + (SS + se) * ROWS * 64 + woff) = PL[s];
+                } else {                                     // compact: channel = output 4 kq + j = 8-byte piece kq of the row
+                    const int woff1 = pos * 64 + ((((kqo >> 1) ^ gml_tkey3(pos)) & 3) << 4) + ((kqo & 1) << 3);
+                    *reinterpret_cast<bf16x4*>(pT + se * ROWS * 64 + woff1) = PH[s];
+                    *reinterpret_cast<bf16x4*>(pT + (SS + se) * ROWS * 64 + woff1) = PL[s];
+                }
+            }
+        };
+        // DIRECT: nothing is left in the value rows' region behind the edge barrier -- the images of slab 0 go there now
+        if constexpr (DIRECT) {
+            if (p.dw_partial && !(GML_ABL & 2)) { write_x(); write_slab(0); }
+        }
+        const bool late_issue = PINGPONG && (waveo & 4) != 0;
+        if (!EARLYI && !late_issue) {
+            latch();
+            issue((GML_ABL & 1) ? g0 : min(g + 1, g1 - 1));
+        }
         GML_T3(8);
 
-        if (p.dval && !(GML_ABL & 8)) {
+        if (!DIRECT && p.dval && !(GML_ABL & 8)) {
             // dval += : a second launch over another slice of the input features (48-wide layers).  Not compiled into the ZINC shape
             // class (S = 8, 32 output columns: no config has 48-wide layers with 8 supports; the host refuses the flag there) -- the
             // mere presence of the branch cost that instantiation 1.5 % through its schedule (tools/ab.sh on one box, round 4)
@@ -489,14 +698,15 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
             }
         }
 
+        if (late_issue) {
+            latch();
+            issue((GML_ABL & 1) ? g0 : min(g + 1, g1 - 1));
+        }
         GML_T3(5);
         // ---- dW += X^T P over the rows of the group.  Row-major bf16 images [position = wave*16 + r16][32 channels]
         //      (a lane's 8 channels = one 16-byte chunk, XOR gml_tkey3(position)); the contraction reads them transposed.
         if (p.dw_partial && !(GML_ABL & 2)) {
-            const int pos = waveo * 16 + r16o;
-            const int woff = pos * 64 + (((kqo ^ gml_tkey3(pos)) & 3) << 4);
-            *reinterpret_cast<bf16x8*>(xT + woff) = xh;
-            *reinterpret_cast<bf16x8*>(xT + ROWS * 64 + woff) = xl;
+            if constexpr (!DIRECT) write_x();
             // transposing-read offsets of K step 0: lane (t, kq): position 8 kq + 4 h + (t >> 2), chunk 4 blk + (t & 3)
             const int tj = r16o >> 2, tc = r16o & 3;
             int roff[2][2];                                  // [h][16-wide channel block]
@@ -509,19 +719,13 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
                 }
 #pragma unroll
             for (int sl = 0; sl < C::NSLAB; ++sl) {
-                __syncthreads();                             // slab region free: the dval copy-out (sl == 0) or the
+                if (!(DIRECT && sl == 0)) {
+                    __syncthreads();                         // slab region free: the dval copy-out (sl == 0) or the
                                                              // previous slab's fragment reads are done in every wave
-#pragma unroll
-                for (int se = 0; se < SS; ++se) {
-                    const int s = sl * SS + se;
-                    if constexpr (NOB == 2) {
-                        *reinterpret_cast<bf16x8*>(pT + se * ROWS * 64 + woff) = PH[s];
-                        *reinterpret_cast<bf16x8*>(pT + (SS + se) * ROWS * 64 + woff) = PL[s];
-                    } else {                                 // compact: channel = output 4 kq + j = 8-byte piece kq of the row
-                        const int woff1 = pos * 64 + ((((kqo >> 1) ^ gml_tkey3(pos)) & 3) << 4) + ((kqo & 1) << 3);
-                        *reinterpret_cast<bf16x4*>(pT + se * ROWS * 64 + woff1) = PH[s];
-                        *reinterpret_cast<bf16x4*>(pT + (SS + se) * ROWS * 64 + woff1) = PL[s];
-                    }
+                    write_slab(sl);
+                }
+                if constexpr (LATEC) {
+                    if (sl == C::NSLAB - 1) commit(gi_c, (int)min((int64_t)ROWS, p.nrows - (int64_t)min(g + 1, g1 - 1) * ROWS));
                 }
                 __syncthreads();
                 GML_T3(11);
@@ -572,6 +776,9 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
                 }
                 GML_T3(7);
             }
+        } else if constexpr (LATEC) {
+            commit(gi_c, (int)min((int64_t)ROWS, p.nrows - (int64_t)min(g + 1, g1 - 1) * ROWS));
+            __syncthreads();
         }
     }
 
