@@ -46,7 +46,7 @@ class DenseSupports(object):
 
 
 def _library():
-    return USE_LIBRARY or Fn.F32_MFMA
+    return USE_LIBRARY or Fn.exact_mode()
 
 
 def dense_supports(edge_index2, edge_attr2, ptr, n):

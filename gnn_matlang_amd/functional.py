@@ -31,21 +31,35 @@ _linear = torch.nn.functional.linear
 F32_MFMA = _os.environ.get('GML_F32_MFMA', '0') not in ('0', '')
 
 
+import threading as _threading
+_TLS = _threading.local()
+
+
+def exact_mode():
+    """True when the launches of THIS thread run on exact f32 products: the process-wide default F32_MFMA (environment, tests,
+    bench) or an exact_products() scope of this thread.  The scope is thread-local: autograd runs a layer's backward on its own
+    worker thread, and a scope entered there (ctx.exact) must not flip the arithmetic of a forward another thread is in the
+    middle of."""
+    return bool(F32_MFMA) or getattr(_TLS, 'exact', 0) > 0
+
+
 class exact_products(object):
-    """``with exact_products():`` -- the launches inside run with F32_MFMA = True (a layer whose gradients a BatchNorm backward
-    amplifies: models.GNNML3(bn=True) runs its FIRST layer so; the layer's backward re-enters the scope through ctx.exact)."""
+    """``with exact_products():`` -- the launches of this thread inside the scope run on exact f32 products (a layer whose gradients
+    a BatchNorm backward amplifies: models.GNNML3(bn=True) runs its FIRST layer so; the layer's backward re-enters the scope through
+    ctx.exact).  Nestable; per thread."""
 
     def __init__(self, on=True):
-        self.on = on
+        self.on = bool(on)
 
     def __enter__(self):
-        global F32_MFMA
-        self.old = F32_MFMA
-        F32_MFMA = F32_MFMA or bool(self.on)
+        if self.on:
+            _TLS.exact = getattr(_TLS, 'exact', 0) + 1
 
     def __exit__(self, *a):
-        global F32_MFMA
-        F32_MFMA = self.old
+        if self.on:
+            _TLS.exact -= 1
+
+
 EDGE_VALU = _os.environ.get('GML_EDGE_VALU', '0') == '1'
 
 
@@ -179,12 +193,12 @@ def _fused_conv(rowptr, col, ginfo, epos, val, x, ldx, w, w_strides, bias, out, 
     _lib.call('gml_spectconv_fwd', _ptr(rowptr), _ptr(col), _ptr(ginfo), _ptr(epos), _ptr(val), _ptr(x), int(ldx),
               _ptr(w), int(w_strides[0]), int(w_strides[1]), int(w_strides[2]), _ptr(bias),
               _off(out, out_off), int(ldo), int(nrows), int(S), int(Fin), int(Fout),
-              int(flags) | (_lib.GML_F32_MFMA if F32_MFMA else 0), _stream(x.device))
+              int(flags) | (_lib.GML_F32_MFMA if exact_mode() else 0), _stream(x.device))
 
 
 def conv_epilogue_applies(S, Fin, Fout):
     """shape class of gml_spectconv_fwd_epi (the ring kernel's ConCat / depthwise epilogues); GML_NO_EPILOGUE=1: the mapping"""
-    return (not F32_MFMA) and S in (4, 8) and Fin <= 32 and Fout <= 32 and not _os.environ.get('GML_NO_EPILOGUE') \
+    return (not exact_mode()) and S in (4, 8) and Fin <= 32 and Fout <= 32 and not _os.environ.get('GML_NO_EPILOGUE') \
         and not _os.environ.get('GML_FWD64') and _os.environ.get('GML_FWD_DMA', '1') != '0'
 
 
@@ -216,13 +230,19 @@ FWD_CHUNKS = _os.environ.get('GML_FWD_CHUNKS', '1') not in ('0', '')
 def fwd_groups(csr, x, S, Fin, Fout):
     """(group records, extra flags) the forward kernel wants for this shape: the 8-wave kernel on 128-row records when
     the shape is compiled for it, else the 64-row kernel."""
-    flags = _lib.GML_F32_MFMA if F32_MFMA else 0
+    flags = _lib.GML_F32_MFMA if exact_mode() else 0
     if _os.environ.get('GML_FWD64'):                         # experiments: force the 4-wave / 64-row kernel family
         return csr.ginfo, 0
     rows = int(_lib.lib().gml_spectconv_fwd_group_rows(int(S), int(Fin), int(Fout), flags))
     L = _lib.lib()
-    gm_e, gm_w = csr.gmax128 if getattr(csr, 'gmax128', None) is not None else (0, 0)
+    gm_known = getattr(csr, 'gmax128', None) is not None
+    gm_e, gm_w = csr.gmax128 if gm_known else (0, 0)
     x4 = x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
+    # the chunked ring kernel (fwd4) addresses x with 32-bit byte offsets and needs the real group maxima to check its window: without
+    # either, the 64-row family (any size, global gathers where a group does not fit) -- ADVICE r04
+    small32 = (int(csr.N) + 16) * int(x.stride(0)) * 4 < 2 ** 31
+    if rows == 128 and (S == 6 or (S == 4 and Fin > 32)) and not (gm_known and small32):
+        rows = 64
     if rows == 128:
         cap = int(L.gml_spectconv_fwd_stage_edges(int(S), int(Fin), int(Fout), flags))      # edges of one work item of the ring kernel
         only4 = S == 6 or (S == 4 and Fin > 32)   # 6 supports / 48 features exist only on the chunked ring kernel: float4 rows, windows it can stage
@@ -235,7 +255,7 @@ def fwd_groups(csr, x, S, Fin, Fout):
                 onewin = _lib.GML_FWD_ONEWIN if (Fin > 32 and _os.environ.get('GML_FWD_ONEWIN', '1') != '0') else 0
                 _path('conv_fwd', 'fused 8-wave bf16x3, edge chunks%s' % (', one X window' if onewin else ''), S, Fin, Fout)
                 return csr.ginfo128, _lib.GML_GROUPS128 | onewin
-        elif cap > 0 and gm_e > cap and FWD_CHUNKS and x4:
+        elif cap > 0 and gm_e > cap and FWD_CHUNKS and x4 and small32:
             # a group beyond what the default ring kernel stages at once: its chunked form instead of global gathers
             win = int(L.gml_spectconv_fwd_stage_window(int(S), int(Fin), int(Fout), flags | _lib.GML_FWD_CHUNKED))
             if gm_w <= win:
@@ -250,7 +270,7 @@ def fwd_groups(csr, x, S, Fin, Fout):
             return csr.ranked64()[0], _lib.GML_GROUPS64R
         _path('conv_fwd', 'fused 8-wave bf16x3', S, Fin, Fout)
         return csr.ginfo128, _lib.GML_GROUPS128
-    _path('conv_fwd', 'fused 4-wave (%s)' % ('f32 MFMA' if (F32_MFMA or Fin <= 16 or Fout > 32) else 'bf16x3'), S, Fin, Fout)
+    _path('conv_fwd', 'fused 4-wave (%s)' % ('f32 MFMA' if (exact_mode() or Fin <= 16 or Fout > 32) else 'bf16x3'), S, Fin, Fout)
     return csr.ginfo, 0
 
 
@@ -259,7 +279,7 @@ def fwd_gathers(S, Fin, Fout):
     (GML_EDGE_DUAL=1 keeps the round-1 scheme -- edge branch in target order, second copy scattered -- for A/B)."""
     if _os.environ.get('GML_FWD64') or _os.environ.get('GML_EDGE_DUAL'):
         return False
-    flags = _lib.GML_F32_MFMA if F32_MFMA else 0
+    flags = _lib.GML_F32_MFMA if exact_mode() else 0
     return int(_lib.lib().gml_spectconv_fwd_group_rows(int(S), int(Fin), int(Fout), flags)) in (128, _lib.GML_GROUPS64_RANKED)
 
 
@@ -533,6 +553,22 @@ def segment_bcast(g, ptr, nrows, mean=False):
     return out
 
 
+_SKIP_LAST_MASK = {}
+
+
+def skip_last_mask(g):
+    """[B, 1] ones with a zero in the last row (cached per (B, device)): the pooled gradient of a batch whose last segment is
+    the padding graph of a static-shape batch (GML_POOL_SKIP_LAST) -- the forward writes that row as zeros WITHOUT reading the
+    padding nodes, so nothing may flow back to them whatever the head or the loss does with the row."""
+    key = (int(g.size(0)), g.device)
+    m = _SKIP_LAST_MASK.get(key)
+    if m is None:
+        m = torch.ones(g.size(0), 1, dtype=g.dtype, device=g.device)
+        m[-1] = 0
+        _SKIP_LAST_MASK[key] = m
+    return m
+
+
 def segment_sum(x, ptr, mean=False):
     """global_add_pool / global_mean_pool over a batch whose nodes are grouped per graph (ptr [B+1] int32).  mean: bool, or the
     flag word of gml_segment_sum (bit 0 mean, bit 1 = _lib.GML_POOL_SKIP_LAST: the last segment is the padding graph of a
@@ -566,7 +602,7 @@ def segment_max_bwd(g, ptr, arg, nrows):
 def _bwd_plan(csr, S, Fin, Fout):
     """(flags, ginfo, (max_edges, max_window), workspace bytes) of the fused backward for this shape, or None."""
     L = _lib.lib()
-    for flags in ((_lib.GML_F32_MFMA,) if F32_MFMA else (0, _lib.GML_F32_MFMA)):
+    for flags in ((_lib.GML_F32_MFMA,) if exact_mode() else (0, _lib.GML_F32_MFMA)):
         rows = int(L.gml_spectconv_bwd_group_rows(int(S), int(Fin), int(Fout), flags))
         if rows == 0:
             continue
@@ -641,7 +677,7 @@ def split48_plan(csr, S, Fin, Fout):
     compiled for Fin <= 32: two launches over the feature slices [0, 32) and [32, Fin).  dX and dW split by input feature; dval is
     linear in x, so the second launch adds its share (GML_DVAL_ACCUM).  The edge loop runs twice -- still ~2 x faster than the
     64-row f32-MFMA kernel these layers ran on (tools/bench_configs.py).  Returns the two plans or None."""
-    if F32_MFMA or _os.environ.get('GML_NO_SPLIT48') or not (32 < Fin <= 48) or (Fin - 32) % 4 != 0 or (S == 8 and Fout > 16):   # (S = 8, 32 columns: no dval += in that kernel)
+    if exact_mode() or _os.environ.get('GML_NO_SPLIT48') or not (32 < Fin <= 48) or (Fin - 32) % 4 != 0 or (S == 8 and Fout > 16):   # (S = 8, 32 columns: no dval += in that kernel)
         return None
     pa, pb = _bwd_plan(csr, S, 32, Fout), _bwd_plan(csr, S, Fin - 32, Fout)
     if pa is None or pb is None or pa[4] != 128 or pb[4] != 128 or (pa[0] | pb[0]) & _lib.GML_F32_MFMA:
@@ -751,7 +787,7 @@ class SpectConvFunction(torch.autograd.Function):
             fused_conv(csr.rowptr, csr.col, gi, None, val, x, int(x.stride(0)), weight, (Fin * Fout, Fout, 1), bias, out,
                        Fout, csr.N, S, Fin, Fout, (_lib.GML_RELU if relu else 0) | gflag)
         ctx.csr, ctx.relu, ctx.has_bias = csr, relu, bias is not None
-        ctx.exact = bool(F32_MFMA)
+        ctx.exact = bool(exact_mode())
         ctx.save_for_backward(x, val, weight, out if relu else None)
         return out
 
@@ -875,12 +911,12 @@ class ML3LayerFunction(torch.autograd.Function):
                           Fin * nout1, nout1, 1, _ptr(cb_), _ptr(w11 if mixk else None),
                           _ptr(b11 if mixk else None), _ptr(w12 if mixk else None),
                           _ptr(b12 if mixk else None), _ptr(out), C, N, S, Fin, nout1, int(nout2) if mixk else 0,
-                          _lib.GML_RELU | gflag | (_lib.GML_F32_MFMA if F32_MFMA else 0), _stream(x.device))
+                          _lib.GML_RELU | gflag | (_lib.GML_F32_MFMA if exact_mode() else 0), _stream(x.device))
             if nout2 > 0 and not mixk:
                 # ninp > 64 or nout2 > 24 (ptc.py:331-338 has ninp = 80): two plain library GEMMs + elementwise
                 out[:, nout1:] = torch.tanh(_linear(x, w11, b11)) * torch.tanh(_linear(x, w12, b12))
         ctx.csr, ctx.learnedge, ctx.nout2, ctx.has_cb = csr, learnedge, nout2, cb is not None
-        ctx.exact = bool(F32_MFMA)
+        ctx.exact = bool(exact_mode())
         ctx.src_order = epos is not None
         ctx.val_is_source = bool(val_is_source)
         ctx.pool = (pool_ptr, pool_seg, int(pool_mean)) if pool_ptr is not None else None     # bit 0 mean, bit 1 GML_POOL_SKIP_LAST
@@ -888,7 +924,10 @@ class ML3LayerFunction(torch.autograd.Function):
         ctx.chain_out = chain_out if (CHAIN and ctx.pool is None) else None
         ctx.save_for_backward(x, val, (ea if learnedge and epos is None else None), w1, w2, w3, w4, cw, w11, b11, w12, b12, out, ea_t)
         if ctx.pool is not None:
-            return segment_sum(out, pool_ptr, pool_mean)
+            pooled = segment_sum(out, pool_ptr, pool_mean)
+            if int(pool_mean) & 2:
+                skip_last_mask(pooled)                         # (created outside any later graph capture of the backward)
+            return pooled
         return out
 
     @staticmethod
@@ -910,6 +949,8 @@ class ML3LayerFunction(torch.autograd.Function):
         gy_seg = None
         if ctx.pool is not None:                               # gy is the POOLED gradient [B, C]
             pptr, pseg, pmean = ctx.pool
+            if pmean & 2:                                      # GML_POOL_SKIP_LAST: the padding graph's pooled row was written, not computed
+                gy = gy * skip_last_mask(gy)
             pmean &= 1
             mixk_ = nout2 > 0 and node_mix_native(Fin, nout2)
             nb_ = int(_lib.lib().gml_ml3_split_bwd_workspace_bytes(int(N), Fin if mixk_ else 0, int(nout1), int(nout2) if mixk_ else 0))

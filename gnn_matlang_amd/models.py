@@ -9,7 +9,7 @@ edge_index2, edge_attr2, batch, ptr, y).
 import torch
 import torch.nn.functional as F
 
-from .functional import segment_bcast, segment_max, segment_max_bwd, segment_sum, tall_linear, _ptr32
+from .functional import segment_bcast, segment_max, segment_max_bwd, segment_sum, skip_last_mask, tall_linear, _ptr32
 from .spect_conv import ML3Layer, SpectConv
 from .dist import SyncBatchNorm1d
 
@@ -22,7 +22,8 @@ class BatchNorm1d(torch.nn.BatchNorm1d):
     def forward(self, x):
         import os
         if not (self.training or self.running_mean is None) or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 2 \
-                or x.size(1) > 64 or x.size(1) % 4 or x.stride(1) != 1 or x.stride(0) % 4 or x.data_ptr() % 16 or x.size(0) < 2 \
+                or x.size(1) > 64 or x.size(1) % 4 or x.stride(1) != 1 or x.stride(0) % 4 or x.stride(0) < x.size(1) or x.data_ptr() % 16 \
+                or x.size(0) < 2 \
                 or os.environ.get('GML_TORCH_BN'):
             return super().forward(x)
         from .functional import BatchNormFunction
@@ -44,12 +45,18 @@ class _SegmentPool(torch.autograd.Function):
     def forward(ctx, x, ptr, batch, mean):
         ctx.save_for_backward(ptr, batch)
         ctx.mean = mean
-        return segment_sum(x.contiguous(), ptr, mean)
+        out = segment_sum(x.contiguous(), ptr, mean)
+        if int(mean) & 2:
+            skip_last_mask(out)
+        return out
 
     @staticmethod
     def backward(ctx, g):
         ptr, batch = ctx.saved_tensors
-        return segment_bcast(g.contiguous(), ptr, batch.numel(), bool(int(ctx.mean) & 1)), None, None, None
+        g = g.contiguous()
+        if int(ctx.mean) & 2:          # GML_POOL_SKIP_LAST: the padding graph's row does not depend on x -- no gradient to its nodes
+            g = g * skip_last_mask(g)
+        return segment_bcast(g, ptr, batch.numel(), bool(int(ctx.mean) & 1)), None, None, None
 
 
 class _SegmentMax(torch.autograd.Function):
@@ -126,6 +133,10 @@ class GNNML3(torch.nn.Module):
 
     def forward(self, data):
         x = data.x
+        if getattr(data, 'pad_graph', False) and self.training and (self.bn or self.readout_bn):
+            # the padding nodes / the padding graph's pooled row would enter the batch statistics
+            raise NotImplementedError('BatchNorm models take plain batches: a padded static batch (pad_graph) would count its padding '
+                                      'rows in the statistics')
         if self.dense_n:
             from .dense_block import dense_supports, spectconv_dense, _library
             sp = getattr(data, '_spT', None)                    # per-batch data, like the CSR

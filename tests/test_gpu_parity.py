@@ -924,6 +924,41 @@ def test_padded_static_batch_equals_plain_batch(dev):
         close(gp[n], p.grad, tol=2e-5, what='padded vs plain grad ' + n)
 
 
+@pytest.mark.parametrize('fused_pool', [True, False])
+def test_padded_batch_loss_that_touches_the_padding_row(dev, monkeypatch, fused_pool):
+    """the padding graph's pooled row is WRITTEN as zeros (GML_POOL_SKIP_LAST), so it does not depend on x -- a loss that
+    gives that row a gradient (here: every pooled row, the padding graph's included) must not send anything back to the padding
+    nodes, whose features are relu(bias) != 0 after the first layer.  Both backward roads: the pool fused into the last layer
+    (un-expanded gradient) and the stand-alone _SegmentPool."""
+    from gnn_matlang_amd import SpectralDesign, models, synthetic
+    from gnn_matlang_amd.dataset import DeviceDataset
+    if not fused_pool:
+        monkeypatch.setenv('GML_NO_POOL_FUSE', '1')
+    raw = synthetic.make_graphs('zinc', 40, seed=8)
+    dsd = DeviceDataset.from_graphs(SpectralDesign(recfield=2, dv=2, nfreq=7).design_many(raw), dev)
+    bd = dsd.bounds(8)
+    ids = torch.tensor([5, 33, 0, 17, 21, 40, 40, 40], device=dev)
+    torch.manual_seed(1)
+    m = models.zinc_gnnml3().to(dev)
+    with torch.no_grad():
+        for i in range(1, 5):
+            getattr(m, 'conv%d' % i).conv1.bias.fill_(0.3)          # padding nodes carry relu(bias) > 0 from layer 1 on
+    bp = dsd.batch_padded(ids, bd)
+    pre = m(bp)                                                   # [8 + 1, 1]: the last row belongs to the padding graph
+    assert pre.size(0) == 9
+    lp = (pre[:8, 0] * bp.graph_valid).sum() + 7.0 * pre[8, 0]    # the padding row enters the loss with a non-zero gradient
+    lp.backward()
+    gp = {n: p.grad.clone() for n, p in m.named_parameters()}
+    m.zero_grad()
+    b = dsd.batch(ids[:5])
+    l = m(b)[:, 0].sum()
+    l.backward()
+    for n, p in m.named_parameters():
+        if n.startswith('fc'):
+            continue                                              # the head does see the (constant) padding row
+        close(gp[n], p.grad, tol=2e-5, what='padded (loss touches the padding row) vs plain grad ' + n)
+
+
 @pytest.mark.parametrize('ids', [[5, 33, 0, 17, 21, 40, 40, 40], [39, 38, 37, 36, 35, 34, 33, 32], [40] * 8, [7, 40, 7, 7, 40, 3, 3, 7]])
 def test_assembled_batch_is_bit_identical_to_the_padded_batch_and_its_index(dev, ids):
     """dataset.DeviceDataset.batch_assembled (csrc/gml_csr.hip gml_batch_assemble: one launch from the per-graph structure
