@@ -151,6 +151,37 @@ def cpu_oracle_rate(host_batch, nsteps, warm, threads):
                 ms_per_step=med * 1e3)
 
 
+def parity_vs_oracle(model, data, base, log):
+    """one forward + backward of the bench's own batch in each arithmetic mode against the float64 oracle (checker leg)."""
+    import torch
+    from gnn_matlang_amd import functional as Fn, models
+    from oracle import parity_at_size as PS
+    host = base.to(torch.device('cpu'))
+    torch.cuda.synchronize()
+    out = dict(graphs=int(data.num_graphs), pool_graphs=int(base.num_graphs), tolerance=1e-4,
+               criterion='|got - ref| <= 1e-4 * T per element; T = sum of |terms| at product level (oracle/termsums.py), ref = oracle in float64',
+               modes={})
+    T = None
+    for mode in ('bf16x3', 'f32'):
+        for p_ in model.parameters():
+            p_.grad = None
+        with Fn.exact_products(mode == 'f32'):
+            pre = model(data)
+            models.zinc_loss(pre, data.y).backward()
+        ref = PS.reference(host, model.state_dict(), data.y, pre_dev=pre[:, 0], T=T)
+        T = ref['T']
+        rep = PS.compare(ref, pre[:, 0].detach().cpu().numpy(), {n: p_.grad.detach().cpu().numpy() for n, p_ in model.named_parameters()})
+        worst = max(rep['tensors'].items(), key=lambda kv: kv[1]['termsum'])
+        out['modes'][mode] = dict(logits_rel_err=rep['logits_rel_err'], max_rel_err_termsum=rep['worst_termsum'],
+                                  max_rel_err_maxnorm=rep['worst_maxnorm'], worst_tensor=worst[0], ok=rep['ok'],
+                                  oracle_seconds=round(ref['seconds'], 2))
+        log('parity at bench size, %s: logits %.2e, gradients %.2e of their term sums (worst: %s), %s' % (
+            mode, rep['logits_rel_err'], rep['worst_termsum'], worst[0], 'ok' if rep['ok'] else 'BEYOND 1e-4'))
+    for p_ in model.parameters():
+        p_.grad = None
+    return out
+
+
 def cpu_baseline(cpu_graphs, log):
     """the oracle at the reference batch size (64) and at a large batch, >= 5 warm-up + >= 20 timed steps,
     median; the thread count is chosen by a short ladder up to os.cpu_count() (ATen's intra-op threading of these
@@ -250,6 +281,11 @@ def main():
     broadcast_parameters(model)
     sync = FlatGradSync(model.parameters())
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)    # same update rule (Zinc12k.py:349), one multi-tensor kernel
+    parity0 = None
+    if world == 1 and not args.no_cpu and base is not None and data.num_graphs % base.num_graphs == 0:
+        log('parity check at the initial parameters')
+        parity0 = parity_vs_oracle(model, data, base, log)
+        parity0['state'] = 'initial parameters (seed 0)'
 
     def step(d=None):
         d = data if d is None else d
@@ -423,8 +459,20 @@ def main():
             res['roofline_step'] = dict(bound='hbm', algorithmic_bytes_per_step=qstep, ms_per_step=ms,
                                         achieved=qstep / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s',
                                         frac=qstep / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
-            log('roofline: dominant kernel %s at %.3f of the HBM roof (%.3f ms/launch); whole step %.3f' % (
-                cands[0]['kernel'].split(' ')[0], cands[0]['frac'], cands[0]['avg_launch_ms'], res['roofline_step']['frac']))
+            # the same step against its COMPULSORY bytes: SURVEY s8(d)'s fusion-agnostic Q_fwd + Q_bwd of the four
+            # SpectConv layers alone -- what a step would move if the edge branch's output never touched HBM (it is written once and
+            # re-read by each conv forward / backward and by the edge backward today) and pooling, head, loss and Adam were free
+            csr_ = data.csr('edge_index2')
+            S_c, widths = int(data.edge_attr2.size(1)), [(int(data.x.size(1)), 30)] + [(32, 30)] * 3      # Zinc12k.py:323-329
+            qc = sum(Fn.conv_cost(csr_.N, csr_.E, S_c, fi, fo)[0] + Fn.conv_cost_bwd(csr_.N, csr_.E, S_c, fi, fo, need_x=li > 0)[0]
+                     for li, (fi, fo) in enumerate(widths))
+            res['roofline_step_compulsory'] = dict(bound='hbm', algorithmic_bytes_per_step=qc, ms_per_step=ms,
+                                                   achieved=qc / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s',
+                                                   frac=qc / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                   note='sum over the 4 layers of SURVEY s8(d) Q_fwd + Q_bwd (fusion-agnostic: no ea\' traffic)')
+            log('roofline: dominant kernel %s at %.3f of the HBM roof (%.3f ms/launch); whole step %.3f (launched bytes), %.3f (compulsory bytes)' % (
+                cands[0]['kernel'].split(' ')[0], cands[0]['frac'], cands[0]['avg_launch_ms'], res['roofline_step']['frac'],
+                res['roofline_step_compulsory']['frac']))
         if world == 1 and not args.no_profile:
             # calibration: what torch's device-to-device copy reaches on THIS box (read + write bytes / time) -- a
             # reference point, not a ceiling (MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy kernel); the
@@ -712,6 +760,18 @@ def main():
                 log('epoch at batch %d, captured: %.3f s for %d graphs (%.3f ms/step)' % (Bq, dt3, G_, dt3 / nb3 * 1e3))
         if world == 1 and not args.no_cpu:
             res['cpu_baseline'] = cpu_baseline(args.cpu_graphs, log)
+            if base is not None and data.num_graphs % base.num_graphs == 0:
+                # ---- checker leg (the oracle as the CHECKER, never the thing measured): the headline batch, one step per arithmetic
+                # mode, logits and every parameter gradient against the oracle in float64 under the term-sum criterion
+                # (oracle/parity_at_size.py; the same check as tests/test_gpu_parity.py::test_bench_size_train_step_vs_fp64_oracle)
+                res['parity_vs_oracle'] = parity_vs_oracle(model, data, base, log)
+                res['parity_vs_oracle']['state'] = 'parameters after the timed steps of this run'
+                if parity0 is not None:
+                    res['parity_vs_oracle_at_init'] = parity0
+                # per mode: worst element of any parameter gradient relative to its layer-local term sum (inputs of the layer taken as
+                # exact: the strict form), at the parameters this run ended with; logits relative to max |logit|
+                res['max_rel_err_vs_oracle'] = {k: dict(gradients_termsum=v['max_rel_err_termsum'], logits=v['logits_rel_err'])
+                                                for k, v in res['parity_vs_oracle']['modes'].items()}
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

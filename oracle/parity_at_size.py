@@ -1,0 +1,127 @@
+"""Parity of one ZINC GNNML3 train step AT BENCH SIZE against the oracle in float64 (TEST INFRASTRUCTURE, see oracle/__init__.py;
+used by tests/test_gpu_parity.py and by the checker leg of bench.py -- never by the package).
+
+The bench's batch (bench.build_batch) tiles a pool of P distinct graphs R times and gives every copy its own target y.  Graphs
+are independent (block-diagonal batch, per-graph pooling; Zinc12k.py:338-343), so in exact arithmetic
+
+    logit(copy r of graph g)            = pre_g                                   (the same for every copy)
+    d loss / d theta over the big batch = sum_g c_g d pre_g / d theta,   c_g = sum_r sign(pre_g - y[r, g])      (L1-sum loss, :365)
+
+and ONE float64 forward + backward of the oracle over the P pool graphs is the exact reference for all B = P R graphs.
+
+The criterion for a parameter gradient is the term-sum one: |got - ref| <= tol * T, T = the sum of the
+absolute values of the TERMS the element is a sum of -- at the level of the products the kernels actually form (a conv weight
+gradient is X^T (A_s G): 3 M rows x ~6 edges of |x| |val| |g| products per element), propagated through each ML3Layer by
+oracle/termsums.py from the float64 activations and the float64 gradient at the layer's output; every copy of a graph contributes
+the same magnitudes, so T(batch) = R * T(pool).  The head's two Linear layers: T_W = |g|^T |input|, T_b = sum |g|.
+(Round 5 first tried T from whole-graph contributions -- one float64 backward pass per pool graph: slow, and blind to the
+cancellation INSIDE a graph, which is where most of a conv weight gradient's terms cancel: the elements that failed under it
+sit at 2e-5 of their tensor's maximum.)
+"""
+import time
+
+import numpy as np
+import torch
+
+from . import models_oracle as MO
+from .termsums import ml3_termsums
+
+
+def reference(pool_batch, state_dict, y_full, pre_dev=None, T=None, threads=16):
+    """pool_batch: the collated pool (CPU tensors x, edge_index2, edge_attr2, batch, num_graphs); state_dict: the model's
+    parameters (any device); y_full [R * P] targets in the bench's order (copy-major); pre_dev [R * P]: the device's own logits -- the
+    L1 loss's sign(pre - y) is then taken from THEM (a copy whose |pre - y| is below the logits' round-off would otherwise flip the
+    sign of its whole contribution: a property of the loss, not an error of the backward); T: term sums of an earlier call with the
+    same parameters and pool (they do not depend on the arithmetic mode).  Returns dict(pre [P] float64, grads {name: float64
+    array}, T {name: float64 array}, seconds)."""
+    t0 = time.perf_counter()
+    torch.set_num_threads(min(int(threads), torch.get_num_threads()))   # (tiny float64 ops: hundreds of threads only contend)
+    b = pool_batch
+    P = int(b.num_graphs)
+    R = int(y_full.numel()) // P
+    m = MO.zinc_gnnml3(int(b.x.size(1)), int(b.edge_attr2.size(1))).double()
+    m.load_state_dict({k: v.detach().cpu().double() for k, v in state_dict.items()})
+    pre = m(b.x.double(), b.edge_index2, b.edge_attr2.double(), b.batch, P)[:, 0]            # [P]
+    y = y_full.detach().cpu().double().view(R, P)
+    pd = pre.detach().unsqueeze(0) if pre_dev is None else pre_dev.detach().cpu().double().view(R, P)
+    c = torch.sign(pd - y).sum(0)                                                             # [P]
+    params = dict(m.named_parameters())
+    names = list(params)
+    g = torch.autograd.grad((c * pre).sum(), [params[n] for n in names], retain_graph=True)
+    grads = {n: v.numpy() for n, v in zip(names, g)}
+    if T is None:
+        T = model_termsums(m, b, P, R)
+    return dict(pre=pre.detach().numpy(), grads=grads, T=T, R=R, P=P, seconds=time.perf_counter() - t0)
+
+
+def model_termsums(m, b, P, R):
+    """Term sums of every parameter gradient of the float64 oracle model `m` over the pool batch `b`, for the UNSIGNED loss
+    sum_g pre_g (the copies' signs only flip terms), times R copies.  Two sweeps: forward, carrying the term sums of the
+    activations from layer to layer (pool, head included); backward, carrying the term sums of the gradients -- so a layer's
+    T accounts for the round-off its inputs arrive with, not only for its own products."""
+    acts, hooks = {}, []
+    for i in range(1, m.nlayers + 1):
+        lay = getattr(m, 'conv%d' % i)
+        hooks.append(lay.register_forward_hook(lambda mod, inp, out, i=i: acts.__setitem__(i, (inp[0], out))))
+    hooks.append(m.fc1.register_forward_hook(lambda mod, inp, out: acts.__setitem__('fc1', (inp[0], out))))
+    hooks.append(m.fc2.register_forward_hook(lambda mod, inp, out: acts.__setitem__('fc2', (inp[0], out))))
+    pre1 = m(b.x.double(), b.edge_index2, b.edge_attr2.double(), b.batch, P)[:, 0]
+    for h in hooks:
+        h.remove()
+    keys = list(acts)
+    gouts = dict(zip(keys, torch.autograd.grad(pre1.sum(), [acts[k][1] for k in keys])))
+    ea64, ei = b.edge_attr2.double(), b.edge_index2
+    S = int(ea64.size(1))
+    metas, params = {}, {}
+    for k in range(1, m.nlayers + 1):
+        lay = getattr(m, 'conv%d' % k)
+        params[k] = {n: v.detach() for n, v in lay.named_parameters()}
+        nout2 = int(params[k]['fc11.weight'].size(0)) if 'fc11.weight' in params[k] else 0
+        metas[k] = (1, S, S, int(acts[k][0].size(1)), int(params[k]['conv1.weight'].size(2)), nout2)
+    # ---- forward sweep: T of every layer's output given T of its input (the batch's x is data: T = |x|)
+    Tx = {1: acts[1][0].detach().abs()}
+    for k in range(1, m.nlayers + 1):
+        ts = ml3_termsums(metas[k], acts[k][0].detach(), ea64, ei, gouts[k].detach(), params[k], Tx=Tx[k])
+        Tx[k + 1] = torch.from_numpy(ts['out'])
+    Tpool = torch.zeros(P, Tx[m.nlayers + 1].size(1), dtype=torch.float64).index_add_(0, b.batch, Tx[m.nlayers + 1])
+    W1, b1, W2 = m.fc1.weight.detach(), m.fc1.bias.detach(), m.fc2.weight.detach()
+    mh = (acts['fc1'][1].detach() > 0).double()
+    Th = (Tpool @ W1.abs().t() + b1.abs()) * mh                  # relu(fc1 pooled)
+    # ---- backward sweep: the gradient at `pre` is exactly 1 per graph (and +-1 per copy)
+    T = {}
+    Tg_pre = torch.ones(P, 1, dtype=torch.float64)
+    T['fc2.weight'] = (Tg_pre.t() @ Th).numpy() * float(R)
+    T['fc2.bias'] = Tg_pre.sum(0).numpy() * float(R)
+    Tg_h = (Tg_pre @ W2.abs()) * mh
+    T['fc1.weight'] = (Tg_h.t() @ Tpool).numpy() * float(R)
+    T['fc1.bias'] = Tg_h.sum(0).numpy() * float(R)
+    Tg = (Tg_h @ W1.abs())[b.batch]                              # pooled gradient broadcast to the nodes of the last layer's output
+    for k in range(m.nlayers, 0, -1):
+        ts = ml3_termsums(metas[k], acts[k][0].detach(), ea64, ei, gouts[k].detach(), params[k], Tx=Tx[k], Tg=Tg)
+        for n in params[k]:
+            T['conv%d.%s' % (k, n)] = ts[n] * float(R)
+        Tg = torch.from_numpy(ts['g_x'])
+    return T
+
+
+def compare(ref, pre_dev, grads_dev, tol=1e-4):
+    """pre_dev [R * P] logits and {name: gradient} of the device step.  Returns a report: the worst |err| / (tol-free) scale per
+    tensor under both criteria -- `termsum`: max |err| / T (must stay <= tol), `maxnorm`: max |err| / max |ref| -- and the logits'
+    worst error relative to max |pre|."""
+    R, P = ref['R'], ref['P']
+    pre = np.asarray(pre_dev, dtype=np.float64).reshape(R, P)
+    e_pre = float(np.abs(pre - ref['pre'][None, :]).max() / max(np.abs(ref['pre']).max(), 1e-300))
+    rep = dict(logits_rel_err=e_pre, tensors={}, worst_termsum=0.0, worst_maxnorm=0.0)
+    for n, gr in ref['grads'].items():
+        got = np.asarray(grads_dev[n], dtype=np.float64).reshape(gr.shape)
+        err = np.abs(got - gr)
+        # sum |terms| >= |sum terms|: where the sub-pool saw no term at all (a rare input feature, a unit dead on those graphs) the
+        # element is held to 1e-4 of its own value; elements that are zero in the reference must be zero to 1e-12 of the tensor
+        floor = 1e-12 * max(float(np.abs(gr).max()), 1e-300)
+        ts = float((err / np.maximum(np.maximum(ref['T'][n], np.abs(gr)), floor)).max())
+        mn = float(err.max() / max(float(np.abs(gr).max()), 1e-300))
+        rep['tensors'][n] = dict(termsum=ts, maxnorm=mn)
+        rep['worst_termsum'] = max(rep['worst_termsum'], ts)
+        rep['worst_maxnorm'] = max(rep['worst_maxnorm'], mn)
+    rep['ok'] = bool(rep['worst_termsum'] <= tol and e_pre <= tol)
+    return rep
