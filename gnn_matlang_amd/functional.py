@@ -342,6 +342,42 @@ def _edge_mlp_pad(ea, w1, w2, w3, w4):
     return torch.nn.functional.pad(ea, (0, P - S)), pad_in(w1), pad_in(w2), pad_in(w3), w4p, P
 
 
+def _edge_branch_torch(ea, w1, w2, w3, w4):
+    """libs/spect_conv.py:205-207 as library calls (fc1_4 on the two halves of its input: no [E, 4S] concatenation)."""
+    h1, h23 = torch.relu(_linear(ea, w1)), torch.tanh(_linear(ea, w2)) * torch.tanh(_linear(ea, w3))
+    return torch.relu(torch.addmm(h1 @ w4[:, :h1.size(1)].t(), h23, w4[:, h1.size(1):].t()))
+
+
+class EdgeBranchWide(torch.autograd.Function):
+    """ML3Layer edge branch for 16 < max(S, Sout) <= 48: forward = ONE launch (gml_edge_mlp_wide_fwd: weights in LDS, exact fp32
+    products, no intermediate in HBM -- the library road writes ~30 GB of them at S = 48 on 13 M edges); backward = the library
+    expression recomputed under autograd (no reference script trains more than 12 supports)."""
+
+    @staticmethod
+    def forward(ctx, ea, w1, w2, w3, w4):
+        ea = _f32c(ea, 'edge_attr')
+        ws = [_f32c(w.detach(), 'edge weight') for w in (w1, w2, w3, w4)]
+        E, S = ea.shape
+        So = int(w4.size(0))
+        out = torch.empty(E, So, dtype=torch.float32, device=ea.device)
+        with torch.cuda.device(ea.device):
+            _lib.call('gml_edge_mlp_wide_fwd', _ptr(ea), _ptr(ws[0]), _ptr(ws[1]), _ptr(ws[2]), _ptr(ws[3]), _ptr(out), int(E), int(S), So,
+                      _stream(ea.device))
+        ctx.save_for_backward(ea, w1, w2, w3, w4)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ea, w1, w2, w3, w4 = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        with torch.enable_grad():
+            ins = [t.detach().requires_grad_(n) for t, n in zip((ea, w1, w2, w3, w4), need)]
+            out = _edge_branch_torch(*ins)
+            wanted = [t for t, n in zip(ins, need) if n]
+            gs = iter(torch.autograd.grad(out, wanted, g) if wanted else ())
+        return tuple(next(gs) if n else None for n in need)
+
+
 def edge_mlp_fwd(ea, w1, w2, w3, w4, tpos=None, ea_split=None):
     """returns out (same edge order as ea) and, when tpos is given, the same rows at out_t[tpos[e]]."""
     E, S = ea.shape

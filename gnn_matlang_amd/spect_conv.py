@@ -12,6 +12,7 @@ row keeps the reference's edge order; the projection is accumulated in a differe
 required (only ``aggr='add'``, ``flow='source_to_target'``, ``node_dim=0`` exist in the reference).
 """
 import math
+import os
 
 import weakref
 
@@ -346,15 +347,20 @@ class ML3Layer(torch.nn.Module):
             # more than 16 supports (no script goes beyond counting.py's 12; the sr25 sweep of SURVEY s8d raises nfreq to 47):
             # the edge branch as four library GEMMs + elementwise under autograd (libs/spect_conv.py:205-207), the node branch on
             # the fused kernels with the learned supports as its (differentiable) values
-            Fn._path('edge', 'library GEMMs (more than 16 supports)', self.fc1_1.weight.size(1), '-', self.fc1_4.weight.size(0))
             _require_cuda(edge_attr, 'edge_attr')
             ea = edge_attr.to(torch.float32)
-            # fc1_4 applied to the two halves of its input separately: the concatenation of libs/spect_conv.py:205 is never
-            # materialised (at S = 48 it is a 2.5e9-element tensor: torch.cat alone took 83 ms of the layer's 90 on 13 M edges)
-            h1, h23 = torch.relu(self.fc1_1(ea)), torch.tanh(self.fc1_2(ea)) * torch.tanh(self.fc1_3(ea))
-            w4 = self.fc1_4.weight
-            out4 = torch.addmm(h1 @ w4[:, :h1.size(1)].t(), h23, w4[:, h1.size(1):].t())
-            val = _sorted_values(csr, edge_index, torch.relu(out4), self.conv1.weight.size(0))
+            wide = max(self.fc1_1.weight.size(1), self.fc1_4.weight.size(0)) <= 48 and ea.size(1) == self.fc1_1.weight.size(1) \
+                and not os.environ.get('GML_EDGE_WIDE_LIB')
+            Fn._path('edge', 'one-launch kernel for 17..48 supports' if wide else 'library GEMMs (more than 48 supports)',
+                     self.fc1_1.weight.size(1), '-', self.fc1_4.weight.size(0))
+            if wide:
+                # round 5: gml_edge_mlp_wide_fwd (csrc/gml_edge_wide.hip) -- one launch, weights in LDS, nothing but e and out in HBM
+                ev = Fn.EdgeBranchWide.apply(ea.contiguous(), self.fc1_1.weight, self.fc1_2.weight, self.fc1_3.weight, self.fc1_4.weight)
+            else:
+                # fc1_4 applied to the two halves of its input separately: the concatenation of libs/spect_conv.py:205 is never
+                # materialised (at S = 48 it is a 2.5e9-element tensor: torch.cat alone took 83 ms of the layer's 90 on 13 M edges)
+                ev = Fn._edge_branch_torch(ea, self.fc1_1.weight, self.fc1_2.weight, self.fc1_3.weight, self.fc1_4.weight)
+            val = _sorted_values(csr, edge_index, ev, self.conv1.weight.size(0))
             return ML3LayerFunction.apply(x, val, None, None, None, None, self.conv1.weight, self.conv1.bias,
                                           self.fc11.weight if n2 > 0 else None, self.fc11.bias if n2 > 0 else None,
                                           self.fc12.weight if n2 > 0 else None, self.fc12.bias if n2 > 0 else None,

@@ -262,6 +262,14 @@ int gml_edge_mlp_fwd(const float* ea, const void* ea_split, const float* w1, con
                      const float* w4, float* out, const int32_t* tpos, float* out_t,
                      int64_t num_edges, int32_t S, int32_t Sout, gml_stream_t stream);
 
+/* The same function for MORE than 16 supports, 16 < max(S, Sout) <= 48 (csrc/gml_edge_wide.hip; SURVEY s8(d)'s sr25 sweep at 24 and
+ * 48 supports; reference: libs/spect_conv.py:190-194, 205-207): one launch, exact fp32 products, weights resident in LDS, no
+ * intermediate in HBM.  ea [num_edges, S], out [num_edges, Sout]; rows 16-byte aligned where S / Sout are multiples of 4.
+ * GML_E_UNSUPPORTED for max(S, Sout) <= 16 (gml_edge_mlp_fwd) or > 48.  Forward only: the host recomputes through the library
+ * for the backward (no reference script trains more than 12 supports). */
+int gml_edge_mlp_wide_fwd(const float* ea, const float* w1, const float* w2, const float* w3, const float* w4, float* out,
+                          int64_t num_edges, int32_t S, int32_t Sout, gml_stream_t stream);
+
 /* The edge branches of a STACK of ML3Layers in one pass: every layer of Zinc12k.py:338-341 / counting.py:361-366 receives the
  * same raw supports (data.edge_attr2), so L launches of gml_edge_mlp_fwd read them L times.  out[l] [num_edges, Sout] =
  * the branch of layer l (weights w1[l] .. w4[l]) applied to the rows whose split image is ea_split (gml_edge_presplit), same

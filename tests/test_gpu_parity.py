@@ -569,7 +569,8 @@ def test_ml3layer_golden(dev, golden, arith):
 @pytest.mark.parametrize('ne,neo,Fin,n1,n2', [(5, 3, 9, 24, 6), (3, 8, 9, 24, 6), (4, 12, 9, 24, 6),
                                               (4, 4, 80, 64, 16), (3, 3, 21, 16, 40),
                                               (12, 12, 32, 30, 2), (12, 12, 32, 29, 3), (12, 12, 28, 12, 4), (12, 12, 32, 16, 16),
-                                              (24, 24, 20, 16, 2)])                     # (> 16 supports: the edge branch as library GEMMs)
+                                              (24, 24, 20, 16, 2), (48, 48, 20, 16, 2), (17, 17, 12, 16, 0), (30, 22, 12, 16, 2),
+                                              (20, 41, 12, 16, 2)])  # (> 16 supports: gml_edge_mlp_wide_fwd, csrc/gml_edge_wide.hip)
 def test_ml3layer_wide_shapes(dev, ne, neo, Fin, n1, n2):
     """Shapes off the fused kernels' main road, against the oracle in fp64: nedgeoutput != nedgeinput (allowed by
     spect_conv.py:66-71, unused by the scripts), ninp = 80 (ptc.py:331-338) and a wide Hadamard branch; the last three
@@ -602,6 +603,31 @@ def test_ml3layer_wide_shapes(dev, ne, neo, Fin, n1, n2):
     gp = dict(m.named_parameters())
     for n, p in ref.named_parameters():
         close(gp[n].grad, p.grad, what=n)
+
+
+@pytest.mark.parametrize('S,So,E', [(24, 24, 5000), (48, 48, 3001), (17, 17, 777), (33, 20, 1000), (20, 47, 64), (48, 48, 1)])
+def test_edge_branch_beyond_16_supports_vs_fp64(dev, S, So, E):
+    """gml_edge_mlp_wide_fwd (the edge branch for 16 < S <= 48, libs/spect_conv.py:190-194, 205-207) against the
+    oracle's expression in float64 -- exact fp32 products, so far inside 1e-4 -- and the same values as the library road it replaces;
+    gradients (library recompute) against float64 autograd."""
+    from gnn_matlang_amd import functional as Fn
+    torch.manual_seed(S * 100 + So)
+    ea = torch.randn(E, S) * 0.7
+    w1, w2, w3 = [torch.randn(2 * S, S) / S ** 0.5 for _ in range(3)]
+    w4 = torch.randn(So, 4 * S) / (4 * S) ** 0.5
+    D = lambda t: t.double().requires_grad_(True)
+    er, r1, r2, r3, r4 = D(ea), D(w1), D(w2), D(w3), D(w4)
+    ref = torch.relu(torch.cat([torch.relu(er @ r1.t()), torch.tanh(er @ r2.t()) * torch.tanh(er @ r3.t())], 1) @ r4.t())
+    go = torch.randn(E, So)
+    (ref * go.double()).sum().backward()
+    C = lambda t: t.to(dev).requires_grad_(True)
+    ed, d1, d2, d3, d4 = C(ea), C(w1), C(w2), C(w3), C(w4)
+    out = Fn.EdgeBranchWide.apply(ed, d1, d2, d3, d4)
+    close(out, ref, tol=1e-5, what='wide edge branch S=%d So=%d' % (S, So))
+    close(out, Fn._edge_branch_torch(ed, d1, d2, d3, d4), tol=1e-5, what='vs the library road')
+    (out * go.to(dev)).sum().backward()
+    for got, want, n in ((ed, er, 'ea'), (d1, r1, 'w1'), (d2, r2, 'w2'), (d3, r3, 'w3'), (d4, r4, 'w4')):
+        close(got.grad, want.grad, what='grad ' + n)
 
 
 # ------------------------------------------------------------------------------------------ models (H1-H5)
