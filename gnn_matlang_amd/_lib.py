@@ -22,6 +22,7 @@ SIGNATURES = {
     'gml_csr_link_transpose': (ctypes.c_int, [_p, _p, _i64, _p, _p, _p]),
     'gml_csr_group_record_ints': (ctypes.c_int32, [_i32]),
     'gml_csr_group_info': (ctypes.c_int, [_p, _p, _i64, _i32, _p, _p]),
+    'gml_csr_group_info2': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _p]),
     'gml_batch_assemble': (ctypes.c_int, [_p, _p]),
     'gml_bn_workspace_bytes': (ctypes.c_size_t, [_i64]),
     'gml_bn_stats': (ctypes.c_int, [_p, _i64, _i64, _i32, ctypes.c_float, _p, _p, _p, _p, ctypes.c_size_t, _p]),
@@ -48,6 +49,8 @@ SIGNATURES = {
     'gml_edge_mlp_fwd_stack': (ctypes.c_int, [_p, _i32, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
     'gml_spectconv_bwd_mix_relu': (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _i32, _i32,
                                                   _i64, _i32, _i32, _i32, _i32, _i32, _u32, _p, _sz, _p]),
+    'gml_spectconv_bwd_mix_relu2': (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _i32, _p, _i32, _i32,
+                                                   _i64, _i32, _i32, _i32, _i32, _i32, _u32, _p, _sz, _p]),
     'gml_spectconv_fwd_epi': (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _p, _p, _i64, _i64, _i32, _i32, _i32,
                                              ctypes.c_uint32, _i32, _p, _i32, _p]),
     'gml_spmm_fwd': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _p, _i64, _i32, _i32, _p]),
@@ -55,6 +58,10 @@ SIGNATURES = {
     'gml_sddmm': (ctypes.c_int, [_p, _p, _p, _p, _i64, _p, _p, _i64, _i32, _i32, _p]),
     'gml_edge_presplit': (ctypes.c_int, [_p, _p, _i64, _i32, _p]),
     'gml_edge_mlp_fwd': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
+    'gml_head_l1_fwd': (ctypes.c_int, [_p, _i64, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p]),
+    'gml_head_l1_bwd': (ctypes.c_int, [_p, _i64, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _i64, _p, _p, _p, _p, _p]),
+    'gml_fold_many': (ctypes.c_int, [_p, _i32, _p]),
+    'gml_edge_mlp_bwd_parts': (_i64, [_i64, _i32, _i32, _i32, _i32]),
     'gml_edge_mlp_wide_fwd': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
     'gml_edge_mlp_bwd_workspace_bytes': (_sz, [_i64, _i32, _i32]),
     'gml_edge_mlp_bwd': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p, _sz, _p]),
@@ -101,6 +108,13 @@ GML_OK, GML_E_BADARG, GML_E_UNSUPPORTED, GML_E_WORKSPACE = 0, -1, -2, -3
 GML_RELU, GML_ACCUM, GML_F32_MFMA, GML_GROUPS128, GML_GROUPS64R, GML_DMA_RING, GML_FWD_CHUNKED, GML_DVAL_ACCUM = 1, 2, 4, 8, 16, 32, 64, 128
 GML_POOL_SKIP_LAST = 2
 GML_FWD_ONEWIN = 256
+GML_NO_FOLD = 512               # gml_spectconv_bwd*: leave the dW partials in ws (gml_fold_many)
+GML_FOLD_MAX_JOBS = 16
+
+
+class FoldJob(ctypes.Structure):
+    """gml_fold_job of include/gml.h"""
+    _fields_ = [('partial', _p), ('nparts', _i64), ('n', _i64), ('dst', _p * 5), ('ndst', _i64 * 5)]
 GML_GROUPS64_RANKED = 1064      # group kind of gml_csr_group_info: 64-row groups with rank bytes
 
 _lib = None

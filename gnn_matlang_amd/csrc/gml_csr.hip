@@ -232,7 +232,10 @@ extern "C" int gml_csr_link_transpose(const int32_t* perm_fwd, const int32_t* pe
 //   Which row a lane serves does not change any row's result (each row keeps its own edge order).
 __global__ __launch_bounds__(128) void gml_k_group_info(const int32_t* __restrict__ rowptr,
                                                        const int32_t* __restrict__ col, int64_t nrows,
-                                                       int32_t group_kind, int32_t* __restrict__ ginfo) {
+                                                       int32_t group_kind, int32_t* __restrict__ ginfo,
+                                                       const int32_t* __restrict__ rowptr_b, const int32_t* __restrict__ col_b,
+                                                       int32_t* __restrict__ ginfo_b) {
+    if (blockIdx.y == 1) { rowptr = rowptr_b; col = col_b; ginfo = ginfo_b; }     // second view of the same rows (gml_csr_group_info2)
     const int group_rows = group_kind == GML_GROUPS64_RANKED ? 64 : group_kind;
     __shared__ int deg[128];
     __shared__ int red[4];
@@ -294,7 +297,19 @@ extern "C" int gml_csr_group_info(const int32_t* rowptr, const int32_t* col, int
     if (num_rows == 0) return GML_OK;
     if (!rowptr || !ginfo) return GML_E_BADARG;
     hipLaunchKernelGGL(gml_k_group_info, dim3((unsigned)gml_cdiv(num_rows, rows)), dim3(128), 0,
-                       (hipStream_t)stream, rowptr, col, num_rows, group_rows, ginfo);
+                       (hipStream_t)stream, rowptr, col, num_rows, group_rows, ginfo, nullptr, nullptr, nullptr);
+    return gml_launch_status();
+}
+
+// the group records of BOTH views of one graph structure (target-keyed and source-keyed CSR over the same rows) in one launch
+extern "C" int gml_csr_group_info2(const int32_t* rowptr_a, const int32_t* col_a, int32_t* ginfo_a, const int32_t* rowptr_b,
+                                   const int32_t* col_b, int32_t* ginfo_b, int64_t num_rows, int32_t group_rows, gml_stream_t stream) {
+    if (num_rows < 0 || (group_rows != 64 && group_rows != 128 && group_rows != GML_GROUPS64_RANKED)) return GML_E_BADARG;
+    const int rows = group_rows == GML_GROUPS64_RANKED ? 64 : group_rows;
+    if (num_rows == 0) return GML_OK;
+    if (!rowptr_a || !ginfo_a || !rowptr_b || !ginfo_b) return GML_E_BADARG;
+    hipLaunchKernelGGL(gml_k_group_info, dim3((unsigned)gml_cdiv(num_rows, rows), 2), dim3(128), 0,
+                       (hipStream_t)stream, rowptr_a, col_a, num_rows, group_rows, ginfo_a, rowptr_b, col_b, ginfo_b);
     return gml_launch_status();
 }
 

@@ -365,6 +365,7 @@ static inline int64_t gml_edge_chain16_bwd_groups(int64_t E) {
                            w3, w4, gout, (float*)ws, E, ntiles);                                                 \
         int rc = gml_launch_status();                                                                            \
         if (rc != GML_OK) return rc;                                                                             \
+        if (!dw1) return GML_OK;   /* partials stay in ws: gml_fold_many */                                      \
         const int n123 = 2 * SV * SV, n4 = SV * 4 * SV;                                                          \
         hipLaunchKernelGGL(gml_k_reduce_partials, dim3((unsigned)gml_cdiv(NW, 16)), dim3(256), 0, st,            \
                            (const float*)ws, grid, NW, dw1, n123, dw2, n123, dw3, n123, dw4, n4);                \

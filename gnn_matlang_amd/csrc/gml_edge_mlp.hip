@@ -238,15 +238,28 @@ extern "C" size_t gml_edge_mlp_bwd_workspace_bytes(int64_t num_edges, int32_t S,
     return (size_t)parts * (size_t)(6 * S * S + Sout * 4 * S) * sizeof(float);
 }
 
+// partial rows gml_edge_mlp_bwd leaves in ws for this call shape (the dispatch below, mirrored)
+extern "C" int64_t gml_edge_mlp_bwd_parts(int64_t num_edges, int32_t S, int32_t Sout, int32_t has_split, int32_t want_gin) {
+    if (num_edges <= 0 || S <= 0 || Sout != S) return 0;
+#ifdef GML_NO_PRESPLIT
+    has_split = 0;
+#endif
+    if (emlp_use_chain(S)) return gml_edge_chain_bwd_groups(num_edges, gml_edge_chain_bwd_wgs());
+    if (emlp_use_chain16(S, has_split ? (const void*)1 : nullptr, want_gin ? (const void*)1 : nullptr)) return gml_edge_chain16_bwd_groups(num_edges);
+    return emlp_bwd_waves(num_edges, S);
+}
+
 extern "C" int gml_edge_mlp_bwd(const float* ea, const void* ea_split, const float* w1, const float* w2, const float* w3,
                                 const float* w4, const float* gout, float* gin, float* dw1, float* dw2,
                                 float* dw3, float* dw4, int64_t num_edges, int32_t S, int32_t Sout,
                                 void* ws, size_t ws_bytes, gml_stream_t stream) {
     if (num_edges < 0 || S <= 0 || Sout <= 0) return GML_E_BADARG;
-    if (!w1 || !w2 || !w3 || !w4 || !dw1 || !dw2 || !dw3 || !dw4) return GML_E_BADARG;
+    const bool nofold = !dw1 && !dw2 && !dw3 && !dw4;        /* all four NULL: the partials stay in ws (gml_fold_many, gml_edge_mlp_bwd_parts) */
+    if (!w1 || !w2 || !w3 || !w4 || (!nofold && (!dw1 || !dw2 || !dw3 || !dw4))) return GML_E_BADARG;
     if (S != Sout) return GML_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     if (num_edges == 0) {
+        if (nofold) return GML_OK;                           /* (gml_edge_mlp_bwd_parts is 0: the fold writes zeros) */
         gml_zero_async(dw1, sizeof(float) * 2 * S * S, st);
         gml_zero_async(dw2, sizeof(float) * 2 * S * S, st);
         gml_zero_async(dw3, sizeof(float) * 2 * S * S, st);

@@ -462,3 +462,51 @@ extern "C" int gml_scatter_rows(const float* in, const int32_t* perm, float* out
                        (hipStream_t)stream, in, perm, out, rows, width);
     return gml_launch_status();
 }
+
+// =============================================================================================
+// gml_fold_many: the partial-sum folds of several weight-gradient kernels in ONE launch (include/gml.h "Deferred folds").
+// blockIdx.y = job, blockIdx.x = block of 16 columns; the same summation order as gml_k_reduce_rows / gml_k_reduce_partials /
+// gml_k_split_fold (16 lanes over the partial index in steps of 16 through gml_fold_column, then the 16 sub-sums in ascending
+// order): bit-identical to the per-kernel folds.
+// =============================================================================================
+struct GmlFoldJobs { gml_fold_job j[GML_FOLD_MAX_JOBS]; };
+
+__global__ __launch_bounds__(256) void gml_k_fold_many(const GmlFoldJobs jobs) {
+    __shared__ float red[16][17];
+    const gml_fold_job& q = jobs.j[blockIdx.y];
+    const int jl = threadIdx.x & 15, wl = threadIdx.x >> 4;
+    const int64_t j = (int64_t)blockIdx.x * 16 + jl;
+    if ((int64_t)blockIdx.x * 16 >= q.n) return;              // (uniform per block)
+    float a = 0.f;
+    if (j < q.n) a = gml_fold_column(q.partial, q.nparts, q.n, j, wl);
+    red[wl][jl] = a;
+    __syncthreads();
+    if (wl != 0 || j >= q.n) return;
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][jl];
+    int64_t off = j;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        if (off < q.ndst[k]) { if (q.dst[k]) q.dst[k][off] = t; return; }
+        off -= q.ndst[k];
+    }
+}
+
+extern "C" int gml_fold_many(const gml_fold_job* jobs, int32_t njobs, gml_stream_t stream) {
+    if (njobs < 0 || njobs > GML_FOLD_MAX_JOBS || (njobs > 0 && !jobs)) return GML_E_BADARG;
+    if (njobs == 0) return GML_OK;
+    GmlFoldJobs a = {};
+    int64_t nmax = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const gml_fold_job& q = jobs[i];
+        int64_t tot = 0;
+        for (int k = 0; k < 5; ++k) { if (q.ndst[k] < 0) return GML_E_BADARG; tot += q.ndst[k]; }
+        if (q.n < 0 || q.nparts < 0 || tot > q.n || (q.n > 0 && q.nparts > 0 && !q.partial)) return GML_E_BADARG;
+        a.j[i] = q;
+        nmax = q.n > nmax ? q.n : nmax;
+    }
+    if (nmax == 0) return GML_OK;
+    hipLaunchKernelGGL(gml_k_fold_many, dim3((unsigned)gml_cdiv(nmax, 16), (unsigned)njobs), dim3(256), 0, (hipStream_t)stream, a);
+    return gml_launch_status();
+}

@@ -408,12 +408,13 @@ static int split_bwd_impl(const float* gy, int64_t ldgy, const int32_t* gy_seg, 
                           size_t ws_bytes, gml_stream_t stream) {
     if (dz != nullptr && (dx != nullptr || F2 < 1 || 2 * F2 > 4 || (((uintptr_t)dz) & 15) != 0)) return GML_E_BADARG;
     if (num_rows < 0 || nout1 <= 0 || F2 < 0 || ldgy < nout1 + F2 || (y && ldy < nout1) || (G && ldg < nout1)) return GML_E_BADARG;
-    if (F2 > 0 && (Fin <= 0 || ldx < Fin || (dx && lddx < Fin) || !w11 || !w12 || !dw11 || !dw12)) return GML_E_BADARG;
+    const bool nofold = !dcb && !dw11 && !db11 && !dw12 && !db12;   /* no destination at all: the partials stay in ws (gml_fold_many) */
+    if (F2 > 0 && (Fin <= 0 || ldx < Fin || (dx && lddx < Fin) || !w11 || !w12 || (!nofold && (!dw11 || !dw12)))) return GML_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     if (F2 == 0) Fin = 0;
     if (num_rows == 0) {
         if (dcb) gml_zero_async(dcb, sizeof(float) * nout1, st);
-        if (F2 > 0) {
+        if (F2 > 0 && !nofold) {
             gml_zero_async(dw11, sizeof(float) * F2 * Fin, st);
             gml_zero_async(dw12, sizeof(float) * F2 * Fin, st);
             if (db11) gml_zero_async(db11, sizeof(float) * F2, st);
@@ -460,6 +461,7 @@ static int split_bwd_impl(const float* gy, int64_t ldgy, const int32_t* gy_seg, 
     }
     int rc = gml_launch_status();
     if (rc != GML_OK) return rc;
+    if (nofold) return GML_OK;                               /* nothing to fold into: the partials stay in ws (gml_fold_many) */
     hipLaunchKernelGGL(gml_k_split_fold, dim3((unsigned)gml_cdiv(p.npart, 16)), dim3(256), 0, st, (const float*)ws,
                        (int64_t)grid, p.npart, dw11, F2 * Fin, dw12, F2 * Fin, db11, F2, db12, F2, dcb, nout1);
     return gml_launch_status();

@@ -159,7 +159,7 @@ static int spectconv_bwd_impl(const int32_t* rowptr, const int32_t* col, const i
                               int64_t num_rows, int32_t S, int32_t Fin, int32_t Fout,
                               int32_t max_group_edges, int32_t max_group_window, uint32_t flags,
                               void* ws, size_t ws_bytes, gml_stream_t stream, const float* dz, const float* wmix, int32_t nmix,
-                              int32_t relu_cols = 0) {
+                              int32_t relu_cols = 0, const float* wmix2 = nullptr, int32_t nmix1 = -1) {
     if (num_rows < 0 || S <= 0 || Fin <= 0 || Fout <= 0 || ldx < Fin || ldg < Fout) return GML_E_BADARG;
     if (dx && lddx < Fin) return GML_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
@@ -179,6 +179,7 @@ static int spectconv_bwd_impl(const int32_t* rowptr, const int32_t* col, const i
     p.w = w; p.dx = dx; p.lddx = lddx; p.dval = dval; p.dw_partial = dw ? (float*)ws : nullptr;
     p.nrows = num_rows; p.S = S; p.Fin = Fin; p.Fout = Fout; p.flags = flags;
     p.dz = dz; p.wmix = wmix; p.nmix = nmix; p.relu_cols = relu_cols;
+    p.wmix2 = wmix2; p.nmix1 = (wmix2 && nmix1 >= 0 && nmix1 <= nmix) ? nmix1 : nmix;
     if (dz != nullptr && (pl.layout != 3 || (flags & GML_ACCUM) || (((uintptr_t)dz) & 15) != 0))
         return GML_E_UNSUPPORTED;
 #ifdef GML_BWD2_TIMING
@@ -229,7 +230,7 @@ static int spectconv_bwd_impl(const int32_t* rowptr, const int32_t* col, const i
     GML_BWD_GO(4, 3, 2) GML_BWD_GO(6, 2, 2) GML_BWD_GO(8, 2, 1) GML_BWD_GO(4, 4, 2)
     }
     if (rc != GML_OK) return rc;
-    if (dw) {
+    if (dw && !(flags & GML_NO_FOLD)) {
         const int64_t n = (int64_t)S * Fin * Fout;
         hipLaunchKernelGGL(gml_k_reduce_rows, dim3((unsigned)gml_cdiv(n, 16)), dim3(256), 0, st,
                            (const float*)ws, (int64_t)pl.grid, n, dw);
@@ -299,3 +300,20 @@ extern "C" int gml_debug_bwd2_prof(unsigned long long* out, int reset) {
     return (int)e;
 }
 #endif
+
+// gml_spectconv_bwd_mix_relu with the rows of wmix in TWO arrays: rows [0, nmix_a) from wmix_a, rows [nmix_a, nmix_a + nmix_b) from
+// wmix_b -- an ML3Layer's fc11.weight and fc12.weight as they are stored (the single-array form needs their concatenation: a
+// launch per layer and step at the reference's batch size)
+extern "C" int gml_spectconv_bwd_mix_relu2(const int32_t* rowptr, const int32_t* col, const int32_t* ginfo, const float* val,
+                                           const float* x, int64_t ldx, const float* g, int64_t ldg, const float* w,
+                                           float* dx, int64_t lddx, float* dval, float* dw, const float* dz, const float* wmix_a,
+                                           int32_t nmix_a, const float* wmix_b, int32_t nmix_b, int32_t relu_cols, int64_t num_rows,
+                                           int32_t S, int32_t Fin, int32_t Fout, int32_t max_group_edges, int32_t max_group_window,
+                                           uint32_t flags, void* ws, size_t ws_bytes, gml_stream_t stream) {
+    if (relu_cols < 0 || relu_cols > Fin || nmix_a < 0 || nmix_b < 0) return GML_E_BADARG;
+    const int nmix = nmix_a + nmix_b;
+    if (!dz || !wmix_a || (nmix_b > 0 && !wmix_b) || !dx || !gml_spectconv_bwd_mix_supported(S, Fin, Fout, nmix, flags)) return GML_E_UNSUPPORTED;
+    if (relu_cols > 0 && (bwd4_env() || (flags & GML_DMA_RING))) return GML_E_UNSUPPORTED;
+    return spectconv_bwd_impl(rowptr, col, ginfo, val, x, ldx, g, ldg, w, dx, lddx, dval, dw, num_rows, S, Fin, Fout,
+                              max_group_edges, max_group_window, flags, ws, ws_bytes, stream, dz, wmix_a, nmix, relu_cols, wmix_b, nmix_a);
+}

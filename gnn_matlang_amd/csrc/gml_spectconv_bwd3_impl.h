@@ -147,7 +147,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
         if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
     }
     if constexpr (DZ) {
-        if (tid < 128) wm_l[tid] = ((tid >> 5) < p.nmix && (tid & 31) < p.Fin) ? p.wmix[(tid >> 5) * p.Fin + (tid & 31)] : 0.f;
+        if (tid < 128) wm_l[tid] = ((tid >> 5) < p.nmix && (tid & 31) < p.Fin) ? ((tid >> 5) < p.nmix1 ? p.wmix[(tid >> 5) * p.Fin + (tid & 31)] : p.wmix2[((tid >> 5) - p.nmix1) * p.Fin + (tid & 31)]) : 0.f;
     }
     // W -> bf16 (hi, lo) image, zero padded to 32 x 32
     constexpr int WO = 16 * NOB;                             // output rows of one support's image

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(512, 1) void gml_k_spectconv_bwd4(const GmlBwdParam
     if (g0 >= g1) return;
 
     if constexpr (DZ) {
-        if (tid < 128) wm_l[tid] = ((tid >> 5) < p.nmix && (tid & 31) < p.Fin) ? p.wmix[(tid >> 5) * p.Fin + (tid & 31)] : 0.f;
+        if (tid < 128) wm_l[tid] = ((tid >> 5) < p.nmix && (tid & 31) < p.Fin) ? ((tid >> 5) < p.nmix1 ? p.wmix[(tid >> 5) * p.Fin + (tid & 31)] : p.wmix2[((tid >> 5) - p.nmix1) * p.Fin + (tid & 31)]) : 0.f;
     }
     // W -> bf16 (hi, lo) image, zero padded to 32 x 32
     for (int e = tid; e < S * 32 * 32; e += NT) {

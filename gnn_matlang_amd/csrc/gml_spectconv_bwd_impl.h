@@ -49,6 +49,8 @@ struct GmlBwdParams {
     const float* dz;
     const float* wmix;
     int32_t nmix;
+    const float* wmix2;      // optional second array: rows nmix1 .. nmix - 1 of wmix come from here (fc11.weight, fc12.weight as they are: no concatenation)
+    int32_t nmix1;           // rows taken from wmix (= nmix when wmix2 is NULL)
     // bwd3 DZ form, optional: the first relu_cols features of x are relu outputs of the layer below (x = [relu(conv) | ...], an
     // ML3Layer feeding an ML3Layer): dx[:, f < relu_cols] is written already multiplied by (x[:, f] > 0) -- it IS the gradient at
     // that layer's conv output, so its output-stage backward needs neither its saved output nor a second [N, C] array

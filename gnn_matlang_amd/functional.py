@@ -60,6 +60,65 @@ class exact_products(object):
             _TLS.exact -= 1
 
 
+_FOLDS = None                      # the open deferred_folds scope's job list (process-wide: autograd runs backward on its own threads)
+_FOLDS_LOCK = _threading.Lock()
+
+
+class deferred_folds(object):
+    """``with deferred_folds(): loss.backward()`` -- every weight-gradient kernel launched inside leaves its per-workgroup partial
+    sums unfolded (include/gml.h "Deferred folds") and ONE launch folds them all when the scope closes (bit-identical sums: the
+    same order).  For the reference's batch size, where a step is a chain of tiny launches (twelve folds at ZINC's four
+    layers).  The gradient tensors autograd hands to the parameters are FILLED AT SCOPE EXIT: read .grad (optimizer, all-reduce)
+    after the ``with`` block, never inside it.  The scope is process-wide (the backward runs on autograd's worker threads, not on
+    the thread that opened it): one at a time, one device, not nestable."""
+
+    def __enter__(self):
+        global _FOLDS
+        with _FOLDS_LOCK:
+            assert _FOLDS is None, 'deferred_folds scopes do not nest / overlap'
+            _FOLDS = []
+        return self
+
+    def __exit__(self, exc_type, *a):
+        global _FOLDS
+        with _FOLDS_LOCK:
+            jobs, _FOLDS = _FOLDS, None
+        if exc_type is None:
+            flush_folds(jobs)
+
+
+class _FoldQueue(object):
+    def __init__(self, jobs):
+        self.jobs = jobs
+
+    def append(self, job):
+        with _FOLDS_LOCK:
+            self.jobs.append(job)
+
+
+def _fold_queue():
+    jobs = _FOLDS
+    return _FoldQueue(jobs) if jobs is not None else None
+
+
+def flush_folds(jobs):
+    """jobs: [(partial tensor, nparts, n, [(dst tensor or None, count), ...])] -> gml_fold_many in chunks of 16"""
+    if not jobs:
+        return
+    dev = jobs[0][0].device
+    with torch.cuda.device(dev):
+        for c0 in range(0, len(jobs), _lib.GML_FOLD_MAX_JOBS):
+            chunk = jobs[c0:c0 + _lib.GML_FOLD_MAX_JOBS]
+            arr = (_lib.FoldJob * len(chunk))()
+            for a, (part, nparts, n, dsts) in zip(arr, chunk):
+                a.partial, a.nparts, a.n = part.data_ptr(), int(nparts), int(n)
+                for k in range(5):
+                    t, c = dsts[k] if k < len(dsts) else (None, 0)
+                    a.dst[k] = t.data_ptr() if t is not None else None
+                    a.ndst[k] = int(c)
+            _lib.call('gml_fold_many', ctypes.addressof(arr), len(chunk), _stream(dev))
+
+
 EDGE_VALU = _os.environ.get('GML_EDGE_VALU', '0') == '1'
 
 
@@ -430,6 +489,18 @@ def edge_mlp_bwd(ea, w1, w2, w3, w4, gout, need_gin, ea_split=None):
     ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=dev)
     gin = torch.empty_like(ea) if need_gin else None
     dw1, dw2, dw3, dw4 = torch.empty_like(w1), torch.empty_like(w2), torch.empty_like(w3), torch.empty_like(w4)
+    fq = _fold_queue()
+    if fq is not None and E > 0:
+        nparts = int(_lib.lib().gml_edge_mlp_bwd_parts(int(E), int(S), int(So), 1 if ea_split is not None else 0, 1 if need_gin else 0))
+        _lib.call('gml_edge_mlp_bwd', _ptr(ea), _ptr(ea_split), _ptr(w1), _ptr(w2), _ptr(w3), _ptr(w4), _ptr(gout), _ptr(gin),
+                  _ptr(None), _ptr(None), _ptr(None), _ptr(None), int(E), int(S), int(So), _ptr(ws), ws.numel(), _stream(dev))
+        # ONE flat destination, the gradients are views of it: autograd takes a view over as .grad without a copy, and the flat
+        # tensor (held by the queue until the fold has run) cannot be freed under the fold's feet -- separate tensors referenced by
+        # the queue would be CLONED by AccumulateGrad (a second owner), before the fold has filled them
+        n1, n4 = 2 * S * S, 4 * S * So
+        flat = torch.empty(3 * n1 + n4, dtype=torch.float32, device=dev)
+        fq.append((ws, nparts, 3 * n1 + n4, [(flat, 3 * n1 + n4)]))
+        return (gin, flat[:n1].view_as(w1), flat[n1:2 * n1].view_as(w2), flat[2 * n1:3 * n1].view_as(w3), flat[3 * n1:].view_as(w4))
     _lib.call('gml_edge_mlp_bwd', _ptr(ea), _ptr(ea_split), _ptr(w1), _ptr(w2), _ptr(w3), _ptr(w4), _ptr(gout), _ptr(gin),
               _ptr(dw1), _ptr(dw2), _ptr(dw3), _ptr(dw4), int(E), int(S), int(So), _ptr(ws), ws.numel(), _stream(dev))
     return gin, dw1, dw2, dw3, dw4
@@ -467,16 +538,33 @@ def ml3_split_bwd(gy, y, nout1, x=None, w11=None, b11=None, w12=None, b12=None, 
     dw12 = torch.empty_like(w12) if F2 else None
     db11 = torch.empty_like(b11) if (F2 and b11 is not None) else None
     db12 = torch.empty_like(b12) if (F2 and b12 is not None) else None
+    fq = _fold_queue()
+    kd = (dcb, dw11, db11, dw12, db12)                       # what the kernel's own fold writes
+    if fq is not None and N > 0 and any(t is not None for t in kd):
+        # deferred: no destinations -> the entry point skips its fold; the partial rows [dw11 | dw12 | db11 | db12 | dcb] stay in ws
+        npart = 2 * F2 * Fin + 2 * F2 + int(nout1)
+        flat = torch.empty(npart, dtype=torch.float32, device=dev)                 # (views of it go to autograd: see edge_mlp_bwd)
+        fq.append((ws, nbytes // (4 * npart), npart, [(flat, npart)]))
+        o = 0
+        if F2:
+            dw11, dw12 = flat[:F2 * Fin].view_as(w11), flat[F2 * Fin:2 * F2 * Fin].view_as(w12)
+            o = 2 * F2 * Fin
+            db11 = flat[o:o + F2] if db11 is not None else None
+            db12 = flat[o + F2:o + 2 * F2] if db12 is not None else None
+            o += 2 * F2
+        dcb = flat[o:o + int(nout1)] if dcb is not None else None
+        kd = (None,) * 5
+    kcb, k11, kb11, k12, kb12 = kd
     with _Timed('ml3_split_bwd', 4 * N * ((1 if premasked else 3) * (nout1 + F2) + (2 * Fin if dx is not None else Fin) + (4 if dz is not None else 0))):
         if dz is not None or gy_seg is not None or premasked:
             _lib.call('gml_ml3_split_bwd_ex', _ptr(gy), int(gy.stride(0)), _ptr(gy_seg), _ptr(None if premasked else y), int(y.stride(0)), _ptr(x),
                       int(x.stride(0)) if F2 else 0, _ptr(w11), _ptr(b11), _ptr(w12), _ptr(b12), _ptr(None if premasked else G), ld, _ptr(dx), Fin,
-                      _ptr(dz), _ptr(dcb), _ptr(dw11), _ptr(db11), _ptr(dw12), _ptr(db12), int(N), Fin, int(nout1), F2,
+                      _ptr(dz), _ptr(kcb), _ptr(k11), _ptr(kb11), _ptr(k12), _ptr(kb12), int(N), Fin, int(nout1), F2,
                       _ptr(ws), ws.numel(), _stream(dev))
         else:
             _lib.call('gml_ml3_split_bwd', _ptr(gy), int(gy.stride(0)), _ptr(y), int(y.stride(0)), _ptr(x),
                       int(x.stride(0)) if F2 else 0, _ptr(w11), _ptr(b11), _ptr(w12), _ptr(b12), _ptr(G), ld, _ptr(dx), Fin,
-                      _ptr(dcb), _ptr(dw11), _ptr(db11), _ptr(dw12), _ptr(db12), int(N), Fin, int(nout1), F2, _ptr(ws),
+                      _ptr(kcb), _ptr(k11), _ptr(kb11), _ptr(k12), _ptr(kb12), int(N), Fin, int(nout1), F2, _ptr(ws),
                       ws.numel(), _stream(dev))
     return G[:, :nout1], (dz if dz is not None else dx), dcb, dw11, db11, dw12, db12
 
@@ -564,6 +652,45 @@ class TallLinearFunction(torch.autograd.Function):
                 gw = g.t().mm(x)
         gb = g.sum(0) if (ctx.has_b and ctx.needs_input_grad[2]) else None
         return gx, gw, gb
+
+
+class HeadL1Function(torch.autograd.Function):
+    """loss = sum_{r < len(y)} valid[r] |fc2(relu(fc1 p[r])) - y[r]| (Zinc12k.py:343-345, :365) as ONE launch forward and ONE launch
+    backward (csrc/gml_head.hip) for small batches -- the reference's batch 64.  p [R, nin] pooled rows (R >= len(y): further rows,
+    e.g. the padding graph of a static batch, are ignored and get zero gradient)."""
+
+    @staticmethod
+    def forward(ctx, p, y, valid, w1, b1, w2, b2):
+        p = _f32c(p, 'pooled')
+        R, nin = p.shape
+        loss = torch.empty((), dtype=torch.float32, device=p.device)
+        with torch.cuda.device(p.device):
+            _lib.call('gml_head_l1_fwd', _ptr(p), int(p.stride(0)), _ptr(y), _ptr(valid), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2),
+                      int(R), int(y.numel()), int(nin), int(w1.size(0)), _ptr(loss), _ptr(None), _stream(p.device))
+        ctx.save_for_backward(p, y, valid, w1, b1, w2, b2)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        p, y, valid, w1, b1, w2, b2 = ctx.saved_tensors
+        R, nin = p.shape
+        nh = int(w1.size(0))
+        gp = torch.empty(R, nin, dtype=torch.float32, device=p.device)
+        dw1, dw2 = torch.empty_like(w1), torch.empty_like(w2)
+        db1 = torch.empty_like(b1) if b1 is not None else None
+        db2 = torch.empty_like(b2) if b2 is not None else None
+        g = g.contiguous()
+        with torch.cuda.device(p.device):
+            _lib.call('gml_head_l1_bwd', _ptr(p), int(p.stride(0)), _ptr(y), _ptr(valid), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2),
+                      int(R), int(y.numel()), int(nin), nh, _ptr(g), _ptr(gp), nin, _ptr(dw1), _ptr(db1), _ptr(dw2), _ptr(db2),
+                      _stream(p.device))
+        return gp, None, None, dw1, db1, dw2, db2
+
+
+def head_l1_supported(p, w1, w2):
+    R, nin, nh = int(p.size(0)), int(p.size(1)), int(w1.size(0))
+    return (p.is_cuda and p.dtype == torch.float32 and R <= 256 and nin <= 64 and nh <= 64 and int(w2.size(0)) == 1
+            and nin % 4 == 0 and nh % 4 == 0 and 4 * (R * nin + 2 * R * nh + 2 * R + nh * nin + 256) <= 160 * 1024)
 
 
 def tall_linear(x, lin):
@@ -692,19 +819,33 @@ def fused_conv_bwd(csr, val_t, x, G, weight, need_x, need_val, need_w, dx_accum_
     dval_t = torch.empty(csr.E, S, dtype=torch.float32, device=dev) if need_val else None
     dw = torch.empty(S, Fin, Fout, dtype=torch.float32, device=dev) if need_w else None
     q, f = conv_cost_bwd(csr.N, csr.E, S, Fin, Fout, need_x, need_val) if PROFILE is not None else (0, 0)
+    fq = _fold_queue() if need_w else None
+    if fq is not None:                                       # the dW partials stay in ws; one launch folds every layer's at scope exit
+        flags |= _lib.GML_NO_FOLD
+        flat = torch.empty(S * Fin * Fout, dtype=torch.float32, device=dev)       # (a view of it goes to autograd: see edge_mlp_bwd)
+        fq.append((ws, nbytes // (4 * S * Fin * Fout), S * Fin * Fout, [(flat, flat.numel())]))
     with _Timed('spectconv_bwd', q, f):
         if mix is not None:
             dz, wmix = mix
-            _lib.call('gml_spectconv_bwd_mix_relu', _ptr(csr.rowptr_t), _ptr(csr.col_t), _ptr(ginfo), _ptr(val_t),
-                      _ptr(x), int(x.stride(0)), _ptr(G), int(G.stride(0)), _ptr(weight), _ptr(dx), Fin, _ptr(dval_t),
-                      _ptr(dw), _ptr(dz), _ptr(wmix), int(wmix.size(0)), int(relu_cols), csr.N, S, Fin, Fout, gmax[0], gmax[1], flags,
-                      _ptr(ws), ws.numel() if ws is not None else 0, _stream(dev))
+            if isinstance(wmix, tuple):                      # (fc11.weight, fc12.weight) as they are stored: no concatenation launch
+                wa, wb = wmix
+                _lib.call('gml_spectconv_bwd_mix_relu2', _ptr(csr.rowptr_t), _ptr(csr.col_t), _ptr(ginfo), _ptr(val_t),
+                          _ptr(x), int(x.stride(0)), _ptr(G), int(G.stride(0)), _ptr(weight), _ptr(dx), Fin, _ptr(dval_t),
+                          _ptr(dw), _ptr(dz), _ptr(wa), int(wa.size(0)), _ptr(wb), int(wb.size(0)), int(relu_cols), csr.N, S, Fin, Fout,
+                          gmax[0], gmax[1], flags, _ptr(ws), ws.numel() if ws is not None else 0, _stream(dev))
+            else:
+                _lib.call('gml_spectconv_bwd_mix_relu', _ptr(csr.rowptr_t), _ptr(csr.col_t), _ptr(ginfo), _ptr(val_t),
+                          _ptr(x), int(x.stride(0)), _ptr(G), int(G.stride(0)), _ptr(weight), _ptr(dx), Fin, _ptr(dval_t),
+                          _ptr(dw), _ptr(dz), _ptr(wmix), int(wmix.size(0)), int(relu_cols), csr.N, S, Fin, Fout, gmax[0], gmax[1], flags,
+                          _ptr(ws), ws.numel() if ws is not None else 0, _stream(dev))
         else:
             assert relu_cols == 0, 'the relu hand-over rides on the dz form of the backward'
             _lib.call('gml_spectconv_bwd', _ptr(csr.rowptr_t), _ptr(csr.col_t), _ptr(ginfo), _ptr(val_t),
                       _ptr(x), int(x.stride(0)), _ptr(G), int(G.stride(0)), _ptr(weight), _ptr(dx), Fin, _ptr(dval_t),
                       _ptr(dw), csr.N, S, Fin, Fout, gmax[0], gmax[1], flags, _ptr(ws),
                       ws.numel() if ws is not None else 0, _stream(dev))
+    if fq is not None:
+        dw = flat.view(S, Fin, Fout)
     return dx, dval_t, dw
 
 
@@ -1016,7 +1157,7 @@ class ML3LayerFunction(torch.autograd.Function):
             if r is not None:
                 # one pass: relu mask, conv1.bias gradient, Hadamard branch (its dx written, conv adds to it)
                 G, dx0, g[7], g[8], g[9], g[10], g[11] = r
-                mix = (dx0, torch.cat([w11, w12], 0).contiguous()) if use_dz else None
+                mix = (dx0, (w11.detach().contiguous(), w12.detach().contiguous())) if use_dz else None    # (rows of wmix from both arrays)
                 # x is the lower ML3Layer's output and only this layer consumes it: hand its relu mask back inside dx
                 rc = ctx.chain_in.cols if (use_dz and ctx.chain_in is not None and not BWD_DMA) else 0
                 dx, dea, dcw, dea_src = _conv_backward(csr, x, ea, cw, G, need[0], need_val, need[6], val_t=ea_t,

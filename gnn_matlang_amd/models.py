@@ -131,7 +131,7 @@ class GNNML3(torch.nn.Module):
         else:
             self.fc1 = torch.nn.Linear(nin, 10)
 
-    def forward(self, data):
+    def forward(self, data, _features=False):
         x = data.x
         if getattr(data, 'pad_graph', False) and self.training and (self.bn or self.readout_bn):
             # the padding nodes / the padding graph's pooled row would enter the batch statistics
@@ -171,9 +171,15 @@ class GNNML3(torch.nn.Module):
             x = {'add': global_add_pool, 'mean': global_mean_pool, 'max': global_max_pool}[self.pool](x, data)
         if self.readout_bn:
             x = self.bnr(x)
+        if _features:
+            return x
         if self.head == 'mlp32':
             return tall_linear(F.relu(tall_linear(x, self.fc1)), self.fc2)
         return torch.tanh(tall_linear(x, self.fc1))
+
+    def features(self, data):
+        """the pooled (and, with readout_bn, normalised) graph features the head is applied to: [num_graphs, nin]"""
+        return self.forward(data, _features=True)
 
 
 class GNNML1Mutag(torch.nn.Module):
@@ -275,6 +281,27 @@ def mutag_gnnml3(ninp=8, ne=4):            # mutag.py:272-288
 
 def zinc_loss(pre, y):                     # Zinc12k.py:365
     return F.l1_loss(pre, y.unsqueeze(-1), reduction='sum')
+
+
+def zinc_step_loss(model, data, valid=None):
+    """zinc_loss(model(data), data.y) -- with the head and the loss as ONE launch each way where the batch is small enough for it
+    (functional.HeadL1Function: the reference's batch 64; a static batch's padding graph and absent slots are masked through
+    `valid` / data.graph_valid).  Same value and gradients up to summation order; large batches take the general path."""
+    from . import functional as Fn
+    valid = valid if valid is not None else getattr(data, 'graph_valid', None)
+    if model.head == 'mlp32' and model.fc2.weight.size(0) == 1 and data.x.is_cuda:
+        x = model.features(data)
+        nl = int(data.y.numel()) if valid is None else int(valid.numel())
+        if Fn.head_l1_supported(x, model.fc1.weight, model.fc2.weight) and nl <= x.size(0):
+            y = data.y[:nl].float().contiguous()
+            return Fn.HeadL1Function.apply(x, y, valid, model.fc1.weight, model.fc1.bias, model.fc2.weight, model.fc2.bias)
+        pre = tall_linear(F.relu(tall_linear(x, model.fc1)), model.fc2)
+    else:
+        pre = model(data)
+    if valid is not None:
+        nl = int(valid.numel())
+        return ((pre[:nl, 0] - data.y[:nl]).abs() * valid).sum()
+    return zinc_loss(pre, data.y)
 
 
 def counting_loss(pre, y):                 # counting.py:411

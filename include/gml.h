@@ -61,9 +61,37 @@ enum {
                          slices of the input features (48-wide layers: features 0..31, then 32..47; dval is linear in x) */
     GML_FWD_ONEWIN = 256, /* gml_spectconv_fwd, 48-feature shapes on the chunked ring kernel: ONE staged X window instead of two, twice the
                          edges per work item -- for batches whose groups need edge chunks (the caller knows the batch's largest group) */
-    GML_DMA_RING = 32   /* gml_spectconv_bwd / _bwd_mix: take the LDS-DMA landing-ring kernel (bwd4) where it applies; the
+    GML_DMA_RING = 32,  /* gml_spectconv_bwd / _bwd_mix: take the LDS-DMA landing-ring kernel (bwd4) where it applies; the
                          forward uses its ring kernel (fwd3) by default (GML_FWD_DMA=0 in the environment turns it off)   */
+    GML_NO_FOLD = 512   /* gml_spectconv_bwd / _bwd_mix / _bwd_mix_relu with dw != NULL: dw is NOT written -- the per-workgroup partial
+                         sums stay in ws as [parts][S * Fin * Fout], parts = gml_spectconv_bwd_workspace_bytes(...) / (4 S Fin Fout) --
+                         for a later gml_fold_many (the reference's batch 64: twelve fold launches of a step become one) */
 };
+
+/* gml_spectconv_bwd_mix_relu with the rows of wmix in two arrays (rows [0, nmix_a) from wmix_a, the next nmix_b from wmix_b): an
+ * ML3Layer's fc11.weight and fc12.weight as they are stored -- no concatenation launch per layer and step. */
+int gml_spectconv_bwd_mix_relu2(const int32_t* rowptr, const int32_t* col, const int32_t* ginfo, const float* val,
+                                const float* x, int64_t ldx, const float* g, int64_t ldg, const float* w,
+                                float* dx, int64_t lddx, float* dval, float* dw, const float* dz, const float* wmix_a,
+                                int32_t nmix_a, const float* wmix_b, int32_t nmix_b, int32_t relu_cols, int64_t num_rows,
+                                int32_t S, int32_t Fin, int32_t Fout, int32_t max_group_edges, int32_t max_group_window,
+                                uint32_t flags, void* ws, size_t ws_bytes, gml_stream_t stream);
+
+/* Deferred folds.  Every weight-gradient kernel of the library leaves one partial sum per workgroup in its workspace and folds
+ * them in a second launch.  At the reference's batch size those folds are launches of a few microseconds of work each; a caller
+ * may skip them -- GML_NO_FOLD above; gml_ml3_split_bwd(_ex) with dcb = dw11 = db11 = dw12 = db12 = NULL (partials [parts][2 F2 Fin +
+ * 2 F2 + nout1] in the order dw11, dw12, db11, db12, dcb; parts = gml_ml3_split_bwd_workspace_bytes / row bytes); gml_edge_mlp_bwd
+ * with dw1 = dw2 = dw3 = dw4 = NULL (partials [gml_edge_mlp_bwd_parts(...)][6 S^2 + 4 S Sout] in the order dw1..dw4) -- and fold all
+ * of them with ONE launch:  dst[k][i] = sum_{w < nparts} partial[w * n + off_k + i]  in ascending w (the order of the per-kernel
+ * folds: bit-identical results), off_k = ndst[0] + .. + ndst[k-1]; a NULL dst[k] skips its segment. */
+typedef struct gml_fold_job {
+    const float* partial; int64_t nparts; int64_t n;
+    float* dst[5]; int64_t ndst[5];
+} gml_fold_job;
+#define GML_FOLD_MAX_JOBS 16
+int gml_fold_many(const gml_fold_job* jobs /* host array */, int32_t njobs /* <= GML_FOLD_MAX_JOBS */, gml_stream_t stream);
+/* number of partial rows gml_edge_mlp_bwd leaves for this call shape (it depends on the kernel family the call takes) */
+int64_t gml_edge_mlp_bwd_parts(int64_t num_edges, int32_t S, int32_t Sout, int32_t has_split, int32_t want_gin);
 
 int gml_version(void);
 /* static string for any return code of this library (hipGetErrorString for >0) */
@@ -105,6 +133,9 @@ int gml_csr_link_transpose(const int32_t* perm_fwd, const int32_t* perm_t, int64
 int32_t gml_csr_group_record_ints(int32_t group_rows);
 int gml_csr_group_info(const int32_t* rowptr, const int32_t* col, int64_t num_rows, int32_t group_rows,
                        int32_t* ginfo, gml_stream_t stream);
+/* the same for two CSR views over the same rows (target- and source-keyed) in ONE launch */
+int gml_csr_group_info2(const int32_t* rowptr_a, const int32_t* col_a, int32_t* ginfo_a, const int32_t* rowptr_b,
+                        const int32_t* col_b, int32_t* ginfo_b, int64_t num_rows, int32_t group_rows, gml_stream_t stream);
 /* One launch: a padded static-shape batch (the graphs `ids`, in that order) and its whole index structure from a device-resident data
  * set whose per-graph structure was computed once.  The reference collates every batch on the host (DataLoader, Zinc12k.py:20-22,359);
  * here a batch is gathers + offsets, because a batch is the block-diagonal union of graphs whose own structure never changes.
@@ -434,6 +465,21 @@ int gml_bn_bwd_apply(const float* dy, int64_t lddy, const float* x, int64_t ldx,
 size_t gml_xty_workspace_bytes(int64_t n, int32_t a, int32_t b);
 int gml_xty(const float* A, int64_t lda, const float* B, int64_t ldb, float* out, int64_t n, int32_t a, int32_t b,
             void* ws, size_t ws_bytes, gml_stream_t stream);
+
+/* Readout head + L1-sum loss of the ZINC GNNML3 in one launch each way (Zinc12k.py:343-345, :365) for the reference's regime, a
+ * batch of 64 graphs, where head, loss and their backward were ~20 of the step's 70 launches (csrc/gml_head.hip):
+ *   loss[0] = sum_{r < rows_loss} valid[r] |w2 . relu(W1 p[r] + b1) + b2 - y[r]|     p [rows, nin] pooled features, W1 [nh, nin]
+ * rows >= rows_loss (the padding graph of a static batch) enter neither the loss nor any gradient.  pre (optional): logits of all
+ * rows.  The backward recomputes from p and scales by gscale[0] (device scalar, NULL = 1): gp [rows, nin], dw1 [nh, nin], db1 [nh]
+ * (NULL allowed), dw2 [nh], db2 [1] (NULL allowed).  One workgroup: rows <= 256, nin, nh <= 64 and everything in LDS, else
+ * GML_E_UNSUPPORTED (large batches run the general path: library GEMMs + gml_xty). */
+int gml_head_l1_fwd(const float* p, int64_t ldp, const float* y, const float* valid, const float* w1, const float* b1,
+                    const float* w2, const float* b2, int32_t rows, int32_t rows_loss, int32_t nin, int32_t nh,
+                    float* loss, float* pre, gml_stream_t stream);
+int gml_head_l1_bwd(const float* p, int64_t ldp, const float* y, const float* valid, const float* w1, const float* b1,
+                    const float* w2, const float* b2, int32_t rows, int32_t rows_loss, int32_t nin, int32_t nh,
+                    const float* gscale, float* gp, int64_t ldgp, float* dw1, float* db1, float* dw2, float* db2,
+                    gml_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -980,6 +980,76 @@ def test_padded_static_batch_equals_plain_batch(dev):
         close(gp[n], p.grad, tol=2e-5, what='padded vs plain grad ' + n)
 
 
+@pytest.mark.parametrize('padded', [False, True])
+def test_fused_head_and_l1_loss_equals_the_plain_path(dev, padded):
+    """models.zinc_step_loss (head + L1-sum loss as one launch each way, csrc/gml_head.hip; Zinc12k.py:343-345, :365) against
+    zinc_loss(model(data)) through library calls: loss and every parameter gradient, on a plain batch and on a padded static batch
+    (absent slots masked by graph_valid, padding graph ignored)."""
+    from gnn_matlang_amd import SpectralDesign, models, synthetic
+    from gnn_matlang_amd.dataset import DeviceDataset
+    raw = synthetic.make_graphs('zinc', 40, seed=8)
+    dsd = DeviceDataset.from_graphs(SpectralDesign(recfield=2, dv=2, nfreq=7).design_many(raw), dev)
+    ids = torch.tensor([5, 33, 0, 17, 21, 40, 40, 40], device=dev)
+    torch.manual_seed(1)
+    m = models.zinc_gnnml3().to(dev)
+    if padded:
+        dsd.y = dsd.y.float()
+        b = dsd.batch_padded(ids, dsd.bounds(8))
+        pre = m(b)
+        lp = ((pre[:8, 0] - b.y[:8]).abs() * b.graph_valid).sum()
+    else:
+        b = dsd.batch(ids[:5])
+        lp = models.zinc_loss(m(b), b.y.float())
+    lp.backward()
+    gp = {n: p.grad.clone() for n, p in m.named_parameters()}
+    m.zero_grad()
+    lf = models.zinc_step_loss(m, b)
+    assert lf.grad_fn is not None and 'HeadL1' in type(lf.grad_fn).__name__, 'the fused head did not run'
+    lf.backward()
+    assert abs(lp.item() - lf.item()) <= 1e-5 * abs(lp.item())
+    for n, p in m.named_parameters():
+        close(p.grad, gp[n], tol=2e-5, what='fused head vs plain path grad ' + n)
+    # an upstream scale reaches every gradient through the kernel
+    m.zero_grad()
+    (0.25 * models.zinc_step_loss(m, b)).backward()
+    for n, p in m.named_parameters():
+        close(p.grad, 0.25 * gp[n], tol=2e-5, what='scaled ' + n)
+
+
+@pytest.mark.parametrize('model', ['zinc', 'counting'])
+def test_deferred_folds_are_bit_identical(dev, model):
+    """functional.deferred_folds (include/gml.h "Deferred folds": the partial-sum folds of a backward pass as ONE gml_fold_many launch)
+    gives bitwise the gradients of the per-kernel folds -- conv weights (gml_k_reduce_rows), the output stage's sums
+    (gml_k_split_fold) and the edge branch's four matrices (gml_k_reduce_partials; counting.py's 12 supports: the chain16 family)."""
+    from gnn_matlang_amd import SpectralDesign, collate, functional as Fn, models, synthetic
+    if model == 'zinc':
+        raw = synthetic.make_graphs('zinc', 48, seed=3)
+        b = collate(SpectralDesign(recfield=2, dv=2, nfreq=7).design_many(raw)).to(dev)
+        torch.manual_seed(2)
+        m, loss = models.zinc_gnnml3().to(dev), models.zinc_loss
+    else:
+        raw = synthetic.make_graphs('counting', 40, seed=3)
+        b = collate(SpectralDesign(recfield=1, dv=1, nfreq=10, adddegree=True, laplacien=False, addadj=True).design_many(raw)).to(dev)
+        torch.manual_seed(2)
+        m, loss = models.counting_gnnml3().to(dev), models.counting_loss
+    y = b.y.float() if b.y.dim() == 1 else b.y[:, 0].float()
+    loss(m(b), y).backward()
+    ref = {n: p.grad.clone() for n, p in m.named_parameters()}
+    m.zero_grad()
+    l = loss(m(b), y)
+    seen = []
+    flush = Fn.flush_folds
+    Fn.flush_folds = lambda jobs: (seen.append(len(jobs)), flush(jobs))
+    try:
+        with Fn.deferred_folds():
+            l.backward()
+    finally:
+        Fn.flush_folds = flush
+    assert seen and seen[0] >= 3 * m.nlayers - 1, ('the folds were not deferred', seen)     # conv + output stage + edge branch per layer
+    for n, p in m.named_parameters():
+        assert torch.equal(p.grad, ref[n]), 'deferred fold differs: ' + n
+
+
 @pytest.mark.parametrize('fused_pool', [True, False])
 def test_padded_batch_loss_that_touches_the_padding_row(dev, monkeypatch, fused_pool):
     """the padding graph's pooled row is WRITTEN as zeros (GML_POOL_SKIP_LAST), so it does not depend on x -- a loss that

@@ -21,8 +21,9 @@ def main():
     ap.add_argument('--replays', type=int, default=200)
     ap.add_argument('--graphs', type=int, default=2000)
     ap.add_argument('--batch', type=int, default=64)
+    ap.add_argument('--plain-head', action='store_true', help='head + loss through library calls (rounds 1-4)')
     args = ap.parse_args()
-    from gnn_matlang_amd import SpectralDesign, models, synthetic
+    from gnn_matlang_amd import SpectralDesign, models, synthetic, functional as Fn
     from gnn_matlang_amd.dataset import DeviceDataset
     dev = torch.device('cuda:0')
     raw = synthetic.make_graphs('zinc', args.graphs, seed=4242)
@@ -37,13 +38,21 @@ def main():
     cm = models.zinc_gnnml3().to(dev)
     co = torch.optim.Adam(cm.parameters(), lr=1e-3, capturable=True, fused=True)
     loss_acc = torch.zeros((), device=dev)
+    one_ = torch.ones((), device=dev)
 
     def padded_step():
         b = assemble(ids_buf, bd)
         co.zero_grad(set_to_none=True)
-        pre = cm(b)
-        l = ((pre[:Bq, 0] - b.y[:Bq]).abs() * b.graph_valid).sum()
-        l.backward()
+        if args.plain_head:
+            pre = cm(b)
+            l = ((pre[:Bq, 0] - b.y[:Bq]).abs() * b.graph_valid).sum()
+        else:
+            l = models.zinc_step_loss(cm, b)
+        if args.plain_head:
+            l.backward()
+        else:
+            with Fn.deferred_folds():
+                l.backward(one_)
         co.step()
         loss_acc.add_(l.detach())
     ids_buf.copy_(torch.arange(Bq, device=dev))
