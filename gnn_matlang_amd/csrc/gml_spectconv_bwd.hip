@@ -2,6 +2,7 @@
 #include "gml_spectconv_bwd2_impl.h"
 #include "gml_spectconv_bwd3_impl.h"
 #include "gml_spectconv_bwd4_impl.h"
+#include "gml_spectconv_bwd5_impl.h"
 #include <stdlib.h>
 
 __global__ __launch_bounds__(256) void gml_k_reduce_rows(const float* __restrict__ partial, int64_t nparts, int64_t n,
@@ -49,6 +50,11 @@ GML_DECL_BWD4(8, 2) GML_DECL_BWD4(8, 1) GML_DECL_BWD4(4, 2) GML_DECL_BWD4(4, 1)
 /* bwd4 (LDS-DMA landing ring) runs when the caller sets GML_DMA_RING in flags or the process was started with GML_BWD_DMA=1.
    It is NOT the default: at ZINC shapes it measures 3-4 % slower than bwd3 (profiles/r03_bwd4_vs_bwd3_phases.txt: what the ring
    saves -- commit and the barriers around it, 4 % -- the two-supports-per-slab dW phase it forces gives back). */
+template <> int gml_launch_bwd5<2>(const GmlBwdParams&, dim3, size_t, hipStream_t);
+/* bwd5 (12 waves: two edge passes over 64 accumulators + four helper waves, VERDICT r04 item 1's form) for the ZINC shape class.
+   OPT-IN (GML_BWD5=1 in the environment): parity-green, but 8-23 % SLOWER than bwd3 in every schedule tried
+   (profiles/r05_bwd5_ab.txt) -- the second edge pass costs more than the third wave per SIMD and the off-loaded phases give back */
+static bool bwd5_env() { static const bool v = [] { const char* e = getenv("GML_BWD5"); return e && e[0] == '1'; }(); return v; }
 static bool bwd4_env() { static const bool v = [] { const char* e = getenv("GML_BWD_DMA"); return e && e[0] == '1'; }(); return v; }
 
 struct BwdPlan {
@@ -206,7 +212,12 @@ static int spectconv_bwd_impl(const int32_t* rowptr, const int32_t* col, const i
         const int ecap4 = S == 8 ? (pl.nfb == 2 ? GmlBwd4Cfg<8, 2>::ECAP : GmlBwd4Cfg<8, 1>::ECAP) : (pl.nfb == 2 ? GmlBwd4Cfg<4, 2>::ECAP : GmlBwd4Cfg<4, 1>::ECAP);
         dma = max_group_edges + 3 <= ecap4 && max_group_window + 7 <= GmlBwd4Cfg<8, 2>::XCAP;
     }
-    if (dma) {
+    const bool five = !dma && pl.layout == 3 && pl.nw == 8 && S == 8 && nob == 2 && nfb == 2 && bwd5_env() && p.gvec &&
+                      !(flags & GML_DVAL_ACCUM) && GmlBwd5Cfg<2>::lds_bytes(pl.ecap, pl.xcap) <= 160 * 1024 &&
+                      (dz == nullptr || (p.xvec && p.dxvec));
+    if (five) {
+        rc = gml_launch_bwd5<2>(p, dim3(pl.grid), GmlBwd5Cfg<2>::lds_bytes(pl.ecap, pl.xcap), st);
+    } else if (dma) {
 #define GML_BWD4_GO(SV, A) if (S == SV && nfb == A) rc = gml_launch_bwd4<SV, A>(p, dim3(pl.grid), st);
         GML_BWD4_GO(8, 2) GML_BWD4_GO(8, 1) GML_BWD4_GO(4, 2) GML_BWD4_GO(4, 1)
     } else if (pl.layout == 3) {

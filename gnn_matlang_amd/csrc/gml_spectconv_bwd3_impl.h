@@ -146,6 +146,20 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
     if constexpr ((GML_B3V & 64) != 0) {
         if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
     }
+#ifdef GML_B3DELAY
+    // experiment (NW = 4, two workgroups per CU): two workgroups started together run IN PHASE (same code, same durations: both in
+    // their VALU-bound edge loop, then both in their matrix-pipe phases); delaying one of each pair by ~half a group puts one's
+    // edge loop beside the other's projections.  GML_B3DELAY = number of s_sleep(127) (8 k cycles each), GML_B3DELAY_ODD: which half
+    if constexpr (NW == 4) {
+#ifdef GML_B3DELAY_ODD
+        const bool late = (blockIdx.x & 1) != 0;
+#else
+        const bool late = blockIdx.x >= gridDim.x / 2;
+#endif
+        if (late)
+            for (int i = 0; i < GML_B3DELAY; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     if constexpr (DZ) {
         if (tid < 128) wm_l[tid] = ((tid >> 5) < p.nmix && (tid & 31) < p.Fin) ? ((tid >> 5) < p.nmix1 ? p.wmix[(tid >> 5) * p.Fin + (tid & 31)] : p.wmix2[((tid >> 5) - p.nmix1) * p.Fin + (tid & 31)]) : 0.f;
     }
