@@ -752,3 +752,193 @@ extern "C" int gml_dense_support_mm(const uint16_t* dimg, const float* act, int6
     DN_CASE(8);
 #undef DN_CASE
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the dense-block layer WITHOUT Hcat and without a library GEMM (the TF reference's
+// autograd of libs/layers_tf.py:231-236):
+//
+//      dW[s][f][o] = sum_b sum_j H_s[b][j][f] g[b n + j][o],      H_s[b] = D[b][s] X[b]     (recomputed per graph, never stored)
+//
+// Rounds 2-4 wrote Hcat [B n, S Fin] in the forward (0.94 GB per step at MNIST's third layer and 4,096 graphs), read it back as a
+// row-slab batched library GEMM and summed the slabs.  Here a workgroup owns (support s, a block of 64 output columns, a slice of
+// the graphs): per graph the X tile goes through LDS as in the support product; a wave forms H for its 16 rows UNtransposed --
+// D[i = row j][n = feature]: lane (f = lane & 15, kq) holds rows j = 4 kq + reg -- which is, after the bf16 (hi, lo) split, exactly
+// the A operand (i = f, k = j = 4 kq + reg) of a K = 16 MFMA; the B operand g[j][o] of the same rows is 4 strided dwords per lane
+// and output tile.  bf16x3 both times.  The (feature tile, output tile) accumulators stay in registers across the slice's graphs;
+// the waves' row blocks are summed through LDS in fixed order at the end; one partial per slice -> gml_fold_many.
+// The support product is recomputed once per output-column block (2 blocks at Fout = 128): 2 x 360 of the kernel's ~1,700 MFMA
+// equivalents per graph and support -- the price of keeping 6 x 128 x 128 accumulators out of one workgroup's registers.
+typedef short dn_s16x4v __attribute__((ext_vector_type(4)));
+
+template <int NFT, int NOTB>
+__global__ __launch_bounds__(384) void gml_k_dense_dw(const uint16_t* __restrict__ dimg, const float* __restrict__ x, int64_t ldx,
+                                                     const float* __restrict__ g, int64_t ldg, float* __restrict__ partial,
+                                                     int B, int S, int n, int KP, int Fin, int Fout, int per_slice, int vec_in) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dn_lds[];
+    constexpr int PA = dn_pitch(NFT), NCH = 4 * NFT, KSMAX = 3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
+    const int t16 = lane & 15, kq = lane >> 4;
+    const int KS = KP >> 5;
+    const int slice = blockIdx.x, s = blockIdx.y, ob0 = blockIdx.z * NOTB;   // first 16-column output tile of this workgroup
+    unsigned char* img_h = dn_lds;
+    unsigned char* img_l = dn_lds + KP * PA;
+    const int row = wave * 16 + t16, rowc = row < n ? row : n - 1;
+    const int aoff = (8 * kq + (t16 >> 2)) * PA + 8 * (t16 & 3);
+    f32x4 acc[NFT][NOTB];
+#pragma unroll
+    for (int ft = 0; ft < NFT; ++ft)
+#pragma unroll
+        for (int ot = 0; ot < NOTB; ++ot) acc[ft][ot] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int b0 = slice * per_slice, b1 = min(b0 + per_slice, B);
+    for (int b = b0; b < b1; ++b) {
+        if (b > b0) __syncthreads();                           // every wave is done with the previous graph's X images
+        const float* xb = x + (int64_t)b * n * ldx;
+        for (int idx = tid; idx < KP * NCH; idx += nthr) {     // X of this graph -> (hi, lo) images [k][f]
+            const int k = idx / NCH, ch = idx % NCH;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (k < n && 4 * ch < Fin) {
+                const float* q = xb + (int64_t)k * ldx + 4 * ch;
+                if (vec_in) v = *reinterpret_cast<const f32x4*>(q);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (4 * ch + j < Fin) v[j] = q[j];
+                }
+            }
+            const uint32_t h0 = dn_pack2(v[0], v[1]), h1 = dn_pack2(v[2], v[3]);
+            const uint32_t l0 = dn_pack2(v[0] - __uint_as_float(h0 << 16), v[1] - __uint_as_float(h0 & 0xffff0000u));
+            const uint32_t l1 = dn_pack2(v[2] - __uint_as_float(h1 << 16), v[3] - __uint_as_float(h1 & 0xffff0000u));
+            *reinterpret_cast<uint2*>(img_h + k * PA + 8 * ch) = uint2{h0, h1};
+            *reinterpret_cast<uint2*>(img_l + k * PA + 8 * ch) = uint2{l0, l1};
+        }
+        // this lane's support row (row rowc, k = 32 ks + 8 kq .. + 7, hi and lo image) and its g values: rows 16 wave + 4 kq + r, column o
+        u32x4 bh[KSMAX], bl[KSMAX];
+        const uint16_t* base = dimg + ((int64_t)(b * S + s) * 2 * n + rowc) * KP + 8 * kq;
+#pragma unroll
+        for (int ks = 0; ks < KSMAX; ++ks) {
+            const int kc = ks < KS ? ks : KS - 1;
+            bh[ks] = *reinterpret_cast<const u32x4*>(base + 32 * kc);
+            bl[ks] = *reinterpret_cast<const u32x4*>(base + (int64_t)n * KP + 32 * kc);
+        }
+        dn_s16x4v gh[NOTB], gl[NOTB];
+#pragma unroll
+        for (int ot = 0; ot < NOTB; ++ot) {
+            const int o = 16 * (ob0 + ot) + t16;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = 16 * wave + 4 * kq + r;
+                v[r] = (j < n && o < Fout) ? g[((int64_t)b * n + j) * ldg + o] : 0.f;     // rows past n contribute nothing
+            }
+            const uint32_t h0 = dn_pack2(v[0], v[1]), h1 = dn_pack2(v[2], v[3]);
+            const uint32_t l0 = dn_pack2(v[0] - __uint_as_float(h0 << 16), v[1] - __uint_as_float(h0 & 0xffff0000u));
+            const uint32_t l1 = dn_pack2(v[2] - __uint_as_float(h1 << 16), v[3] - __uint_as_float(h1 & 0xffff0000u));
+            gh[ot] = __builtin_bit_cast(dn_s16x4v, uint2{h0, h1});
+            gl[ot] = __builtin_bit_cast(dn_s16x4v, uint2{l0, l1});
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ft = 0; ft < NFT; ++ft) {
+            // H tile (rows of this wave x features 16 ft .. + 15), untransposed: A = the support rows, B = X^T fragments
+            f32x4 h = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KSMAX; ++ks) {
+                if (ks < KS) {
+                    const bf16x8 Dh = __builtin_bit_cast(bf16x8, bh[ks]), Dl = __builtin_bit_cast(bf16x8, bl[ks]);
+                    const unsigned char* ah = img_h + 32 * ks * PA + aoff + 32 * ft;
+                    const unsigned char* al = img_l + 32 * ks * PA + aoff + 32 * ft;
+                    const bf16x8 Xh = dn_tr_frag(ah, ah + 4 * PA);
+                    const bf16x8 Xl = dn_tr_frag(al, al + 4 * PA);
+                    h = DN_MFMA(Dl, Xh, h);
+                    h = DN_MFMA(Dh, Xl, h);
+                    h = DN_MFMA(Dh, Xh, h);
+                }
+            }
+            // lane (f = 16 ft + t16, kq) holds H[j = 16 wave + 4 kq + reg][f]: the A operand (i = f, k = j) of the K = 16 contraction
+            const uint32_t h0 = dn_pack2(h[0], h[1]), h1 = dn_pack2(h[2], h[3]);
+            const uint32_t l0 = dn_pack2(h[0] - __uint_as_float(h0 << 16), h[1] - __uint_as_float(h0 & 0xffff0000u));
+            const uint32_t l1 = dn_pack2(h[2] - __uint_as_float(h1 << 16), h[3] - __uint_as_float(h1 & 0xffff0000u));
+            const dn_s16x4v Hh = __builtin_bit_cast(dn_s16x4v, uint2{h0, h1}), Hl = __builtin_bit_cast(dn_s16x4v, uint2{l0, l1});
+#pragma unroll
+            for (int ot = 0; ot < NOTB; ++ot) {
+                acc[ft][ot] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Hl, gh[ot], acc[ft][ot], 0, 0, 0);
+                acc[ft][ot] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Hh, gl[ot], acc[ft][ot], 0, 0, 0);
+                acc[ft][ot] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Hh, gh[ot], acc[ft][ot], 0, 0, 0);
+            }
+        }
+    }
+    // ---- the waves' row blocks summed in fixed order, one feature tile at a time through red[wave][ot][lane] (f32x4; NOTB KB per wave:
+    //      all tiles at once would be 160 KB at Fin = 128 -- one workgroup per CU), then one partial per slice
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(dn_lds);
+    const int nw = nthr >> 6;
+    float* P = partial + ((int64_t)slice * S + s) * Fin * Fout;
+#pragma unroll
+    for (int ft = 0; ft < NFT; ++ft) {
+        if (ft > 0) __syncthreads();
+#pragma unroll
+        for (int ot = 0; ot < NOTB; ++ot) red[(wave * NOTB + ot) * 64 + lane] = acc[ft][ot];
+        __syncthreads();
+        for (int idx = tid; idx < NOTB * 64; idx += nthr) {
+            const int ot = idx >> 6, ln = idx & 63;
+            f32x4 t = red[ot * 64 + ln];
+            for (int w = 1; w < nw; ++w) t += red[(w * NOTB + ot) * 64 + ln];
+            // D layout of the contraction: lane (o = ln & 15, kq = ln >> 4) holds features 16 ft + 4 kq + reg
+            const int o = 16 * (ob0 + ot) + (ln & 15);
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int f = 16 * ft + 4 * (ln >> 4) + reg;
+                if (f < Fin && o < Fout) P[(int64_t)f * Fout + o] = t[reg];
+            }
+        }
+    }
+}
+
+extern "C" int32_t gml_dense_dw_slices(int32_t B) {
+    int s = B < 64 ? B : 64;
+    return s < 1 ? 1 : s;
+}
+extern "C" size_t gml_dense_dw_workspace_bytes(int32_t B, int32_t S, int32_t Fin, int32_t Fout) {
+    if (B <= 0 || S <= 0 || Fin <= 0 || Fout <= 0) return 0;
+    return (size_t)gml_dense_dw_slices(B) * S * Fin * Fout * sizeof(float);
+}
+
+template <int NFT>
+static int dn_launch_dw(const uint16_t* dimg, const float* x, int64_t ldx, const float* g, int64_t ldg, float* partial, int B, int S, int n,
+                        int KP, int Fin, int Fout, hipStream_t st) {
+    constexpr int NOTB = 4;                                    // (2 at Fin = 128 -- a second workgroup per CU -- measured slower: twice the recomputed support products)
+    const int slices = gml_dense_dw_slices(B), per = (B + slices - 1) / slices;
+    const int nwaves = (n + 15) / 16;
+    size_t lds = (size_t)2 * KP * dn_pitch(NFT);
+    const size_t red = (size_t)nwaves * NOTB * 64 * 16;
+    if (red > lds) lds = red;
+    if (lds > 160 * 1024) return GML_E_UNSUPPORTED;
+    GML_ALLOW_BIG_LDS(rc, (gml_k_dense_dw<NFT, NOTB>), 160 * 1024);
+    if (rc != hipSuccess) return (int)rc;
+    const int vec_in = (Fin % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)x & 15) == 0) ? 1 : 0;
+    hipLaunchKernelGGL((gml_k_dense_dw<NFT, NOTB>), dim3((unsigned)slices, (unsigned)S, (unsigned)((Fout + 16 * NOTB - 1) / (16 * NOTB))),
+                       dim3(64 * nwaves), lds, st, dimg, x, ldx, g, ldg, partial, B, S, n, KP, Fin, Fout, per, vec_in);
+    return gml_launch_status();
+}
+
+// dW[s][f][o] = sum over the batch of (D[b][s] X[b])^T g[b]: the partial sums of gml_dense_dw_slices(B) graph slices into ws
+// ([slices][S][Fin][Fout]) and their fold in slice order into dw (when dw != NULL; NULL: the partials stay for gml_fold_many).
+extern "C" int gml_dense_conv_bwd_w(const uint16_t* dimg, const float* x, int64_t ldx, const float* g, int64_t ldg, float* dw,
+                                    int32_t B, int32_t S, int32_t n, int32_t KP, int32_t Fin, int32_t Fout, void* ws, size_t ws_bytes,
+                                    void* stream) {
+    if (!dimg || !x || !g || ldx < Fin || ldg < Fout) return GML_E_BADARG;
+    if (n < 1 || n > 96 || KP % 32 != 0 || KP < n || KP > 96 || Fin < 1 || Fin > 128 || Fout < 1 || S < 1 || B < 0) return GML_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nw = (int64_t)S * Fin * Fout;
+    if (B == 0) { if (dw) gml_zero_async(dw, sizeof(float) * nw, st); return gml_launch_status(); }
+    if (!ws || ws_bytes < gml_dense_dw_workspace_bytes(B, S, Fin, Fout)) return GML_E_WORKSPACE;
+    const int nft = (Fin + 15) / 16;
+    int rc;
+    if (nft <= 1) rc = dn_launch_dw<1>(dimg, x, ldx, g, ldg, (float*)ws, B, S, n, KP, Fin, Fout, st);
+    else if (nft <= 2) rc = dn_launch_dw<2>(dimg, x, ldx, g, ldg, (float*)ws, B, S, n, KP, Fin, Fout, st);
+    else if (nft <= 4) rc = dn_launch_dw<4>(dimg, x, ldx, g, ldg, (float*)ws, B, S, n, KP, Fin, Fout, st);
+    else rc = dn_launch_dw<8>(dimg, x, ldx, g, ldg, (float*)ws, B, S, n, KP, Fin, Fout, st);
+    if (rc != GML_OK || !dw) return rc;
+    gml_fold_job job = {};
+    job.partial = (const float*)ws; job.nparts = gml_dense_dw_slices(B); job.n = nw; job.dst[0] = dw; job.ndst[0] = nw;
+    return gml_fold_many(&job, 1, stream);
+}

@@ -126,6 +126,12 @@ class _TallGemm(torch.autograd.Function):
         return dh, dw, db
 
 
+# Weight gradient: by default Hcat is written in the forward and dW = Hcat^T g runs as a row-slab batched library GEMM (rounds 2-4).
+# GML_DENSE_DW_HIP=1: gml_dense_conv_bwd_w (round 5) -- no Hcat, the support product recomputed per graph and contracted with g on the
+# matrix cores, hand-written.  Parity-tested, but SLOWER (MNIST-75 step at 4,096 graphs: 5.5 ms against 3.6 ms; 1,024 graphs: 1.55 against
+# 1.19): a workgroup per (support, 64-column block, graph slice) recomputes the product per column block and pays the full load
+# latency per graph (208 VGPRs at Fin = 128: one workgroup per CU).  What it needs is in DESIGN s8.
+DW_LIBRARY = os.environ.get('GML_DENSE_DW_HIP', '0') in ('0', '')
 CHAIN = os.environ.get('GML_DENSE_CHAIN', '1') not in ('0', '')      # projection chained behind the support product (gml_dense_conv_fwd)
 CHAIN_BWD = os.environ.get('GML_DENSE_CHAIN_BWD', '1') not in ('0', '')   # and the dX path: projection in front of the transposed product
 
@@ -144,14 +150,14 @@ class _DenseConv(torch.autograd.Function):
         rows = sup.B * sup.n
         wimg = torch.empty(int(_lib.lib().gml_dense_wimg_elems(S, Fin, Fout)), dtype=torch.int16, device=dev)
         _lib.call('gml_dense_pack_w', _ptr(weight.contiguous()), _ptr(wimg), S, Fin, Fout, _stream(dev))
-        need_h = ctx.needs_input_grad[1]
+        need_h = ctx.needs_input_grad[1] and DW_LIBRARY           # (round 5: the weight gradient recomputes the support product -- no Hcat)
         hcat = torch.empty(rows, S * Fin, dtype=torch.float32, device=dev) if need_h else None
         out = torch.empty(rows, Fout, dtype=torch.float32, device=dev)
         Fn._path('dense', 'support product + projection chained (bf16x3 HIP)', S, Fin, Fout)
         _lib.call('gml_dense_conv_fwd', _ptr(sup.fwd), _ptr(x), int(x.stride(0)), _ptr(wimg), _ptr(bias), _ptr(out), Fout,
                   _ptr(hcat), sup.B, S, sup.n, sup.KP, Fin, Fout, 0, _stream(dev))
-        ctx.save_for_backward(hcat, weight)
-        ctx.sup, ctx.has_bias = sup, bias is not None
+        ctx.save_for_backward(hcat if hcat is not None else x, weight)
+        ctx.sup, ctx.has_bias, ctx.has_h = sup, bias is not None, hcat is not None
         return out
 
     @staticmethod
@@ -174,7 +180,16 @@ class _DenseConv(torch.autograd.Function):
             else:
                 dh = g.mm(weight.reshape(S * Fin, Fout).t())
                 dx = support_mm(sup.bwd, dh, sup, Fin, Fin, 0, True)
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and not ctx.has_h:
+            # dW = sum over the graphs of (D_s X)^T g: the support product recomputed on the matrix cores, contracted with g over the graph's
+            # rows, no Hcat in HBM and no library GEMM (gml_dense_conv_bwd_w, csrc/gml_dense.hip)
+            x, dev = hcat, g.device
+            Fn._path('dense', 'weight gradient: support product recomputed + row contraction (bf16x3 HIP)', S, Fin, Fout)
+            ws = torch.empty(max(int(_lib.lib().gml_dense_dw_workspace_bytes(sup.B, S, Fin, Fout)), 4), dtype=torch.uint8, device=dev)
+            dw = torch.empty(S, Fin, Fout, dtype=torch.float32, device=dev)
+            _lib.call('gml_dense_conv_bwd_w', _ptr(sup.fwd), _ptr(x), int(x.stride(0)), _ptr(g), int(g.stride(0)), _ptr(dw), sup.B, S, sup.n,
+                      sup.KP, Fin, Fout, _ptr(ws), ws.numel(), _stream(dev))
+        elif ctx.needs_input_grad[1]:
             rows = int(hcat.size(0))
             P = _splits(rows)
             dw = (torch.bmm(hcat.view(P, rows // P, S * Fin).transpose(1, 2), g.view(P, rows // P, Fout)).sum(0) if P > 1

@@ -427,6 +427,14 @@ size_t gml_dense_wimgt_elems(int32_t S, int32_t Fin, int32_t Fout);
 int gml_dense_pack_wt(const float* w, uint16_t* wimgT, int32_t S, int32_t Fin, int32_t Fout, void* stream);
 int gml_dense_conv_bwd_x(const uint16_t* dimgT, const float* g, int64_t ldg, const uint16_t* wimgT, float* dx, int64_t lddx,
                          int32_t B, int32_t S, int32_t n, int32_t KP, int32_t Fin, int32_t Fout, void* stream);
+/* the layer's weight gradient WITHOUT Hcat and without a library GEMM: dW[s][f][o] = sum_b sum_j (D[b][s] X[b])[j][f] g[b n + j][o] -- the
+ * support product recomputed per graph on the matrix cores and contracted with g over the graph's rows (K = 16 MFMAs on the
+ * untransposed product), per-slice partial sums in ws ([gml_dense_dw_slices(B)][S][Fin][Fout]) folded in slice order into dw
+ * (dw == NULL: the partials stay for gml_fold_many).  dimg: the forward images (gml_dense_pack(transpose = 0)); Fin <= 128. */
+int32_t gml_dense_dw_slices(int32_t B);
+size_t gml_dense_dw_workspace_bytes(int32_t B, int32_t S, int32_t Fin, int32_t Fout);
+int gml_dense_conv_bwd_w(const uint16_t* dimg, const float* x, int64_t ldx, const float* g, int64_t ldg, float* dw,
+                         int32_t B, int32_t S, int32_t n, int32_t KP, int32_t Fin, int32_t Fout, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------- support precompute on the device (adjacent step, P1)
  * SpectralDesign.__call__ (libs/utils.py:546-610) for a batch of graphs with at most 80 nodes each (larger: host

@@ -1494,6 +1494,25 @@ def test_spmm_ring_kernel_any_support_count(dev, deg):
             close(h, href, what='spmm ring N=%d deg=%d S=%d Fin=%d' % (N, deg, S, fin))
 
 
+@pytest.mark.parametrize('n,S,Fin,Fout', [(75, 6, 2, 64), (75, 6, 64, 128), (75, 6, 128, 128), (40, 3, 20, 24), (96, 2, 33, 70)])
+def test_dense_weight_gradient_kernel_vs_fp64(dev, monkeypatch, n, S, Fin, Fout):
+    """gml_dense_conv_bwd_w (csrc/gml_dense.hip: dW without Hcat and without a library GEMM -- VERDICT r04 item 7; opt-in through
+    GML_DENSE_DW_HIP, see dense_block.py for the measured reason) against fp64 einsum, MNIST-75's three layer shapes + ragged ones."""
+    from gnn_matlang_amd import dense_block as DB
+    monkeypatch.setattr(DB, 'DW_LIBRARY', False)
+    g = torch.Generator().manual_seed(n + Fin + 3 * Fout)
+    B = 70                                                   # (more graphs than slices: several graphs per workgroup, a ragged last slice)
+    blocks = (torch.randn(B, S, n, n, generator=g) * (torch.rand(B, S, n, n, generator=g) < 0.8)).to(dev)
+    x = torch.randn(B * n, Fin, generator=g).to(dev)
+    w = (torch.randn(S, Fin, Fout, generator=g) * 0.3).to(dev).requires_grad_(True)
+    sup = DB.DenseSupports(blocks, keep_blocks=False)
+    out = DB._DenseConv.apply(x, w, None, sup)
+    go = torch.randn(B * n, Fout, generator=g).to(dev)
+    out.backward(go)
+    h = torch.einsum('bsji,bif->bjsf', blocks.double(), x.double().view(B, n, Fin))
+    close(w.grad, torch.einsum('bjsf,bjo->sfo', h, go.double().view(B, n, Fout)).float(), what='dW without Hcat n=%d S=%d %d->%d' % (n, S, Fin, Fout))
+
+
 @pytest.mark.parametrize('n,S,Fin,Fout', [(75, 6, 2, 64), (75, 6, 64, 128), (75, 6, 128, 128), (5, 4, 48, 10), (33, 3, 7, 30), (64, 2, 20, 64),
                                            (96, 2, 33, 100), (20, 1, 16, 16)])
 def test_dense_conv_chained_vs_fp64(dev, n, S, Fin, Fout):
