@@ -238,11 +238,18 @@ def main():
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     assert torch.cuda.is_available(), 'bench.py needs the MI355X (no CPU fallback)'
+    # GML_BENCH_SHARE_DEVICE=1 (tests on a 1-GPU box): every rank on cuda:0 over gloo -- the N > 1 code path without RCCL
+    share = os.environ.get('GML_BENCH_SHARE_DEVICE') == '1'
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if share:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     from gnn_matlang_amd import functional as Fn, models
     from gnn_matlang_amd.dist import FlatGradSync, broadcast_parameters
@@ -370,6 +377,51 @@ def main():
                          max_over_mean=max(edges) / (sum(edges) / len(edges)))
     lossv = float(loss.item())
     assert np.isfinite(lossv) or os.environ.get('GML_BENCH_NOCHECK'), 'loss diverged'   # (NOCHECK: ablation builds)
+    dp = None
+    if world > 1:
+        # ---- what the collective costs (every rank runs this: collectives): each rank's own median block, the flat gradient
+        #      all-reduce alone, and the reference's batch size per rank as ONE captured HIP graph with the all-reduce inside
+        from gnn_matlang_amd.dist import TrainStep
+        own = torch.tensor([float(np.median(blocks)) / args.steps * 1e3], dtype=torch.float64, device=dev)
+        per_rank = [torch.zeros_like(own) for _ in range(world)]
+        dist.all_gather(per_rank, own)
+        nparam = sum(p.numel() for p in model.parameters())
+        flat = torch.zeros(nparam, dtype=torch.float32, device=dev)
+        for _ in range(5):
+            dist.all_reduce(flat)
+        fence()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            dist.all_reduce(flat)
+        e1.record()
+        torch.cuda.synchronize()
+        ar_ms = torch.tensor([e0.elapsed_time(e1) / 50], dtype=torch.float64, device=dev)
+        dist.all_reduce(ar_ms, op=dist.ReduceOp.MAX)
+        dp = dict(per_rank_ms_per_step=[float(t.item()) for t in per_rank], allreduce_ms=float(ar_ms.item()), allreduce_bytes=4 * nparam,
+                  allreduce='ONE flat fp32 SUM all-reduce per step (dist.FlatGradSync), RCCL')
+        try:
+            rb64, _ = build_batch(64, 64, seed=7 + rank, device=dev)
+            rb64.csr('edge_index2')
+            torch.manual_seed(0)
+            m64 = models.zinc_gnnml3().to(dev)
+            broadcast_parameters(m64)
+            ts = TrainStep(m64, lambda mod, d_: models.zinc_step_loss(mod, d_), torch.optim.Adam(m64.parameters(), lr=1e-3, capturable=True, fused=True))
+            replay, gl64 = ts.capture(rb64)
+            for _ in range(20):
+                replay()
+            fence()
+            t64 = time.perf_counter()
+            for _ in range(200):
+                replay()
+            fence()
+            t64 = torch.tensor([(time.perf_counter() - t64) / 200 * 1e3], dtype=torch.float64, device=dev)
+            dist.all_reduce(t64, op=dist.ReduceOp.MAX)
+            dp['captured_bs64_per_rank'] = dict(ms_per_step=float(t64.item()), value=64 * world / (float(t64.item()) * 1e-3), unit='graphs/s',
+                                                order=ts.order, mode='batch 64 per rank: forward + loss + backward + fold + flat all-reduce + fused '
+                                                'Adam replayed from ONE HIP graph per rank (the collective is a graph node)')
+        except Exception as e:                                 # noqa: BLE001  (recorded, not fatal: the eager path above is the measured one)
+            dp['captured_bs64_per_rank'] = dict(error=repr(e)[:300])
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -383,9 +435,11 @@ def main():
                                parallelism='dp%d' % world, params=sum(p.numel() for p in model.parameters())),
                    final_loss=lossv, blocks=len(blocks), block_seconds=[round(b, 4) for b in blocks],
                    n_ranks_seen=dist.get_world_size() if world > 1 else 1,
-                   rccl_version='.'.join(str(v) for v in torch.cuda.nccl.version()) if world > 1 else None)
+                   rccl_version='.'.join(str(v) for v in torch.cuda.nccl.version()) if (world > 1 and not share) else None)
         if shard_imb is not None:
             res['sharding'] = shard_imb
+        if dp is not None:
+            res['data_parallel'] = dp
         def rooflines(prof_):
             """(dominant kernel's roofline record, the other candidates, per-tag ms per step) of one profiled block"""
             summ = Fn.profile_summary(prof_)

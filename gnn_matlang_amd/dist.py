@@ -108,3 +108,57 @@ class SyncBatchNorm1d(torch.nn.BatchNorm1d):
             self.running_mean.mul_(1 - m).add_(mean, alpha=m)
             self.running_var.mul_(1 - m).add_(var * (n / (n - 1).clamp(min=1)), alpha=m)
         return y
+
+
+class TrainStep(object):
+    """One data-parallel training step in the order its pieces need:
+
+        zero -> forward + loss -> backward (the weight-gradient folds deferred: functional.deferred_folds) -> fold flush
+             -> ONE flat SUM all-reduce (FlatGradSync.sync; nothing with one rank) -> optimizer
+
+    ``step(data)`` runs it eagerly.  ``capture(data)`` records the SAME sequence, the all-reduce included, into one HIP graph
+    over static tensors and returns a replay function (RCCL collectives are stream-ordered and capturable like kernels; the flat
+    gradient buffer and every .grad view live in the graph's private pool, so a replay rewrites the memory the optimizer reads).
+    ``loss_fn(model, data) -> scalar``.  SURVEY s8e: the collective is latency-bound at the reference's batch size -- inside the graph
+    it costs no host launch."""
+
+    def __init__(self, model, loss_fn, optimizer, sync=None, defer_folds=True, group=None):
+        self.model, self.loss_fn, self.opt = model, loss_fn, optimizer
+        self.sync = sync if sync is not None else FlatGradSync(model.parameters(), group)
+        self.defer = bool(defer_folds)
+        self.order = []                                        # what ran, in order (tests)
+
+    def step(self, data):
+        self.order = ['zero']
+        self.sync.zero()
+        loss = self.loss_fn(self.model, data)
+        self.order.append('forward')
+        if self.defer and loss.is_cuda:
+            from . import functional as Fn
+            with Fn.deferred_folds():
+                loss.backward()
+            self.order.append('backward+fold')
+        else:
+            loss.backward()
+            self.order.append('backward')
+        flat = self.sync.sync()
+        self.order.append('allreduce' if flat is not None else 'no-allreduce')
+        self.opt.step()
+        self.order.append('optimizer')
+        return loss.detach()
+
+    __call__ = step
+
+    def capture(self, data, warmup=3):
+        """-> (replay, loss tensor): ``replay()`` re-runs the captured step on the CURRENT contents of data's tensors."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                          # warm-up off the capture stream (allocator, lazy init, RCCL channels)
+            for _ in range(warmup):
+                self.step(data)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            loss = self.step(data)
+        return g.replay, loss

@@ -17,8 +17,14 @@ T = lambda a: torch.tensor(np.asarray(a))
 def main():
     out, balanced = sys.argv[1], sys.argv[2] == '1'
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
-    dist.init_process_group('gloo', rank=rank, world_size=world)
-    dev = torch.device('cuda:0')
+    # a device per rank: RCCL ('nccl'), as on the 8-GPU node; the 1-GPU test box: both ranks on cuda:0 over gloo
+    nccl = torch.cuda.device_count() >= world and os.environ.get('GML_TEST_GLOO') != '1'
+    dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', rank)) if nccl else 0)
+    torch.cuda.set_device(dev)
+    if nccl:
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
     from gnn_matlang_amd import models
     from gnn_matlang_amd.dist import FlatGradSync, broadcast_parameters
     from gnn_matlang_amd.graph import Batch, shard_graphs, shard_graphs_balanced

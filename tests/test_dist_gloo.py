@@ -127,3 +127,59 @@ def test_two_rank_mnist_step_with_synced_readout_batchnorm(tmp_path):
     for n, v in r['grads'].items():                    # == the TF graph's full-batch gradients
         ref = g['grad/' + n]
         assert np.abs(v.numpy() - ref).max() <= 1e-4 * np.abs(ref).max(), n
+
+
+def _worker_trainstep(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from gnn_matlang_amd.dist import TrainStep, broadcast_parameters
+    from gnn_matlang_amd.graph import shard_graphs
+    from oracle import models_oracle as MO
+    torch.set_num_threads(1)
+    g = np.load(os.path.join(GOLDEN, 'model_zinc_gnnml3.npz'))
+    b = {k[len('batch/'):]: g[k] for k in g.files if k.startswith('batch/')}
+    torch.manual_seed(7 + rank)
+    m = MO.zinc_gnnml3(25, 8)
+    if rank == 0:
+        m.load_state_dict({k[len('param/'):]: T(g[k]) for k in g.files if k.startswith('param/')})
+    broadcast_parameters(m)
+    lo, hi = shard_graphs(len(b['y']), rank, world)
+    s = _shard(b, lo, hi)
+
+    class D(object):
+        pass
+    d = D()
+    d.x, d.ei, d.ea, d.batch, d.y, d.B = T(s['x']), T(s['edge_index2']), T(s['edge_attr2']), T(s['batch']), T(s['y']), hi - lo
+    ts = TrainStep(m, lambda mod, dd: MO.zinc_loss(mod(dd.x, dd.ei, dd.ea, dd.batch, dd.B), dd.y), torch.optim.Adam(m.parameters(), lr=1e-3))
+    losses, order = [], None
+    for step in range(3):
+        l = ts(d)
+        if step == 0:
+            order = list(ts.order)
+            grads = {n: p.grad.clone() for n, p in m.named_parameters()}
+            # the all-reduced gradients are views of ONE flat buffer: what the optimizer reads is what the collective wrote
+            flat = ts.sync.flat
+            assert all(flat.data_ptr() <= p.grad.data_ptr() < flat.data_ptr() + flat.numel() * 4 for p in ts.sync.params)
+        lt = l.clone()
+        dist.all_reduce(lt)
+        losses.append(lt.item())
+    if rank == 0:
+        torch.save(dict(grads=grads, losses=losses, order=order), out)
+    dist.destroy_process_group()
+
+
+def test_trainstep_orders_backward_fold_allreduce_optimizer(tmp_path):
+    """dist.TrainStep -- the sequence bench.py times and, on RCCL, captures into one HIP graph with the all-reduce inside: zero ->
+    forward -> backward (folds flushed) -> ONE flat all-reduce -> optimizer.  Two gloo ranks on the oracle model: the order is as
+    stated, the summed shard gradients are the reference's full-batch gradients and the loss trajectory is the fixture's."""
+    out = str(tmp_path / 'ts.pt')
+    mp.spawn(_worker_trainstep, args=(2, _free_port(), out), nprocs=2, join=True)
+    res = torch.load(out)
+    assert res['order'] == ['zero', 'forward', 'backward', 'allreduce', 'optimizer']
+    g = np.load(os.path.join(GOLDEN, 'model_zinc_gnnml3.npz'))
+    for n, v in res['grads'].items():
+        ref = g['grad/' + n]
+        assert np.abs(v.numpy() - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-30), n
+    np.testing.assert_allclose(res['losses'], g['loss_traj'][:3], rtol=1e-5)

@@ -62,6 +62,23 @@ def test_bench_strong_scaling_shards_one_global_batch():
     assert abs(sh['max_over_mean'] - 1.0) < 1e-12
 
 
+def test_bench_two_ranks_share_the_device_over_gloo():
+    """bench.py's N > 1 code path on the 1-GPU box: two spawned ranks on cuda:0 over gloo
+    (GML_BENCH_SHARE_DEVICE=1) -- sharded batch, flat all-reduce per step, per-rank times, all-reduce timing and the captured
+    batch-64 step (gloo collectives cannot be captured: that record carries the error string here, the graph on RCCL)."""
+    import json
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '1', '--no-cpu', '--no-extras', '--ref-batch', '0',
+           '--min-seconds', '0', '--gpus', '2', '--batch', '2048']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', GML_BENCH_SHARE_DEVICE='1'))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d['n_gpus'] == 2 and d['n_ranks_seen'] == 2 and d['config']['global_batch'] == 4096
+    dp = d['data_parallel']
+    assert len(dp['per_rank_ms_per_step']) == 2 and dp['allreduce_ms'] > 0 and dp['allreduce_bytes'] == 4 * d['config']['params']
+    assert 'captured_bs64_per_rank' in dp
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs: RCCL wants one device per rank')
 def test_bench_two_gpus_over_rccl():
     """the real entry point on the first box that has two GPUs: bench.py --gpus 2 spawns its ranks, backend nccl (= RCCL),
