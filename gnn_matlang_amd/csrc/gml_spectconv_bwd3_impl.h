@@ -533,6 +533,28 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
             if (k < ((GML_ABL & 4) ? kbeg : kend)) {
                 float eA[S], eB[S];
                 ldval(k, eA);
+                if constexpr ((GML_B3V & 8192) != 0) {
+                    // the column id of edge k + 1 travels one trip ahead (one register, one clamp): the loop's chain column id -> G row ->
+                    // arithmetic loses its first LDS round trip (the full two-set pipeline of G rows costs more than it hides: bit 1024)
+                    auto edge_c = [&](int kk, int c, const float (&ev)[S]) {
+                        f32x2 gv[NH];
+                        ldg_row(c, gv);
+                        edge_g(kk, ev, gv);
+                    };
+                    int c = col_l[k];
+                    for (;;) {
+                        const int kn = min(k + 1, klast);
+                        const int cn = col_l[kn];
+                        ldval(kn, eB);
+                        edge_c(k, c, eA);
+                        if (++k >= kend) break;
+                        const int kn2 = min(k + 1, klast);
+                        c = col_l[kn2];
+                        ldval(kn2, eA);
+                        edge_c(k, cn, eB);
+                        if (++k >= kend) break;
+                    }
+                } else {
                 for (;;) {
                     ldval(min(k + 1, klast), eB);
                     edge(k, eA);
@@ -540,6 +562,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
                     ldval(min(k + 1, klast), eA);
                     edge(k, eB);
                     if (++k >= kend) break;
+                }
                 }
             }
         } else {
