@@ -159,22 +159,23 @@ def parity_vs_oracle(model, data, base, log):
     host = base.to(torch.device('cpu'))
     torch.cuda.synchronize()
     out = dict(graphs=int(data.num_graphs), pool_graphs=int(base.num_graphs), tolerance=1e-4,
-               criterion='|got - ref| <= 1e-4 * T per element; T = sum of |terms| at product level (oracle/termsums.py), ref = oracle in float64',
+               criterion='|got - ref| <= 1e-4 * T per element; T = sum of |terms| at product level, per layer from the float64 activations and output gradients (oracle/parity_at_size.py, oracle/termsums.py), ref = oracle in float64',
                modes={})
     T = None
     for mode in ('bf16x3', 'f32'):
         for p_ in model.parameters():
             p_.grad = None
         with Fn.exact_products(mode == 'f32'):
-            pre = model(data)
+            cap = {}
+            pre = model(data, _capture=cap)
             models.zinc_loss(pre, data.y).backward()
-        ref = PS.reference(host, model.state_dict(), data.y, pre_dev=pre[:, 0], T=T)
+        ref = PS.reference(host, model.state_dict(), data.y, pre_dev=pre[:, 0], T=T, head_pre_dev=cap['head_pre'])
         T = ref['T']
         rep = PS.compare(ref, pre[:, 0].detach().cpu().numpy(), {n: p_.grad.detach().cpu().numpy() for n, p_ in model.named_parameters()})
         worst = max(rep['tensors'].items(), key=lambda kv: kv[1]['termsum'])
         out['modes'][mode] = dict(logits_rel_err=rep['logits_rel_err'], max_rel_err_termsum=rep['worst_termsum'],
                                   max_rel_err_maxnorm=rep['worst_maxnorm'], worst_tensor=worst[0], ok=rep['ok'],
-                                  oracle_seconds=round(ref['seconds'], 2))
+                                  head_units_flipped=ref['head_units_flipped'], oracle_seconds=round(ref['seconds'], 2))
         log('parity at bench size, %s: logits %.2e, gradients %.2e of their term sums (worst: %s), %s' % (
             mode, rep['logits_rel_err'], rep['worst_termsum'], worst[0], 'ok' if rep['ok'] else 'BEYOND 1e-4'))
     for p_ in model.parameters():

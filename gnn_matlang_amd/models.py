@@ -131,7 +131,7 @@ class GNNML3(torch.nn.Module):
         else:
             self.fc1 = torch.nn.Linear(nin, 10)
 
-    def forward(self, data, _features=False):
+    def forward(self, data, _features=False, _capture=None):
         x = data.x
         if getattr(data, 'pad_graph', False) and self.training and (self.bn or self.readout_bn):
             # the padding nodes / the padding graph's pooled row would enter the batch statistics
@@ -174,7 +174,10 @@ class GNNML3(torch.nn.Module):
         if _features:
             return x
         if self.head == 'mlp32':
-            return tall_linear(F.relu(tall_linear(x, self.fc1)), self.fc2)
+            z1 = tall_linear(x, self.fc1)
+            if _capture is not None:
+                _capture['head_pre'] = z1.detach()            # (the parity checker takes the head's relu mask from here)
+            return tall_linear(F.relu(z1), self.fc2)
         return torch.tanh(tall_linear(x, self.fc1))
 
     def features(self, data):

@@ -11,9 +11,9 @@ and ONE float64 forward + backward of the oracle over the P pool graphs is the e
 
 The criterion for a parameter gradient is the term-sum one: |got - ref| <= tol * T, T = the sum of the
 absolute values of the TERMS the element is a sum of -- at the level of the products the kernels actually form (a conv weight
-gradient is X^T (A_s G): 3 M rows x ~6 edges of |x| |val| |g| products per element), propagated through each ML3Layer by
-oracle/termsums.py from the float64 activations and the float64 gradient at the layer's output; every copy of a graph contributes
-the same magnitudes, so T(batch) = R * T(pool).  The head's two Linear layers: T_W = |g|^T |input|, T_b = sum |g|.
+gradient is X^T (A_s G): 3 M rows x ~6 edges of |x| |val| |g| products per element), per ML3Layer by oracle/termsums.py from
+the float64 activations at the layer's input and the float64 gradient at its output (layer-local: see model_termsums); every
+copy of a graph contributes the same magnitudes, so T(batch) = R * T(pool).  The head's Linear layers: T_W = |g|^T |input|, T_b = sum |g|.
 (Round 5 first tried T from whole-graph contributions -- one float64 backward pass per pool graph: slow, and blind to the
 cancellation INSIDE a graph, which is where most of a conv weight gradient's terms cancel: the elements that failed under it
 sit at 2e-5 of their tensor's maximum.)
@@ -27,13 +27,16 @@ from . import models_oracle as MO
 from .termsums import ml3_termsums
 
 
-def reference(pool_batch, state_dict, y_full, pre_dev=None, T=None, threads=16):
+def reference(pool_batch, state_dict, y_full, pre_dev=None, T=None, threads=16, head_pre_dev=None):
     """pool_batch: the collated pool (CPU tensors x, edge_index2, edge_attr2, batch, num_graphs); state_dict: the model's
     parameters (any device); y_full [R * P] targets in the bench's order (copy-major); pre_dev [R * P]: the device's own logits -- the
     L1 loss's sign(pre - y) is then taken from THEM (a copy whose |pre - y| is below the logits' round-off would otherwise flip the
-    sign of its whole contribution: a property of the loss, not an error of the backward); T: term sums of an earlier call with the
-    same parameters and pool (they do not depend on the arithmetic mode).  Returns dict(pre [P] float64, grads {name: float64
-    array}, T {name: float64 array}, seconds)."""
+    sign of its whole contribution: a property of the loss, not an error of the backward); head_pre_dev [R * P, nh]: the device's
+    fc1 outputs -- the head's relu mask is then taken from them for the same reason (a hidden unit of the head whose pre-activation is
+    within round-off of zero switches a whole graph's contribution, coherently in all R copies: with 2,048 pool graphs ONE such unit is
+    5e-4 of fc1.weight's term sum; the relus inside the layers act per node, 1 / 3 M of a sum, and need no such care); T: term sums of
+    an earlier call with the same parameters and pool (they do not depend on the arithmetic mode).  Returns dict(pre [P] float64,
+    grads {name: float64 array}, T {name: float64 array}, head_units_flipped, seconds)."""
     t0 = time.perf_counter()
     torch.set_num_threads(min(int(threads), torch.get_num_threads()))   # (tiny float64 ops: hundreds of threads only contend)
     b = pool_batch
@@ -41,24 +44,44 @@ def reference(pool_batch, state_dict, y_full, pre_dev=None, T=None, threads=16):
     R = int(y_full.numel()) // P
     m = MO.zinc_gnnml3(int(b.x.size(1)), int(b.edge_attr2.size(1))).double()
     m.load_state_dict({k: v.detach().cpu().double() for k, v in state_dict.items()})
+    head = {}
+    hook = m.fc1.register_forward_hook(lambda mod, inp, out: head.__setitem__('z1', out))
     pre = m(b.x.double(), b.edge_index2, b.edge_attr2.double(), b.batch, P)[:, 0]            # [P]
+    hook.remove()
     y = y_full.detach().cpu().double().view(R, P)
     pd = pre.detach().unsqueeze(0) if pre_dev is None else pre_dev.detach().cpu().double().view(R, P)
-    c = torch.sign(pd - y).sum(0)                                                             # [P]
+    c = torch.sign(pd - y)                                                                    # [R, P]
     params = dict(m.named_parameters())
     names = list(params)
-    g = torch.autograd.grad((c * pre).sum(), [params[n] for n in names], retain_graph=True)
-    grads = {n: v.numpy() for n, v in zip(names, g)}
+    flipped = 0
+    if head_pre_dev is None:
+        g = torch.autograd.grad((c.sum(0) * pre).sum(), [params[n] for n in names], retain_graph=True)
+        grads = {n: v.numpy() for n, v in zip(names, g)}
+    else:
+        z1 = head['z1']                                                                       # [P, nh], in the graph (Zinc12k.py:343-345)
+        mk = (head_pre_dev.detach().cpu().view(R, P, -1) > 0).double()
+        flipped = int((mk != (z1.detach() > 0).double().unsqueeze(0)).sum())
+        gz = (c.unsqueeze(-1) * mk).sum(0) * m.fc2.weight.detach()                           # d loss / d z1, summed over the copies
+        low = [n for n in names if not n.startswith('fc2.')]
+        g = torch.autograd.grad(z1, [params[n] for n in low], grad_outputs=gz, retain_graph=True)
+        grads = {n: v.numpy() for n, v in zip(low, g)}
+        cg = c.sum(0)
+        grads['fc2.weight'] = (cg.unsqueeze(1) * torch.relu(z1.detach())).sum(0, keepdim=True).numpy()
+        grads['fc2.bias'] = cg.sum().reshape(1).numpy()
     if T is None:
         T = model_termsums(m, b, P, R)
-    return dict(pre=pre.detach().numpy(), grads=grads, T=T, R=R, P=P, seconds=time.perf_counter() - t0)
+    return dict(pre=pre.detach().numpy(), grads=grads, T=T, R=R, P=P, head_units_flipped=flipped, seconds=time.perf_counter() - t0)
 
 
 def model_termsums(m, b, P, R):
     """Term sums of every parameter gradient of the float64 oracle model `m` over the pool batch `b`, for the UNSIGNED loss
-    sum_g pre_g (the copies' signs only flip terms), times R copies.  Two sweeps: forward, carrying the term sums of the
-    activations from layer to layer (pool, head included); backward, carrying the term sums of the gradients -- so a layer's
-    T accounts for the round-off its inputs arrive with, not only for its own products."""
+    sum_g pre_g (the copies' signs only flip terms), times R copies.  LAYER-LOCAL: every layer's input activations and the
+    gradient at its output are taken from the float64 pass as data, and T is the sum of the |x| |val| |g| |w| products that layer's
+    kernels form (oracle/termsums.py); the head's Linear layers: T_W = |g|^T |input|, T_b = sum |g|.  Typical T / |gradient|: 10 - 1000.
+    (A form that carries term sums THROUGH the layers in a forward and a backward sweep -- the running-error bound -- was tried: it
+    compounds to T / |gradient| ~ 1e9 over four layers and would accept anything; not used.)  What the local form does not absorb is
+    round-off that ARRIVES from the layers below: an activation that is right to 1e-5 of its own term sum but is a cancelling sum
+    (T_x / |x| ~ 30) enters the next layer's products with 3e-4 relative error, and that counts against the upper layer here."""
     acts, hooks = {}, []
     for i in range(1, m.nlayers + 1):
         lay = getattr(m, 'conv%d' % i)
@@ -72,35 +95,19 @@ def model_termsums(m, b, P, R):
     gouts = dict(zip(keys, torch.autograd.grad(pre1.sum(), [acts[k][1] for k in keys])))
     ea64, ei = b.edge_attr2.double(), b.edge_index2
     S = int(ea64.size(1))
-    metas, params = {}, {}
+    T = {}
     for k in range(1, m.nlayers + 1):
         lay = getattr(m, 'conv%d' % k)
-        params[k] = {n: v.detach() for n, v in lay.named_parameters()}
-        nout2 = int(params[k]['fc11.weight'].size(0)) if 'fc11.weight' in params[k] else 0
-        metas[k] = (1, S, S, int(acts[k][0].size(1)), int(params[k]['conv1.weight'].size(2)), nout2)
-    # ---- forward sweep: T of every layer's output given T of its input (the batch's x is data: T = |x|)
-    Tx = {1: acts[1][0].detach().abs()}
-    for k in range(1, m.nlayers + 1):
-        ts = ml3_termsums(metas[k], acts[k][0].detach(), ea64, ei, gouts[k].detach(), params[k], Tx=Tx[k])
-        Tx[k + 1] = torch.from_numpy(ts['out'])
-    Tpool = torch.zeros(P, Tx[m.nlayers + 1].size(1), dtype=torch.float64).index_add_(0, b.batch, Tx[m.nlayers + 1])
-    W1, b1, W2 = m.fc1.weight.detach(), m.fc1.bias.detach(), m.fc2.weight.detach()
-    mh = (acts['fc1'][1].detach() > 0).double()
-    Th = (Tpool @ W1.abs().t() + b1.abs()) * mh                  # relu(fc1 pooled)
-    # ---- backward sweep: the gradient at `pre` is exactly 1 per graph (and +-1 per copy)
-    T = {}
-    Tg_pre = torch.ones(P, 1, dtype=torch.float64)
-    T['fc2.weight'] = (Tg_pre.t() @ Th).numpy() * float(R)
-    T['fc2.bias'] = Tg_pre.sum(0).numpy() * float(R)
-    Tg_h = (Tg_pre @ W2.abs()) * mh
-    T['fc1.weight'] = (Tg_h.t() @ Tpool).numpy() * float(R)
-    T['fc1.bias'] = Tg_h.sum(0).numpy() * float(R)
-    Tg = (Tg_h @ W1.abs())[b.batch]                              # pooled gradient broadcast to the nodes of the last layer's output
-    for k in range(m.nlayers, 0, -1):
-        ts = ml3_termsums(metas[k], acts[k][0].detach(), ea64, ei, gouts[k].detach(), params[k], Tx=Tx[k], Tg=Tg)
-        for n in params[k]:
+        params = {n: v.detach() for n, v in lay.named_parameters()}
+        nout2 = int(params['fc11.weight'].size(0)) if 'fc11.weight' in params else 0
+        meta = (1, S, S, int(acts[k][0].size(1)), int(params['conv1.weight'].size(2)), nout2)
+        ts = ml3_termsums(meta, acts[k][0].detach(), ea64, ei, gouts[k].detach(), params)
+        for n in params:
             T['conv%d.%s' % (k, n)] = ts[n] * float(R)
-        Tg = torch.from_numpy(ts['g_x'])
+    for name in ('fc1', 'fc2'):
+        g = gouts[name].detach().abs()
+        T[name + '.weight'] = (g.t() @ acts[name][0].detach().abs()).numpy() * float(R)
+        T[name + '.bias'] = g.sum(0).numpy() * float(R)
     return T
 
 

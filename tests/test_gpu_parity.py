@@ -875,8 +875,10 @@ def test_bench_size_train_step_vs_fp64_oracle(dev):
     """the HEADLINE mode (bf16x3 products) at the HEADLINE size -- bench.py's own batch, 131,072 ZINC-like
     graphs = 2,048 distinct graphs x 64 copies with a target each -- one train step, logits and EVERY parameter gradient against the
     oracle in float64 under the term-sum criterion (oracle/parity_at_size.py: the copies make one float64 pass over the pool
-    the exact reference for the whole batch; T = sum over the 131,072 copies of |d pre / d theta|).  The exact-product mode
-    runs through the same check (its own numbers are what bench.py prints as max_rel_err_vs_oracle)."""
+    the exact reference for the whole batch; T = the layer-local sums of |x| |val| |g| |w| products over all copies).  At the initial
+    parameters AND after 100 Adam steps on the batch (weights grown, sums cancelling harder: the state bench.py's own parity block
+    is in after its timed steps).  The exact-product mode runs through the same check (its own numbers are what bench.py prints as
+    max_rel_err_vs_oracle).  sign(pre - y) and the head's relu mask are the device's own (see PS.reference)."""
     import bench
     from gnn_matlang_amd import functional as Fn, models
     from oracle import parity_at_size as PS
@@ -885,20 +887,34 @@ def test_bench_size_train_step_vs_fp64_oracle(dev):
     m = models.zinc_gnnml3().to(dev)
     host = base.to(torch.device('cpu'))
     torch.cuda.synchronize()
-    T = None
     worst = {}
-    for mode in ('bf16x3', 'f32'):
-        m.zero_grad()
-        with Fn.exact_products(mode == 'f32'):
-            pre = m(full)
-            models.zinc_loss(pre, full.y).backward()
-        ref = PS.reference(host, m.state_dict(), full.y, pre_dev=pre[:, 0], T=T)
-        T = ref['T']
-        rep = PS.compare(ref, pre[:, 0].detach().cpu().numpy(), {n: p.grad.detach().cpu().numpy() for n, p in m.named_parameters()}, tol=TOL)
-        worst[mode] = (rep['logits_rel_err'], rep['worst_termsum'], rep['worst_maxnorm'])
-        bad = {n: v for n, v in rep['tensors'].items() if v['termsum'] > TOL}
-        assert rep['ok'], (mode, rep['logits_rel_err'], bad)
-    print('bench-size parity (logits, worst term-sum, worst max-norm):', worst)
+    for state in ('init', 'trained'):
+        if state == 'trained':
+            opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+            for _ in range(100):
+                opt.zero_grad(set_to_none=True)
+                models.zinc_loss(m(full), full.y).backward()
+                opt.step()
+        T = None
+        for mode in ('bf16x3', 'f32'):
+            m.zero_grad()
+            with Fn.exact_products(mode == 'f32'):
+                cap = {}
+                pre = m(full, _capture=cap)
+                models.zinc_loss(pre, full.y).backward()
+            ref = PS.reference(host, m.state_dict(), full.y, pre_dev=pre[:, 0], T=T, head_pre_dev=cap['head_pre'])
+            T = ref['T']
+            rep = PS.compare(ref, pre[:, 0].detach().cpu().numpy(), {n: p.grad.detach().cpu().numpy() for n, p in m.named_parameters()}, tol=TOL)
+            worst[state, mode] = (rep['logits_rel_err'], rep['worst_termsum'], rep['worst_maxnorm'], ref['head_units_flipped'])
+            # the trained state is held to 1e-3, not 1e-4: after 100 steps on random targets some relu units of the layers are nearly
+            # dead (a handful of live nodes), and ONE node whose pre-activation is within round-off of zero -- switched together in
+            # all 64 copies -- is then 1e-3 of that unit's column of conv.bias / conv.weight in EITHER arithmetic (tools/parity_diag.py
+            # counts them: 5 of 1.4 M units in the exact mode, 1.8e-3 of the worst column's sum |g|).  The initial state has no such
+            # unit and is held to the bar itself.
+            tol = TOL if state == 'init' else 10 * TOL
+            bad = {n: v for n, v in rep['tensors'].items() if v['termsum'] > tol}
+            assert rep['logits_rel_err'] <= TOL and not bad, (state, mode, rep['logits_rel_err'], bad)
+    print('bench-size parity (logits, worst term-sum, worst max-norm, head units taken from the device):', worst)
 
 
 # ------------------------------------------------------------------------------------------ randomised sweeps (short)
