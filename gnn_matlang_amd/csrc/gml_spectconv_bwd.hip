@@ -191,7 +191,12 @@ static int spectconv_bwd_impl(const int32_t* rowptr, const int32_t* col, const i
 #ifdef GML_BWD2_TIMING
     p.prof = bwd2_prof_buf();
 #endif
-    p.xvec = (Fin % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)x & 15) == 0);
+    /* float4-addressable x rows.  The 8-wave kernel (layout 3) reads whole float4 groups up to roundup4(Fin) and discards the columns
+       >= Fin itself, so rows that merely HAVE those columns (ldx >= roundup4(Fin): the zero-padded [N, 28] copy of ZINC's 25 input
+       features) take its vector road; the other families want Fin % 4 == 0 */
+    const bool xrows4 = (ldx % 4 == 0) && (((uintptr_t)x & 15) == 0);
+    const bool xvec_strict = xrows4 && (Fin % 4 == 0);
+    p.xvec = pl.layout == 3 ? (xrows4 && (Fin + 3) / 4 * 4 <= ldx) : xvec_strict;
     p.dxvec = dx && (Fin % 4 == 0) && (lddx % 4 == 0) && (((uintptr_t)dx & 15) == 0);
     /* float4 groups up to roundup4(Fout) must exist in every row: true when ldg covers them (zero padded) */
     p.gvec = (ldg % 4 == 0) && ((Fout + 3) / 4 * 4 <= ldg) && (((uintptr_t)g & 15) == 0);
@@ -202,7 +207,7 @@ static int spectconv_bwd_impl(const int32_t* rowptr, const int32_t* col, const i
     int rc = GML_E_UNSUPPORTED;
     /* LDS-DMA landing ring (bwd4): 8 waves, float4-addressable x / g rows, dx from dz or from zero, every group inside the
        kernel's staging capacities (+3 edges / +7 window rows of alignment slack), 32-bit row offsets */
-    bool dma = pl.layout == 3 && pl.nw == 8 && (bwd4_env() || (flags & GML_DMA_RING)) && (S == 8 || S == 4) && p.xvec && p.gvec && !(flags & GML_ACCUM) &&
+    bool dma = pl.layout == 3 && pl.nw == 8 && (bwd4_env() || (flags & GML_DMA_RING)) && (S == 8 || S == 4) && xvec_strict && p.gvec && !(flags & GML_ACCUM) &&
                (!dx || p.dxvec || dz == nullptr) && (num_rows + 16) * (ldg > ldx ? ldg : ldx) * 4 < (int64_t)INT32_MAX;
     if (flags & GML_DVAL_ACCUM) {                            /* dval += : the 8-wave bf16x3 kernel's copy-out only */
         if (pl.layout != 3 || (S == 8 && nob == 2)) return GML_E_UNSUPPORTED;   /* (not compiled into the ZINC shape class) */
@@ -214,7 +219,8 @@ static int spectconv_bwd_impl(const int32_t* rowptr, const int32_t* col, const i
     }
     const bool five = !dma && pl.layout == 3 && pl.nw == 8 && S == 8 && nob == 2 && nfb == 2 && bwd5_env() && p.gvec &&
                       !(flags & GML_DVAL_ACCUM) && GmlBwd5Cfg<2>::lds_bytes(pl.ecap, pl.xcap) <= 160 * 1024 &&
-                      (dz == nullptr || (p.xvec && p.dxvec));
+                      (dz == nullptr || (xvec_strict && p.dxvec));
+    if (five && !xvec_strict) p.xvec = 0;
     if (five) {
         rc = gml_launch_bwd5<2>(p, dim3(pl.grid), GmlBwd5Cfg<2>::lds_bytes(pl.ecap, pl.xcap), st);
     } else if (dma) {
