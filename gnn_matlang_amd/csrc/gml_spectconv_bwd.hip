@@ -40,6 +40,7 @@ GML_DECL_BWD2(4, 2) GML_DECL_BWD2(4, 1) GML_DECL_BWD2(2, 2) GML_DECL_BWD2(2, 1)
 GML_DECL_BWD3(8, 2, 8) GML_DECL_BWD3(8, 1, 8) GML_DECL_BWD3(6, 2, 8) GML_DECL_BWD3(6, 1, 8)
 GML_DECL_BWD3(4, 2, 8) GML_DECL_BWD3(4, 1, 8) GML_DECL_BWD3(2, 2, 8) GML_DECL_BWD3(2, 1, 8)
 GML_DECL_BWD3(8, 2, 4) GML_DECL_BWD3(8, 1, 4)
+GML_DECL_BWD3(6, 3, 8) GML_DECL_BWD3(4, 3, 8)             /* 33 .. 48 input features in one launch (gml_bwd3_fam_g.hip) */
 template <> int gml_launch_bwd3<12, 2, 8, 1>(const GmlBwdParams&, dim3, size_t, hipStream_t);   /* counting.py: S = 12, Fout <= 16 */
 template <> int gml_launch_bwd3<12, 1, 8, 1>(const GmlBwdParams&, dim3, size_t, hipStream_t);
 template <> int gml_launch_bwd3<8, 2, 8, 1>(const GmlBwdParams&, dim3, size_t, hipStream_t);    /* S = 8, Fout <= 16 (gml_bwd3_fam_f.hip) */
@@ -79,6 +80,13 @@ static bool bwd2_shape(int S, int Fin, int Fout, uint32_t flags) {
     return !(flags & GML_F32_MFMA) && (S == 2 || S == 4 || S == 6 || S == 8) && Fin <= 32 && Fout > 16 && Fout <= 32;
 }
 
+/* 33 .. 48 input features on the 8-wave kernel in ONE launch (NFB = 3; GML_BWD_WIDE48=0 in the environment: off, for A/B against the
+   two feature-slice launches the host otherwise makes) */
+static bool bwd48_env() { static const bool v = [] { const char* e = getenv("GML_BWD_WIDE48"); return !(e && e[0] == '0'); }(); return v; }
+static bool bwd3_wide_shape(int S, int Fin, int Fout, uint32_t flags) {
+    return !(flags & GML_F32_MFMA) && (S == 4 || S == 6) && Fin > 32 && Fin <= 48 && Fout > 16 && Fout <= 32 && bwd48_env();
+}
+
 /* shapes of the third layout alone: counting.py's 12 supports with Fout <= 16 (gml_k_spectconv_bwd3<12, NFB, 8, XV, false, 1>) */
 static bool bwd3_only_shape(int S, int Fin, int Fout, uint32_t flags) {
     return !(flags & GML_F32_MFMA) && (S == 12 || S == 8) && Fin <= 32 && Fout <= 16;
@@ -93,7 +101,7 @@ static BwdPlan plan_bwd(int64_t num_rows, int S, int Fin, int Fout, int max_edge
     if (pl.ecap < 64) pl.ecap = 64;
     pl.xcap = (max_window + 15) / 16 * 16;
     if (pl.xcap < 64) pl.xcap = 64;
-    if ((bwd2_shape(S, Fin, Fout, flags) && bwd_layout_env() != 2) || bwd3_only_shape(S, Fin, Fout, flags)) {   /* bf16x3 kernel, third layout */
+    if ((bwd2_shape(S, Fin, Fout, flags) && bwd_layout_env() != 2) || bwd3_only_shape(S, Fin, Fout, flags) || bwd3_wide_shape(S, Fin, Fout, flags)) {   /* bf16x3 kernel, third layout */
         pl.layout = 3; pl.nw = (S == 8 && nob == 1) ? 8 : bwd3_nw(S); pl.rows = 16 * pl.nw;
         pl.nfb = (Fin + 15) / 16;
         const int ng = (int)gml_cdiv(num_rows, pl.rows);
@@ -106,7 +114,7 @@ static BwdPlan plan_bwd(int64_t num_rows, int S, int Fin, int Fout, int max_edge
         pl.lds = 0;
         GML_BWD3_LDS(8, 2, 8) GML_BWD3_LDS(8, 1, 8) GML_BWD3_LDS(6, 2, 8) GML_BWD3_LDS(6, 1, 8)
         GML_BWD3_LDS(4, 2, 8) GML_BWD3_LDS(4, 1, 8) GML_BWD3_LDS(2, 2, 8) GML_BWD3_LDS(2, 1, 8)
-        GML_BWD3_LDS(8, 2, 4) GML_BWD3_LDS(8, 1, 4)
+        GML_BWD3_LDS(8, 2, 4) GML_BWD3_LDS(8, 1, 4) GML_BWD3_LDS(6, 3, 8) GML_BWD3_LDS(4, 3, 8)
         if (S == 12) pl.lds = pl.nfb == 2 ? GmlBwd3Cfg<12, 2, 8, 1>::lds_bytes(pl.ecap, pl.xcap) : GmlBwd3Cfg<12, 1, 8, 1>::lds_bytes(pl.ecap, pl.xcap);
         if (S == 8 && nob == 1) { pl.lds = pl.nfb == 2 ? GmlBwd3Cfg<8, 2, 8, 1>::lds_bytes(pl.ecap, pl.xcap) : GmlBwd3Cfg<8, 1, 8, 1>::lds_bytes(pl.ecap, pl.xcap); }
         if (pl.lds > 0) pl.lds += 512;                      /* the DZ instantiation's wmix rows (gml_spectconv_bwd_mix) */
@@ -146,7 +154,7 @@ static BwdPlan plan_bwd(int64_t num_rows, int S, int Fin, int Fout, int max_edge
 extern "C" int gml_spectconv_bwd_group_rows(int32_t S, int32_t Fin, int32_t Fout, uint32_t flags) {
     if (S <= 0 || Fin <= 0 || Fout <= 0) return 0;
     if (bwd2_shape(S, Fin, Fout, flags)) return (bwd_layout_env() != 2 && bwd3_nw(S) == 4) ? GML_GROUPS64_RANKED : 128;
-    if (bwd3_only_shape(S, Fin, Fout, flags)) return 128;
+    if (bwd3_only_shape(S, Fin, Fout, flags) || bwd3_wide_shape(S, Fin, Fout, flags)) return 128;
     const BwdPlan pl = plan_bwd(64, S, Fin, Fout, 64, 64, flags | GML_F32_MFMA);
     return pl.ok ? 64 : 0;
 }
@@ -232,7 +240,7 @@ static int spectconv_bwd_impl(const int32_t* rowptr, const int32_t* col, const i
         else {
         GML_BWD3_GO(8, 2, 8) GML_BWD3_GO(8, 1, 8) GML_BWD3_GO(6, 2, 8) GML_BWD3_GO(6, 1, 8)
         GML_BWD3_GO(4, 2, 8) GML_BWD3_GO(4, 1, 8) GML_BWD3_GO(2, 2, 8) GML_BWD3_GO(2, 1, 8)
-        GML_BWD3_GO(8, 2, 4) GML_BWD3_GO(8, 1, 4)
+        GML_BWD3_GO(8, 2, 4) GML_BWD3_GO(8, 1, 4) GML_BWD3_GO(6, 3, 8) GML_BWD3_GO(4, 3, 8)
         }
         if (S == 12) rc = nfb == 2 ? gml_launch_bwd3<12, 2, 8, 1>(p, dim3(pl.grid), pl.lds, st) : gml_launch_bwd3<12, 1, 8, 1>(p, dim3(pl.grid), pl.lds, st);
     } else if (pl.layout == 2) {

@@ -63,17 +63,23 @@ struct GmlBwd3Cfg {
     static constexpr int ECAP_MAX = (S > 8 ? 12 : (S == 6 ? 16 : 8)) * ROWS;
     static constexpr int XCAP_MAX = NW == 8 ? 224 : 160;
     static constexpr int LDG = 16 * NOB + 4;                 // G window rows (floats, b128 aligned)
-    static constexpr int W_HALF = S * 16 * NOB * 32;         // bf16 elements of one (hi or lo) W image [s][o][32 f]
+    // NFB = 3 (33 .. 48 input features: sr25.py's 32 + 16, mutag.py's 24 + 24 hidden widths, round 5): a SECOND image of everything
+    // that is laid out in 32-feature rows -- W [s][o][f 32 .. 63], the X rows -- with the same keys and access code; features >= Fin zero
+    static constexpr int NIMG = NFB > 2 ? 2 : 1;
+    static constexpr int W_IMG = S * 16 * NOB * 32;          // bf16 elements of one image of one half
+    static constexpr int W_HALF = NIMG * W_IMG;              // bf16 elements of one (hi or lo) W image [img][s][o][32 f]
     static constexpr int W_BYTES = 2 * W_HALF * 2;
     static constexpr int SS = (S % 4 == 0) ? 4 : ((S % 3 == 0) ? 3 : S);   // supports per dW slab
     static constexpr int NSLAB = S / SS;
     static constexpr int NBLK = SS * NFB * NOB;              // 16 x 16 output blocks of a slab: (se, fb, ob)
     static constexpr int BPW = (NBLK + NW - 1) / NW;         // blocks per wave
-    static constexpr int XT_BYTES = 2 * ROWS * 64;           // X hi, lo   [position][32 f]
+    static constexpr int XT_IMG = 2 * ROWS * 64;             // X hi, lo   [position][32 f] of one image
+    static constexpr int XT_BYTES = NIMG * XT_IMG;
     static constexpr int PT_BYTES = 2 * SS * ROWS * 64;      // P hi, lo   [se][position][32 o]
     static constexpr int GREC = 4 + ROWS / 4;                // ints per group record (ranked)
-    static constexpr bool OK = (S % SS == 0) && (NFB == 1 || NFB == 2) && (NW == 4 || NW == 8) && (NOB == 1 || NOB == 2) &&
-                               NW % (NOB * NFB) == 0;
+    static constexpr bool ASHARE = NW % (NOB * NFB) == 0;    // a wave's blocks share one X fragment (fb the same for all of them)
+    static constexpr bool OK = (S % SS == 0) && (NFB >= 1 && NFB <= 3) && (NW == 4 || NW == 8) && (NOB == 1 || NOB == 2) &&
+                               (NFB < 3 || (NOB == 2 && NW == 8 && S <= 6));
     __host__ __device__ static size_t stage_bytes(int ecap, int xcap) { return (size_t)ecap * S * 4 + (size_t)xcap * LDG * 4; }
     __host__ __device__ static size_t r_bytes(int ecap, int xcap) {          // staged values + G window, later the P slab
         const size_t a = stage_bytes(ecap, xcap);
@@ -165,12 +171,14 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
     }
     // W -> bf16 (hi, lo) image, zero padded to 32 x 32
     constexpr int WO = 16 * NOB;                             // output rows of one support's image
-    for (int e = tid; e < S * WO * 32; e += NT) {
-        const int f = e & 31, o = (e >> 5) % WO, s = (e >> 5) / WO;
+    constexpr int NIMG = C::NIMG;
+    for (int e = tid; e < NIMG * S * WO * 32; e += NT) {
+        const int fl = e & 31, o = (e >> 5) % WO, s = ((e >> 5) / WO) % S, img = (e >> 5) / (WO * S);
+        const int f = 32 * img + fl;
         const float v = (f < p.Fin && o < p.Fout) ? p.w[((int64_t)s * p.Fin + f) * p.Fout + o] : 0.f;
         const __bf16 h = (__bf16)v;
         const __bf16 l = (__bf16)(v - (float)h);
-        const int i = (s * WO + o) * 32 + ((((f >> 3) ^ gml_wkey3(o)) & 3) << 3) + (f & 7);
+        const int i = img * C::W_IMG + (s * WO + o) * 32 + ((((fl >> 3) ^ gml_wkey3(o)) & 3) << 3) + (fl & 7);
         W_h[i] = h; W_l[i] = l;
     }
 
@@ -203,6 +211,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
     EV ev4[NE4];
     f32x4 gv4[NG4];
     float xb[8];
+    float xb2[NIMG == 2 ? 8 : 1];                            // NFB = 3: features 32 + 8 kq .. + 7 of the own row (kq >= 2: beyond 48, zero)
     auto vec_group = [&](const int4 gi) {
         return (VW > 1) && p.gvec && gi.y <= C::ECAP_MAX && gi.w <= C::XCAP_MAX;
     };
@@ -252,6 +261,10 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
             for (int q4 = 0; q4 < 2; ++q4) {
                 const f32x4 t = *reinterpret_cast<const f32x4*>(xr + min(8 * kq + 4 * q4, f4max));
                 xb[4 * q4] = t.x; xb[4 * q4 + 1] = t.y; xb[4 * q4 + 2] = t.z; xb[4 * q4 + 3] = t.w;
+                if constexpr (NIMG == 2) {
+                    const f32x4 u = *reinterpret_cast<const f32x4*>(xr + min(32 + 8 * kq + 4 * q4, f4max));
+                    xb2[4 * q4] = u.x; xb2[4 * q4 + 1] = u.y; xb2[4 * q4 + 2] = u.z; xb2[4 * q4 + 3] = u.w;
+                }
             }
         }
         rpv = p.rowptr[min(r0 + tid, p.nrows)];
@@ -327,9 +340,14 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
             const float* xr = p.x + (r0 + row) * p.ldx + 8 * kq;
 #pragma unroll
             for (int t = 0; t < 8; ++t) xb[t] = (rvalid && 8 * kq + t < p.Fin) ? xr[t] : 0.f;
+            if constexpr (NIMG == 2) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) xb2[t] = (rvalid && 32 + 8 * kq + t < p.Fin) ? xr[32 + t] : 0.f;
+            }
         }
         if constexpr (!LATEC) commit(gi, nr);
         bf16x8 xh, xl;                                       // own X row, features 8*kq .. 8*kq+7: B fragment of Z^T, row of the X image
+        bf16x8 xh2, xl2;                                     // NFB = 3: features 32 + 8*kq .. + 7 (the second K block / image)
         unsigned xpos = 0;                                   // DZ, relu_cols > 0: bit j = (x[row][8 kq + j] > 0), the relu mask of the layer below
         f32x2 Z[S][NH], P[S][NH];
         auto zproj = [&]() {
@@ -339,6 +357,12 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
                 if (!(rvalid && 8 * kq + j < p.Fin)) xb[j] = 0.f;
         }
         gml_split8(xb, xh, xl);
+        if constexpr (NIMG == 2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (!(rvalid && 32 + 8 * kq + j < p.Fin)) xb2[j] = 0.f;
+            gml_split8(xb2, xh2, xl2);
+        }
         if constexpr (DZ) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) xpos |= (xb[j] > 0.f ? 1u : 0u) << j;
@@ -349,6 +373,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
         {
             const int oa0 = NOB == 2 ? 8 * (r16 >> 2) + (r16 & 3) : r16;   // (NOB = 1: MFMA row i = output i, lane kq receives 4 kq + reg)
             bf16x8 wh[2][NOB], wl[2][NOB];
+            bf16x8 wh2[2][NIMG == 2 ? NOB : 1], wl2[2][NIMG == 2 ? NOB : 1];
             auto frag = [&](int s, int st) {
 #pragma unroll
                 for (int ob = 0; ob < NOB; ++ob) {
@@ -356,6 +381,10 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
                     const int off = (s * WO + oa) * 32 + (((kq ^ gml_wkey3(oa)) & 3) << 3);
                     wh[st][ob] = *reinterpret_cast<const bf16x8*>(W_h + off);
                     wl[st][ob] = *reinterpret_cast<const bf16x8*>(W_l + off);
+                    if constexpr (NIMG == 2) {
+                        wh2[st][ob] = *reinterpret_cast<const bf16x8*>(W_h + C::W_IMG + off);
+                        wl2[st][ob] = *reinterpret_cast<const bf16x8*>(W_l + C::W_IMG + off);
+                    }
                 }
             };
             if (!(GML_ABL & 16)) frag(0, 0);
@@ -377,6 +406,14 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
                 for (int ob = 0; ob < NOB; ++ob) dd[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[st][ob], xl, dd[ob], 0, 0, 0);
 #pragma unroll
                 for (int ob = 0; ob < NOB; ++ob) dd[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[st][ob], xh, dd[ob], 0, 0, 0);
+                if constexpr (NIMG == 2) {
+#pragma unroll
+                    for (int ob = 0; ob < NOB; ++ob) dd[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl2[st][ob], xh2, dd[ob], 0, 0, 0);
+#pragma unroll
+                    for (int ob = 0; ob < NOB; ++ob) dd[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh2[st][ob], xl2, dd[ob], 0, 0, 0);
+#pragma unroll
+                    for (int ob = 0; ob < NOB; ++ob) dd[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh2[st][ob], xh2, dd[ob], 0, 0, 0);
+                }
 #pragma unroll
                 for (int ob = 0; ob < NOB; ++ob) { Z[s][2 * ob] = f32x2{dd[ob][0], dd[ob][1]}; Z[s][2 * ob + 1] = f32x2{dd[ob][2], dd[ob][3]}; }
 #pragma unroll
@@ -385,11 +422,11 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
                     else P[s][h] = f32x2{0.f, 0.f};
                 }
             }
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * NOB, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * NOB * NIMG, 0);
 #pragma unroll
             for (int s = 0; s < S; ++s) {
-                if (s + 1 < S) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NOB, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 3 * NOB, 0);
+                if (s + 1 < S) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NOB * NIMG, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3 * NOB * NIMG, 0);
             }
         }
         };
@@ -605,6 +642,10 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
         auto write_x = [&]() {
             *reinterpret_cast<bf16x8*>(xT + woff) = xh;
             *reinterpret_cast<bf16x8*>(xT + ROWS * 64 + woff) = xl;
+            if constexpr (NIMG == 2) {
+                *reinterpret_cast<bf16x8*>(xT + C::XT_IMG + woff) = xh2;
+                *reinterpret_cast<bf16x8*>(xT + C::XT_IMG + ROWS * 64 + woff) = xl2;
+            }
         };
         auto write_slab = [&](int sl) {
 #pragma unroll
@@ -669,8 +710,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
 #pragma unroll
                 for (int fb = 0; fb < NFB; ++fb) {
                     // (NOB = 1: k slots 8 kq + j, j < 4, are outputs 4 kq + j; the slots j >= 4 meet zeros in P -- any finite A will do)
-                    const int o = NOB == 2 ? 8 * kqo + 4 * h + tj : 4 * kqo + tj, cidx = 4 * fb + tc;
-                    aoff[h][fb] = o * 64 + ((((cidx >> 1) ^ gml_wkey3(o)) & 3) << 4) + ((cidx & 1) << 3);
+                    const int o = NOB == 2 ? 8 * kqo + 4 * h + tj : 4 * kqo + tj, cidx = 4 * (fb & 1) + tc;
+                    aoff[h][fb] = (fb >> 1) * (C::W_IMG * 2) + o * 64 + ((((cidx >> 1) ^ gml_wkey3(o)) & 3) << 4) + ((cidx & 1) << 3);
                 }
             const unsigned char* Wh8 = reinterpret_cast<const unsigned char*>(W_h);
             const unsigned char* Wl8 = reinterpret_cast<const unsigned char*>(W_l);
@@ -746,14 +787,27 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
             if constexpr (!DIRECT) write_x();
             // transposing-read offsets of K step 0: lane (t, kq): position 8 kq + 4 h + (t >> 2), chunk 4 blk + (t & 3)
             const int tj = r16o >> 2, tc = r16o & 3;
-            int roff[2][2];                                  // [h][16-wide channel block]
+            auto roffs = [&](int h, int blk) {               // [h][16-wide channel block of a 32-channel row]
+                const int ps = 8 * kqo + 4 * h + tj, cidx = 4 * blk + tc;
+                return ps * 64 + ((((cidx >> 1) ^ gml_tkey3(ps)) & 3) << 4) + ((cidx & 1) << 3);
+            };
+            // wave's blocks b = wave + NW i: ob = b % NOB (the same for every i: NW is even), fb = (b / NOB) % NFB, se = (b / NOB) / NFB.
+            // ASHARE (NW a multiple of NOB NFB): fb is the same for every i as well -- one X fragment serves the wave's blocks.
+            constexpr int NB_ = (C::NBLK >= NW) ? BPW : 1;         // (fewer blocks than waves: one block on the first waves)
+            constexpr int NA_ = C::ASHARE ? 1 : NB_;               // X fragments per K step
+            const int ob = wave % NOB;
+            const int offB[2] = {roffs(0, ob), roffs(1, ob)};
+            int offA[NA_][2], seo[NB_];
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int blk = 0; blk < 2; ++blk) {
-                    const int ps = 8 * kqo + 4 * h + tj, cidx = 4 * blk + tc;
-                    roff[h][blk] = ps * 64 + ((((cidx >> 1) ^ gml_tkey3(ps)) & 3) << 4) + ((cidx & 1) << 3);
+            for (int i = 0; i < NB_; ++i) {
+                const int b = min(wave + NW * i, C::NBLK - 1);           // (a wave without an i-th block re-reads its last one)
+                seo[i] = ((b / NOB) / NFB) * ROWS * 64;
+                if (i < NA_) {
+                    const int fb = (b / NOB) % NFB;
+                    offA[i][0] = (fb >> 1) * C::XT_IMG + roffs(0, fb & 1);
+                    offA[i][1] = (fb >> 1) * C::XT_IMG + roffs(1, fb & 1);
                 }
+            }
 #pragma unroll
             for (int sl = 0; sl < C::NSLAB; ++sl) {
                 if (!(DIRECT && sl == 0)) {
@@ -766,24 +820,22 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
                 }
                 __syncthreads();
                 GML_T3(11);
-                // wave's blocks b = wave + NW i: ob = b % NOB, fb = (b / NOB) % NFB (the same for every i), se = (b / NOB) / NFB.
                 // The fragments of K step st + 1 are requested before the MFMAs of step st, and the blocks' accumulator
                 // chains are interleaved (one chain of dependent MFMAs behind its own reads is pure latency).
-                const int ob = wave % NOB, fb = (wave / NOB) % NFB;
-                constexpr int NB_ = (C::NBLK >= NW) ? BPW : 1;     // (fewer blocks than waves: one block on the first waves)
                 if (wave < C::NBLK) {
-                    bf16x8 fah[2], fal[2], fbh[2][NB_], fbl[2][NB_];
+                    bf16x8 fah[2][NA_], fal[2][NA_], fbh[2][NB_], fbl[2][NB_];
                     auto fragw = [&](int st, int sg) {
                         const unsigned char* xa = xT + st * 2048;
-                        fah[sg] = gml_tr_frag(xa + roff[0][fb], xa + roff[1][fb]);
-                        fal[sg] = gml_tr_frag(xa + ROWS * 64 + roff[0][fb], xa + ROWS * 64 + roff[1][fb]);
+#pragma unroll
+                        for (int i = 0; i < NA_; ++i) {
+                            fah[sg][i] = gml_tr_frag(xa + offA[i][0], xa + offA[i][1]);
+                            fal[sg][i] = gml_tr_frag(xa + ROWS * 64 + offA[i][0], xa + ROWS * 64 + offA[i][1]);
+                        }
 #pragma unroll
                         for (int i = 0; i < NB_; ++i) {
-                            const int b = min(wave + NW * i, C::NBLK - 1);       // (a wave without an i-th block re-reads its last one)
-                            const int se = (b / NOB) / NFB;
-                            const unsigned char* pa = pT + se * ROWS * 64 + st * 2048;
-                            fbh[sg][i] = gml_tr_frag(pa + roff[0][ob], pa + roff[1][ob]);
-                            fbl[sg][i] = gml_tr_frag(pa + SS * ROWS * 64 + roff[0][ob], pa + SS * ROWS * 64 + roff[1][ob]);
+                            const unsigned char* pa = pT + seo[i] + st * 2048;
+                            fbh[sg][i] = gml_tr_frag(pa + offB[0], pa + offB[1]);
+                            fbl[sg][i] = gml_tr_frag(pa + SS * ROWS * 64 + offB[0], pa + SS * ROWS * 64 + offB[1]);
                         }
                     };
                     f32x4 d[NB_];
@@ -795,16 +847,16 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
                         const int sg = st & 1;
                         if (st + 1 < ROWS / 32) fragw(st + 1, sg ^ 1);
 #pragma unroll
-                        for (int i = 0; i < NB_; ++i) d[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fal[sg], fbh[sg][i], d[i], 0, 0, 0);
+                        for (int i = 0; i < NB_; ++i) d[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fal[sg][i < NA_ ? i : 0], fbh[sg][i], d[i], 0, 0, 0);
 #pragma unroll
-                        for (int i = 0; i < NB_; ++i) d[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[sg], fbl[sg][i], d[i], 0, 0, 0);
+                        for (int i = 0; i < NB_; ++i) d[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[sg][i < NA_ ? i : 0], fbl[sg][i], d[i], 0, 0, 0);
 #pragma unroll
-                        for (int i = 0; i < NB_; ++i) d[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[sg], fbh[sg][i], d[i], 0, 0, 0);
+                        for (int i = 0; i < NB_; ++i) d[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[sg][i < NA_ ? i : 0], fbh[sg][i], d[i], 0, 0, 0);
                     }
-                    __builtin_amdgcn_sched_group_barrier(0x100, 4 + 4 * NB_, 2);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4 * NA_ + 4 * NB_, 2);
 #pragma unroll
                     for (int st = 0; st < ROWS / 32; ++st) {
-                        if (st + 1 < ROWS / 32) __builtin_amdgcn_sched_group_barrier(0x100, 4 + 4 * NB_, 2);
+                        if (st + 1 < ROWS / 32) __builtin_amdgcn_sched_group_barrier(0x100, 4 * NA_ + 4 * NB_, 2);
                         __builtin_amdgcn_sched_group_barrier(0x008, 3 * NB_, 2);
                     }
 #pragma unroll

@@ -904,7 +904,14 @@ def _conv_backward(csr, x, val, weight, G, need_x, need_val, need_w, val_t=None,
     dx = dval = dw = None
     if G.stride(1) != 1:
         G = G.contiguous()
-    sp48 = split48_plan(csr, S, Fin, Fout) if (mix is None and relu_cols == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0) else None
+    # 33 .. 48 input features: ONE launch of the 8-wave kernel where the library has that shape (round 5: S = 4, 6; GML_BWD_WIDE48=0
+    # turns it off), else two launches over the feature slices
+    one48 = None
+    if 32 < Fin <= 48 and not exact_mode():
+        one48 = _bwd_plan(csr, S, Fin, Fout)
+        if one48 is not None and (one48[4] != 128 or (one48[0] & _lib.GML_F32_MFMA)):
+            one48 = None
+    sp48 = split48_plan(csr, S, Fin, Fout) if (one48 is None and mix is None and relu_cols == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0) else None
     if sp48 is not None or fused_bwd_available(csr, S, Fin, Fout):
         if val_t is None:
             with _Timed('val_to_source_order'):
