@@ -64,6 +64,11 @@ SIGNATURES = {
     'gml_dense_dw_workspace_bytes': (_sz, [_i32, _i32, _i32, _i32]),
     'gml_dense_conv_bwd_w': (ctypes.c_int, [_p, _p, _i64, _p, _i64, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _sz, _p]),
     'gml_fold_many': (ctypes.c_int, [_p, _i32, _p]),
+    'gml_gnnml1_supported': (_i32, [_i32, _i32, _i32, _i32, _i32]),
+    'gml_gnnml1_g4_cols': (_i32, [_i32, _i32, _i32, _i32]),
+    'gml_gnnml1_fwd': (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _p, _p, _i32, _p, _p, _i32, _p, _p, _p, _p, _i32, _i32, _i32, _p, _i64, _p]),
+    'gml_gnnml1_bwd': (ctypes.c_int, [_p, _p, _p, _p, _i64, _p, _i64, _p, _i64, _i64, _i32, _p, _i32, _p, _i32, _p, _p, _p, _p, _i32, _i32, _i32,
+                                      _p, _i64, _p, _i64, _p, _i64, _p]),
     'gml_edge_mlp_bwd_parts': (_i64, [_i64, _i32, _i32, _i32, _i32]),
     'gml_edge_mlp_wide_fwd': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
     'gml_edge_mlp_bwd_workspace_bytes': (_sz, [_i64, _i32, _i32]),

@@ -582,6 +582,80 @@ def xty(a, b):
     return out
 
 
+def gnnml1_block_supported(x, Fin, n1, n2, n3, mode):
+    return (x.is_cuda and x.dtype == torch.float32 and not _os.environ.get('GML_NO_GNNML1_FUSED')
+            and bool(_lib.lib().gml_gnnml1_supported(int(Fin), int(n1), int(n2), int(n3), int(mode))))
+
+
+class GNNML1BlockFunction(torch.autograd.Function):
+    """One GNNML1 block (sr25.py:231-240, mnist75.py:296-318, mutag.py:253-262) as ONE launch forward and one launch + four gml_xty
+    backward (csrc/gml_gnnml1.hip): a = fc_i1 x, c = conv_i1 x (SpectConv K = 1), f2 = fc_i2 x, f3 = fc_i3 x;
+    mode 0: act(a + c + f2 f3); 1: [act a | act c | act(f2 f3)]; 2: [act a | act c | act f2 . act f3]; act 0 tanh / 1 relu.
+    val: per-edge values in TARGET order ([E] / [E, 1]) or None for ones (the scripts pass torch.ones); they carry no gradient here
+    (the module takes the unfused road when edge_attr requires one).  Exact fp32 products."""
+
+    @staticmethod
+    def forward(ctx, x, csr, val, w1, b1, wc, bc, w2, b2, w3, b3, mode, act):
+        x = _f32rows(x, 'x')
+        N, Fin = int(x.size(0)), int(x.size(1))
+        n1, n2, n3 = int(w1.size(0)), int(wc.size(-1)), int(w2.size(0))
+        w1, w2, w3, wc = _f32c(w1, 'fc1.weight'), _f32c(w2, 'fc2.weight'), _f32c(w3, 'fc3.weight'), _f32c(wc, 'conv.weight')
+        C = n1 if mode == 0 else n1 + n2 + n3
+        dev = x.device
+        if val is not None:
+            val = _f32c(val.reshape(-1), 'edge_attr')
+        with torch.cuda.device(dev):
+            out = torch.empty(N, C, dtype=torch.float32, device=dev)
+            with _Timed('gnnml1_fwd'):
+                _lib.call('gml_gnnml1_fwd', _ptr(csr.rowptr), _ptr(csr.col), _ptr(val), _ptr(x), int(x.stride(0)), N, Fin,
+                          _ptr(w1), _ptr(b1), n1, _ptr(wc), _ptr(bc), n2, _ptr(w2), _ptr(b2), _ptr(w3), _ptr(b3), n3, int(mode), int(act),
+                          _ptr(out), C, _stream(dev))
+        ctx.csr, ctx.mode, ctx.act, ctx.dims = csr, int(mode), int(act), (N, Fin, n1, n2, n3, C)
+        ctx.has_b = (b1 is not None, bc is not None, b2 is not None, b3 is not None)
+        ctx.save_for_backward(x, val, w1, wc, w2, b2, w3, b3, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, val, w1, wc, w2, b2, w3, b3, out = ctx.saved_tensors
+        N, Fin, n1, n2, n3, C = ctx.dims
+        csr, mode, act = ctx.csr, ctx.mode, ctx.act
+        dev = x.device
+        gout = _f32rows(gout, 'grad_output')
+        L = _lib.lib()
+        ng4 = int(L.gml_gnnml1_g4_cols(n1, n2, n3, mode))
+        p1, p2, p3 = (n1 + 15) // 16 * 16, (n2 + 15) // 16 * 16, (n3 + 15) // 16 * 16
+        need_x = ctx.needs_input_grad[0]
+        with torch.cuda.device(dev):
+            val_t = csr.to_source_order(val.view(-1, 1)).view(-1) if val is not None else None
+            g4 = torch.empty(N, ng4, dtype=torch.float32, device=dev)
+            q = torch.empty(N, p2, dtype=torch.float32, device=dev)
+            dx = torch.empty(N, Fin, dtype=torch.float32, device=dev) if need_x else None
+            with _Timed('gnnml1_bwd'):
+                _lib.call('gml_gnnml1_bwd', _ptr(csr.rowptr_t), _ptr(csr.col_t), _ptr(val_t), _ptr(x), int(x.stride(0)), _ptr(out), C,
+                          _ptr(gout), int(gout.stride(0)), N, Fin, _ptr(w1), n1, _ptr(wc), n2, _ptr(w2), _ptr(b2), _ptr(w3), _ptr(b3), n3,
+                          mode, act, _ptr(dx), Fin, _ptr(g4), ng4, _ptr(q), p2, _stream(dev))
+            oa, oc = 0, p1
+            o2 = p1 if mode == 0 else p1 + p2
+            o3 = o2 + p3
+            with _Timed('gnnml1_dw'):
+                xc = x if x.stride(0) == Fin else x              # (gml_xty takes the leading dimension)
+                dw1 = xty(g4[:, oa:oa + n1], xc)
+                dw2 = xty(g4[:, o2:o2 + n3], xc)
+                dw3 = xty(g4[:, o3:o3 + n3], xc)
+                dwc = xty(xc, q[:, :n2])
+                if dw1 is None or dw2 is None or dw3 is None or dwc is None:
+                    dw1, dw2, dw3 = g4[:, oa:oa + n1].t() @ x, g4[:, o2:o2 + n3].t() @ x, g4[:, o3:o3 + n3].t() @ x
+                    dwc = x.t() @ q[:, :n2]
+                sums = g4.sum(0)
+        hb1, hbc, hb2, hb3 = ctx.has_b
+        db1 = sums[oa:oa + n1] if hb1 else None
+        dbc = (sums[oa:oa + n2] if mode == 0 else sums[oc:oc + n2]) if hbc else None
+        db2 = sums[o2:o2 + n3] if hb2 else None
+        db3 = sums[o3:o3 + n3] if hb3 else None
+        return dx, None, None, dw1, db1, dwc.view(1, Fin, n2), dbc, dw2, db2, dw3, db3, None, None
+
+
 class BatchNormFunction(torch.autograd.Function):
     """torch.nn.BatchNorm1d in training mode on the HIP kernels of csrc/gml_bn.hip (mutag.py:272-288: BatchNorm between the layers).
     Returns (y, batch mean, biased batch variance); raises NotImplementedError for shapes the kernels do not take (the module then

@@ -185,6 +185,19 @@ class GNNML3(torch.nn.Module):
         return self.forward(data, _features=True)
 
 
+def _gnnml1_block(x, csr, fc1, conv, fc2, fc3, mode, act):
+    """the block as one fused launch (functional.GNNML1BlockFunction) or None when the widths are outside the kernel (> 64) or the
+    conv is not the plain K = 1 form the scripts use.  Unit edge values (sr25.py:231, mutag.py:253: torch.ones)."""
+    from . import functional as Fn
+    if conv.weight.size(0) != 1 or conv.selfconn or conv.depthwise:
+        return None
+    Fin, n1, n2, n3 = int(x.size(1)), int(fc1.weight.size(0)), int(conv.weight.size(2)), int(fc2.weight.size(0))
+    if not Fn.gnnml1_block_supported(x, Fin, n1, n2, n3, mode):
+        return None
+    return Fn.GNNML1BlockFunction.apply(x, csr, None, fc1.weight, fc1.bias, conv.weight, conv.bias, fc2.weight, fc2.bias,
+                                        fc3.weight, fc3.bias, mode, act)
+
+
 class GNNML1Mutag(torch.nn.Module):
     """mutag.py:214-266: three blocks of [relu(fc x) | relu(SpectConv_{S=1}(x)) | relu(fc x)*relu(fc x)] + BN."""
 
@@ -206,9 +219,11 @@ class GNNML1Mutag(torch.nn.Module):
         ones = torch.ones(csr.E, 1, dtype=x.dtype, device=x.device)      # mutag.py:253
         for i in (1, 2, 3):
             g = lambda n: getattr(self, n % i)
-            x = torch.cat([F.relu(g('fc%d1')(x)), F.relu(g('conv%d1')(x, csr, ones)),
-                           F.relu(g('fc%d2')(x)) * F.relu(g('fc%d3')(x))], 1)
-            x = g('bn%d')(x)
+            y = _gnnml1_block(x, csr, g('fc%d1'), g('conv%d1'), g('fc%d2'), g('fc%d3'), 2, 1)      # one launch (csrc/gml_gnnml1.hip)
+            if y is None:
+                y = torch.cat([F.relu(g('fc%d1')(x)), F.relu(g('conv%d1')(x, csr, ones)),
+                               F.relu(g('fc%d2')(x)) * F.relu(g('fc%d3')(x))], 1)
+            x = g('bn%d')(y)
         x = global_mean_pool(x, data)
         return tall_linear(F.relu(tall_linear(x, self.fc1)), self.fc2)
 
@@ -242,8 +257,13 @@ class GNNML1(torch.nn.Module):
         x = data.x
         csr = data.csr('edge_index')
         ones = torch.ones(csr.E, 1, dtype=x.dtype, device=x.device)      # sr25.py:231
+        actid = 0 if self.act is torch.tanh else 1
         for i in (1, 2, 3):
             g = lambda n: getattr(self, n % i)
+            y = _gnnml1_block(x, csr, g('fc%d1'), g('conv%d1'), g('fc%d2'), g('fc%d3'), 1 if self.concat else 0, actid)
+            if y is not None:
+                x = y
+                continue
             a, c, h = g('fc%d1')(x), g('conv%d1')(x, csr, ones), g('fc%d2')(x) * g('fc%d3')(x)
             x = torch.cat([self.act(a), self.act(c), self.act(h)], 1) if self.concat else self.act(a + c + h)
         x = {'add': global_add_pool, 'mean': global_mean_pool, 'max': global_max_pool}[self.pool](x, data)

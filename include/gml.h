@@ -489,6 +489,31 @@ int gml_head_l1_bwd(const float* p, int64_t ldp, const float* y, const float* va
                     const float* gscale, float* gp, int64_t ldgp, float* dw1, float* db1, float* dw2, float* db2,
                     gml_stream_t stream);
 
+/* GNNML1 block in one launch each way (csrc/gml_gnnml1.hip) -- /root/reference/sr25.py:231-240 (graph8c.py: the same class),
+ * mnist75.py:296-318, mutag.py:253-262.  a = fc_i1(x), c = conv_i1(x) = (A^T x) Wc + bc (SpectConv, K = 1, selfconn = False,
+ * libs/spect_conv.py:64-96 with one support), f2 = fc_i2(x), f3 = fc_i3(x):
+ *   mode 0: out [N, n] = act(a + c + f2 * f3)   (n1 = n2 = n3 = n)        mode 1: out [N, n1 + n2 + n3] = [act(a) | act(c) | act(f2 * f3)]
+ *   mode 2: out = [act(a) | act(c) | act(f2) * act(f3)]  (mutag.py)       act: 0 = tanh, 1 = relu
+ * w1, w2, w3: Linear weights [n, Fin] row-major, b*: [n] or NULL; wc: the SpectConv weight [Fin, n2]; val: one value per edge in the
+ * order of `col` (NULL: ones, the scripts' torch.ones edge_attr).  Exact fp32 products.  Fin, n1, n2, n3 <= 64 (gml_gnnml1_supported),
+ * else GML_E_UNSUPPORTED and the caller composes the block from gml_spectconv_fwd and library Linears.
+ * Backward (source-keyed view rowptr_t / col_t / val_t; `out` = the saved forward output, gout = dL/dout):
+ *   dx (optional) = da W1 + df2 W2 + df3 W3 + (A dc) Wc^T                    da, dc, df2, df3 = gradients at a, c, f2, f3
+ *   g4 [N, ldg4 >= gml_gnnml1_g4_cols()] = [da | dc (modes 1, 2 only: dc = da in mode 0) | df2 | df3], each block 16 ceil(n / 16) columns wide
+ *   q  [N, ldq >= 16 ceil(n2 / 16)]      = A dc
+ * from which the caller forms dW1 = da^T x, dW2 = df2^T x, dW3 = df3^T x, dWc = x^T q (gml_xty) and the bias gradients (column sums). */
+int gml_gnnml1_supported(int32_t Fin, int32_t n1, int32_t n2, int32_t n3, int32_t mode);
+int gml_gnnml1_g4_cols(int32_t n1, int32_t n2, int32_t n3, int32_t mode);
+int gml_gnnml1_fwd(const int32_t* rowptr, const int32_t* col, const float* val, const float* x, int64_t ldx, int64_t num_rows,
+                   int32_t Fin, const float* w1, const float* b1, int32_t n1, const float* wc, const float* bc, int32_t n2,
+                   const float* w2, const float* b2, const float* w3, const float* b3, int32_t n3, int32_t mode, int32_t act,
+                   float* out, int64_t ldo, gml_stream_t stream);
+int gml_gnnml1_bwd(const int32_t* rowptr_t, const int32_t* col_t, const float* val_t, const float* x, int64_t ldx,
+                   const float* out, int64_t ldo, const float* gout, int64_t ldgo, int64_t num_rows, int32_t Fin,
+                   const float* w1, int32_t n1, const float* wc, int32_t n2, const float* w2, const float* b2, const float* w3,
+                   const float* b3, int32_t n3, int32_t mode, int32_t act, float* dx, int64_t lddx, float* g4, int64_t ldg4,
+                   float* q, int64_t ldq, gml_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1813,3 +1813,59 @@ def test_batchnorm_kernels_vs_torch(dev, N, C, affine):
         close(m.bias.grad, ref.bias.grad, tol=2e-5, what='d bias')
     m.eval()
     close(m(x0.to(dev)), ref.eval()(x0.double()), tol=2e-5, what='eval')
+
+
+# ------------------------------------------------------------------------------------------ fused GNNML1 block (round 5)
+@pytest.mark.parametrize('mode,act', [(0, 0), (0, 1), (1, 0), (1, 1), (2, 1), (2, 0)])
+@pytest.mark.parametrize('N,Fin,n1,n2,n3,unit', [(1000, 64, 64, 64, 64, True), (777, 2, 64, 64, 64, True), (333, 8, 16, 32, 16, True),
+                                                 (500, 64, 16, 32, 16, False), (130, 25, 10, 20, 7, False), (1, 3, 64, 64, 64, True),
+                                                 (65, 33, 48, 48, 48, False)])
+def test_gnnml1_block_vs_fp64(dev, mode, act, N, Fin, n1, n2, n3, unit):
+    """csrc/gml_gnnml1.hip: one GNNML1 block (sr25.py:231-240 sum / concat forms, mutag.py:253-262 factor form) forward and backward --
+    output, dx and all eight parameter gradients -- against the same formulas in float64 (a directed random graph: the backward's
+    transposed view is a different matrix; per-edge values or the scripts' ones).  Exact fp32 products: 2e-5 of the tensor's scale."""
+    from gnn_matlang_amd import functional as Fn
+    from gnn_matlang_amd.graph import GraphCSR
+    if mode == 0:
+        n2 = n3 = n1
+    rng = np.random.default_rng(N + Fin)
+    torch.manual_seed(N)
+    deg = 5
+    src = rng.integers(0, N, size=N * deg)
+    dst = np.clip(src + rng.integers(-20, 21, size=src.shape), 0, N - 1)
+    ei = torch.from_numpy(np.unique(np.vstack((src, dst)), axis=1).astype(np.int64))
+    E = ei.size(1)
+    val = None if unit else torch.randn(E)
+    x = torch.randn(N, Fin)
+    W = dict(w1=torch.randn(n1, Fin) * 0.3, b1=torch.randn(n1) * 0.1, wc=torch.randn(1, Fin, n2) * 0.2, bc=torch.randn(n2) * 0.1,
+             w2=torch.randn(n3, Fin) * 0.3, b2=torch.randn(n3) * 0.1, w3=torch.randn(n3, Fin) * 0.3, b3=torch.randn(n3) * 0.1)
+    C = n1 if mode == 0 else n1 + n2 + n3
+    gout = torch.randn(N, C)
+
+    def ref(x, W, val):
+        A = torch.tanh if act == 0 else torch.relu
+        v = torch.ones(E, dtype=x.dtype) if val is None else val
+        h = torch.zeros_like(x).index_add_(0, ei[1], v.unsqueeze(1) * x[ei[0]])          # libs/spect_conv.py:98-99: aggregate at the target
+        a, c = x @ W['w1'].t() + W['b1'], h @ W['wc'][0] + W['bc']
+        f2, f3 = x @ W['w2'].t() + W['b2'], x @ W['w3'].t() + W['b3']
+        if mode == 0:
+            return A(a + c + f2 * f3)
+        return torch.cat([A(a), A(c), A(f2 * f3) if mode == 1 else A(f2) * A(f3)], 1)
+
+    x64 = x.double().requires_grad_(True)
+    W64 = {k: v.double().requires_grad_(True) for k, v in W.items()}
+    y64 = ref(x64, W64, None if val is None else val.double())
+    (y64 * gout.double()).sum().backward()
+
+    csr = GraphCSR.from_edge_index(ei.to(dev), N)
+    xd = x.to(dev).requires_grad_(True)
+    Wd = {k: v.to(dev).requires_grad_(True) for k, v in W.items()}
+    vs = None if val is None else csr.sort_values(val.to(dev).view(-1, 1)).view(-1)
+    assert Fn.gnnml1_block_supported(xd, Fin, n1, n2, n3, mode)
+    y = Fn.GNNML1BlockFunction.apply(xd, csr, vs, Wd['w1'], Wd['b1'], Wd['wc'], Wd['bc'], Wd['w2'], Wd['b2'], Wd['w3'], Wd['b3'], mode, act)
+    (y * gout.to(dev)).sum().backward()
+    tol = 2e-5
+    close(y, y64.float(), tol=tol, what='out')
+    close(xd.grad, x64.grad.float(), tol=tol, what='dx')
+    for k in W:
+        close(Wd[k].grad, W64[k].grad.float(), tol=tol, what=k)
