@@ -66,6 +66,9 @@ SIGNATURES = {
     'gml_fold_many': (ctypes.c_int, [_p, _i32, _p]),
     'gml_gnnml1_supported': (_i32, [_i32, _i32, _i32, _i32, _i32]),
     'gml_gnnml1_g4_cols': (_i32, [_i32, _i32, _i32, _i32]),
+    'gml_gnnml1_dw_floats': (_i64, [_i32, _i32, _i32, _i32, _i32]),
+    'gml_gnnml1_dw_workspace_bytes': (_sz, [_i64, _i32, _i32, _i32, _i32, _i32]),
+    'gml_gnnml1_dw': (ctypes.c_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _p, _p, _sz, _p]),
     'gml_gnnml1_fwd': (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _p, _p, _i32, _p, _p, _i32, _p, _p, _p, _p, _i32, _i32, _i32, _p, _i64, _p]),
     'gml_gnnml1_bwd': (ctypes.c_int, [_p, _p, _p, _p, _i64, _p, _i64, _p, _i64, _i64, _i32, _p, _i32, _p, _i32, _p, _p, _p, _p, _i32, _i32, _i32,
                                       _p, _i64, _p, _i64, _p, _i64, _p]),

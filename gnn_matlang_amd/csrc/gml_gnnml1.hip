@@ -403,3 +403,162 @@ extern "C" int gml_gnnml1_bwd(const int32_t* rowptr_t, const int32_t* col_t, con
     }
     return gml_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------------- weight gradients
+// dW1 = da^T x, dW2 = df2^T x, dW3 = df3^T x ([n, Fin]),  dWc = x^T q ([Fin, n2]),  column sums of g4 (the bias gradients): ONE pass
+// over the rows.  Contraction over ROWS on the f32 matrix instruction: A[i][k = row 4 t + (l >> 4)], B[k][j] are dword loads of 64-byte
+// row segments (lane l & 15 = column inside a 16-wide block); a "group" = one 16-column block of g4 against all x blocks (type 0) or
+// one x block against all q blocks (dWc); wave w of a workgroup owns the g4 blocks w and w + 8 (<= 16 blocks: the 64-wide concat form),
+// walks the rows of the workgroup's chunk ONCE for both (the x fragments of a step loaded once, 8 accumulator tiles), and -- waves
+// 0 .. 3 -- a second time for its x block of dWc.  One partial per workgroup, laid out as
+// the flat result [dW1 | dW2 | dW3 | dWc | sums], folded in workgroup order by gml_fold_many (deterministic).
+struct GmlG1DwParams {
+    const float* x; int64_t ldx; const float* g4; int64_t ldg4; const float* q; int64_t ldq;
+    int64_t nrows; int32_t Fin, n1, n2, n3, mode;
+    float* part; int64_t nflat; int32_t rows_per_wg;
+};
+
+__global__ __launch_bounds__(64 * G1_NW) void gml_k_gnnml1_dw(const GmlG1DwParams p) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c16 = lane & 15, k4 = lane >> 4;
+    const int nb1 = (p.n1 + 15) / 16, nb2 = (p.n2 + 15) / 16, nb3 = (p.n3 + 15) / 16, nfb = (p.Fin + 15) / 16;
+    const int ngb = nb1 + (p.mode == 0 ? 0 : nb2) + 2 * nb3;          // 16-column blocks of g4 (<= 16)
+    const int64_t r_begin = (int64_t)blockIdx.x * p.rows_per_wg;
+    const int64_t r_end = min(r_begin + (int64_t)p.rows_per_wg, p.nrows);
+    float* out = p.part + (int64_t)blockIdx.x * p.nflat;
+    // flat offsets: dW1 [n1, Fin], dW2 [n3, Fin], dW3 [n3, Fin], dWc [Fin, n2], sums [16 ngb]
+    const int64_t o_w1 = 0, o_w2 = (int64_t)p.n1 * p.Fin, o_w3 = o_w2 + (int64_t)p.n3 * p.Fin, o_wc = o_w3 + (int64_t)p.n3 * p.Fin,
+                  o_s = o_wc + (int64_t)p.Fin * p.n2;
+    constexpr int U = 4;                                               // K steps (4 rows each) of loads in flight in front of their MFMAs
+    // ---- pass 1: the wave's g4 blocks (wave, wave + 8: <= 2 of <= 16) against ALL x blocks, the x fragments loaded once per step
+    {
+        const int na = (wave < ngb ? 1 : 0) + (wave + G1_NW < ngb ? 1 : 0);
+        f32x4 acc[2][4];
+        float bsum[2] = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[i][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (na > 0) {
+            for (int64_t r = r_begin; r < r_end; r += 4 * U) {
+                float av[U][2], bv[U][4];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int64_t row = r + 4 * u + k4;
+                    const bool rv = row < r_end;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) av[u][i] = (i < na && rv) ? p.g4[row * p.ldg4 + 16 * (wave + G1_NW * i) + c16] : 0.f;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) bv[u][b] = (b < nfb && rv && 16 * b + c16 < p.Fin) ? p.x[row * p.ldx + 16 * b + c16] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        if (i >= na) break;
+                        bsum[i] += av[u][i];
+#pragma unroll
+                        for (int b = 0; b < 4; ++b)
+                            if (b < nfb) acc[i][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][i], bv[u][b], acc[i][b], 0, 0, 0);
+                    }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (i >= na) break;
+            const int grp = wave + G1_NW * i;
+            // which matrix does g4 block `grp` belong to: [da nb1 | dc nb2 (modes 1, 2) | df2 nb3 | df3 nb3]
+            int m, nb;
+            if (grp < nb1) { m = 0; nb = grp; }
+            else if (p.mode != 0 && grp < nb1 + nb2) { m = 3; nb = grp - nb1; }
+            else { const int g2 = grp - nb1 - (p.mode == 0 ? 0 : nb2); m = g2 < nb3 ? 1 : 2; nb = g2 < nb3 ? g2 : g2 - nb3; }
+            if (m != 3) {                                             // (the dc block has no Linear weight: its sums only)
+                const int n = m == 0 ? p.n1 : p.n3;
+                float* w = out + (m == 0 ? o_w1 : (m == 1 ? o_w2 : o_w3));
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    if (b >= nfb) break;
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {               // D[i = g4 column 4 k4 + reg][j = x column c16]
+                        const int c = 16 * nb + 4 * k4 + reg, f = 16 * b + c16;
+                        if (c < n && f < p.Fin) w[(int64_t)c * p.Fin + f] = acc[i][b][reg];
+                    }
+                }
+            }
+            float t = bsum[i];
+            t += __shfl_xor(t, 16);
+            t += __shfl_xor(t, 32);
+            if (k4 == 0) out[o_s + 16 * grp + c16] = t;
+        }
+    }
+    // ---- pass 2: dWc = x^T q: x block `wave` (< nfb <= 4) against all q blocks
+    if (wave < nfb) {
+        const int fb = wave, acols = min(16, p.Fin - 16 * fb);
+        f32x4 acc[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int64_t r = r_begin; r < r_end; r += 4 * U) {
+            float av[U], bv[U][4];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t row = r + 4 * u + k4;
+                const bool rv = row < r_end;
+                av[u] = (rv && c16 < acols) ? p.x[row * p.ldx + 16 * fb + c16] : 0.f;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) bv[u][b] = (b < nb2 && rv) ? p.q[row * p.ldq + 16 * b + c16] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (b < nb2) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u][b], acc[b], 0, 0, 0);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (b >= nb2) break;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int f = 16 * fb + 4 * k4 + reg, c = 16 * b + c16;
+                if (f < p.Fin && c < p.n2) out[o_wc + (int64_t)f * p.n2 + c] = acc[b][reg];
+            }
+        }
+    }
+}
+
+// floats of the flat result [dW1 (n1 x Fin) | dW2 (n3 x Fin) | dW3 (n3 x Fin) | dWc (Fin x n2) | column sums of g4 (gml_gnnml1_g4_cols)]
+extern "C" int64_t gml_gnnml1_dw_floats(int32_t Fin, int32_t n1, int32_t n2, int32_t n3, int32_t mode) {
+    return (int64_t)n1 * Fin + 2 * (int64_t)n3 * Fin + (int64_t)Fin * n2 + gml_gnnml1_g4_cols(n1, n2, n3, mode);
+}
+
+static int g1_dw_grid(int64_t n) {
+    int64_t g = gml_cdiv(n, 128);
+    if (g > 2 * GML_NUM_CU) g = 2 * GML_NUM_CU;
+    return g < 1 ? 1 : (int)g;
+}
+
+extern "C" size_t gml_gnnml1_dw_workspace_bytes(int64_t num_rows, int32_t Fin, int32_t n1, int32_t n2, int32_t n3, int32_t mode) {
+    return (size_t)g1_dw_grid(num_rows) * (size_t)gml_gnnml1_dw_floats(Fin, n1, n2, n3, mode) * sizeof(float);
+}
+
+extern "C" int gml_gnnml1_dw(const float* x, int64_t ldx, const float* g4, int64_t ldg4, const float* q, int64_t ldq, int64_t num_rows,
+                             int32_t Fin, int32_t n1, int32_t n2, int32_t n3, int32_t mode, float* out_flat, void* ws, size_t ws_bytes,
+                             gml_stream_t stream) {
+    if (!gml_gnnml1_supported(Fin, n1, n2, n3, mode)) return GML_E_UNSUPPORTED;
+    if (num_rows < 0 || !x || !g4 || !q || !out_flat || ldx < Fin || ldg4 < gml_gnnml1_g4_cols(n1, n2, n3, mode) || ldq < 16 * ((n2 + 15) / 16))
+        return GML_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nflat = gml_gnnml1_dw_floats(Fin, n1, n2, n3, mode);
+    if (num_rows == 0) { gml_zero_async(out_flat, sizeof(float) * nflat, st); return gml_launch_status(); }
+    if (!ws || ws_bytes < gml_gnnml1_dw_workspace_bytes(num_rows, Fin, n1, n2, n3, mode)) return GML_E_WORKSPACE;
+    GmlG1DwParams p;
+    p.x = x; p.ldx = ldx; p.g4 = g4; p.ldg4 = ldg4; p.q = q; p.ldq = ldq; p.nrows = num_rows; p.Fin = Fin; p.n1 = n1; p.n2 = n2; p.n3 = n3;
+    p.mode = mode; p.part = (float*)ws; p.nflat = nflat;
+    const int grid = g1_dw_grid(num_rows);
+    p.rows_per_wg = (int)((gml_cdiv(num_rows, grid) + 3) / 4 * 4);
+    gml_zero_async(ws, (size_t)grid * nflat * sizeof(float), st);       // (elements outside the written blocks: the dc block has no weight)
+    hipLaunchKernelGGL(gml_k_gnnml1_dw, dim3((unsigned)grid), dim3(64 * G1_NW), 0, st, p);
+    int rc = gml_launch_status();
+    if (rc != GML_OK) return rc;
+    gml_fold_job job = {};
+    job.partial = (const float*)ws; job.nparts = grid; job.n = nflat; job.dst[0] = out_flat; job.ndst[0] = nflat;
+    return gml_fold_many(&job, 1, stream);
+}

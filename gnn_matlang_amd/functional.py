@@ -606,7 +606,7 @@ class GNNML1BlockFunction(torch.autograd.Function):
             val = _f32c(val.reshape(-1), 'edge_attr')
         with torch.cuda.device(dev):
             out = torch.empty(N, C, dtype=torch.float32, device=dev)
-            with _Timed('gnnml1_fwd'):
+            with _Timed('gnnml1_fwd', 4 * (N * (Fin + C) + csr.E + N + Fin * (n1 + n2 + 2 * n3)) if PROFILE is not None else 0, 0):
                 _lib.call('gml_gnnml1_fwd', _ptr(csr.rowptr), _ptr(csr.col), _ptr(val), _ptr(x), int(x.stride(0)), N, Fin,
                           _ptr(w1), _ptr(b1), n1, _ptr(wc), _ptr(bc), n2, _ptr(w2), _ptr(b2), _ptr(w3), _ptr(b3), n3, int(mode), int(act),
                           _ptr(out), C, _stream(dev))
@@ -631,7 +631,7 @@ class GNNML1BlockFunction(torch.autograd.Function):
             g4 = torch.empty(N, ng4, dtype=torch.float32, device=dev)
             q = torch.empty(N, p2, dtype=torch.float32, device=dev)
             dx = torch.empty(N, Fin, dtype=torch.float32, device=dev) if need_x else None
-            with _Timed('gnnml1_bwd'):
+            with _Timed('gnnml1_bwd', 4 * (N * (Fin + 2 * C + (Fin if need_x else 0) + ng4 + p2) + csr.E + N) if PROFILE is not None else 0, 0):
                 _lib.call('gml_gnnml1_bwd', _ptr(csr.rowptr_t), _ptr(csr.col_t), _ptr(val_t), _ptr(x), int(x.stride(0)), _ptr(out), C,
                           _ptr(gout), int(gout.stride(0)), N, Fin, _ptr(w1), n1, _ptr(wc), n2, _ptr(w2), _ptr(b2), _ptr(w3), _ptr(b3), n3,
                           mode, act, _ptr(dx), Fin, _ptr(g4), ng4, _ptr(q), p2, _stream(dev))
@@ -639,15 +639,15 @@ class GNNML1BlockFunction(torch.autograd.Function):
             o2 = p1 if mode == 0 else p1 + p2
             o3 = o2 + p3
             with _Timed('gnnml1_dw'):
-                xc = x if x.stride(0) == Fin else x              # (gml_xty takes the leading dimension)
-                dw1 = xty(g4[:, oa:oa + n1], xc)
-                dw2 = xty(g4[:, o2:o2 + n3], xc)
-                dw3 = xty(g4[:, o3:o3 + n3], xc)
-                dwc = xty(xc, q[:, :n2])
-                if dw1 is None or dw2 is None or dw3 is None or dwc is None:
-                    dw1, dw2, dw3 = g4[:, oa:oa + n1].t() @ x, g4[:, o2:o2 + n3].t() @ x, g4[:, o3:o3 + n3].t() @ x
-                    dwc = x.t() @ q[:, :n2]
-                sums = g4.sum(0)
+                nflat = int(L.gml_gnnml1_dw_floats(Fin, n1, n2, n3, mode))
+                nws = int(L.gml_gnnml1_dw_workspace_bytes(N, Fin, n1, n2, n3, mode))
+                flat = torch.empty(nflat, dtype=torch.float32, device=dev)
+                ws = torch.empty(max(nws, 4), dtype=torch.uint8, device=dev)
+                _lib.call('gml_gnnml1_dw', _ptr(x), int(x.stride(0)), _ptr(g4), ng4, _ptr(q), p2, N, Fin, n1, n2, n3, mode, _ptr(flat),
+                          _ptr(ws), ws.numel(), _stream(dev))
+                e1, e2, e3, e4 = n1 * Fin, n1 * Fin + n3 * Fin, n1 * Fin + 2 * n3 * Fin, n1 * Fin + 2 * n3 * Fin + Fin * n2
+                dw1, dw2, dw3, dwc = flat[:e1].view(n1, Fin), flat[e1:e2].view(n3, Fin), flat[e2:e3].view(n3, Fin), flat[e3:e4].view(Fin, n2)
+                sums = flat[e4:]
         hb1, hbc, hb2, hb3 = ctx.has_b
         db1 = sums[oa:oa + n1] if hb1 else None
         dbc = (sums[oa:oa + n2] if mode == 0 else sums[oc:oc + n2]) if hbc else None

@@ -508,6 +508,14 @@ int gml_gnnml1_fwd(const int32_t* rowptr, const int32_t* col, const float* val, 
                    int32_t Fin, const float* w1, const float* b1, int32_t n1, const float* wc, const float* bc, int32_t n2,
                    const float* w2, const float* b2, const float* w3, const float* b3, int32_t n3, int32_t mode, int32_t act,
                    float* out, int64_t ldo, gml_stream_t stream);
+/* the block's weight and bias gradients from g4 / q in one pass over the rows + one fold:
+ *   out_flat = [dW1 (n1 x Fin) | dW2 (n3 x Fin) | dW3 (n3 x Fin) | dWc (Fin x n2) | column sums of g4 (gml_gnnml1_g4_cols floats)]
+ * (db1 = sums of the da block, dbc = sums of the dc block -- the da block in mode 0 --, db2 / db3 = sums of the df2 / df3 blocks) */
+int64_t gml_gnnml1_dw_floats(int32_t Fin, int32_t n1, int32_t n2, int32_t n3, int32_t mode);
+size_t gml_gnnml1_dw_workspace_bytes(int64_t num_rows, int32_t Fin, int32_t n1, int32_t n2, int32_t n3, int32_t mode);
+int gml_gnnml1_dw(const float* x, int64_t ldx, const float* g4, int64_t ldg4, const float* q, int64_t ldq, int64_t num_rows,
+                  int32_t Fin, int32_t n1, int32_t n2, int32_t n3, int32_t mode, float* out_flat, void* ws, size_t ws_bytes,
+                  gml_stream_t stream);
 int gml_gnnml1_bwd(const int32_t* rowptr_t, const int32_t* col_t, const float* val_t, const float* x, int64_t ldx,
                    const float* out, int64_t ldo, const float* gout, int64_t ldgo, int64_t num_rows, int32_t Fin,
                    const float* w1, int32_t n1, const float* wc, int32_t n2, const float* w2, const float* b2, const float* w3,

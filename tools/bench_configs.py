@@ -50,6 +50,11 @@ def _configs():
          'sr25.py:16,248-280 (GNNML3, S = 6, input [1, degree], 3 layers 32+16; the 15 REAL sr25 graphs, tiled)'),
         ('mutag_gnnml3', lambda: _mutag_like(512, 2), (600000, 150000), dict(recfield=1, dv=4, nfreq=3, adddegree=True), lambda: models.mutag_gnnml3(8, 4),
          models.mutag_loss, 'mutag.py:14,272-288 (GNNML3, S = 4, 7 atom types + degree, 3 layers 24+24 + BatchNorm, learnedge=False; ZINC-like synthetic graphs)'),
+        ('mutag_gnnml1', lambda: _mutag_like(512, 2), (600000, 150000), dict(recfield=1, dv=4, nfreq=3, adddegree=True), lambda: models.GNNML1Mutag(8),
+         models.mutag_loss, 'mutag.py:14,214-266 (GNNML1: three blocks [relu fc | relu SpectConv(K=1) | relu fc . relu fc] 16 + 32 + 16 + BatchNorm; BASELINE config 0\'s model; '
+         'each block one fused launch, csrc/gml_gnnml1.hip)'),
+        ('sr25_gnnml1', _sr25_real, (600000, 150000), dict(recfield=1, dv=2, nfreq=5, adddegree=True), lambda: models.sr25_gnnml1(2), None,
+         'sr25.py:16,192-246 (GNNML1, sum form tanh(fc + SpectConv(K=1) + fc . fc), 64 wide, the 15 REAL sr25 graphs, tiled)'),
     ]
 
 
