@@ -295,14 +295,13 @@ def main():
         parity0 = parity_vs_oracle(model, data, base, log)
         parity0['state'] = 'initial parameters (seed 0)'
 
+    # the framework's own training step (dist.TrainStep): zero -> forward + L1-sum loss -> backward with the weight-gradient folds deferred
+    # into ONE launch (functional.deferred_folds: bit-identical sums) -> flat all-reduce (nothing with one rank) -> fused Adam
+    from gnn_matlang_amd.dist import TrainStep
+    trainer = TrainStep(model, lambda mod, d_: models.zinc_loss(mod(d_), d_.y), opt, sync=sync)
+
     def step(d=None):
-        d = data if d is None else d
-        sync.zero()
-        loss = models.zinc_loss(model(d), d.y)
-        loss.backward()
-        sync.sync()
-        opt.step()
-        return loss
+        return trainer.step(data if d is None else d)
 
     def fence():
         torch.cuda.synchronize()

@@ -154,8 +154,11 @@ class _DenseConv(torch.autograd.Function):
         hcat = torch.empty(rows, S * Fin, dtype=torch.float32, device=dev) if need_h else None
         out = torch.empty(rows, Fout, dtype=torch.float32, device=dev)
         Fn._path('dense', 'support product + projection chained (bf16x3 HIP)', S, Fin, Fout)
-        _lib.call('gml_dense_conv_fwd', _ptr(sup.fwd), _ptr(x), int(x.stride(0)), _ptr(wimg), _ptr(bias), _ptr(out), Fout,
-                  _ptr(hcat), sup.B, S, sup.n, sup.KP, Fin, Fout, 0, _stream(dev))
+        # algorithmic bytes: the packed support images (bf16 hi + lo), x, out, and Hcat when the weight gradient wants it
+        q_img = sup.B * S * 2 * sup.n * sup.KP * 2
+        with Fn._Timed('dense_conv_fwd', q_img + 4 * rows * (Fin + Fout + (S * Fin if need_h else 0)), 2 * sup.B * S * sup.n * sup.n * Fin + 2 * rows * S * Fin * Fout):
+            _lib.call('gml_dense_conv_fwd', _ptr(sup.fwd), _ptr(x), int(x.stride(0)), _ptr(wimg), _ptr(bias), _ptr(out), Fout,
+                      _ptr(hcat), sup.B, S, sup.n, sup.KP, Fin, Fout, 0, _stream(dev))
         ctx.save_for_backward(hcat if hcat is not None else x, weight)
         ctx.sup, ctx.has_bias, ctx.has_h = sup, bias is not None, hcat is not None
         return out
@@ -175,8 +178,10 @@ class _DenseConv(torch.autograd.Function):
                 _lib.call('gml_dense_pack_wt', _ptr(weight.contiguous()), _ptr(wimgT), S, Fin, Fout, _stream(dev))
                 dx = torch.empty(sup.B * sup.n, Fin, dtype=torch.float32, device=dev)
                 Fn._path('dense', 'projection + support product chained, backward (bf16x3 HIP)', S, Fin, Fout)
-                _lib.call('gml_dense_conv_bwd_x', _ptr(sup.bwd), _ptr(g), int(g.stride(0)), _ptr(wimgT), _ptr(dx), Fin,
-                          sup.B, S, sup.n, sup.KP, Fin, Fout, _stream(dev))
+                with Fn._Timed('dense_conv_bwd_x', sup.B * S * 2 * sup.n * sup.KP * 2 + 4 * sup.B * sup.n * (Fin + Fout),
+                               2 * sup.B * S * sup.n * sup.n * Fin + 2 * sup.B * sup.n * S * Fin * Fout):
+                    _lib.call('gml_dense_conv_bwd_x', _ptr(sup.bwd), _ptr(g), int(g.stride(0)), _ptr(wimgT), _ptr(dx), Fin,
+                              sup.B, S, sup.n, sup.KP, Fin, Fout, _stream(dev))
             else:
                 dh = g.mm(weight.reshape(S * Fin, Fout).t())
                 dx = support_mm(sup.bwd, dh, sup, Fin, Fin, 0, True)
@@ -192,8 +197,9 @@ class _DenseConv(torch.autograd.Function):
         elif ctx.needs_input_grad[1]:
             rows = int(hcat.size(0))
             P = _splits(rows)
-            dw = (torch.bmm(hcat.view(P, rows // P, S * Fin).transpose(1, 2), g.view(P, rows // P, Fout)).sum(0) if P > 1
-                  else hcat.t().mm(g)).view(S, Fin, Fout)
+            with Fn._Timed('dense_dw_library_gemm', 4 * rows * (S * Fin + Fout), 2 * rows * S * Fin * Fout):
+                dw = (torch.bmm(hcat.view(P, rows // P, S * Fin).transpose(1, 2), g.view(P, rows // P, Fout)).sum(0) if P > 1
+                      else hcat.t().mm(g)).view(S, Fin, Fout)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = g.sum(0)
         return dx, dw, db, None

@@ -42,4 +42,24 @@ for name, dn in (('sparse', 0), ('dense_lib', 75), ('dense', 75)):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
     out[name] = dict(ms_per_step=dt * 1e3, graphs_per_s=B / dt, loss=float(l))
+    if name == 'dense':
+        # roofline of the dominant hand-written kernel: live HIP events around every tagged launch, a second pass
+        from gnn_matlang_amd import functional as Fn
+        Fn.PROFILE = {}
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        summ = Fn.profile_summary(Fn.PROFILE)
+        Fn.PROFILE = None
+        kern = {k: dict(launches_per_step=v['launches'] / n, avg_launch_ms=round(v['ms'], 4), ms_per_step=round(v['ms'] * v['launches'] / n, 4),
+                        GBps=round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1), TFLOPs=round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2))
+                for k, v in summ.items() if v['bytes'] > 0}
+        top = max((k for k in kern if k.startswith('dense_conv')), key=lambda k: kern[k]['ms_per_step'], default=None)
+        if top is not None:
+            v = summ[top]
+            gbs = v['bytes'] / (v['ms'] * 1e-3) / 1e9
+            out[name]['roofline'] = dict(bound='hbm', kernel=top, achieved=gbs, peak=8000.0, unit='GB/s', frac=gbs / 8000.0, traffic=None,
+                                         avg_launch_ms=v['ms'], algorithmic_bytes_per_launch=v['bytes'],
+                                         note='mean over the three layers of the model; the same kernel on the matrix pipe: %.1f TFLOP/s' % (v['flops'] / (v['ms'] * 1e-3) / 1e12))
+        out[name]['kernels'] = kern
 print(json.dumps(dict(graphs=B, nodes=int(data.x.size(0)), support_edges=int(data.edge_index2.size(1)), **out)))
