@@ -117,7 +117,7 @@ static BwdPlan plan_bwd(int64_t num_rows, int S, int Fin, int Fout, int max_edge
         GML_BWD3_LDS(8, 2, 4) GML_BWD3_LDS(8, 1, 4) GML_BWD3_LDS(6, 3, 8) GML_BWD3_LDS(4, 3, 8)
         if (S == 12) pl.lds = pl.nfb == 2 ? GmlBwd3Cfg<12, 2, 8, 1>::lds_bytes(pl.ecap, pl.xcap) : GmlBwd3Cfg<12, 1, 8, 1>::lds_bytes(pl.ecap, pl.xcap);
         if (S == 8 && nob == 1) { pl.lds = pl.nfb == 2 ? GmlBwd3Cfg<8, 2, 8, 1>::lds_bytes(pl.ecap, pl.xcap) : GmlBwd3Cfg<8, 1, 8, 1>::lds_bytes(pl.ecap, pl.xcap); }
-        if (pl.lds > 0) pl.lds += 512;                      /* the DZ instantiation's wmix rows (gml_spectconv_bwd_mix) */
+        if (pl.lds > 0 && S == 8) pl.lds += 512;            /* the DZ instantiation's wmix rows (gml_spectconv_bwd_mix: compiled for S = 8) */
         /* (a group too large for the LDS: not ok -- the caller then asks for the f32-MFMA kernel with ITS group records) */
         pl.ok = pl.lds > 0 && pl.lds <= (pl.nw == 4 ? 80 : 160) * 1024;
         return pl;

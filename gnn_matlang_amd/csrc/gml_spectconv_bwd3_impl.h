@@ -87,7 +87,8 @@ struct GmlBwd3Cfg {
     }
     // VALG (GML_B3V & 256, the ZINC shape class): the value rows are read from global memory inside the edge loop, so the LDS holds
     // column ids + G window and -- in regions of their own, aliasing nothing -- the X image and one P slab
-    static constexpr bool VALG = (GML_B3V & 256) && S == 8 && NOB == 2 && NW == 8;
+    // (round 5: also sr25's one-launch 48-feature class, S = 6 / NFB = 3 -- its staged value rows, 24 registers, were spilling)
+    static constexpr bool VALG = (GML_B3V & 256) && NOB == 2 && NW == 8 && (S == 8 || (S == 6 && NFB == 3 && !(GML_B3V & 16384)));
     __host__ __device__ static size_t lds_bytes(int ecap, int xcap) {
         if (VALG) return (size_t)W_BYTES + (ROWS + 8) * 4 + (size_t)ecap * 4 + (size_t)xcap * LDG * 4 + XT_BYTES + PT_BYTES;
         return (size_t)W_BYTES + (ROWS + 8) * 4 + (size_t)ecap * 4 + r_bytes(ecap, xcap) + XT_BYTES;
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
     static_assert(!DZ || NOB == 2, "the dz hand-over is compiled for the ZINC shape class");
     constexpr int LDG = C::LDG, ROWS = C::ROWS, NT = C::NT, SS = C::SS, BPW = C::BPW;
     constexpr int VAL_ALIGN = (S % 4 == 0) ? 4 : ((S % 2 == 0) ? 2 : 1);
-    constexpr bool DIRECT = (GML_B3V & 1) && S == 8 && NOB == 2;      // (the shape class without the dval += branch)
+    constexpr bool DIRECT = (GML_B3V & 1) && NOB == 2 && (S == 8 || C::VALG);      // (the shape classes without the dval += branch)
     constexpr bool ZEARLY = (GML_B3V & 2) != 0;
     constexpr bool PINGPONG = (GML_B3V & 8) != 0;
     constexpr bool BUFLD = (GML_B3V & 4) && S == 8 && NOB == 2 && XV;
@@ -497,15 +498,18 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
                 float tot2[2];
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
+                    const float d6 = (S > 6) ? d[(S > 6) ? 6 + c : 0] : 0.f;       // (S = 6: slots 6, 7 are empty -- lane kq = 3 stores nothing)
                     const auto a01 = __builtin_amdgcn_permlane16_swap(__float_as_uint(d[c]), __float_as_uint(d[2 + c]), false, false);
-                    const auto a23 = __builtin_amdgcn_permlane16_swap(__float_as_uint(d[4 + c]), __float_as_uint(d[6 + c]), false, false);
+                    const auto a23 = __builtin_amdgcn_permlane16_swap(__float_as_uint(d[4 + c]), __float_as_uint(d6), false, false);
                     const float c01 = __uint_as_float(a01[0]) + __uint_as_float(a01[1]);
                     const float c23 = __uint_as_float(a23[0]) + __uint_as_float(a23[1]);
                     const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(c01), __float_as_uint(c23), false, false);
                     tot2[c] = __uint_as_float(b[0]) + __uint_as_float(b[1]);
                 }
                 typedef uint32_t u32x2_ __attribute__((ext_vector_type(2)));
-                __builtin_amdgcn_raw_buffer_store_b64(u32x2_{__float_as_uint(tot2[0]), __float_as_uint(tot2[1])}, dvrs, (k * S + 2 * kq) * 4, 0, 0);
+                // (S = 6: the offset of lane kq = 3 lies beyond every record: the hardware drops its store)
+                const int doff = (S == 8 || kq < S / 2) ? (k * S + 2 * kq) * 4 : 0x7ffffff0;
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2_{__float_as_uint(tot2[0]), __float_as_uint(tot2[1])}, dvrs, doff, 0, 0);
             } else {
 #pragma unroll
             for (int c = 0; c < (S + 3) / 4; ++c) {
@@ -530,9 +534,15 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
             asm volatile("" :: "v"(vtouch));
             auto ldval = [&](int k, float (&ev)[S]) {
                 const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(vrs, k * (S * 4), 0, 0);
-                const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(vrs, k * (S * 4) + 16, 0, 0);
                 ev[0] = __uint_as_float(a.x); ev[1] = __uint_as_float(a.y); ev[2] = __uint_as_float(a.z); ev[3] = __uint_as_float(a.w);
-                ev[4] = __uint_as_float(b.x); ev[5] = __uint_as_float(b.y); ev[6] = __uint_as_float(b.z); ev[7] = __uint_as_float(b.w);
+                if constexpr (S == 8) {
+                    const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(vrs, k * (S * 4) + 16, 0, 0);
+                    ev[4] = __uint_as_float(b.x); ev[5] = __uint_as_float(b.y); ev[6] = __uint_as_float(b.z); ev[7] = __uint_as_float(b.w);
+                } else {                                     // 24-byte rows
+                    typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
+                    const u32x2v b = __builtin_amdgcn_raw_buffer_load_b64(vrs, k * (S * 4) + 16, 0, 0);
+                    ev[4] = __uint_as_float(b.x); ev[5] = __uint_as_float(b.y);
+                }
             };
             int k = kbeg;
             const int klast = kend - 1;
@@ -561,9 +571,15 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
             asm volatile("" :: "v"(vtouch));
             auto ldval = [&](int k, float (&ev)[S]) {
                 const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(vrs, k * (S * 4), 0, 0);
-                const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(vrs, k * (S * 4) + 16, 0, 0);
                 ev[0] = __uint_as_float(a.x); ev[1] = __uint_as_float(a.y); ev[2] = __uint_as_float(a.z); ev[3] = __uint_as_float(a.w);
-                ev[4] = __uint_as_float(b.x); ev[5] = __uint_as_float(b.y); ev[6] = __uint_as_float(b.z); ev[7] = __uint_as_float(b.w);
+                if constexpr (S == 8) {
+                    const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(vrs, k * (S * 4) + 16, 0, 0);
+                    ev[4] = __uint_as_float(b.x); ev[5] = __uint_as_float(b.y); ev[6] = __uint_as_float(b.z); ev[7] = __uint_as_float(b.w);
+                } else {                                     // 24-byte rows
+                    typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
+                    const u32x2v b = __builtin_amdgcn_raw_buffer_load_b64(vrs, k * (S * 4) + 16, 0, 0);
+                    ev[4] = __uint_as_float(b.x); ev[5] = __uint_as_float(b.y);
+                }
             };
             int k = kbeg;
             const int klast = kend - 1;
