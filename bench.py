@@ -406,7 +406,8 @@ def main():
             torch.manual_seed(0)
             m64 = models.zinc_gnnml3().to(dev)
             broadcast_parameters(m64)
-            ts = TrainStep(m64, lambda mod, d_: models.zinc_step_loss(mod, d_), torch.optim.Adam(m64.parameters(), lr=1e-3, capturable=True, fused=True))
+            from gnn_matlang_amd.optim import OneLaunchAdam      # Adam as ONE launch (gml_adam_many), step count on the device
+            ts = TrainStep(m64, lambda mod, d_: models.zinc_step_loss(mod, d_), OneLaunchAdam(m64.parameters(), lr=1e-3))
             replay, gl64 = ts.capture(rb64)
             for _ in range(20):
                 replay()
@@ -660,7 +661,8 @@ def main():
             rb.csr('edge_index2')
             torch.manual_seed(0)
             rm = models.zinc_gnnml3().to(dev)
-            o = torch.optim.Adam(rm.parameters(), lr=1e-3, capturable=True, fused=True)
+            from gnn_matlang_amd.optim import OneLaunchAdam      # Adam as ONE launch (gml_adam_many), step count on the device
+            o = OneLaunchAdam(rm.parameters(), lr=1e-3)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):                      # warm-up on a side stream (allocator, lazy init)
@@ -760,7 +762,8 @@ def main():
                 def captured_epoch(assemble):
                     torch.manual_seed(0)
                     cm = models.zinc_gnnml3().to(dev)
-                    co = torch.optim.Adam(cm.parameters(), lr=1e-3, capturable=True, fused=True)
+                    from gnn_matlang_amd.optim import OneLaunchAdam      # Adam as ONE launch (gml_adam_many), step count on the device
+                    co = OneLaunchAdam(cm.parameters(), lr=1e-3)
                     loss_acc = torch.zeros((), device=dev)
                     one_ = torch.ones((), device=dev)
 

@@ -64,6 +64,7 @@ SIGNATURES = {
     'gml_dense_dw_workspace_bytes': (_sz, [_i32, _i32, _i32, _i32]),
     'gml_dense_conv_bwd_w': (ctypes.c_int, [_p, _p, _i64, _p, _i64, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _sz, _p]),
     'gml_fold_many': (ctypes.c_int, [_p, _i32, _p]),
+    'gml_adam_many': (ctypes.c_int, [_p, _i32, _p, _p, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _p]),
     'gml_gnnml1_supported': (_i32, [_i32, _i32, _i32, _i32, _i32]),
     'gml_gnnml1_g4_cols': (_i32, [_i32, _i32, _i32, _i32]),
     'gml_gnnml1_dw_floats': (_i64, [_i32, _i32, _i32, _i32, _i32]),
@@ -121,6 +122,12 @@ GML_POOL_SKIP_LAST = 2
 GML_FWD_ONEWIN = 256
 GML_NO_FOLD = 512               # gml_spectconv_bwd*: leave the dW partials in ws (gml_fold_many)
 GML_FOLD_MAX_JOBS = 16
+
+
+class AdamJob(ctypes.Structure):
+    """gml_adam_job of include/gml.h"""
+    _fields_ = [('p', _p), ('g', _p), ('m', _p), ('v', _p), ('n', _i64)]
+GML_ADAM_MAX_JOBS = 64
 
 
 class FoldJob(ctypes.Structure):

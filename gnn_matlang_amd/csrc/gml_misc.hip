@@ -510,3 +510,59 @@ extern "C" int gml_fold_many(const gml_fold_job* jobs, int32_t njobs, gml_stream
     hipLaunchKernelGGL(gml_k_fold_many, dim3((unsigned)gml_cdiv(nmax, 16), (unsigned)njobs), dim3(256), 0, (hipStream_t)stream, a);
     return gml_launch_status();
 }
+
+// =============================================================================================
+// Adam over a list of parameter tensors in ONE launch (torch.optim.Adam's update, Zinc12k.py:349: no weight decay, no amsgrad):
+//   t = step[0] + 1;  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// step [1] (fp32, on the device: the launch is capturable in a HIP graph and every replay advances it) is read by every workgroup
+// at its start and written back as t by the LAST workgroup to finish (done [1], uint32, zero between launches), i.e. after every
+// other workgroup has read it.  torch's fused Adam is two multi-tensor launches for ZINC's 44 tensors plus one for the step counts: at
+// the reference's batch size (a step = ~30 launches of microseconds each) that is 17 of a step's 270 us.
+// =============================================================================================
+struct GmlAdamJobs { gml_adam_job j[GML_ADAM_MAX_JOBS]; };
+
+__global__ __launch_bounds__(256) void gml_k_adam_many(const GmlAdamJobs jobs, float* step, unsigned* done, float lr, float b1, float b2,
+                                                       float eps, unsigned total_blocks) {
+    const gml_adam_job& q = jobs.j[blockIdx.y];
+    const float t = step[0] + 1.f;
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 < q.n) {
+        const float c1 = 1.f - __powf(b1, t), c2 = 1.f - __powf(b2, t);
+        const float ss = lr / c1, rc2 = 1.f / sqrtf(c2);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = i0 + u;
+            if (i < q.n) {
+                const float g = q.g[i];
+                const float m = fmaf(b1, q.m[i], (1.f - b1) * g);
+                const float v = fmaf(b2, q.v[i], (1.f - b2) * g * g);
+                q.m[i] = m; q.v[i] = v;
+                q.p[i] -= ss * m / fmaf(sqrtf(v), rc2, eps);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(done, 1u) == total_blocks - 1) { step[0] = t; *done = 0u; __threadfence(); }
+    }
+}
+
+extern "C" int gml_adam_many(const gml_adam_job* jobs, int32_t njobs, float* step, uint32_t* done, float lr, float beta1, float beta2,
+                             float eps, gml_stream_t stream) {
+    if (njobs < 0 || njobs > GML_ADAM_MAX_JOBS || (njobs > 0 && !jobs) || !step || !done) return GML_E_BADARG;
+    if (njobs == 0) return GML_OK;
+    GmlAdamJobs a = {};
+    int64_t nmax = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const gml_adam_job& q = jobs[i];
+        if (q.n < 0 || (q.n > 0 && (!q.p || !q.g || !q.m || !q.v))) return GML_E_BADARG;
+        a.j[i] = q;
+        nmax = q.n > nmax ? q.n : nmax;
+    }
+    if (nmax == 0) return GML_OK;
+    const unsigned gx = (unsigned)gml_cdiv(nmax, 1024);
+    hipLaunchKernelGGL(gml_k_adam_many, dim3(gx, (unsigned)njobs), dim3(256), 0, (hipStream_t)stream, a, step, done, lr, beta1, beta2, eps,
+                       gx * (unsigned)njobs);
+    return gml_launch_status();
+}

@@ -42,3 +42,62 @@ class TFAdam(torch.optim.Optimizer):
             torch._foreach_add_(den, group['eps'])
             lr_t = group['lr'] * math.sqrt(1 - b2 ** t) / (1 - b1 ** t)
             torch._foreach_addcdiv_(ps, ms, den, value=-lr_t)
+
+
+class OneLaunchAdam(torch.optim.Optimizer):
+    """torch.optim.Adam's update (no weight decay, no amsgrad: Zinc12k.py:349) as ONE launch over all parameter tensors
+    (gml_adam_many, csrc/gml_misc.hip) -- for the reference's batch size, where a training step is a chain of ~30 launches of
+    microseconds each and torch's fused Adam is three of them.  The step count lives on the device (capturable: every replay of a
+    captured step advances it).  Moments are kept in one flat buffer; gradients may be any tensors (views of the fold buffers).
+    Parameters without a gradient at the FIRST step are left out for good (the job list is built once per gradient layout)."""
+
+    def __init__(self, params, lr=0.001, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self._built = None
+
+    def _build(self):
+        from . import _lib
+        import ctypes
+        chunks = []
+        for group in self.param_groups:
+            ps = [p for p in group['params'] if p.grad is not None]
+            if not ps:
+                continue
+            dev = ps[0].device
+            if not all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in ps):
+                raise ValueError('OneLaunchAdam: contiguous float32 parameters on the GPU')
+            flat = torch.zeros(2, sum(p.numel() for p in ps), dtype=torch.float32, device=dev)
+            off = 0
+            for p in ps:
+                st = self.state[p]
+                st['exp_avg'], st['exp_avg_sq'] = flat[0, off:off + p.numel()].view_as(p), flat[1, off:off + p.numel()].view_as(p)
+                off += p.numel()
+            for i in range(0, len(ps), _lib.GML_ADAM_MAX_JOBS):
+                part = ps[i:i + _lib.GML_ADAM_MAX_JOBS]
+                # (every chunk advances a step count of its own, in lockstep: no copy between the launches of one optimizer step)
+                chunks.append(dict(group=group, ps=part, step=torch.zeros(1, dtype=torch.float32, device=dev),
+                                   done=torch.zeros(1, dtype=torch.int32, device=dev), dev=dev))
+        self._built = chunks
+
+    @torch.no_grad()
+    def step(self):
+        from . import _lib
+        from .graph import _ptr, _stream
+        import ctypes
+        if self._built is None:
+            self._build()
+        for c in self._built:
+            ps = c['ps']
+            arr = (_lib.AdamJob * len(ps))()
+            for k, p in enumerate(ps):
+                g = p.grad
+                if g is None:
+                    raise RuntimeError('OneLaunchAdam: a parameter that had a gradient at the first step has none now')
+                if not g.is_contiguous():
+                    g = g.contiguous()
+                st = self.state[p]
+                arr[k].p, arr[k].g, arr[k].m, arr[k].v, arr[k].n = p.data_ptr(), g.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(), p.numel()
+            b1, b2 = c['group']['betas']
+            with torch.cuda.device(c['dev']):
+                _lib.call('gml_adam_many', ctypes.addressof(arr), len(ps), _ptr(c['step']), _ptr(c['done']), float(c['group']['lr']), float(b1),
+                          float(b2), float(c['group']['eps']), _stream(c['dev']))

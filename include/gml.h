@@ -90,6 +90,15 @@ typedef struct gml_fold_job {
 } gml_fold_job;
 #define GML_FOLD_MAX_JOBS 16
 int gml_fold_many(const gml_fold_job* jobs /* host array */, int32_t njobs /* <= GML_FOLD_MAX_JOBS */, gml_stream_t stream);
+/* Adam (torch.optim.Adam's update as the reference scripts configure it, Zinc12k.py:349: no weight decay, no amsgrad) over a list of
+ * tensors in ONE launch: t = step[0] + 1; m = b1 m + (1 - b1) g; v = b2 v + (1 - b2) g^2; p -= lr / (1 - b1^t) m / (sqrt(v / (1 - b2^t)) + eps);
+ * step[0] = t afterwards.  step [1] fp32 and done [1] uint32 (zero) live on the device: the launch is capturable, every replay of a
+ * captured step advances the count.  More than GML_ADAM_MAX_JOBS tensors: several calls -- all but the last with a scratch copy of
+ * step (the count must advance once per optimizer step). */
+typedef struct gml_adam_job { float* p; const float* g; float* m; float* v; int64_t n; } gml_adam_job;
+#define GML_ADAM_MAX_JOBS 64
+int gml_adam_many(const gml_adam_job* jobs /* host array */, int32_t njobs, float* step, uint32_t* done, float lr, float beta1,
+                  float beta2, float eps, gml_stream_t stream);
 /* number of partial rows gml_edge_mlp_bwd leaves for this call shape (it depends on the kernel family the call takes) */
 int64_t gml_edge_mlp_bwd_parts(int64_t num_edges, int32_t S, int32_t Sout, int32_t has_split, int32_t want_gin);
 

@@ -1869,3 +1869,44 @@ def test_gnnml1_block_vs_fp64(dev, mode, act, N, Fin, n1, n2, n3, unit):
     close(xd.grad, x64.grad.float(), tol=tol, what='dx')
     for k in W:
         close(Wd[k].grad, W64[k].grad.float(), tol=tol, what=k)
+
+
+def test_one_launch_adam_follows_torch_adam(dev):
+    """optim.OneLaunchAdam (gml_adam_many: every parameter tensor of the model in one launch, step count on the device) against
+    torch.optim.Adam over 8 steps with fresh random gradients: parameters equal to 1e-6 of their scale; 70 tensors (two chunks of the
+    job table), sizes 1 .. 5000, a non-contiguous gradient; then captured in a HIP graph and replayed -- the count keeps advancing."""
+    from gnn_matlang_amd.optim import OneLaunchAdam
+    torch.manual_seed(0)
+    sizes = [1, 3, 4, 5, 1023, 1024, 1025, 5000] + [int(v) for v in torch.randint(1, 2000, (62,))]
+    pa = [torch.randn(n, device=dev).requires_grad_(True) for n in sizes]
+    pb = [p.detach().clone().requires_grad_(True) for p in pa]
+    oa, ob = OneLaunchAdam(pa, lr=1e-2), torch.optim.Adam(pb, lr=1e-2)
+    for it in range(8):
+        for a, b in zip(pa, pb):
+            g = torch.randn_like(a) * (10.0 ** (it % 3 - 1))
+            a.grad = g.clone() if a.numel() != 1024 else g.repeat_interleave(2)[::2]       # (a strided view: made contiguous by the optimizer)
+            b.grad = g.clone()
+        oa.step()
+        ob.step()
+    for a, b in zip(pa, pb):
+        close(a, b, tol=1e-6, what='adam n=%d' % a.numel())
+    # capture: static gradients, replays advance the device step count
+    for a, b in zip(pa, pb):
+        a.grad = torch.randn_like(a)
+        b.grad = a.grad.clone()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        oa.step()
+    torch.cuda.current_stream().wait_stream(side)
+    ob.step()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):                                  # (recorded, not run)
+        oa.step()
+    for _ in range(3):
+        g.replay()
+        ob.step()
+    torch.cuda.synchronize()
+    for a, b in zip(pa, pb):
+        close(a, b, tol=2e-6, what='adam replay n=%d' % a.numel())

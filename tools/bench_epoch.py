@@ -25,6 +25,7 @@ def main():
     args = ap.parse_args()
     from gnn_matlang_amd import SpectralDesign, models, synthetic, functional as Fn
     from gnn_matlang_amd.dataset import DeviceDataset
+    from gnn_matlang_amd.optim import OneLaunchAdam
     dev = torch.device('cuda:0')
     raw = synthetic.make_graphs('zinc', args.graphs, seed=4242)
     dsd = DeviceDataset.from_graphs(SpectralDesign(recfield=2, dv=2, nfreq=7).design_many(raw), dev)
@@ -36,7 +37,7 @@ def main():
     assemble = dsd.batch_padded if args.torch_assembly else dsd.batch_assembled
     torch.manual_seed(0)
     cm = models.zinc_gnnml3().to(dev)
-    co = torch.optim.Adam(cm.parameters(), lr=1e-3, capturable=True, fused=True)
+    co = OneLaunchAdam(cm.parameters(), lr=1e-3)
     loss_acc = torch.zeros((), device=dev)
     one_ = torch.ones((), device=dev)
 
