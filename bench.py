@@ -770,11 +770,10 @@ def main():
                     def padded_step():
                         b = assemble(ids_buf, bd)
                         co.zero_grad(set_to_none=True)
-                        l = models.zinc_step_loss(cm, b)                               # L1-sum over the real graphs (Zinc12k.py:365); head + loss: one launch each way
+                        l = models.zinc_step_loss(cm, b, loss_sum=loss_acc)                               # L1-sum over the real graphs (Zinc12k.py:365); head + loss: one launch each way
                         with Fn.deferred_folds():                                      # the twelve partial-sum folds of the backward as ONE launch
                             l.backward(one_)                                           # (a resident unit gradient: no fill launch per step)
                         co.step()
-                        loss_acc.add_(l.detach())
                     ids_buf.copy_(torch.arange(Bq, device=dev))
                     side2 = torch.cuda.Stream()
                     side2.wait_stream(torch.cuda.current_stream())

@@ -18,6 +18,7 @@ struct GmlHeadParams {
     const float* w1; const float* b1; const float* w2; const float* b2;   // [nh, nin], [nh], [1, nh], [1]
     int32_t R, Rl, nin, nh;                                    // pooled rows, rows that enter the loss (<= R)
     float* loss;                                               // forward: scalar out
+    float* loss_sum;                                           // forward: optional running sum (loss_sum[0] += loss: an epoch's loss without a launch of its own)
     float* pre;                                                // forward: [R] logits out (may be NULL)
     const float* gscale;                                       // backward: upstream gradient of the loss (device scalar; NULL = 1)
     float* gp; int64_t ldgp;                                   // backward: d loss / d p [R, nin]
@@ -72,7 +73,10 @@ __global__ __launch_bounds__(256) void gml_k_head_l1_fwd(const GmlHeadParams q) 
         if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) q.loss[0] = red[0];
+    if (threadIdx.x == 0) {
+        q.loss[0] = red[0];
+        if (q.loss_sum) q.loss_sum[0] += red[0];
+    }
 }
 
 __global__ __launch_bounds__(256) void gml_k_head_l1_bwd(const GmlHeadParams q) {
@@ -141,12 +145,12 @@ static int head_check(const GmlHeadParams& q) {
 
 // loss[0] = sum_{r < rows_loss} valid[r] |fc2(relu(fc1(p[r]))) - y[r]|; pre (optional) receives the logits of all `rows` rows.
 // One workgroup: rows <= 256, nin, nh <= 64 (GML_E_UNSUPPORTED beyond: the caller uses its general path).
-extern "C" int gml_head_l1_fwd(const float* p, int64_t ldp, const float* y, const float* valid, const float* w1, const float* b1,
-                               const float* w2, const float* b2, int32_t rows, int32_t rows_loss, int32_t nin, int32_t nh,
-                               float* loss, float* pre, gml_stream_t stream) {
+static int head_l1_fwd_impl(const float* p, int64_t ldp, const float* y, const float* valid, const float* w1, const float* b1,
+                            const float* w2, const float* b2, int32_t rows, int32_t rows_loss, int32_t nin, int32_t nh,
+                            float* loss, float* loss_sum, float* pre, gml_stream_t stream) {
     GmlHeadParams q = {};
     q.p = p; q.ldp = ldp; q.y = y; q.valid = valid; q.w1 = w1; q.b1 = b1; q.w2 = w2; q.b2 = b2;
-    q.R = rows; q.Rl = rows_loss; q.nin = nin; q.nh = nh; q.loss = loss; q.pre = pre;
+    q.R = rows; q.Rl = rows_loss; q.nin = nin; q.nh = nh; q.loss = loss; q.loss_sum = loss_sum; q.pre = pre;
     const int rc = head_check(q);
     if (rc != GML_OK) return rc;
     if (!loss) return GML_E_BADARG;
@@ -156,6 +160,19 @@ extern "C" int gml_head_l1_fwd(const float* p, int64_t ldp, const float* y, cons
     if (rca != hipSuccess) return (int)rca;
     hipLaunchKernelGGL(gml_k_head_l1_fwd, dim3(1), dim3(256), lds, (hipStream_t)stream, q);
     return gml_launch_status();
+}
+
+extern "C" int gml_head_l1_fwd(const float* p, int64_t ldp, const float* y, const float* valid, const float* w1, const float* b1,
+                               const float* w2, const float* b2, int32_t rows, int32_t rows_loss, int32_t nin, int32_t nh,
+                               float* loss, float* pre, gml_stream_t stream) {
+    return head_l1_fwd_impl(p, ldp, y, valid, w1, b1, w2, b2, rows, rows_loss, nin, nh, loss, nullptr, pre, stream);
+}
+
+// the same + loss_sum[0] += loss (a running epoch loss -- Zinc12k.py:366 accumulates loss.item() on the host -- without a launch of its own)
+extern "C" int gml_head_l1_fwd_acc(const float* p, int64_t ldp, const float* y, const float* valid, const float* w1, const float* b1,
+                                   const float* w2, const float* b2, int32_t rows, int32_t rows_loss, int32_t nin, int32_t nh,
+                                   float* loss, float* loss_sum, float* pre, gml_stream_t stream) {
+    return head_l1_fwd_impl(p, ldp, y, valid, w1, b1, w2, b2, rows, rows_loss, nin, nh, loss, loss_sum, pre, stream);
 }
 
 // every gradient of the loss above times gscale[0] (NULL: 1): gp [rows, nin] (rows >= rows_loss receive zeros), dw1 [nh, nin], db1 [nh]

@@ -519,32 +519,38 @@ extern "C" int gml_fold_many(const gml_fold_job* jobs, int32_t njobs, gml_stream
 // other workgroup has read it.  torch's fused Adam is two multi-tensor launches for ZINC's 44 tensors plus one for the step counts: at
 // the reference's batch size (a step = ~30 launches of microseconds each) that is 17 of a step's 270 us.
 // =============================================================================================
-struct GmlAdamJobs { gml_adam_job j[GML_ADAM_MAX_JOBS]; };
+struct GmlAdamJobs { gml_adam_job j[GML_ADAM_MAX_JOBS]; int32_t first_block[GML_ADAM_MAX_JOBS + 1]; };
 
-__global__ __launch_bounds__(256) void gml_k_adam_many(const GmlAdamJobs jobs, float* step, unsigned* done, float lr, float b1, float b2,
-                                                       float eps, unsigned total_blocks) {
-    const gml_adam_job& q = jobs.j[blockIdx.y];
+__device__ __forceinline__ void gml_adam_elem(const gml_adam_job& q, int64_t i, float b1, float b2, float ss, float rc2, float eps) {
+    const float g = q.g[i];
+    const float m = fmaf(b1, q.m[i], (1.f - b1) * g);
+    const float v = fmaf(b2, q.v[i], (1.f - b2) * g * g);
+    q.m[i] = m; q.v[i] = v;
+    q.p[i] -= ss * m / fmaf(sqrtf(v), rc2, eps);
+}
+
+// 4096 elements per workgroup, workgroups laid out job after job (first_block: ZINC's 33 k parameters in 44 tensors are 52 workgroups
+// -- one per 1024 elements on a [chunks of the largest tensor] x [tensors] grid was 352, and their 352 same-address atomics cost more
+// than the update; ONE workgroup walking everything is a chain of 33 dependent memory round trips per thread: 40 us).  The LAST
+// workgroup to finish writes the step count back (every other one has read it by then).
+__global__ __launch_bounds__(256) void gml_k_adam_many(const GmlAdamJobs jobs, int njobs, float* step, unsigned* done, float lr, float b1,
+                                                       float b2, float eps) {
+    int j = 0;
+    while (j + 1 < njobs && (int)blockIdx.x >= jobs.first_block[j + 1]) ++j;
+    const gml_adam_job& q = jobs.j[j];
     const float t = step[0] + 1.f;
-    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i0 < q.n) {
-        const float c1 = 1.f - __powf(b1, t), c2 = 1.f - __powf(b2, t);
-        const float ss = lr / c1, rc2 = 1.f / sqrtf(c2);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t i = i0 + u;
-            if (i < q.n) {
-                const float g = q.g[i];
-                const float m = fmaf(b1, q.m[i], (1.f - b1) * g);
-                const float v = fmaf(b2, q.v[i], (1.f - b2) * g * g);
-                q.m[i] = m; q.v[i] = v;
-                q.p[i] -= ss * m / fmaf(sqrtf(v), rc2, eps);
-            }
-        }
+    const float c1 = 1.f - __powf(b1, t), c2 = 1.f - __powf(b2, t);
+    const float ss = lr / c1, rc2 = 1.f / sqrtf(c2);
+    const int64_t base = (int64_t)((int)blockIdx.x - jobs.first_block[j]) * 4096;
+#pragma unroll 4
+    for (int u = 0; u < 16; ++u) {
+        const int64_t i = base + u * 256 + threadIdx.x;
+        if (i < q.n) gml_adam_elem(q, i, b1, b2, ss, rc2, eps);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
-        if (atomicAdd(done, 1u) == total_blocks - 1) { step[0] = t; *done = 0u; __threadfence(); }
+        if (atomicAdd(done, 1u) == gridDim.x - 1) { step[0] = t; *done = 0u; __threadfence(); }
     }
 }
 
@@ -553,16 +559,18 @@ extern "C" int gml_adam_many(const gml_adam_job* jobs, int32_t njobs, float* ste
     if (njobs < 0 || njobs > GML_ADAM_MAX_JOBS || (njobs > 0 && !jobs) || !step || !done) return GML_E_BADARG;
     if (njobs == 0) return GML_OK;
     GmlAdamJobs a = {};
-    int64_t nmax = 0;
+    int64_t total = 0, blocks = 0;
     for (int i = 0; i < njobs; ++i) {
         const gml_adam_job& q = jobs[i];
         if (q.n < 0 || (q.n > 0 && (!q.p || !q.g || !q.m || !q.v))) return GML_E_BADARG;
         a.j[i] = q;
-        nmax = q.n > nmax ? q.n : nmax;
+        a.first_block[i] = (int32_t)blocks;
+        blocks += gml_cdiv(q.n, 4096);
+        total += q.n;
+        if (blocks > 0x7fffffff) return GML_E_UNSUPPORTED;
     }
-    if (nmax == 0) return GML_OK;
-    const unsigned gx = (unsigned)gml_cdiv(nmax, 1024);
-    hipLaunchKernelGGL(gml_k_adam_many, dim3(gx, (unsigned)njobs), dim3(256), 0, (hipStream_t)stream, a, step, done, lr, beta1, beta2, eps,
-                       gx * (unsigned)njobs);
+    a.first_block[njobs] = (int32_t)blocks;
+    if (total == 0) return GML_OK;
+    hipLaunchKernelGGL(gml_k_adam_many, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, njobs, step, done, lr, beta1, beta2, eps);
     return gml_launch_status();
 }

@@ -734,13 +734,14 @@ class HeadL1Function(torch.autograd.Function):
     e.g. the padding graph of a static batch, are ignored and get zero gradient)."""
 
     @staticmethod
-    def forward(ctx, p, y, valid, w1, b1, w2, b2):
+    def forward(ctx, p, y, valid, w1, b1, w2, b2, loss_sum=None):
         p = _f32c(p, 'pooled')
         R, nin = p.shape
         loss = torch.empty((), dtype=torch.float32, device=p.device)
         with torch.cuda.device(p.device):
-            _lib.call('gml_head_l1_fwd', _ptr(p), int(p.stride(0)), _ptr(y), _ptr(valid), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2),
-                      int(R), int(y.numel()), int(nin), int(w1.size(0)), _ptr(loss), _ptr(None), _stream(p.device))
+            # loss_sum (optional, a float32 scalar on the device): += loss inside the same launch -- an epoch's running loss
+            _lib.call('gml_head_l1_fwd_acc', _ptr(p), int(p.stride(0)), _ptr(y), _ptr(valid), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2),
+                      int(R), int(y.numel()), int(nin), int(w1.size(0)), _ptr(loss), _ptr(loss_sum), _ptr(None), _stream(p.device))
         ctx.save_for_backward(p, y, valid, w1, b1, w2, b2)
         return loss
 
@@ -758,7 +759,7 @@ class HeadL1Function(torch.autograd.Function):
             _lib.call('gml_head_l1_bwd', _ptr(p), int(p.stride(0)), _ptr(y), _ptr(valid), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2),
                       int(R), int(y.numel()), int(nin), nh, _ptr(g), _ptr(gp), nin, _ptr(dw1), _ptr(db1), _ptr(dw2), _ptr(db2),
                       _stream(p.device))
-        return gp, None, None, dw1, db1, dw2, db2
+        return gp, None, None, dw1, db1, dw2, db2, None
 
 
 def head_l1_supported(p, w1, w2):
@@ -1182,7 +1183,7 @@ class ML3LayerFunction(torch.autograd.Function):
         ctx.chain_out = chain_out if (CHAIN and ctx.pool is None) else None
         ctx.save_for_backward(x, val, (ea if learnedge and epos is None else None), w1, w2, w3, w4, cw, w11, b11, w12, b12, out, ea_t)
         if ctx.pool is not None:
-            pooled = segment_sum(out, pool_ptr, pool_mean)
+            pooled = segment_sum(out, pool_ptr, int(pool_mean) & 3)
             if int(pool_mean) & 2:
                 skip_last_mask(pooled)                         # (created outside any later graph capture of the backward)
             return pooled
@@ -1207,7 +1208,10 @@ class ML3LayerFunction(torch.autograd.Function):
         gy_seg = None
         if ctx.pool is not None:                               # gy is the POOLED gradient [B, C]
             pptr, pseg, pmean = ctx.pool
-            if pmean & 2:                                      # GML_POOL_SKIP_LAST: the padding graph's pooled row was written, not computed
+            # GML_POOL_SKIP_LAST: the padding graph's pooled row was written, not computed -- its gradient must not reach the nodes.
+            # Bit 2 (4): the caller vouches that the loss gives that row a ZERO gradient already (models.zinc_step_loss: the fused
+            # head + loss ignore rows beyond the labelled ones) -- the masking launch is skipped
+            if (pmean & 2) and not (pmean & 4):
                 gy = gy * skip_last_mask(gy)
             pmean &= 1
             mixk_ = nout2 > 0 and node_mix_native(Fin, nout2)

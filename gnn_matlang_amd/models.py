@@ -131,7 +131,7 @@ class GNNML3(torch.nn.Module):
         else:
             self.fc1 = torch.nn.Linear(nin, 10)
 
-    def forward(self, data, _features=False, _capture=None):
+    def forward(self, data, _features=False, _capture=None, _pad_grad_zero=False):
         x = data.x
         if getattr(data, 'pad_graph', False) and self.training and (self.bn or self.readout_bn):
             # the padding nodes / the padding graph's pooled row would enter the batch statistics
@@ -154,7 +154,7 @@ class GNNML3(torch.nn.Module):
                 if getattr(data, '_batch_i32', None) is None:
                     data._batch_i32 = data.batch.to(torch.int32).contiguous()
                 x = layer.forward_pooled(x, csr, data.edge_attr2, _ptr32(data.ptr), data._batch_i32,
-                                         int(self.pool == 'mean') | (2 if getattr(data, 'pad_graph', False) else 0))   # 2: GML_POOL_SKIP_LAST
+                                         int(self.pool == 'mean') | (2 if getattr(data, 'pad_graph', False) else 0) | (4 if _pad_grad_zero else 0))   # 2: GML_POOL_SKIP_LAST; 4: its gradient is zero already
                 pooled = True
             elif self.bn and i == 0:
                 # BatchNorm layers behind the first layer amplify the ~1e-5 relative error of the split bf16 products in ITS weight /
@@ -180,9 +180,10 @@ class GNNML3(torch.nn.Module):
             return tall_linear(F.relu(z1), self.fc2)
         return torch.tanh(tall_linear(x, self.fc1))
 
-    def features(self, data):
-        """the pooled (and, with readout_bn, normalised) graph features the head is applied to: [num_graphs, nin]"""
-        return self.forward(data, _features=True)
+    def features(self, data, pad_grad_zero=False):
+        """the pooled (and, with readout_bn, normalised) graph features the head is applied to: [num_graphs, nin].
+        pad_grad_zero: the caller's loss gives the padding graph's row (static batches) a zero gradient -- no masking launch."""
+        return self.forward(data, _features=True, _pad_grad_zero=pad_grad_zero)
 
 
 def _gnnml1_block(x, csr, fc1, conv, fc2, fc3, mode, act):
@@ -306,25 +307,33 @@ def zinc_loss(pre, y):                     # Zinc12k.py:365
     return F.l1_loss(pre, y.unsqueeze(-1), reduction='sum')
 
 
-def zinc_step_loss(model, data, valid=None):
+def zinc_step_loss(model, data, valid=None, loss_sum=None):
     """zinc_loss(model(data), data.y) -- with the head and the loss as ONE launch each way where the batch is small enough for it
     (functional.HeadL1Function: the reference's batch 64; a static batch's padding graph and absent slots are masked through
     `valid` / data.graph_valid).  Same value and gradients up to summation order; large batches take the general path."""
     from . import functional as Fn
     valid = valid if valid is not None else getattr(data, 'graph_valid', None)
     if model.head == 'mlp32' and model.fc2.weight.size(0) == 1 and data.x.is_cuda:
-        x = model.features(data)
         nl = int(data.y.numel()) if valid is None else int(valid.numel())
+        ng = int(data.num_graphs) if hasattr(data, 'num_graphs') else nl
+        small = ng <= 256                                   # (the one-workgroup head: its rows beyond nl get a zero gradient)
+        x = model.features(data, pad_grad_zero=small and nl <= ng)
         if Fn.head_l1_supported(x, model.fc1.weight, model.fc2.weight) and nl <= x.size(0):
             y = data.y[:nl].float().contiguous()
-            return Fn.HeadL1Function.apply(x, y, valid, model.fc1.weight, model.fc1.bias, model.fc2.weight, model.fc2.bias)
+            return Fn.HeadL1Function.apply(x, y, valid, model.fc1.weight, model.fc1.bias, model.fc2.weight, model.fc2.bias, loss_sum)
+        if small and nl <= ng:                              # (not the fused head after all: the promise above does not hold -- redo)
+            x = model.features(data)
         pre = tall_linear(F.relu(tall_linear(x, model.fc1)), model.fc2)
     else:
         pre = model(data)
     if valid is not None:
         nl = int(valid.numel())
-        return ((pre[:nl, 0] - data.y[:nl]).abs() * valid).sum()
-    return zinc_loss(pre, data.y)
+        l = ((pre[:nl, 0] - data.y[:nl]).abs() * valid).sum()
+    else:
+        l = zinc_loss(pre, data.y)
+    if loss_sum is not None:
+        loss_sum.add_(l.detach())
+    return l
 
 
 def counting_loss(pre, y):                 # counting.py:411

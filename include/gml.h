@@ -493,6 +493,10 @@ int gml_xty(const float* A, int64_t lda, const float* B, int64_t ldb, float* out
 int gml_head_l1_fwd(const float* p, int64_t ldp, const float* y, const float* valid, const float* w1, const float* b1,
                     const float* w2, const float* b2, int32_t rows, int32_t rows_loss, int32_t nin, int32_t nh,
                     float* loss, float* pre, gml_stream_t stream);
+/* gml_head_l1_fwd + loss_sum[0] += loss (NULL: none): the epoch's running loss (Zinc12k.py:366) without a launch of its own */
+int gml_head_l1_fwd_acc(const float* p, int64_t ldp, const float* y, const float* valid, const float* w1, const float* b1,
+                        const float* w2, const float* b2, int32_t rows, int32_t rows_loss, int32_t nin, int32_t nh,
+                        float* loss, float* loss_sum, float* pre, gml_stream_t stream);
 int gml_head_l1_bwd(const float* p, int64_t ldp, const float* y, const float* valid, const float* w1, const float* b1,
                     const float* w2, const float* b2, int32_t rows, int32_t rows_loss, int32_t nin, int32_t nh,
                     const float* gscale, float* gp, int64_t ldgp, float* dw1, float* db1, float* dw2, float* db2,

@@ -1877,7 +1877,7 @@ def test_one_launch_adam_follows_torch_adam(dev):
     job table), sizes 1 .. 5000, a non-contiguous gradient; then captured in a HIP graph and replayed -- the count keeps advancing."""
     from gnn_matlang_amd.optim import OneLaunchAdam
     torch.manual_seed(0)
-    sizes = [1, 3, 4, 5, 1023, 1024, 1025, 5000] + [int(v) for v in torch.randint(1, 2000, (62,))]
+    sizes = [1, 3, 4, 5, 1023, 1024, 1025, 5000, 4096, 4097, 150000] + [int(v) for v in torch.randint(1, 2000, (59,))]     # chunk 1: one workgroup; chunk 0: the multi-workgroup form
     pa = [torch.randn(n, device=dev).requires_grad_(True) for n in sizes]
     pb = [p.detach().clone().requires_grad_(True) for p in pa]
     oa, ob = OneLaunchAdam(pa, lr=1e-2), torch.optim.Adam(pb, lr=1e-2)

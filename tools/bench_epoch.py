@@ -48,14 +48,15 @@ def main():
             pre = cm(b)
             l = ((pre[:Bq, 0] - b.y[:Bq]).abs() * b.graph_valid).sum()
         else:
-            l = models.zinc_step_loss(cm, b)
+            l = models.zinc_step_loss(cm, b, loss_sum=loss_acc)       # (the epoch's running loss: accumulated inside the head's launch)
         if args.plain_head:
             l.backward()
         else:
             with Fn.deferred_folds():
                 l.backward(one_)
         co.step()
-        loss_acc.add_(l.detach())
+        if args.plain_head:
+            loss_acc.add_(l.detach())
     ids_buf.copy_(torch.arange(Bq, device=dev))
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
