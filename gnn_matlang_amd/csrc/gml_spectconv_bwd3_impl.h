@@ -88,7 +88,7 @@ struct GmlBwd3Cfg {
     // VALG (GML_B3V & 256, the ZINC shape class): the value rows are read from global memory inside the edge loop, so the LDS holds
     // column ids + G window and -- in regions of their own, aliasing nothing -- the X image and one P slab
     // (round 5: also sr25's one-launch 48-feature class, S = 6 / NFB = 3 -- its staged value rows, 24 registers, were spilling)
-    static constexpr bool VALG = (GML_B3V & 256) && NOB == 2 && NW == 8 && (S == 8 || (S == 6 && NFB == 3 && !(GML_B3V & 16384)));
+    static constexpr bool VALG = (GML_B3V & 256) && NOB == 2 && NW == 8 && (S == 8 || ((S == 6 || S == 4) && NFB == 3 && !(GML_B3V & 16384)));
     __host__ __device__ static size_t lds_bytes(int ecap, int xcap) {
         if (VALG) return (size_t)W_BYTES + (ROWS + 8) * 4 + (size_t)ecap * 4 + (size_t)xcap * LDG * 4 + XT_BYTES + PT_BYTES;
         return (size_t)W_BYTES + (ROWS + 8) * 4 + (size_t)ecap * 4 + r_bytes(ecap, xcap) + XT_BYTES;
@@ -494,7 +494,14 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
                 }
                 d[s] = a2.x + a2.y;
             }
-            if constexpr (DIRECT) {                          // fold slot j of chunk c = support 2 j + c: lane kq ends with supports 2 kq, 2 kq + 1
+            if constexpr (DIRECT && S == 4) {                // four supports: lane kq ends with support kq (one dword store)
+                const auto a01 = __builtin_amdgcn_permlane16_swap(__float_as_uint(d[0]), __float_as_uint(d[1]), false, false);
+                const auto a23 = __builtin_amdgcn_permlane16_swap(__float_as_uint(d[2]), __float_as_uint(d[3]), false, false);
+                const float c01 = __uint_as_float(a01[0]) + __uint_as_float(a01[1]);
+                const float c23 = __uint_as_float(a23[0]) + __uint_as_float(a23[1]);
+                const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(c01), __float_as_uint(c23), false, false);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__uint_as_float(b[0]) + __uint_as_float(b[1])), dvrs, (k * S + kq) * 4, 0, 0);
+            } else if constexpr (DIRECT) {                   // fold slot j of chunk c = support 2 j + c: lane kq ends with supports 2 kq, 2 kq + 1
                 float tot2[2];
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
@@ -538,7 +545,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
                 if constexpr (S == 8) {
                     const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(vrs, k * (S * 4) + 16, 0, 0);
                     ev[4] = __uint_as_float(b.x); ev[5] = __uint_as_float(b.y); ev[6] = __uint_as_float(b.z); ev[7] = __uint_as_float(b.w);
-                } else {                                     // 24-byte rows
+                } else if constexpr (S == 6) {               // 24-byte rows
                     typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
                     const u32x2v b = __builtin_amdgcn_raw_buffer_load_b64(vrs, k * (S * 4) + 16, 0, 0);
                     ev[4] = __uint_as_float(b.x); ev[5] = __uint_as_float(b.y);
@@ -575,7 +582,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
                 if constexpr (S == 8) {
                     const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(vrs, k * (S * 4) + 16, 0, 0);
                     ev[4] = __uint_as_float(b.x); ev[5] = __uint_as_float(b.y); ev[6] = __uint_as_float(b.z); ev[7] = __uint_as_float(b.w);
-                } else {                                     // 24-byte rows
+                } else if constexpr (S == 6) {               // 24-byte rows
                     typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
                     const u32x2v b = __builtin_amdgcn_raw_buffer_load_b64(vrs, k * (S * 4) + 16, 0, 0);
                     ev[4] = __uint_as_float(b.x); ev[5] = __uint_as_float(b.y);

@@ -111,6 +111,28 @@ def model_termsums(m, b, P, R):
     return T
 
 
+def oracle_fp32_as_device(pool_batch, state_dict, y_full, pre_dev, head_pre_dev=None, threads=16):
+    """The reference arithmetic itself as the thing under test: the oracle in float32 on the CPU over the pool, its copies weighted by
+    the same signs as the device's run (pre_dev) and -- like the device's run in reference() -- its own head mask.  Returns
+    (pre [R * P] float32 logits tiled, {name: gradient}): what compare() takes.  Shows what the criterion says about plain fp32
+    (a relu unit of a layer within round-off of zero flips in fp32 as it does on the device)."""
+    torch.set_num_threads(min(int(threads), torch.get_num_threads()))
+    b = pool_batch
+    P = int(b.num_graphs)
+    R = int(y_full.numel()) // P
+    m = MO.zinc_gnnml3(int(b.x.size(1)), int(b.edge_attr2.size(1))).float()
+    m.load_state_dict({k: v.detach().cpu().float() for k, v in state_dict.items()})
+    head = {}
+    hook = m.fc1.register_forward_hook(lambda mod, inp, out: head.__setitem__('z1', out.detach()))
+    pre = m(b.x.float(), b.edge_index2, b.edge_attr2.float(), b.batch, P)[:, 0]
+    hook.remove()
+    y = y_full.detach().cpu().float().view(R, P)
+    c = torch.sign(pre_dev.detach().cpu().float().view(R, P) - y).sum(0)
+    params = dict(m.named_parameters())
+    g = torch.autograd.grad((c * pre).sum(), list(params.values()))
+    return pre.detach().repeat(R).numpy(), {n: v.numpy() for n, v in zip(params, g)}, head['z1'].repeat(R, 1)
+
+
 def compare(ref, pre_dev, grads_dev, tol=1e-4):
     """pre_dev [R * P] logits and {name: gradient} of the device step.  Returns a report: the worst |err| / (tol-free) scale per
     tensor under both criteria -- `termsum`: max |err| / T (must stay <= tol), `maxnorm`: max |err| / max |ref| -- and the logits'

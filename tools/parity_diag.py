@@ -73,10 +73,22 @@ def main():
                     float(((ga * mism).sum(0) / (ga * (acts[i][:, :c1] > 0)).sum(0).clamp(min=1e-300)).max()), small))
                 print('   act %d: max err %.2e of max |x| %.2e  (rel %.2e), rms err / rms x %.2e' % (
                     i, e.max(), acts[i].abs().max(), e.max() / acts[i].abs().max(), e.pow(2).mean().sqrt() / acts[i].pow(2).mean().sqrt()))
+        if mode == 'f32':
+            fp32_oracle_line(host, m, full, pre[:, 0], T)
         for n, v in sorted(rep['tensors'].items(), key=lambda kv: -kv[1]['termsum']):
             g = ref['grads'][n]
             print('   %-22s termsum %.2e  maxnorm %.2e   median T/|g| %.0f' % (n, v['termsum'], v['maxnorm'],
                   np.median(ref['T'][n] / np.maximum(np.abs(g), 1e-300))))
+
+
+def fp32_oracle_line(host, m, full, pre_dev, T):
+    """the reference arithmetic (oracle, float32, CPU) under the same criterion"""
+    pre32, g32, z32 = PS.oracle_fp32_as_device(host, m.state_dict(), full.y, pre_dev)
+    ref = PS.reference(host, m.state_dict(), full.y, pre_dev=pre_dev, T=T, head_pre_dev=z32)
+    rep = PS.compare(ref, pre32, g32)
+    worst = max(rep['tensors'].items(), key=lambda kv: kv[1]['termsum'])
+    print('== oracle fp32 (CPU)  logits %.2e  worst termsum %.2e (%s)  maxnorm %.2e  head units flipped %d' % (
+        rep['logits_rel_err'], rep['worst_termsum'], worst[0], rep['worst_maxnorm'], ref['head_units_flipped']))
 
 
 if __name__ == '__main__':
