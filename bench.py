@@ -178,6 +178,19 @@ def parity_vs_oracle(model, data, base, log):
                                   head_units_flipped=ref['head_units_flipped'], oracle_seconds=round(ref['seconds'], 2))
         log('parity at bench size, %s: logits %.2e, gradients %.2e of their term sums (worst: %s), %s' % (
             mode, rep['logits_rel_err'], rep['worst_termsum'], worst[0], 'ok' if rep['ok'] else 'BEYOND 1e-4'))
+    # the reference arithmetic itself under the same criterion: the oracle in float32 on the CPU (what "fp32-class" means here)
+    try:
+        pre32, g32, z32 = PS.oracle_fp32_as_device(host, model.state_dict(), data.y, pre[:, 0])
+        ref = PS.reference(host, model.state_dict(), data.y, pre_dev=pre[:, 0], T=T, head_pre_dev=z32)
+        rep = PS.compare(ref, pre32, g32)
+        worst = max(rep['tensors'].items(), key=lambda kv: kv[1]['termsum'])
+        out['modes']['reference_fp32_cpu'] = dict(logits_rel_err=rep['logits_rel_err'], max_rel_err_termsum=rep['worst_termsum'],
+                                                  max_rel_err_maxnorm=rep['worst_maxnorm'], worst_tensor=worst[0], ok=rep['ok'],
+                                                  note='the oracle (op-for-op port of the reference) in float32 on the host, same pool, same signs')
+        log('parity at bench size, the reference arithmetic (oracle fp32 on the CPU): logits %.2e, gradients %.2e of their term sums' % (
+            rep['logits_rel_err'], rep['worst_termsum']))
+    except Exception as e:                                   # (never let the context line break the bench)
+        out['modes']['reference_fp32_cpu'] = dict(error=repr(e))
     for p_ in model.parameters():
         p_.grad = None
     return out
@@ -583,7 +596,7 @@ def main():
             candx, kmsx = rooflines(profx)
             Fn.F32_MFMA = False
             res['value_exact_fp32'] = dict(value=data.num_graphs * args.steps / dtx, unit='graphs/s', ms_per_step=dtx / args.steps * 1e3,
-                                           arithmetic='f32-input MFMA (GML_F32_MFMA=1): every product exact fp32',
+                                           arithmetic='exact fp32 (GML_F32_MFMA=1): f32-input MFMA conv kernels, the edge branch on the one-edge-per-lane fp32 family with the library tanh (round 5: before, it stayed on the bf16-split chains)',
                                            kernels_ms_per_step=kmsx)
             res['roofline_exact_fp32'] = candx[0]
             res['roofline_exact_fp32_other'] = candx[1:]
@@ -829,7 +842,10 @@ def main():
                 # per mode: worst element of any parameter gradient relative to its layer-local term sum (inputs of the layer taken as
                 # exact: the strict form), at the parameters this run ended with; logits relative to max |logit|
                 res['max_rel_err_vs_oracle'] = {k: dict(gradients_termsum=v['max_rel_err_termsum'], logits=v['logits_rel_err'])
-                                                for k, v in res['parity_vs_oracle']['modes'].items()}
+                                                for k, v in res['parity_vs_oracle']['modes'].items() if 'max_rel_err_termsum' in v}
+                if parity0 is not None:
+                    res['max_rel_err_vs_oracle_at_init'] = {k: dict(gradients_termsum=v['max_rel_err_termsum'], logits=v['logits_rel_err'])
+                                                            for k, v in parity0['modes'].items() if 'max_rel_err_termsum' in v}
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

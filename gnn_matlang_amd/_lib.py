@@ -58,6 +58,8 @@ SIGNATURES = {
     'gml_sddmm': (ctypes.c_int, [_p, _p, _p, _p, _i64, _p, _p, _i64, _i32, _i32, _p]),
     'gml_edge_presplit': (ctypes.c_int, [_p, _p, _i64, _i32, _p]),
     'gml_edge_mlp_fwd': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
+    'gml_edge_mlp_fwd_exact': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
+    'gml_edge_mlp_bwd_exact': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p, _sz, _p]),
     'gml_head_l1_fwd': (ctypes.c_int, [_p, _i64, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p]),
     'gml_head_l1_fwd_acc': (ctypes.c_int, [_p, _i64, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p]),
     'gml_head_l1_bwd': (ctypes.c_int, [_p, _i64, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _i64, _p, _p, _p, _p, _p]),

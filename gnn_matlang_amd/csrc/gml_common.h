@@ -124,24 +124,51 @@ __device__ __forceinline__ void gml_load_row(const float* __restrict__ p, float 
     }
 }
 
-// tanh for the edge / Hadamard branches: tanh(x) = 1 - 2 / (2^(2 log2(e) x) + 1), five instructions
-// (v_exp_f32, v_rcp_f32), branch-free, saturates correctly at +-inf.  Absolute error <= ~2e-7 (a few
-// ulp of 1.0); near 0 that is absolute, not relative, accuracy -- fp32-roundoff class for the sums and
-// products the layer forms from it (parity tolerance: 1e-4 of the tensor's max).
+// tanh for the Hadamard branch and the exact-mode edge kernels.  |x| >= 1/4: tanh(x) = 1 - 2 / (2^(2 log2(e) x) + 1) (v_exp_f32,
+// v_rcp_f32; branch-free, saturates correctly at +-inf): absolute error <= ~2e-7, i.e. <= 8e-7 relative there.  |x| < 1/4: the odd
+// series x + x^3 (c1 + c2 x^2 + c3 x^4 + c4 x^6) (truncation 2e-9): RELATIVE accuracy ~1e-7 down to zero.  Rounds 1-4 used the first
+// form everywhere -- tanh(1e-3) came back with 2e-4 relative error -- and that, not the split products, was the floor of the forward
+// error (4e-6 rms of the activations in BOTH arithmetic modes; the reference's fp32 on the CPU: 1e-7; tools/parity_diag.py).  The
+// matrix-core edge chains (gml_edge_chain*_impl.h), whose issue slots are the step's second largest cost, keep the short form.
+__device__ __forceinline__ float gml_tanh_short(float x) {   // the short form alone: ~2e-7 ABSOLUTE (the 8-wave forward's Hadamard columns,
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);   // whose argument is a bf16x3 product anyway)
+    return fmaf(-2.f, __builtin_amdgcn_rcpf(e + 1.f), 1.f);
+}
+#ifndef GML_TANH_SHORT
+__device__ __forceinline__ float gml_tanh_small(float x) {
+    const float x2 = x * x;
+    const float p = fmaf(x2, fmaf(x2, fmaf(x2, 0.021869488536155203f, -0.053968253968253971f), 0.13333333333333333f), -0.33333333333333331f);
+    return fmaf(x * x2, p, x);
+}
 __device__ __forceinline__ float gml_tanh(float x) {
     const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
-    return fmaf(-2.f, __builtin_amdgcn_rcpf(e + 1.f), 1.f);
+    const float tb = fmaf(-2.f, __builtin_amdgcn_rcpf(e + 1.f), 1.f);
+    return fabsf(x) < 0.25f ? gml_tanh_small(x) : tb;
 }
 
 // tanh(x) and its derivative 1 - tanh(x)^2 without the cancellation of 1 - t * t near saturation (t = 1 - 1.7e-6 already loses
 // 4 % there in fp32): with e = exp(2x), r = 1 / (e + 1):  t = 1 - 2 r,  1 - t^2 = 4 e r^2.  |x| is clamped to 40 (tanh = +-1 to the
-// last bit far earlier; keeps e finite).
+// last bit far earlier; keeps e finite).  |x| < 1/4: the series value and 1 - t^2 (no cancellation there).
+__device__ __forceinline__ void gml_tanh_d(float x, float& t, float& d) {
+    const float e = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(x, -40.f, 40.f) * 2.8853900817779268f);
+    const float r = __builtin_amdgcn_rcpf(e + 1.f);
+    const float ts = gml_tanh_small(x);
+    const bool small = fabsf(x) < 0.25f;
+    t = small ? ts : fmaf(-2.f, r, 1.f);
+    d = small ? fmaf(-ts, ts, 1.f) : 4.f * (e * r) * r;
+}
+#else
+__device__ __forceinline__ float gml_tanh(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+    return fmaf(-2.f, __builtin_amdgcn_rcpf(e + 1.f), 1.f);
+}
 __device__ __forceinline__ void gml_tanh_d(float x, float& t, float& d) {
     const float e = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(x, -40.f, 40.f) * 2.8853900817779268f);
     const float r = __builtin_amdgcn_rcpf(e + 1.f);
     t = fmaf(-2.f, r, 1.f);
     d = 4.f * (e * r) * r;
 }
+#endif
 
 // fp32 -> (hi, lo) bf16 pair with hi + lo = x to ~2^-17 relative (round-to-nearest both times).  Products of
 // two such splits, a_hi b_hi + a_hi b_lo + a_lo b_hi accumulated in fp32 by the bf16 matrix cores, carry a

@@ -222,6 +222,21 @@ extern "C" int gml_edge_mlp_fwd(const float* ea, const void* ea_split, const flo
     GML_EMLP_SWITCH(GML_CALL_F)
 }
 
+// the same on the exact-arithmetic family whatever the shape (one edge per lane, fp32 FMAs, f32-input MFMA for the weight gradients, the
+// library's tanh): what GML_F32_MFMA is to the conv kernels.  The matrix-core chains split their operands into bf16 pairs and use a
+// short tanh (~2e-7 absolute): 5e-7 rms on the learned supports where this family -- like torch's fp32 on the CPU -- carries ~1e-8.
+extern "C" int gml_edge_mlp_fwd_exact(const float* ea, const float* w1, const float* w2, const float* w3, const float* w4, float* out,
+                                      const int32_t* tpos, float* out_t, int64_t num_edges, int32_t S, int32_t Sout, gml_stream_t stream) {
+    if (num_edges < 0 || S <= 0 || Sout <= 0) return GML_E_BADARG;
+    if (num_edges == 0) return GML_OK;
+    if (!ea || !w1 || !w2 || !w3 || !w4 || !out) return GML_E_BADARG;
+    if (S != Sout) return GML_E_UNSUPPORTED;
+    if ((((uintptr_t)ea | (uintptr_t)out | (uintptr_t)out_t) & 15) != 0) return GML_E_BADARG;
+    if (out_t && !tpos) return GML_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    GML_EMLP_SWITCH(GML_CALL_F)
+}
+
 static int64_t emlp_bwd_waves(int64_t E, int S) {
     const int chb = 7 * S, cha = 5 * S;
     const int str = (chb > cha ? chb : cha) | 1;
@@ -285,5 +300,26 @@ extern "C" int gml_edge_mlp_bwd(const float* ea, const void* ea_split, const flo
     }
 #define GML_CALL_B(SV) \
     gml_launch_edge_mlp_bwd<SV, SV>(ea, w1, w2, w3, w4, gout, gin, dw1, dw2, dw3, dw4, num_edges, ws, ws_bytes, st)
+    GML_EMLP_SWITCH(GML_CALL_B)
+}
+
+// gml_edge_mlp_bwd on the exact-arithmetic family (see gml_edge_mlp_fwd_exact); dw1 .. dw4 are required (no deferred fold);
+// ws: gml_edge_mlp_bwd_workspace_bytes (it covers both families)
+extern "C" int gml_edge_mlp_bwd_exact(const float* ea, const float* w1, const float* w2, const float* w3, const float* w4,
+                                      const float* gout, float* gin, float* dw1, float* dw2, float* dw3, float* dw4,
+                                      int64_t num_edges, int32_t S, int32_t Sout, void* ws, size_t ws_bytes, gml_stream_t stream) {
+    if (num_edges < 0 || S <= 0 || Sout <= 0) return GML_E_BADARG;
+    if (!w1 || !w2 || !w3 || !w4 || !dw1 || !dw2 || !dw3 || !dw4) return GML_E_BADARG;
+    if (S != Sout) return GML_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (num_edges == 0) {
+        gml_zero_async(dw1, sizeof(float) * 2 * S * S, st);
+        gml_zero_async(dw2, sizeof(float) * 2 * S * S, st);
+        gml_zero_async(dw3, sizeof(float) * 2 * S * S, st);
+        gml_zero_async(dw4, sizeof(float) * 4 * S * Sout, st);
+        return gml_launch_status();
+    }
+    if (!ea || !gout || !ws) return GML_E_BADARG;
+    if ((((uintptr_t)ea | (uintptr_t)gout | (uintptr_t)gin) & 15) != 0) return GML_E_BADARG;
     GML_EMLP_SWITCH(GML_CALL_B)
 }

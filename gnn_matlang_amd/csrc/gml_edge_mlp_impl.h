@@ -42,7 +42,9 @@ struct GmlEdgeMlp {
                 b = fmaf(w2[o * S + i], e[i], b);
                 c = fmaf(w3[o * S + i], e[i], c);
             }
-            z1[o] = a; t2[o] = gml_tanh(b); t3[o] = gml_tanh(c);
+            // (this family IS the exact-arithmetic road -- GML_F32_MFMA / S = 1 / d supports at S > 8: the library's tanh, <= 2 ulp,
+            //  not gml_tanh's ~2e-7 absolute: with it the learned supports carried 5e-7 rms where torch's fp32 carries 5e-9)
+            z1[o] = a; t2[o] = tanhf(b); t3[o] = tanhf(c);
         }
     }
 };

@@ -534,7 +534,7 @@ __global__ __launch_bounds__(GmlFwd3Cfg<S>::NT, 1) void gml_k_spectconv_fwd3(con
                     const bool mine = r16 >= m0 && r16 < m0 + p.F2;
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
-                        const float t = gml_tanh(z[reg] + mbias);
+                        const float t = gml_tanh_short(z[reg] + mbias);
                         const float u = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t), 0x128, 0xf, 0xf, true));   // row_ror:8 = lane ^ 8
                         if (mine) ov[NOB - 1][reg] = t * u;
                     }
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(GmlFwd3Cfg<S>::NT, 1) void gml_k_spectconv_fwd3(con
                     z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, mwh, z, 0, 0, 0);
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
-                        const float t = gml_tanh(z[reg] + mbias);
+                        const float t = gml_tanh_short(z[reg] + mbias);
                         const float u = __shfl(t, lane + p.F2);    // partner column c + F2 of the same 16-lane row group
                         const int lr = (int)((out_rows >> (8 * reg)) & 255u);
                         const int off = (r16 < p.F2 && lr < nr) ? (lr * (int)p.ldo + p.mix_col + r16) * 4 : 0x7fffff00;

@@ -447,6 +447,10 @@ def edge_mlp_fwd(ea, w1, w2, w3, w4, tpos=None, ea_split=None):
         return out[:, :So].contiguous(), (out_t[:, :So].contiguous() if out_t is not None else None)
     out = torch.empty(E, So, dtype=torch.float32, device=ea.device)
     out_t = torch.empty(E, So, dtype=torch.float32, device=ea.device) if tpos is not None else None
+    if exact_mode():                                      # exact arithmetic covers the edge branch too (round 5: it did not)
+        _lib.call('gml_edge_mlp_fwd_exact', _ptr(ea), _ptr(w1), _ptr(w2), _ptr(w3), _ptr(w4), _ptr(out), _ptr(tpos), _ptr(out_t),
+                  int(E), int(S), int(So), _stream(ea.device))
+        return out, out_t
     _lib.call('gml_edge_mlp_fwd', _ptr(ea), _ptr(ea_split), _ptr(w1), _ptr(w2), _ptr(w3), _ptr(w4), _ptr(out), _ptr(tpos),
               _ptr(out_t), int(E), int(S), int(So), _stream(ea.device))
     return out, out_t
@@ -461,8 +465,8 @@ def edge_mlp_fwd_stack(ea, ea_split, weights):
     import ctypes
     E, S = ea.shape
     L = len(weights)
-    if ea_split is None or not (2 <= L <= 4) or any(w[3].size(0) != S or w[0].size(1) != S for w in weights):
-        return None
+    if exact_mode() or ea_split is None or not (2 <= L <= 4) or any(w[3].size(0) != S or w[0].size(1) != S for w in weights):
+        return None                                       # (the stacked kernel is a matrix-core chain: not the exact arithmetic)
     outs = [torch.empty(E, S, dtype=torch.float32, device=ea.device) for _ in range(L)]
     arr = lambda ts: (ctypes.c_void_p * L)(*[t.data_ptr() for t in ts])
     rc = _lib.lib().gml_edge_mlp_fwd_stack(_ptr(ea_split), L, arr([w[0] for w in weights]), arr([w[1] for w in weights]),
@@ -489,6 +493,10 @@ def edge_mlp_bwd(ea, w1, w2, w3, w4, gout, need_gin, ea_split=None):
     ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=dev)
     gin = torch.empty_like(ea) if need_gin else None
     dw1, dw2, dw3, dw4 = torch.empty_like(w1), torch.empty_like(w2), torch.empty_like(w3), torch.empty_like(w4)
+    if exact_mode():
+        _lib.call('gml_edge_mlp_bwd_exact', _ptr(ea), _ptr(w1), _ptr(w2), _ptr(w3), _ptr(w4), _ptr(gout), _ptr(gin),
+                  _ptr(dw1), _ptr(dw2), _ptr(dw3), _ptr(dw4), int(E), int(S), int(So), _ptr(ws), ws.numel(), _stream(dev))
+        return gin, dw1, dw2, dw3, dw4
     fq = _fold_queue()
     if fq is not None and E > 0:
         nparts = int(_lib.lib().gml_edge_mlp_bwd_parts(int(E), int(S), int(So), 1 if ea_split is not None else 0, 1 if need_gin else 0))
@@ -1132,7 +1140,7 @@ class ML3LayerFunction(torch.autograd.Function):
                 src_order = bool(val_is_source) or (fused_b and fwd_gathers(S, Fin, nout1))
                 # (forward kernels without the gather: both orders from the edge kernel, second copy scattered through tpos)
                 dual = fused_b and not src_order and val.numel() * 4 < 0xffffff00
-                _path('edge', 'matrix-core chain' if max(val.size(1), w4.size(0)) <= 8 else ('matrix-core chain16' if max(val.size(1), w4.size(0)) <= 16 and not EDGE_VALU else 'VALU kernels'), val.size(1), '-', w4.size(0))
+                _path('edge', 'exact family (one edge per lane, fp32)' if exact_mode() else 'matrix-core chain' if max(val.size(1), w4.size(0)) <= 8 else ('matrix-core chain16' if max(val.size(1), w4.size(0)) <= 16 and not EDGE_VALU else 'VALU kernels'), val.size(1), '-', w4.size(0))
                 if src_order:
                     val_s = val if val_is_source else csr.to_source_order(val, cache=not val.requires_grad)
                     ea_t = ea_pre if val_is_source else None

@@ -325,6 +325,14 @@ int gml_edge_mlp_bwd(const float* ea, const void* ea_split, const float* w1, con
                      const float* w4, const float* gout, float* gin, float* dw1, float* dw2, float* dw3, float* dw4,
                      int64_t num_edges, int32_t S, int32_t Sout,
                      void* ws, size_t ws_bytes, gml_stream_t stream);
+/* the edge branch on the exact-arithmetic family whatever the shape -- one edge per lane, fp32 FMAs, f32-input MFMA for the weight
+ * gradients, the library's tanh: what GML_F32_MFMA is to gml_spectconv_fwd / _bwd (the default entries above take the bf16-split
+ * matrix-core chains for 2 <= S <= 16).  Same arguments minus the pre-split image; the backward's dw1 .. dw4 are required. */
+int gml_edge_mlp_fwd_exact(const float* ea, const float* w1, const float* w2, const float* w3, const float* w4, float* out,
+                           const int32_t* tpos, float* out_t, int64_t num_edges, int32_t S, int32_t Sout, gml_stream_t stream);
+int gml_edge_mlp_bwd_exact(const float* ea, const float* w1, const float* w2, const float* w3, const float* w4,
+                           const float* gout, float* gin, float* dw1, float* dw2, float* dw3, float* dw4,
+                           int64_t num_edges, int32_t S, int32_t Sout, void* ws, size_t ws_bytes, gml_stream_t stream);
 
 /* ---------------------------------------------------------------- ML3Layer forward without the edge branch
  * (libs/spect_conv.py:204-212): out[:, :nout1] = act(SpectConv(x)), out[:, nout1:nout1+F2] = tanh(fc11 x) * tanh(fc12 x).

@@ -56,6 +56,27 @@ def main():
             models.zinc_loss(pre, full.y).backward()
         for h in hs:
             h.remove()
+        # where the forward error enters: layer 1's edge branch alone (device, both kernel families) and layer 1's conv / Hadamard columns
+        with torch.no_grad(), Fn.exact_products(mode == 'f32'):
+            l1 = m.conv1
+            e = base.edge_attr2.contiguous()
+            W = [l1.fc1_1.weight, l1.fc1_2.weight, l1.fc1_3.weight, l1.fc1_4.weight]
+            if mode == 'f32':
+                ead, _ = Fn.edge_mlp_fwd(e, *W)
+            else:
+                ead, _ = Fn.edge_mlp_fwd(e, *W, None, Fn.edge_presplit(e))
+            e64 = e.cpu().double()
+            W64 = [w.detach().cpu().double() for w in W]
+            h = torch.cat([torch.relu(e64 @ W64[0].t()), torch.tanh(e64 @ W64[1].t()) * torch.tanh(e64 @ W64[2].t())], 1)
+            ea64 = torch.relu(h @ W64[3].t())
+            e32 = e.cpu().float()
+            W32 = [w.detach().cpu().float() for w in W]
+            h32 = torch.cat([torch.relu(e32 @ W32[0].t()), torch.tanh(e32 @ W32[1].t()) * torch.tanh(e32 @ W32[2].t())], 1)
+            ea32 = torch.relu(h32 @ W32[3].t())
+            d = (ead.cpu().double() - ea64).abs()
+            d32 = (ea32.double() - ea64).abs()
+            print('   layer-1 edge branch: device max err %.2e rms %.2e | torch fp32 CPU max err %.2e rms %.2e  (max |ea| %.2e)' % (
+                d.max(), d.pow(2).mean().sqrt(), d32.max(), d32.pow(2).mean().sqrt(), ea64.abs().max()))
         ref = PS.reference(host, m.state_dict(), full.y, pre_dev=pre[:, 0], T=T, head_pre_dev=cap['head_pre'])
         T = ref['T']
         rep = PS.compare(ref, pre[:, 0].detach().cpu().numpy(), {n: p.grad.detach().cpu().numpy() for n, p in m.named_parameters()})
@@ -71,6 +92,9 @@ def main():
                 print('   layer %d relu units: %d of %d differ from the float64 mask (copy 0); sum |g| there / sum |g| over live units = %.2e worst column %.2e;  live units below 1e-7/1e-6/1e-5/1e-4: %s' % (
                     i, int(mism.sum()), mism.numel(), float((ga * mism).sum() / (ga * (acts[i][:, :c1] > 0)).sum()),
                     float(((ga * mism).sum(0) / (ga * (acts[i][:, :c1] > 0)).sum(0).clamp(min=1e-300)).max()), small))
+                ec, eh = e[:, :c1], e[:, c1:]
+                print('   act %d columns: conv max err %.2e rms %.2e | Hadamard max err %.2e rms %.2e' % (i, ec.max(), ec.pow(2).mean().sqrt(),
+                      eh.max() if eh.numel() else 0.0, eh.pow(2).mean().sqrt() if eh.numel() else 0.0))
                 print('   act %d: max err %.2e of max |x| %.2e  (rel %.2e), rms err / rms x %.2e' % (
                     i, e.max(), acts[i].abs().max(), e.max() / acts[i].abs().max(), e.pow(2).mean().sqrt() / acts[i].pow(2).mean().sqrt()))
         if mode == 'f32':
