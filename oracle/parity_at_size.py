@@ -133,6 +133,39 @@ def oracle_fp32_as_device(pool_batch, state_dict, y_full, pre_dev, head_pre_dev=
     return pre.detach().repeat(R).numpy(), {n: v.numpy() for n, v in zip(params, g)}, head['z1'].repeat(R, 1)
 
 
+def relu_mask_diffs(pool_batch, state_dict, y_full, pre_dev, outs_dev):
+    """How many relu units of each ML3Layer's conv columns come out on the OTHER side of zero on the device than in float64 (first
+    copy of the pool: outs_dev = {layer index: [>= n_pool, C] device output}), and how much of a column's gradient mass sits on such
+    units.  A unit within the forward round-off of zero flips its derivative -- in every copy together, since the copies share their
+    values -- and on a column with few live nodes ONE such node is 1e-3 .. 1e-2 of the column's term sum: the one way the bench-size
+    criterion is exceeded in a trained state, in either arithmetic (it is a property of relu at zero, not an error of a kernel)."""
+    b = pool_batch
+    P = int(b.num_graphs)
+    R = int(y_full.numel()) // P
+    m = MO.zinc_gnnml3(int(b.x.size(1)), int(b.edge_attr2.size(1))).double()
+    m.load_state_dict({k: v.detach().cpu().double() for k, v in state_dict.items()})
+    live = {}
+    hooks = [getattr(m, 'conv%d' % i).register_forward_hook(lambda mod, inp, out, i=i: live.__setitem__(i, out)) for i in range(1, m.nlayers + 1)]
+    pre = m(b.x.double(), b.edge_index2, b.edge_attr2.double(), b.batch, P)[:, 0]
+    for h in hooks:
+        h.remove()
+    c = torch.sign(pre_dev.detach().cpu().double().view(R, P) - y_full.detach().cpu().double().view(R, P)).sum(0)
+    gouts = torch.autograd.grad((c * pre).sum(), [live[i] for i in sorted(live)])
+    n0 = int(b.x.size(0))
+    rep = {}
+    for (i, g) in zip(sorted(live), gouts):
+        if i not in outs_dev:
+            continue
+        c1 = int(getattr(m, 'conv%d' % i).conv1.weight.size(2))
+        ref_on = live[i].detach()[:, :c1] > 0
+        dev_on = outs_dev[i][:n0, :c1].detach().cpu() > 0
+        diff = ref_on != dev_on
+        ga = g[:, :c1].abs()
+        col = (ga * diff).sum(0) / (ga * ref_on).sum(0).clamp(min=1e-300)
+        rep['layer%d' % i] = dict(units=int(diff.numel()), differing=int(diff.sum()), worst_column_share_of_gradient_mass=float(col.max()))
+    return rep
+
+
 def compare(ref, pre_dev, grads_dev, tol=1e-4):
     """pre_dev [R * P] logits and {name: gradient} of the device step.  Returns a report: the worst |err| / (tol-free) scale per
     tensor under both criteria -- `termsum`: max |err| / T (must stay <= tol), `maxnorm`: max |err| / max |ref| -- and the logits'
