@@ -189,7 +189,12 @@ __global__ __launch_bounds__(64 * G1_NW) void gml_k_gnnml1_fwd(const GmlG1Params
 // dx[r] = da[r] W1 + df2[r] W2 + df3[r] W3 + (sum_{e: src = r} val_e dc[dst_e]) Wc^T;   g4 = [da | dc | df2 | df3] (blocks of 16 nb
 // columns, the SUM mode without the dc block: dc = da there) and q = A dc [N, 16 nb2] are written for the weight gradients:
 //   dW1 = da^T x, dW2 = df2^T x, dW3 = df3^T x (gml_xty),  dWc = x^T q,  db = column sums of g4.
-template <int FPL>
+// Two launches (PH = 1, then PH = 2).  One kernel doing both had to form dc of a NEIGHBOUR row on the fly (two gathered 16-byte
+// pieces per block and edge: gout and out) and kept 96 KB of weight images -- one workgroup per CU, 0.85 ms per launch on sr25's
+// 13-entry rows, bound by the gathers at two waves per SIMD.  Phase 1 (forward-form W2 / W3 only: 32 KB) recomputes the factors and
+// writes g4; phase 2 (transposed forms: 64 KB, two workgroups per CU) gathers dc from g4 -- half the gathered bytes --, re-reads its
+// own row's blocks, writes q and forms dx.
+template <int FPL, int PH>
 __global__ __launch_bounds__(64 * G1_NW) void gml_k_gnnml1_bwd(const GmlG1Params p) {
     extern __shared__ __attribute__((aligned(16))) float wl[];
     using C = GmlG1Cfg<FPL>;
@@ -197,13 +202,15 @@ __global__ __launch_bounds__(64 * G1_NW) void gml_k_gnnml1_bwd(const GmlG1Params
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, kq = lane >> 4;
     const int nb1 = (p.n1 + 15) / 16, nb2 = (p.n2 + 15) / 16, nb3 = (p.n3 + 15) / 16;
     // image: forward-form W2, W3 (the factors are recomputed), then the transposed forms of W1, W2, W3, Wc
-    float* wf = wl;                                           // [2 nb3][FPL][64]
-    float* wt1 = wf + C::fwd_floats(2 * nb3);                 // [fb][nb1][4][64]
+    float* wf = wl;                                           // [2 nb3][FPL][64]   (phase 1 only)
+    float* wt1 = PH == 1 ? wl : wl;                           // [fb][nb1][4][64]   (phase 2 only: the image starts here)
     float* wt2 = wt1 + C::tr_floats(nb1);
     float* wt3 = wt2 + C::tr_floats(nb3);
     float* wtc = wt3 + C::tr_floats(nb3);                     // [fb][nb2][4][64]: lane (f, k) holds Wc[16 fb + f][16 nb + 4 k + reg]
-    g1_fill_fwd<FPL>(wf, p.w2, p.n3, p.Fin, false, 0, nb3, tid, blockDim.x);
-    g1_fill_fwd<FPL>(wf, p.w3, p.n3, p.Fin, false, nb3, nb3, tid, blockDim.x);
+    if constexpr (PH == 1) {
+        g1_fill_fwd<FPL>(wf, p.w2, p.n3, p.Fin, false, 0, nb3, tid, blockDim.x);
+        g1_fill_fwd<FPL>(wf, p.w3, p.n3, p.Fin, false, nb3, nb3, tid, blockDim.x);
+    }
     auto fill_tr = [&](float* dst, const float* w, int n, int nkb, bool conv) {
         for (int i = tid; i < NFB * nkb * 4 * 64; i += blockDim.x) {
             const int ln = i & 63, reg = (i >> 6) & 3, nb = (i >> 8) % nkb, fb = (i >> 8) / nkb;
@@ -211,10 +218,12 @@ __global__ __launch_bounds__(64 * G1_NW) void gml_k_gnnml1_bwd(const GmlG1Params
             dst[i] = (c < n && f < p.Fin) ? (conv ? w[(int64_t)f * n + c] : w[(int64_t)c * p.Fin + f]) : 0.f;
         }
     };
-    fill_tr(wt1, p.w1, p.n1, nb1, false);
-    fill_tr(wt2, p.w2, p.n3, nb3, false);
-    fill_tr(wt3, p.w3, p.n3, nb3, false);
-    fill_tr(wtc, p.wc, p.n2, nb2, true);
+    if (PH == 2 && p.dx) {
+        fill_tr(wt1, p.w1, p.n1, nb1, false);
+        fill_tr(wt2, p.w2, p.n3, nb3, false);
+        fill_tr(wt3, p.w3, p.n3, nb3, false);
+        fill_tr(wtc, p.wc, p.n2, nb2, true);
+    }
     __syncthreads();
     const int sum = p.mode == 0;
     const int oc_c = sum ? 0 : p.n1, op_c = sum ? 0 : p.n1 + p.n2;               // column bases in out / gout
@@ -222,9 +231,19 @@ __global__ __launch_bounds__(64 * G1_NW) void gml_k_gnnml1_bwd(const GmlG1Params
     for (int t = blockIdx.x * G1_NW + wave; t < p.ntiles; t += gridDim.x * G1_NW) {
         const int64_t row = (int64_t)t * 16 + r16;
         const bool valid = row < p.nrows;
+        f32x4 da[4], dc[4], d2[4], d3[4];
+        if constexpr (PH == 2) {                             // the own row's blocks back from g4
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                const int c0 = 16 * nb + 4 * kq;
+                da[nb] = (nb < nb1 && p.dx) ? g1_load4(p.g4 + ga_o, p.ldg4, row, c0, 16 * nb1, valid) : f32x4{0.f, 0.f, 0.f, 0.f};
+                d2[nb] = (nb < nb3 && p.dx) ? g1_load4(p.g4 + g2_o, p.ldg4, row, c0, 16 * nb3, valid) : f32x4{0.f, 0.f, 0.f, 0.f};
+                d3[nb] = (nb < nb3 && p.dx) ? g1_load4(p.g4 + g3_o, p.ldg4, row, c0, 16 * nb3, valid) : f32x4{0.f, 0.f, 0.f, 0.f};
+                dc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        } else {
         float xr[FPL];
         g1_load_row<FPL>(p.x, p.ldx, row, valid, p.Fin, kq, xr);
-        f32x4 da[4], dc[4], d2[4], d3[4];
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
             da[nb] = dc[nb] = d2[nb] = d3[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -274,7 +293,10 @@ __global__ __launch_bounds__(64 * G1_NW) void gml_k_gnnml1_bwd(const GmlG1Params
             if (!sum && nb < nb2) g1_store4(p.g4 + gc_o, p.ldg4, row, c0, 16 * nb2, valid, dc[nb]);
             if (nb < nb3) { g1_store4(p.g4 + g2_o, p.ldg4, row, c0, 16 * nb3, valid, d2[nb]); g1_store4(p.g4 + g3_o, p.ldg4, row, c0, 16 * nb3, valid, d3[nb]); }
         }
-        // q[row] = sum over the row's OUT-edges (source-keyed view) of val * dc[destination]; dc of another row = gout . act'(out) there
+        continue;                                            // (phase 1 ends here)
+        }
+        // q[row] = sum over the row's OUT-edges (source-keyed view) of val * dc[destination], dc read from g4 (mode 0: its da block)
+        const float* dcb = p.g4 + (sum ? ga_o : gc_o);
         f32x4 qa[4];
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) qa[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -286,9 +308,9 @@ __global__ __launch_bounds__(64 * G1_NW) void gml_k_gnnml1_bwd(const GmlG1Params
             for (int nb = 0; nb < 4; ++nb) {
                 if (nb >= nb2) break;
                 const int c0 = 16 * nb + 4 * kq;
-                const f32x4 go = g1_load4(p.gout + oc_c, p.ldgo, d, c0, p.n2, true), oo = g1_load4(p.out + oc_c, p.ldo, d, c0, p.n2, true);
+                const f32x4 dn = g1_load4(dcb, p.ldg4, d, c0, 16 * nb2, true);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) qa[nb][u] = fmaf(v, go[u] * g1_dact_out(oo[u], p.act), qa[nb][u]);
+                for (int u = 0; u < 4; ++u) qa[nb][u] = fmaf(v, dn[u], qa[nb][u]);
             }
         }
 #pragma unroll
@@ -388,18 +410,20 @@ extern "C" int gml_gnnml1_bwd(const int32_t* rowptr_t, const int32_t* col_t, con
     const int nb1 = (n1 + 15) / 16, nb2 = (n2 + 15) / 16, nb3 = (n3 + 15) / 16;
     hipStream_t st = (hipStream_t)stream;
     int64_t grid = gml_cdiv(p.ntiles, G1_NW);
-    if (grid > GML_NUM_CU) grid = GML_NUM_CU;
+    if (grid > 2 * GML_NUM_CU) grid = 2 * GML_NUM_CU;
     if (fpl == 4) {
-        const size_t lds = (size_t)(GmlG1Cfg<4>::fwd_floats(2 * nb3) + GmlG1Cfg<4>::tr_floats(nb1 + 2 * nb3 + nb2)) * 4;
-        GML_ALLOW_BIG_LDS(rc4, (&gml_k_gnnml1_bwd<4>), 160 * 1024)
+        const size_t lds1 = (size_t)GmlG1Cfg<4>::fwd_floats(2 * nb3) * 4, lds2 = dx ? (size_t)GmlG1Cfg<4>::tr_floats(nb1 + 2 * nb3 + nb2) * 4 : 0;
+        GML_ALLOW_BIG_LDS(rc4, (&gml_k_gnnml1_bwd<4, 2>), 160 * 1024)
         if (rc4 != hipSuccess) return (int)rc4;
-        hipLaunchKernelGGL((gml_k_gnnml1_bwd<4>), dim3((unsigned)grid), dim3(64 * G1_NW), lds, st, p);
+        hipLaunchKernelGGL((gml_k_gnnml1_bwd<4, 1>), dim3((unsigned)grid), dim3(64 * G1_NW), lds1, st, p);
+        hipLaunchKernelGGL((gml_k_gnnml1_bwd<4, 2>), dim3((unsigned)grid), dim3(64 * G1_NW), lds2, st, p);
     } else {
-        const size_t lds = (size_t)(GmlG1Cfg<16>::fwd_floats(2 * nb3) + GmlG1Cfg<16>::tr_floats(nb1 + 2 * nb3 + nb2)) * 4;
-        if (lds > 160 * 1024) return GML_E_UNSUPPORTED;
-        GML_ALLOW_BIG_LDS(rc16, (&gml_k_gnnml1_bwd<16>), 160 * 1024)
+        const size_t lds1 = (size_t)GmlG1Cfg<16>::fwd_floats(2 * nb3) * 4, lds2 = dx ? (size_t)GmlG1Cfg<16>::tr_floats(nb1 + 2 * nb3 + nb2) * 4 : 0;
+        if (lds2 > 160 * 1024) return GML_E_UNSUPPORTED;
+        GML_ALLOW_BIG_LDS(rc16, (&gml_k_gnnml1_bwd<16, 2>), 160 * 1024)
         if (rc16 != hipSuccess) return (int)rc16;
-        hipLaunchKernelGGL((gml_k_gnnml1_bwd<16>), dim3((unsigned)grid), dim3(64 * G1_NW), lds, st, p);
+        hipLaunchKernelGGL((gml_k_gnnml1_bwd<16, 1>), dim3((unsigned)grid), dim3(64 * G1_NW), lds1, st, p);
+        hipLaunchKernelGGL((gml_k_gnnml1_bwd<16, 2>), dim3((unsigned)grid), dim3(64 * G1_NW), lds2, st, p);
     }
     return gml_launch_status();
 }
