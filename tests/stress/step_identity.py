@@ -27,8 +27,24 @@ elif cfg == 'mutag':         # 48-wide hidden layers + BatchNorm (first layer on
         raw.append((x7, ei, np.float32(rng.integers(2))))
     pool = SpectralDesign(recfield=1, dv=4, nfreq=3, adddegree=True).design_many(raw)
     ctor, loss = (lambda: models.mutag_gnnml3(8, 4)), models.mutag_loss
+elif cfg in ('mutag_gnnml1', 'sr25_gnnml1'):   # round 5: the fused GNNML1 block (csrc/gml_gnnml1.hip), mutag.py factor form / sr25.py sum form
+    if cfg == 'mutag_gnnml1':
+        rng = np.random.default_rng(2)
+        raw = []
+        for x, ei, y in synthetic.make_graphs('zinc', 2048, seed=11):
+            x7 = np.zeros((x.shape[0], 7), dtype=np.float32)
+            x7[np.arange(x.shape[0]), rng.integers(7, size=x.shape[0])] = 1
+            raw.append((x7, ei, np.float32(rng.integers(2))))
+        pool = SpectralDesign(recfield=1, dv=4, nfreq=3, adddegree=True).design_many(raw)
+        ctor, loss = (lambda: models.GNNML1Mutag(8)), models.mutag_loss
+    else:
+        from gnn_matlang_amd import readers
+        root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        raw = readers.load_sr(os.path.join(root, 'tests', 'golden', 'raw', 'sr251256.g6')) * 40
+        pool = SpectralDesign(recfield=1, dv=2, nfreq=5, adddegree=True).design_many(raw)
+        ctor, loss = (lambda: models.sr25_gnnml1(2)), (lambda pre, y: pre.square().sum())
 data = collate(pool).to(dev)
-data.y = torch.rand(data.num_graphs, generator=torch.Generator().manual_seed(3)).to(dev) if cfg in ('zinc', 'sr25') else data.y.to(dev)
+data.y = torch.rand(data.num_graphs, generator=torch.Generator().manual_seed(3)).to(dev) if cfg in ('zinc', 'sr25', 'sr25_gnnml1') else data.y.to(dev)
 torch.manual_seed(5)
 m = ctor().to(dev).train()
 opt = torch.optim.Adam(m.parameters(), lr=1e-3)
