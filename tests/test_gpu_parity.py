@@ -1912,3 +1912,40 @@ def test_one_launch_adam_follows_torch_adam(dev):
     torch.cuda.synchronize()
     for a, b in zip(pa, pb):
         close(a, b, tol=2e-6, what='adam replay n=%d' % a.numel())
+
+
+@pytest.mark.parametrize('S,fin,fout,deg,N', [(6, 33, 17, 5, 517), (6, 37, 32, 13, 300), (6, 48, 30, 16, 1000), (6, 44, 24, 3, 129),
+                                               (4, 47, 31, 5, 517), (4, 48, 24, 8, 2049), (4, 36, 32, 2, 1), (6, 40, 32, 13, 128)])
+def test_one_launch_48_feature_backward_odd_shapes(dev, S, fin, fout, deg, N):
+    """bwd3 with a third 16-feature block (NFB = 3, round 5): 33 .. 48 input features in ONE launch for S = 4 and 6 -- widths that are
+    not multiples of 4 (scalar x rows), of 16 (partial third block), ragged row counts, one node, sr25's 13 entries per row (the
+    S = 6 class reads its value rows inside the edge loop and stores dval from it; lane kq = 3 of the padded fold stores nothing).
+    Output, dx, d edge_attr, dW, db against the oracle; GML_VERBOSE confirms the one-launch road."""
+    from gnn_matlang_amd import SpectConv, functional as Fn
+    from oracle import spect_conv_oracle as O
+    rng = np.random.default_rng(S * 100 + fin)
+    torch.manual_seed(fin)
+    ei = _banded_graph(rng, N, deg, 12) if N > 1 else np.zeros((2, 1), dtype=np.int64)
+    ea, x = torch.randn(ei.shape[1], S), torch.randn(N, fin)
+    m = SpectConv(fin, fout, S, selfconn=False).to(dev)
+    w, b = m.weight.detach().cpu(), m.bias.detach().cpu()
+    xo, eo, wo, bo = (t.clone().requires_grad_(True) for t in (x, ea, w, b))
+    yo = O.spectconv_forward(xo, T(ei), eo, wo, bo, False)
+    gout = torch.randn_like(yo)
+    (yo * gout).sum().backward()
+    xg, eg = x.to(dev).requires_grad_(True), ea.to(dev).requires_grad_(True)
+    old = Fn.VERBOSE
+    Fn.VERBOSE = True
+    Fn.PATHS.clear()
+    try:
+        y = m(xg, T(ei).to(dev), eg)
+        (y * gout.to(dev)).sum().backward()
+        paths = dict(Fn.PATHS)
+    finally:
+        Fn.VERBOSE = old
+    assert any('conv_bwd: fused (group kind 128)' in k and 'two launches' not in k for k in paths), paths
+    close(y, yo, what='out')
+    close(xg.grad, xo.grad, what='g_x')
+    close(eg.grad, eo.grad, what='g_edge_attr')
+    close(m.weight.grad, wo.grad, what='g_weight')
+    close(m.bias.grad, bo.grad, what='g_bias')
