@@ -183,8 +183,10 @@ def parity_vs_oracle(model, data, base, log):
                                   max_rel_err_maxnorm=rep['worst_maxnorm'], worst_tensor=worst[0], ok=rep['ok'],
                                   head_units_flipped=ref['head_units_flipped'], relu_units_on_the_other_side_of_zero=flips,
                                   oracle_seconds=round(ref['seconds'], 2))
-        log('parity at bench size, %s: logits %.2e, gradients %.2e of their term sums (worst: %s), %s' % (
-            mode, rep['logits_rel_err'], rep['worst_termsum'], worst[0], 'ok' if rep['ok'] else 'BEYOND 1e-4'))
+        nflip = sum(v['differing'] for v in flips.values())
+        log('parity at bench size, %s: logits %.2e, gradients %.2e of their term sums (worst: %s), %s; %d of %d relu units on the other side of zero' % (
+            mode, rep['logits_rel_err'], rep['worst_termsum'], worst[0], 'within 1e-4' if rep['ok'] else 'beyond 1e-4 (see relu flips)',
+            nflip, sum(v['units'] for v in flips.values())))
     # the reference arithmetic itself under the same criterion: the oracle in float32 on the CPU (what "fp32-class" means here)
     try:
         pre32, g32, z32 = PS.oracle_fp32_as_device(host, model.state_dict(), data.y, pre[:, 0])
