@@ -143,7 +143,7 @@ class _DenseConv(torch.autograd.Function):
     the library GEMM g Wcat^T followed by the support product on the transposed images."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, sup):
+    def forward(ctx, x, weight, bias, sup, relu=False):
         S, Fin, Fout = weight.shape
         x = x.contiguous()
         dev = x.device
@@ -158,18 +158,30 @@ class _DenseConv(torch.autograd.Function):
         q_img = sup.B * S * 2 * sup.n * sup.KP * 2
         with Fn._Timed('dense_conv_fwd', q_img + 4 * rows * (Fin + Fout + (S * Fin if need_h else 0)), 2 * sup.B * S * sup.n * sup.n * Fin + 2 * rows * S * Fin * Fout):
             _lib.call('gml_dense_conv_fwd', _ptr(sup.fwd), _ptr(x), int(x.stride(0)), _ptr(wimg), _ptr(bias), _ptr(out), Fout,
-                      _ptr(hcat), sup.B, S, sup.n, sup.KP, Fin, Fout, 0, _stream(dev))
-        ctx.save_for_backward(hcat if hcat is not None else x, weight)
-        ctx.sup, ctx.has_bias, ctx.has_h = sup, bias is not None, hcat is not None
+                      _ptr(hcat), sup.B, S, sup.n, sup.KP, Fin, Fout, 1 if relu else 0, _stream(dev))
+        # relu (round 5): applied in the kernel's epilogue (libs/layers_tf.py:238: act(output)); the backward's mask and the bias
+        # gradient come out of ONE pass over g and the saved output (functional.ml3_split_bwd) -- before: a relu launch forward, a
+        # threshold launch and a column sum backward, 1.6 GB of elementwise traffic per MNIST-75 step at 4,096 graphs
+        ctx.save_for_backward(hcat if hcat is not None else x, weight, out if relu else None)
+        ctx.sup, ctx.has_bias, ctx.has_h, ctx.relu = sup, bias is not None, hcat is not None, bool(relu)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        hcat, weight = ctx.saved_tensors
+        hcat, weight, yout = ctx.saved_tensors
         sup = ctx.sup
         S, Fin, Fout = weight.shape
         g = g.contiguous()
         dx = dw = db = None
+        if ctx.relu:
+            r = Fn.ml3_split_bwd(g, yout, Fout, need_dcb=ctx.has_bias and ctx.needs_input_grad[2])
+            if r is not None:
+                g = r[0]
+                db = r[2]
+                if not g.is_contiguous():
+                    g = g.contiguous()
+            else:
+                g = g * (yout > 0)
         if ctx.needs_input_grad[0]:
             if CHAIN_BWD:
                 # dX = sum_s D_s^T (g W_s^T) in one launch: d Hcat stays on the CU (gml_k_dense_conv_bwdx)
@@ -200,13 +212,13 @@ class _DenseConv(torch.autograd.Function):
             with Fn._Timed('dense_dw_library_gemm', 4 * rows * (S * Fin + Fout), 2 * rows * S * Fin * Fout):
                 dw = (torch.bmm(hcat.view(P, rows // P, S * Fin).transpose(1, 2), g.view(P, rows // P, Fout)).sum(0) if P > 1
                       else hcat.t().mm(g)).view(S, Fin, Fout)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if ctx.has_bias and ctx.needs_input_grad[2] and db is None:
             db = g.sum(0)
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
-def spectconv_dense(x, sup, weight, bias, n):
-    """x [B*n, Fin], sup from dense_supports, weight [S, Fin, Fout] -> [B*n, Fout] = sum_s (D_s x) W_s + bias."""
+def spectconv_dense(x, sup, weight, bias, n, relu=False):
+    """x [B*n, Fin], sup from dense_supports, weight [S, Fin, Fout] -> [B*n, Fout] = act(sum_s (D_s x) W_s + bias), act = relu or none."""
     S, Fin, Fout = weight.shape
     if sup.n != n or sup.S != S or x.size(0) != sup.B * n:
         raise ValueError('supports [%d graphs, S=%d, n=%d] do not match x %s / weight %s' %
@@ -219,6 +231,7 @@ def spectconv_dense(x, sup, weight, bias, n):
         if Fin > 128:
             raise ValueError('the dense-block kernel covers Fin <= 128, got %d' % Fin)
         if CHAIN and Fout <= 128:
-            return _DenseConv.apply(x, weight, bias, sup)
+            return _DenseConv.apply(x, weight, bias, sup, relu)
         h = _SupportProduct.apply(x, sup)
-    return _TallGemm.apply(h, weight.reshape(S * Fin, Fout), bias)
+    out = _TallGemm.apply(h, weight.reshape(S * Fin, Fout), bias)
+    return torch.relu(out) if relu else out

@@ -148,7 +148,7 @@ class GNNML3(torch.nn.Module):
         for i in range(self.nlayers):
             layer = getattr(self, 'conv%d' % (i + 1))
             if self.dense_n:
-                x = F.relu(spectconv_dense(x, data._spT, layer.conv1.weight, layer.conv1.bias, self.dense_n))
+                x = spectconv_dense(x, data._spT, layer.conv1.weight, layer.conv1.bias, self.dense_n, relu=True)
             elif i == self.nlayers - 1 and not self.bn and self.pool in ('add', 'mean') and torch.is_grad_enabled():
                 # the pool directly follows the last layer: one autograd node, the pool's gradient is not expanded to [N, C]
                 if getattr(data, '_batch_i32', None) is None:
