@@ -102,6 +102,9 @@ SIGNATURES = {
                                            _i32, _i32, _p, _i64, _p, _p, _p, _p]),
     'gml_xty_workspace_bytes': (_sz, [_i64, _i32, _i32]),
     'gml_xty': (ctypes.c_int, [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _p, _sz, _p]),
+    'gml_xty_wide_supported': (_i32, [_i64, _i32, _i32]),
+    'gml_xty_wide_workspace_bytes': (_sz, [_i64, _i32, _i32]),
+    'gml_xty_wide': (ctypes.c_int, [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _p, _sz, _p]),
     'gml_ml3_split_bwd_workspace_bytes': (_sz, [_i64, _i32, _i32, _i32]),
     'gml_ml3_split_bwd_ex': (ctypes.c_int, [_p, _i64, _p, _p, _i64, _p, _i64, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p,
                                             _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _sz, _p]),

@@ -132,6 +132,7 @@ class _TallGemm(torch.autograd.Function):
 # 1.19): a workgroup per (support, 64-column block, graph slice) recomputes the product per column block and pays the full load
 # latency per graph (208 VGPRs at Fin = 128: one workgroup per CU).  What it needs is in DESIGN s8.
 DW_LIBRARY = os.environ.get('GML_DENSE_DW_HIP', '0') in ('0', '')
+DW_GEMM_LIB = os.environ.get('GML_DENSE_DW_GEMM_LIB', '0') not in ('0', '')   # A/B: the dW GEMM Hcat^T g through the library instead of gml_xty_wide
 CHAIN = os.environ.get('GML_DENSE_CHAIN', '1') not in ('0', '')      # projection chained behind the support product (gml_dense_conv_fwd)
 CHAIN_BWD = os.environ.get('GML_DENSE_CHAIN_BWD', '1') not in ('0', '')   # and the dX path: projection in front of the transposed product
 
@@ -209,9 +210,15 @@ class _DenseConv(torch.autograd.Function):
         elif ctx.needs_input_grad[1]:
             rows = int(hcat.size(0))
             P = _splits(rows)
-            with Fn._Timed('dense_dw_library_gemm', 4 * rows * (S * Fin + Fout), 2 * rows * S * Fin * Fout):
-                dw = (torch.bmm(hcat.view(P, rows // P, S * Fin).transpose(1, 2), g.view(P, rows // P, Fout)).sum(0) if P > 1
-                      else hcat.t().mm(g)).view(S, Fin, Fout)
+            dw = None
+            if not DW_GEMM_LIB:                                   # round 5: Hcat^T g on the bf16 matrix cores (gml_xty_wide), not a library GEMM
+                with Fn._Timed('dense_dw_xty_wide', 4 * rows * (S * Fin + Fout), 2 * rows * S * Fin * Fout):
+                    dw = Fn.xty_wide(hcat, g)
+                dw = dw.view(S, Fin, Fout) if dw is not None else None
+            if dw is None:
+                with Fn._Timed('dense_dw_library_gemm', 4 * rows * (S * Fin + Fout), 2 * rows * S * Fin * Fout):
+                    dw = (torch.bmm(hcat.view(P, rows // P, S * Fin).transpose(1, 2), g.view(P, rows // P, Fout)).sum(0) if P > 1
+                          else hcat.t().mm(g)).view(S, Fin, Fout)
         if ctx.has_bias and ctx.needs_input_grad[2] and db is None:
             db = g.sum(0)
         return dx, dw, db, None, None

@@ -664,6 +664,21 @@ class GNNML1BlockFunction(torch.autograd.Function):
         return dx, None, None, dw1, db1, dwc.view(1, Fin, n2), dbc, dw2, db2, dw3, db3, None, None
 
 
+def xty_wide(a, b):
+    """a^T b for a tall wide a [n, p <= 4096] and b [n, q <= 128] on the bf16 matrix cores (bf16x3 products; gml_xty_wide): the dense
+    block's dW = Hcat^T g; None if outside the kernel range."""
+    n, p, q = int(a.size(0)), int(a.size(1)), int(b.size(1))
+    L = _lib.lib()
+    if not L.gml_xty_wide_supported(n, p, q) or exact_mode() or a.stride(1) != 1 or b.stride(1) != 1:
+        return None
+    nbytes = int(L.gml_xty_wide_workspace_bytes(n, p, q))
+    out = torch.empty(p, q, dtype=torch.float32, device=a.device)
+    ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=a.device)
+    _lib.call('gml_xty_wide', _ptr(a), int(a.stride(0)), _ptr(b), int(b.stride(0)), _ptr(out), n, p, q, _ptr(ws), ws.numel(),
+              _stream(a.device))
+    return out
+
+
 class BatchNormFunction(torch.autograd.Function):
     """torch.nn.BatchNorm1d in training mode on the HIP kernels of csrc/gml_bn.hip (mutag.py:272-288: BatchNorm between the layers).
     Returns (y, batch mean, biased batch variance); raises NotImplementedError for shapes the kernels do not take (the module then

@@ -491,6 +491,14 @@ size_t gml_xty_workspace_bytes(int64_t n, int32_t a, int32_t b);
 int gml_xty(const float* A, int64_t lda, const float* B, int64_t ldb, float* out, int64_t n, int32_t a, int32_t b,
             void* ws, size_t ws_bytes, gml_stream_t stream);
 
+/* out[i, j] = sum_r A[r, i] * B[r, j] for a wide A (a <= 4096 columns) and b <= 128: the dense-block layer's weight gradient
+ * dW = Hcat^T g (libs/layers_tf.py:231-236, its autograd: a = S Fin, b = Fout) on the bf16 matrix cores (bf16x3 split products, fp32
+ * accumulate), rows along K through transposing LDS reads; per-row-range partials folded in order.  ws: gml_xty_wide_workspace_bytes. */
+int gml_xty_wide_supported(int64_t n, int32_t a, int32_t b);
+size_t gml_xty_wide_workspace_bytes(int64_t n, int32_t a, int32_t b);
+int gml_xty_wide(const float* A, int64_t lda, const float* B, int64_t ldb, float* out, int64_t n, int32_t a, int32_t b,
+                 void* ws, size_t ws_bytes, gml_stream_t stream);
+
 /* Readout head + L1-sum loss of the ZINC GNNML3 in one launch each way (Zinc12k.py:343-345, :365) for the reference's regime, a
  * batch of 64 graphs, where head, loss and their backward were ~20 of the step's 70 launches (csrc/gml_head.hip):
  *   loss[0] = sum_{r < rows_loss} valid[r] |w2 . relu(W1 p[r] + b1) + b2 - y[r]|     p [rows, nin] pooled features, W1 [nh, nin]

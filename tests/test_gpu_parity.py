@@ -1949,3 +1949,17 @@ def test_one_launch_48_feature_backward_odd_shapes(dev, S, fin, fout, deg, N):
     close(eg.grad, eo.grad, what='g_edge_attr')
     close(m.weight.grad, wo.grad, what='g_weight')
     close(m.bias.grad, bo.grad, what='g_bias')
+
+
+@pytest.mark.parametrize('n,a,b', [(1000, 768, 128), (129, 384, 64), (5, 12, 64), (70000, 768, 128), (4097, 130, 10), (128, 128, 128), (1, 33, 1)])
+def test_xty_wide_vs_fp64(dev, n, a, b):
+    """gml_xty_wide (csrc/gml_xty_wide.hip): Hcat^T g of the dense-block layer -- a wide tall matrix against a <= 128-column one on the
+    bf16 matrix cores (bf16x3) -- against float64; row counts and widths off every tile size, strided row views."""
+    from gnn_matlang_amd import functional as Fn
+    torch.manual_seed(n + a)
+    A = torch.randn(n, a + 3, device=dev)[:, :a]
+    B = torch.randn(n, b + 5, device=dev)[:, 1:b + 1]
+    out = Fn.xty_wide(A, B)
+    assert out is not None
+    ref = A.double().t() @ B.double()
+    close(out, ref.float(), tol=2e-5, what='xty_wide')
