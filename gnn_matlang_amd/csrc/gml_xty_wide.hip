@@ -67,6 +67,9 @@ __global__ __launch_bounds__(512, 2) void gml_k_xty_wide(const GmlXtyWideParams 
         }
     };
 
+    // B slabs beyond b are never written by the group loop: zero them once (their blocks are computed and dropped, not stored)
+    for (int i = tid; i < (4 - nbs) * 2 * XW_IMG / 16; i += 512)
+        *reinterpret_cast<f32x4*>(bimg + 2 * nbs * XW_IMG + 16 * i) = f32x4{0.f, 0.f, 0.f, 0.f};
     // the next group's row pieces travel in registers while this group's contraction runs (one workgroup per CU: nothing else hides
     // the loads' latency)
     float va[4][8], vb[4][8];
