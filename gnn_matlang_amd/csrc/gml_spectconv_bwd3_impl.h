@@ -614,6 +614,21 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
                         edge_c(k, cn, eB);
                         if (++k >= kend) break;
                     }
+                } else if constexpr ((GML_B3V & 32768) != 0) {
+                    // pairs: the G rows of edges k and k + 1 are both requested at the top of a two-edge trip (two fixed register sets,
+                    // no rotation): the second gather's LDS round trip runs behind the first edge's arithmetic
+                    for (;;) {
+                        f32x2 gA[NH], gB[NH];
+                        const int kn = min(k + 1, klast);
+                        ldg_row(col_l[k], gA);
+                        ldg_row(col_l[kn], gB);
+                        ldval(kn, eB);
+                        edge_g(k, eA, gA);
+                        if (++k >= kend) break;
+                        ldval(min(k + 1, klast), eA);
+                        edge_g(k, eB, gB);
+                        if (++k >= kend) break;
+                    }
                 } else {
                 for (;;) {
                     ldval(min(k + 1, klast), eB);
