@@ -165,28 +165,42 @@ def parity_vs_oracle(model, data, base, log):
     for mode in ('bf16x3', 'f32'):
         for p_ in model.parameters():
             p_.grad = None
-        outs = {}
-        hooks = [getattr(model, 'conv%d' % i).register_forward_hook(lambda mod, inp, o, i=i: outs.__setitem__(i, o.detach()[:int(base.x.size(0))].clone()))
-                 for i in range(1, model.nlayers)]            # (the last layer is pooled inside its own autograd node: no per-node output)
+        outs, n0_ = {}, int(base.x.size(0))
+        hooks = [getattr(model, 'conv%d' % i).register_forward_hook(lambda mod, inp, o, i=i: outs.__setitem__(i, o.detach()))
+                 for i in range(1, model.nlayers)]
         with Fn.exact_products(mode == 'f32'):
             cap = {}
             pre = model(data, _capture=cap)
             models.zinc_loss(pre, data.y).backward()
-        for h_ in hooks:
-            h_.remove()
+            for h_ in hooks:
+                h_.remove()
+            with torch.no_grad():                          # the last layer's per-node output (inside the model it is pooled in its own
+                L_ = model.nlayers                         # autograd node): the same kernels on the same input -- the same values
+                outs[L_] = getattr(model, 'conv%d' % L_)(outs[L_ - 1], data.csr('edge_index2'), data.edge_attr2)
+        outs = {i: o[:n0_].clone() for i, o in outs.items()}      # first copy (the copies are bit-identical on the device: tools/parity_diag.py)
+        grads_dev = {n: p_.grad.detach().cpu().numpy() for n, p_ in model.named_parameters()}
         ref = PS.reference(host, model.state_dict(), data.y, pre_dev=pre[:, 0], T=T, head_pre_dev=cap['head_pre'])
         flips = PS.relu_mask_diffs(host, model.state_dict(), data.y, pre[:, 0], outs)
         T = ref['T']
-        rep = PS.compare(ref, pre[:, 0].detach().cpu().numpy(), {n: p_.grad.detach().cpu().numpy() for n, p_ in model.named_parameters()})
+        rep = PS.compare(ref, pre[:, 0].detach().cpu().numpy(), grads_dev)
+        # the same with the float64 pass evaluated on the DEVICE's activation pattern of every layer's relu(conv) columns: the gradients
+        # given the forward's discrete decisions
+        c1s = {i: int(getattr(model, 'conv%d' % i).conv1.weight.size(2)) for i in outs}
+        ref_m = PS.reference(host, model.state_dict(), data.y, pre_dev=pre[:, 0], T=T, head_pre_dev=cap['head_pre'],
+                             layer_masks_dev={i: o[:, :c1s[i]] > 0 for i, o in outs.items()})
+        rep_m = PS.compare(ref_m, pre[:, 0].detach().cpu().numpy(), grads_dev)
         worst = max(rep['tensors'].items(), key=lambda kv: kv[1]['termsum'])
         out['modes'][mode] = dict(logits_rel_err=rep['logits_rel_err'], max_rel_err_termsum=rep['worst_termsum'],
                                   max_rel_err_maxnorm=rep['worst_maxnorm'], worst_tensor=worst[0], ok=rep['ok'],
+                                  max_rel_err_termsum_on_the_device_activation_pattern=rep_m['worst_termsum'], ok_on_the_device_activation_pattern=rep_m['ok'],
                                   head_units_flipped=ref['head_units_flipped'], relu_units_on_the_other_side_of_zero=flips,
                                   oracle_seconds=round(ref['seconds'], 2))
         nflip = sum(v['differing'] for v in flips.values())
         log('parity at bench size, %s: logits %.2e, gradients %.2e of their term sums (worst: %s), %s; %d of %d relu units on the other side of zero' % (
-            mode, rep['logits_rel_err'], rep['worst_termsum'], worst[0], 'within 1e-4' if rep['ok'] else 'beyond 1e-4 (see relu flips)',
-            nflip, sum(v['units'] for v in flips.values())))
+            mode, rep['logits_rel_err'], rep['worst_termsum'], worst[0], 'within 1e-4' if rep['ok'] else 'beyond 1e-4 (forward error of the bf16 splits: relu flips / small activations, DESIGN s6)',
+            nflip, sum(v['units'] for v in flips.values())) + '; with the float64 pass on the device\'s activation pattern: %.2e' % rep_m['worst_termsum'])
+        wm = max(rep_m['tensors'].items(), key=lambda kv: kv[1]['termsum'])
+        log('   worst element on the device pattern: %s%s got %.6e ref %.6e T %.3e (tensor max %.3e)' % (wm[0], wm[1]['worst_index'], wm[1]['worst_got'], wm[1]['worst_ref'], wm[1]['worst_T'], wm[1]['tensor_max_abs']))
     # the reference arithmetic itself under the same criterion: the oracle in float32 on the CPU (what "fp32-class" means here)
     try:
         pre32, g32, z32 = PS.oracle_fp32_as_device(host, model.state_dict(), data.y, pre[:, 0])
@@ -844,11 +858,11 @@ def main():
                 # ---- checker leg (the oracle as the CHECKER, never the thing measured): the headline batch, one step per arithmetic
                 # mode, logits and every parameter gradient against the oracle in float64 under the term-sum criterion
                 # (oracle/parity_at_size.py; the same check as tests/test_gpu_parity.py::test_bench_size_train_step_vs_fp64_oracle)
-                # Two states.  The INITIAL parameters are the pinned one (no relu unit of the model sits within round-off of zero there:
-                # the figures are reproducible and held to 1e-4 by the GPU test).  The parameters the timed steps leave are reported as
-                # they come: after hundreds of Adam steps on random targets some units are nearly dead, and a node whose pre-activation
-                # is within the forward round-off of zero -- flipping its relu derivative in all 64 copies at once -- can be 1e-3 .. 1e-2
-                # of such a column's term sum in EITHER arithmetic (relu_units_on_the_other_side_of_zero counts them per layer).
+                # Two states.  The INITIAL parameters are the pinned one (the figures are reproducible and held to 1e-4 by the GPU test).
+                # The parameters the timed steps leave are reported as they come: after hundreds of Adam steps on random targets some units
+                # are nearly dead; the headline mode's forward error (1e-5 of a layer's scale) then shows as relu units on the other side
+                # of zero (counted per layer) and as large relative errors of small activations -- elements of nearly dead units' gradients
+                # exceed 1e-4 of their own term sums (DESIGN s6); the exact mode and the CPU fp32 reference stay at 1e-6.
                 res['parity_vs_oracle_after_training'] = parity_vs_oracle(model, data, base, log)
                 res['parity_vs_oracle_after_training']['state'] = 'parameters after the timed steps of this run (informational: see relu_units_on_the_other_side_of_zero)'
                 if parity0 is not None:

@@ -27,7 +27,7 @@ from . import models_oracle as MO
 from .termsums import ml3_termsums
 
 
-def reference(pool_batch, state_dict, y_full, pre_dev=None, T=None, threads=16, head_pre_dev=None):
+def reference(pool_batch, state_dict, y_full, pre_dev=None, T=None, threads=16, head_pre_dev=None, layer_masks_dev=None):
     """pool_batch: the collated pool (CPU tensors x, edge_index2, edge_attr2, batch, num_graphs); state_dict: the model's
     parameters (any device); y_full [R * P] targets in the bench's order (copy-major); pre_dev [R * P]: the device's own logits -- the
     L1 loss's sign(pre - y) is then taken from THEM (a copy whose |pre - y| is below the logits' round-off would otherwise flip the
@@ -35,7 +35,11 @@ def reference(pool_batch, state_dict, y_full, pre_dev=None, T=None, threads=16, 
     fc1 outputs -- the head's relu mask is then taken from them for the same reason (a hidden unit of the head whose pre-activation is
     within round-off of zero switches a whole graph's contribution, coherently in all R copies: with 2,048 pool graphs ONE such unit is
     5e-4 of fc1.weight's term sum; the relus inside the layers act per node, 1 / 3 M of a sum, and need no such care); T: term sums of
-    an earlier call with the same parameters and pool (they do not depend on the arithmetic mode).  Returns dict(pre [P] float64,
+    an earlier call with the same parameters and pool (they do not depend on the arithmetic mode); layer_masks_dev {layer index: bool
+    [>= n_pool, nout1]}: the device's activation pattern of that layer's relu(conv) columns (first copy: the copies share their values on
+    the device as in exact arithmetic -- every row's result depends on its own row only) -- the float64 pass is then evaluated WITH that
+    pattern (a = z * mask): "given the forward's discrete decisions, are the gradients right", the same treatment as the loss's sign and
+    the head's mask.  Returns dict(pre [P] float64,
     grads {name: float64 array}, T {name: float64 array}, head_units_flipped, seconds)."""
     t0 = time.perf_counter()
     torch.set_num_threads(min(int(threads), torch.get_num_threads()))   # (tiny float64 ops: hundreds of threads only contend)
@@ -46,6 +50,10 @@ def reference(pool_batch, state_dict, y_full, pre_dev=None, T=None, threads=16, 
     m.load_state_dict({k: v.detach().cpu().double() for k, v in state_dict.items()})
     head = {}
     hook = m.fc1.register_forward_hook(lambda mod, inp, out: head.__setitem__('z1', out))
+    n0 = int(b.x.size(0))
+    for i, mk in (layer_masks_dev or {}).items():
+        lay = getattr(m, 'conv%d' % i)
+        lay._relu_mask = mk[:n0, :int(lay.conv1.weight.size(2))].detach().cpu()
     pre = m(b.x.double(), b.edge_index2, b.edge_attr2.double(), b.batch, P)[:, 0]            # [P]
     hook.remove()
     y = y_full.detach().cpu().double().view(R, P)
@@ -182,7 +190,11 @@ def compare(ref, pre_dev, grads_dev, tol=1e-4):
         floor = 1e-12 * max(float(np.abs(gr).max()), 1e-300)
         ts = float((err / np.maximum(np.maximum(ref['T'][n], np.abs(gr)), floor)).max())
         mn = float(err.max() / max(float(np.abs(gr).max()), 1e-300))
-        rep['tensors'][n] = dict(termsum=ts, maxnorm=mn)
+        ratio = err / np.maximum(np.maximum(ref['T'][n], np.abs(gr)), floor)
+        wi = int(np.argmax(ratio))
+        rep['tensors'][n] = dict(termsum=ts, maxnorm=mn, worst_index=[int(v) for v in np.unravel_index(wi, gr.shape)],
+                                 worst_got=float(got.flat[wi]), worst_ref=float(gr.flat[wi]), worst_T=float(ref['T'][n].flat[wi]),
+                                 tensor_max_abs=float(np.abs(gr).max()))
         rep['worst_termsum'] = max(rep['worst_termsum'], ts)
         rep['worst_maxnorm'] = max(rep['worst_maxnorm'], mn)
     rep['ok'] = bool(rep['worst_termsum'] <= tol and e_pre <= tol)

@@ -96,14 +96,16 @@ def edge_mlp_forward(edge_attr, w1, w2, w3, w4):
     return F.relu(F.linear(t, w4))
 
 
-def ml3layer_forward(x, edge_index, edge_attr, p, learnedge, nout2):
+def ml3layer_forward(x, edge_index, edge_attr, p, learnedge, nout2, relu_mask=None):
     """p: dict with the reference state_dict keys (fc1_1.weight ... conv1.weight,
-    conv1.bias, fc11.weight, fc11.bias, fc12.weight, fc12.bias)."""
+    conv1.bias, fc11.weight, fc11.bias, fc12.weight, fc12.bias).
+    relu_mask (checker only, oracle/parity_at_size.py): evaluate the layer with a GIVEN activation pattern of its conv columns
+    (a = z * mask instead of relu(z)) -- the pattern another evaluation of the same layer (the device's) produced."""
     if learnedge:
         edge_attr = edge_mlp_forward(edge_attr, p['fc1_1.weight'], p['fc1_2.weight'],
                                      p['fc1_3.weight'], p['fc1_4.weight'])
-    a = F.relu(spectconv_forward(x, edge_index, edge_attr, p['conv1.weight'],
-                                 p.get('conv1.bias'), selfconn=False))
+    a = spectconv_forward(x, edge_index, edge_attr, p['conv1.weight'], p.get('conv1.bias'), selfconn=False)
+    a = F.relu(a) if relu_mask is None else a * relu_mask.to(a.dtype)
     if nout2 > 0:
         b = torch.tanh(F.linear(x, p['fc11.weight'], p['fc11.bias'])) * \
             torch.tanh(F.linear(x, p['fc12.weight'], p['fc12.bias']))
@@ -193,4 +195,4 @@ class OracleML3Layer(torch.nn.Module):
 
     def forward(self, x, edge_index, edge_attr):
         p = dict(self.named_parameters())
-        return ml3layer_forward(x, edge_index, edge_attr, p, self.learnedge, self.nout2)
+        return ml3layer_forward(x, edge_index, edge_attr, p, self.learnedge, self.nout2, getattr(self, '_relu_mask', None))

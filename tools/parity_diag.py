@@ -82,6 +82,9 @@ def main():
         rep = PS.compare(ref, pre[:, 0].detach().cpu().numpy(), {n: p.grad.detach().cpu().numpy() for n, p in m.named_parameters()})
         print('== %s  logits %.2e  worst termsum %.2e  maxnorm %.2e  head units flipped %d' % (mode, rep['logits_rel_err'], rep['worst_termsum'], rep['worst_maxnorm'], ref['head_units_flipped']))
         for i in range(1, 5):
+            if i in dacts and dacts[i].size(0) >= 3 * n0:
+                print('   layer %d: copies 0 / 1 / last of the device output bit-identical: %s %s' % (
+                    i, bool(torch.equal(dacts[i][:n0], dacts[i][n0:2 * n0])), bool(torch.equal(dacts[i][:n0], dacts[i][-n0:]))))
             if i in dacts and dacts[i].size(0) >= n0:
                 d = dacts[i][:n0].cpu().double()
                 e = (d[:, :acts[i].size(1)] - acts[i]).abs()
