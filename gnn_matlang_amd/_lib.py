@@ -119,7 +119,7 @@ class BatchDesc(ctypes.Structure):
     _fields_ = [(n, _p) for n in ('node_ptr', 'edge_ptr2', 'x', 'edge_index2', 'edge_attr2', 'es', 'tperm', 'tinv', 'rp_src', 'rp_dst', 'y')] + \
                [('G', _i64), ('E2all', _i64), ('F', _i32), ('S', _i32), ('ids', _p), ('B', _i32), ('n_pad', _i32), ('e2_pad', _i32), ('dmax', _i32)] + \
                [(n, _p) for n in ('x_out', 'ea_out', 'es_out', 'y_out', 'valid_out', 'ptr_out', 'batch_out', 'rowptr', 'col', 'perm', 'rowptr_t',
-                                  'col_t', 'pos_t')] + [('ldx_out', _i32)]
+                                  'col_t', 'pos_t')] + [('ldx_out', _i32), ('nblk_main', _i32), ('ginfo128', _p), ('ginfo_t128', _p)]
 
 
 GML_OK, GML_E_BADARG, GML_E_UNSUPPORTED, GML_E_WORKSPACE = 0, -1, -2, -3

@@ -356,6 +356,77 @@ __global__ __launch_bounds__(256) void gml_k_batch_assemble(const gml_batch_desc
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (ptr[mid + 1] > i) hi = mid; else lo = mid + 1; }
         return lo;
     };
+    // ---- blocks behind the element blocks: the 128-row group records of both CSR views (gml_csr_group_info's records, computed from the
+    //      same formulas the element blocks write -- no block reads another block's output), when the caller wants them
+    if ((int)blockIdx.x >= d.nblk_main) {
+        const int gb = (int)blockIdx.x - d.nblk_main, ngr = (d.n_pad + 127) / 128;
+        const int view = gb / ngr;                           // 0: target-keyed (rowptr / col -> ginfo128), 1: source-keyed (-> ginfo_t128)
+        const int64_t gidx = gb % ngr;
+        auto rowptr_of = [&](int64_t r) -> int {
+            if (r >= d.n_pad) return d.e2_pad;
+            if (r < n_real) {
+                const int g = seg_of(nnew, r);
+                const int64_t src = r - nnew[g] + nlo[g];
+                return (int)(enew[g] + (view ? d.rp_src[src] : d.rp_dst[src]));
+            }
+            const int64_t q = e_real + (r - n_real) * (int64_t)d.dmax;
+            return (int)(q < d.e2_pad ? q : d.e2_pad);
+        };
+        auto col_of = [&](int64_t k) -> int {
+            if (k < e_real) {
+                const int g = seg_of(enew, k);
+                const int64_t sp = elo[g] + (k - enew[g]);
+                return view ? (int)(d.edge_index2[d.E2all + sp] + nnew[g]) : (int)(d.edge_index2[elo[g] + d.tperm[sp]] + nnew[g]);
+            }
+            int64_t node = n_real + (k - e_real) / d.dmax;
+            return (int)(node > d.n_pad - 1 ? d.n_pad - 1 : node);
+        };
+        __shared__ int deg[128];
+        __shared__ int red[8];
+        __shared__ unsigned char row_of_rank[128];
+        __shared__ int rpl[129];
+        const int t = threadIdx.x;
+        const int64_t r0 = gidx * 128, r1 = min(r0 + 128, (int64_t)d.n_pad);
+        if (t <= 128) rpl[t] = rowptr_of(min(r0 + t, (int64_t)d.n_pad));
+        __syncthreads();
+        const int kb = rpl[0], ke = rpl[(int)(r1 - r0)];
+        int mn = INT32_MAX, mx = -1;
+        for (int k = kb + t; k < ke; k += 256) {
+            const int c = col_of(k);
+            mn = min(mn, c);
+            mx = max(mx, c);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            mn = min(mn, __shfl_xor(mn, off));
+            mx = max(mx, __shfl_xor(mx, off));
+        }
+        if ((t & 63) == 0) { red[2 * (t >> 6)] = mn; red[2 * (t >> 6) + 1] = mx; }
+        if (t < 128) deg[t] = (r0 + t < d.n_pad) ? rpl[t + 1] - rpl[t] : -1;      // rows past the end rank last
+        __syncthreads();
+        int32_t* rec = (view ? d.ginfo_t128 : d.ginfo128) + gidx * GML_GREC_INTS(128);
+        if (t == 0) {
+            mn = min(min(red[0], red[2]), min(red[4], red[6]));
+            mx = max(max(red[1], red[3]), max(red[5], red[7]));
+            int4 o;
+            o.x = kb; o.y = ke - kb; o.z = (ke > kb) ? mn : 0; o.w = (ke > kb) ? mx - mn + 1 : 0;
+            *reinterpret_cast<int4*>(rec) = o;
+        }
+        if (t < 128) {
+            const int dg = deg[t];
+            int rank = 0;
+            for (int u = 0; u < 128; ++u) rank += (deg[u] > dg || (deg[u] == dg && u < t)) ? 1 : 0;
+            row_of_rank[rank] = (unsigned char)t;
+        }
+        __syncthreads();
+        if (t < 128) {                                       // (the dealing of rank blocks to waves: gml_k_group_info, 128-row groups)
+            const int wave = t >> 4, i16 = t & 15;
+            const int a = ((wave & 3) + (int)gidx) & 3;
+            const int blk = (wave < 4) ? a : 7 - a;
+            reinterpret_cast<unsigned char*>(rec + 4)[t] = row_of_rank[blk * 16 + i16];
+        }
+        return;
+    }
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t ldo = d.ldx_out > d.F ? d.ldx_out : d.F;
     // ---- graphs
@@ -426,6 +497,10 @@ extern "C" int gml_batch_assemble(const gml_batch_desc* d, gml_stream_t stream) 
     const int64_t n = (d->n_pad + 1 > d->e2_pad ? d->n_pad + 1 : d->e2_pad);
     const int64_t m = n > d->B + 2 ? n : d->B + 2;
     const size_t lds = (size_t)(4 * d->B + 2) * sizeof(int64_t);
-    hipLaunchKernelGGL(gml_k_batch_assemble, dim3((unsigned)gml_cdiv(m, 256)), dim3(256), lds, (hipStream_t)stream, *d);
+    gml_batch_desc dd = *d;
+    if ((dd.ginfo128 == nullptr) != (dd.ginfo_t128 == nullptr)) return GML_E_BADARG;
+    dd.nblk_main = (int32_t)gml_cdiv(m, 256);
+    const int extra = dd.ginfo128 ? 2 * ((dd.n_pad + 127) / 128) : 0;
+    hipLaunchKernelGGL(gml_k_batch_assemble, dim3((unsigned)(dd.nblk_main + extra)), dim3(256), lds, (hipStream_t)stream, dd);
     return gml_launch_status();
 }

@@ -208,13 +208,12 @@ class DeviceDataset(object):
         with torch.cuda.device(dev):
             st = _stream(dev)
             import ctypes
-            _lib.call('gml_batch_assemble', ctypes.addressof(d), st)
             ng2 = max((n_pad + 127) // 128, 1)
             rec128 = int(_lib.lib().gml_csr_group_record_ints(128))
-            both = torch.empty(2, ng2, rec128, **i32)                      # (gml_csr_group_info writes every int of a 128-row record: no fill)
+            both = torch.empty(2, ng2, rec128, **i32)                      # (every int of a 128-row record is written: no fill)
             g.ginfo_t128, g.ginfo128 = both[0], both[1]
-            _lib.call('gml_csr_group_info2', _ptr(g.rowptr_t), _ptr(g.col_t), _ptr(g.ginfo_t128), _ptr(g.rowptr), _ptr(g.col), _ptr(g.ginfo128),
-                      n_pad, 128, st)                              # (both views: one launch)
+            d.ginfo128, d.ginfo_t128 = _ptr(g.ginfo128), _ptr(g.ginfo_t128)  # round 5: the group records of both views come out of the same launch
+            _lib.call('gml_batch_assemble', ctypes.addressof(d), st)
         g.gmax_t128 = g.gmax128 = (int(bounds['caps'][0]), int(bounds['caps'][1]))
         g.src_sorted = True
         if es is not None:                                                # the pre-split supports travel with the batch (functional.presplit_of)

@@ -163,6 +163,10 @@ typedef struct gml_batch_desc {
     float* x_out; float* ea_out; int32_t* es_out; float* y_out; float* valid_out; int32_t* ptr_out; int32_t* batch_out;
     int32_t* rowptr; int32_t* col; int32_t* perm; int32_t* rowptr_t; int32_t* col_t; int32_t* pos_t;
     int32_t ldx_out;   /* floats between rows of x_out (0: F); columns F .. ldx_out - 1 are written as zeros (float4-addressable rows) */
+    int32_t nblk_main; /* (set by the library) */
+    /* optional (both or neither): the 128-row group records of the target-keyed / source-keyed view, [ceil(n_pad / 128)][gml_csr_group_record_ints(128)]
+       ints each -- what gml_csr_group_info2 would compute from the assembled index arrays, written by the same launch (round 5) */
+    int32_t* ginfo128; int32_t* ginfo_t128;
 } gml_batch_desc;
 int gml_batch_assemble(const gml_batch_desc* d, gml_stream_t stream);
 /* out[k, :] = in[perm[k], :]   (rows of `width` floats) */
