@@ -531,14 +531,19 @@ __device__ __forceinline__ void gml_adam_elem(const gml_adam_job& q, int64_t i, 
 
 // 4096 elements per workgroup, workgroups laid out job after job (first_block: ZINC's 33 k parameters in 44 tensors are 52 workgroups
 // -- one per 1024 elements on a [chunks of the largest tensor] x [tensors] grid was 352, and their 352 same-address atomics cost more
-// than the update; ONE workgroup walking everything is a chain of 33 dependent memory round trips per thread: 40 us).  The LAST
-// workgroup to finish writes the step count back (every other one has read it by then).
+// than the update; ONE workgroup walking everything is a chain of 33 dependent memory round trips per thread: 40 us).
 __global__ __launch_bounds__(256) void gml_k_adam_many(const GmlAdamJobs jobs, int njobs, float* step, unsigned* done, float lr, float b1,
                                                        float b2, float eps) {
+    // step count hand-shake at the START of the workgroup, off the update's critical path: every thread reads step[0]; behind a barrier
+    // thread 0 counts the workgroup in; the LAST workgroup to be counted writes the new count (every other one has read the old one by
+    // then and carries it in registers) and clears the counter for the next launch
+    const float t = __builtin_nontemporal_load(step) + 1.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(done, 1u) == gridDim.x - 1) { *done = 0u; step[0] = t; }
     int j = 0;
     while (j + 1 < njobs && (int)blockIdx.x >= jobs.first_block[j + 1]) ++j;
     const gml_adam_job& q = jobs.j[j];
-    const float t = step[0] + 1.f;
     const float c1 = 1.f - __powf(b1, t), c2 = 1.f - __powf(b2, t);
     const float ss = lr / c1, rc2 = 1.f / sqrtf(c2);
     const int64_t base = (int64_t)((int)blockIdx.x - jobs.first_block[j]) * 4096;
@@ -546,11 +551,6 @@ __global__ __launch_bounds__(256) void gml_k_adam_many(const GmlAdamJobs jobs, i
     for (int u = 0; u < 16; ++u) {
         const int64_t i = base + u * 256 + threadIdx.x;
         if (i < q.n) gml_adam_elem(q, i, b1, b2, ss, rc2, eps);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        if (atomicAdd(done, 1u) == gridDim.x - 1) { step[0] = t; *done = 0u; __threadfence(); }
     }
 }
 
