@@ -277,3 +277,55 @@ def test_chain_after_bookkeeping():
     with torch.no_grad():
         c2.fc1_3.weight.add_(1.0)
     assert c2._edge_key(val, 'csr') != k0
+
+
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('gml_bench', os.path.join(ROOT, 'bench.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_line_is_compact():
+    """a 24 KB line made the driver's record unparseable.  The contract line is built from the full record by
+    bench.compact_line: json.loads round-trips, < 8,000 characters (budget 6,000), roofline + cpu_baseline + config kept
+    whatever else the record grows."""
+    import json
+    bench = _load_bench()
+    long = 'x' * 3000
+    res = {'metric': 'GNNML3 training graphs/sec on ZINC-12k', 'value': 14182965.75530812, 'unit': 'graphs/s', 'n_gpus': 1,
+           'steps': 20, 'warmup': 5, 'ms_per_step': 9.241508599916415, 'higher_is_better': True, 'scaling': 'weak',
+           'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+           'config': {'workload': long, 'graphs_per_gpu': 131072, 'parallelism': 'dp1'},
+           'roofline': {'bound': 'hbm', 'achieved': 2518.5193540469654, 'peak': 8000.0, 'unit': 'GB/s', 'frac': 0.3148149192558707,
+                        'traffic': 2560695226.6666665, 'kernel': long, 'traffic_source': long, 'note': long},
+           'cpu_baseline': {'value': 6320.123172658106, 'unit': 'graphs/s', 'cores': 16, 'kind': 'port', 'sample': long,
+                            'thread_ladder': [{'threads': t, 'value': 1.0} for t in range(200)]},
+           'other_configs': [{'note': long}] * 10, 'sr25_sweep': [{'note': long}] * 10, 'mnist75': {'note': long},
+           'parity_vs_oracle': {'note': long}, 'parity_vs_oracle_after_training': {'note': long},
+           'block_seconds': [0.1] * 500, 'per_rank_ms_per_step': [9.0] * 8,
+           'max_rel_err_vs_oracle': {m: {'gradients_termsum': 1e-5, 'logits': 1e-6} for m in ('a', 'b', 'c')},
+           'spmm': {'bound': 'hbm', 'achieved': 6025.0, 'peak': 8000.0, 'unit': 'GB/s', 'frac': 0.753, 'block_ms': [0.7] * 100},
+           'epoch_bs64': {'value': 244599.0, 'unit': 'graphs/s', 'ms_per_step': 0.26, 'mode': long, 'eager': {'note': long}},
+           'value_exact_fp32': {'value': 5.6e6, 'unit': 'graphs/s', 'ms_per_step': 23.3, 'arithmetic': long}}
+    line = bench.compact_line(res)
+    assert '\n' not in line and len(line) <= bench.LINE_BUDGET < 8000
+    back = json.loads(line)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in back, k
+    assert abs(back['value'] - res['value']) <= 1e-5 * res['value']
+    assert set(('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')) <= set(back['roofline'])
+    assert set(('value', 'unit', 'cores', 'kind', 'sample')) <= set(back['cpu_baseline'])
+    assert 'other_configs' not in back and 'sr25_sweep' not in back and 'block_seconds' not in back
+    # a record stuffed far beyond the budget still yields a parseable line with the mandatory objects
+    res['max_rel_err_vs_oracle_after_training'] = {('mode%d' % i): {'gradients_termsum': 1e-5, 'logits': 1e-6} for i in range(200)}
+    line = bench.compact_line(res)
+    back = json.loads(line)
+    assert len(line) <= bench.LINE_BUDGET and 'roofline' in back and 'cpu_baseline' in back and 'config' in back
+    # and the real round-5 record (24 KB) comes out well inside the budget
+    rec = os.path.join(ROOT, 'profiles', 'r05_f_bench_default.json')
+    if os.path.exists(rec):
+        line = bench.compact_line(json.load(open(rec)))
+        assert len(line) <= bench.LINE_BUDGET and json.loads(line)['roofline']['frac'] > 0
