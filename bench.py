@@ -804,7 +804,7 @@ def main():
             with torch.cuda.graph(gr):
                 o.zero_grad(set_to_none=True)               # gradients are handed over, not accumulated
                 gl = models.zinc_step_loss(rm, rb)
-                with Fn.deferred_folds():
+                with Fn.deferred_folds(list(rm.parameters())):
                     gl.backward()
                 o.step()
             for _ in range(20):
@@ -899,7 +899,7 @@ def main():
                         b = assemble(ids_buf, bd)
                         co.zero_grad(set_to_none=True)
                         l = models.zinc_step_loss(cm, b, loss_sum=loss_acc)                               # L1-sum over the real graphs (Zinc12k.py:365); head + loss: one launch each way
-                        with Fn.deferred_folds():                                      # the twelve partial-sum folds of the backward as ONE launch
+                        with Fn.deferred_folds(list(cm.parameters())):                 # the twelve partial-sum folds of the backward as ONE launch
                             l.backward(one_)                                           # (a resident unit gradient: no fill launch per step)
                         co.step()
                     ids_buf.copy_(torch.arange(Bq, device=dev))

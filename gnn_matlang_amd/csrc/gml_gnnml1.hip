@@ -413,13 +413,18 @@ extern "C" int gml_gnnml1_bwd(const int32_t* rowptr_t, const int32_t* col_t, con
     if (grid > 2 * GML_NUM_CU) grid = 2 * GML_NUM_CU;
     if (fpl == 4) {
         const size_t lds1 = (size_t)GmlG1Cfg<4>::fwd_floats(2 * nb3) * 4, lds2 = dx ? (size_t)GmlG1Cfg<4>::tr_floats(nb1 + 2 * nb3 + nb2) * 4 : 0;
+        if (lds1 > 160 * 1024 || lds2 > 160 * 1024) return GML_E_UNSUPPORTED;
+        GML_ALLOW_BIG_LDS(rc4a, (&gml_k_gnnml1_bwd<4, 1>), 160 * 1024)
+        if (rc4a != hipSuccess) return (int)rc4a;
         GML_ALLOW_BIG_LDS(rc4, (&gml_k_gnnml1_bwd<4, 2>), 160 * 1024)
         if (rc4 != hipSuccess) return (int)rc4;
         hipLaunchKernelGGL((gml_k_gnnml1_bwd<4, 1>), dim3((unsigned)grid), dim3(64 * G1_NW), lds1, st, p);
         hipLaunchKernelGGL((gml_k_gnnml1_bwd<4, 2>), dim3((unsigned)grid), dim3(64 * G1_NW), lds2, st, p);
     } else {
         const size_t lds1 = (size_t)GmlG1Cfg<16>::fwd_floats(2 * nb3) * 4, lds2 = dx ? (size_t)GmlG1Cfg<16>::tr_floats(nb1 + 2 * nb3 + nb2) * 4 : 0;
-        if (lds2 > 160 * 1024) return GML_E_UNSUPPORTED;
+        if (lds1 > 160 * 1024 || lds2 > 160 * 1024) return GML_E_UNSUPPORTED;
+        GML_ALLOW_BIG_LDS(rc16a, (&gml_k_gnnml1_bwd<16, 1>), 160 * 1024)
+        if (rc16a != hipSuccess) return (int)rc16a;
         GML_ALLOW_BIG_LDS(rc16, (&gml_k_gnnml1_bwd<16, 2>), 160 * 1024)
         if (rc16 != hipSuccess) return (int)rc16;
         hipLaunchKernelGGL((gml_k_gnnml1_bwd<16, 1>), dim3((unsigned)grid), dim3(64 * G1_NW), lds1, st, p);

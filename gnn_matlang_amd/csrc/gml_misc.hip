@@ -544,7 +544,9 @@ __global__ __launch_bounds__(256) void gml_k_adam_many(const GmlAdamJobs jobs, i
     int j = 0;
     while (j + 1 < njobs && (int)blockIdx.x >= jobs.first_block[j + 1]) ++j;
     const gml_adam_job& q = jobs.j[j];
-    const float c1 = 1.f - __powf(b1, t), c2 = 1.f - __powf(b2, t);
+    // 1 - b^t without the cancellation of 1 - pow(b, t) at small t (b2 = 0.999, t = 1: 4e-5 relative in fp32 with the fast pow --
+    // torch computes the corrections on the host in double): -expm1(t log(b)), log(b) = log1p(b - 1); once per thread
+    const float c1 = -expm1f(t * log1pf(b1 - 1.f)), c2 = -expm1f(t * log1pf(b2 - 1.f));
     const float ss = lr / c1, rc2 = 1.f / sqrtf(c2);
     const int64_t base = (int64_t)((int)blockIdx.x - jobs.first_block[j]) * 4096;
 #pragma unroll 4

@@ -135,7 +135,7 @@ class TrainStep(object):
         self.order.append('forward')
         if self.defer and loss.is_cuda:
             from . import functional as Fn
-            with Fn.deferred_folds():
+            with Fn.deferred_folds(list(self.model.parameters())):      # inert (plain folds) if a .grad survived zero()
                 loss.backward()
             self.order.append('backward+fold')
         else:

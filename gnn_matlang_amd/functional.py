@@ -65,15 +65,27 @@ _FOLDS_LOCK = _threading.Lock()
 
 
 class deferred_folds(object):
-    """``with deferred_folds(): loss.backward()`` -- every weight-gradient kernel launched inside leaves its per-workgroup partial
-    sums unfolded (include/gml.h "Deferred folds") and ONE launch folds them all when the scope closes (bit-identical sums: the
-    same order).  For the reference's batch size, where a step is a chain of tiny launches (twelve folds at ZINC's four
-    layers).  The gradient tensors autograd hands to the parameters are FILLED AT SCOPE EXIT: read .grad (optimizer, all-reduce)
-    after the ``with`` block, never inside it.  The scope is process-wide (the backward runs on autograd's worker threads, not on
-    the thread that opened it): one at a time, one device, not nestable."""
+    """``with deferred_folds(model.parameters()): loss.backward()`` -- every weight-gradient kernel launched inside leaves its
+    per-workgroup partial sums unfolded (include/gml.h "Deferred folds") and ONE launch folds them all when the scope closes
+    (bit-identical sums: the same order).  For the reference's batch size, where a step is a chain of tiny launches (twelve folds at
+    ZINC's four layers).  The gradient tensors autograd hands to the parameters are FILLED AT SCOPE EXIT: read .grad (optimizer,
+    all-reduce) after the ``with`` block, never inside it.
+
+    REQUIREMENT: every parameter's ``.grad`` is None when the backward runs (``zero_grad(set_to_none=True)``), so that autograd ADOPTS
+    the not-yet-filled tensor as ``.grad``.  With an existing ``.grad`` (``zero_grad(set_to_none=False)``, micro-batch accumulation)
+    AccumulateGrad would add the unfilled memory into it inside the scope and the fold would never reach it.  Pass the
+    parameters the backward reaches: if any of them already holds a gradient the scope is INERT -- the folds run undeferred, launch by
+    launch, and accumulation behaves as without the scope.  ``deferred_folds(None)`` = the caller vouches for the requirement.
+    The scope is process-wide (the backward runs on autograd's worker threads, not on the thread that opened it): one at a time, one
+    device, not nestable."""
+
+    def __init__(self, params):
+        self.active = params is None or all(p.grad is None for p in params)
 
     def __enter__(self):
         global _FOLDS
+        if not self.active:
+            return self
         with _FOLDS_LOCK:
             assert _FOLDS is None, 'deferred_folds scopes do not nest / overlap'
             _FOLDS = []
@@ -81,6 +93,8 @@ class deferred_folds(object):
 
     def __exit__(self, exc_type, *a):
         global _FOLDS
+        if not self.active:
+            return
         with _FOLDS_LOCK:
             jobs, _FOLDS = _FOLDS, None
         if exc_type is None:
@@ -658,7 +672,9 @@ class GNNML1BlockFunction(torch.autograd.Function):
                 sums = flat[e4:]
         hb1, hbc, hb2, hb3 = ctx.has_b
         db1 = sums[oa:oa + n1] if hb1 else None
-        dbc = (sums[oa:oa + n2] if mode == 0 else sums[oc:oc + n2]) if hbc else None
+        # mode 0: fc_i1's and conv_i1's biases receive the SAME column sums -- as two tensors with their own memory (autograd adopts a
+        # returned gradient as .grad; two parameters sharing one buffer would double every in-place op on the gradients: ADVICE r05)
+        dbc = ((sums[oa:oa + n2].clone() if hb1 else sums[oa:oa + n2]) if mode == 0 else sums[oc:oc + n2]) if hbc else None
         db2 = sums[o2:o2 + n3] if hb2 else None
         db3 = sums[o3:o3 + n3] if hb3 else None
         return dx, None, None, dw1, db1, dwc.view(1, Fin, n2), dbc, dw2, db2, dw3, db3, None, None

@@ -49,11 +49,21 @@ class OneLaunchAdam(torch.optim.Optimizer):
     (gml_adam_many, csrc/gml_misc.hip) -- for the reference's batch size, where a training step is a chain of ~30 launches of
     microseconds each and torch's fused Adam is three of them.  The step count lives on the device (capturable: every replay of a
     captured step advances it).  Moments are kept in one flat buffer; gradients may be any tensors (views of the fold buffers).
-    Parameters without a gradient at the FIRST step are left out for good (the job list is built once per gradient layout)."""
+    Parameters without a gradient at the FIRST step are left out for good (the job list is built once per gradient layout).
+
+    Checkpoints: ``state[p]`` holds ``step`` (the device count, one tensor shared by the parameters of a launch), ``exp_avg`` and
+    ``exp_avg_sq`` -- torch.optim.Adam's keys -- so ``state_dict()`` / ``load_state_dict()`` round-trip the count and the moments
+    (loading re-packs them into the flat buffer at the next step).  ``lr`` / ``betas`` / ``eps`` are passed to the launch BY VALUE:
+    a captured step (HIP graph) replays the values it was captured with -- a scheduler changing ``param_groups[..]['lr']`` needs a
+    re-capture (eager steps read the current value every time)."""
 
     def __init__(self, params, lr=0.001, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self._built = None
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._built = None                                   # the loaded moments / count are re-packed by the next step
 
     def _build(self):
         from . import _lib
@@ -70,13 +80,22 @@ class OneLaunchAdam(torch.optim.Optimizer):
             off = 0
             for p in ps:
                 st = self.state[p]
-                st['exp_avg'], st['exp_avg_sq'] = flat[0, off:off + p.numel()].view_as(p), flat[1, off:off + p.numel()].view_as(p)
+                for row, key in enumerate(('exp_avg', 'exp_avg_sq')):
+                    view = flat[row, off:off + p.numel()].view_as(p)
+                    if key in st:                            # loaded from a checkpoint (or a rebuild): keep the values
+                        view.copy_(st[key])
+                    st[key] = view
                 off += p.numel()
             for i in range(0, len(ps), _lib.GML_ADAM_MAX_JOBS):
                 part = ps[i:i + _lib.GML_ADAM_MAX_JOBS]
                 # (every chunk advances a step count of its own, in lockstep: no copy between the launches of one optimizer step)
-                chunks.append(dict(group=group, ps=part, step=torch.zeros(1, dtype=torch.float32, device=dev),
-                                   done=torch.zeros(1, dtype=torch.int32, device=dev), dev=dev))
+                step = torch.zeros(1, dtype=torch.float32, device=dev)
+                old = [self.state[p]['step'] for p in part if 'step' in self.state[p]]
+                if old:                                      # resume: the count the checkpoint holds (the same for every parameter)
+                    step.fill_(float(torch.as_tensor(old[0]).reshape(-1)[0]))
+                for p in part:
+                    self.state[p]['step'] = step
+                chunks.append(dict(group=group, ps=part, step=step, done=torch.zeros(1, dtype=torch.int32, device=dev), dev=dev))
         self._built = chunks
 
     @torch.no_grad()

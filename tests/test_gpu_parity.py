@@ -1060,7 +1060,7 @@ def test_deferred_folds_are_bit_identical(dev, model):
     flush = Fn.flush_folds
     Fn.flush_folds = lambda jobs: (seen.append(len(jobs)), flush(jobs))
     try:
-        with Fn.deferred_folds():
+        with Fn.deferred_folds(m.parameters()):
             l.backward()
     finally:
         Fn.flush_folds = flush
@@ -1964,3 +1964,118 @@ def test_xty_wide_vs_fp64(dev, n, a, b):
     assert out is not None
     ref = A.double().t() @ B.double()
     close(out, ref.float(), tol=2e-5, what='xty_wide')
+
+
+def test_deferred_folds_with_existing_grads_accumulate_correctly(dev):
+    """a deferred-fold scope hands autograd tensors that are filled only at scope exit -- correct only when every .grad is
+    None.  With gradients already present (zero_grad(set_to_none=False), micro-batch accumulation) the scope must be inert: two
+    backward passes inside scopes accumulate exactly what two plain backward passes accumulate."""
+    from gnn_matlang_amd import SpectralDesign, collate, functional as Fn, models, synthetic
+    raw = synthetic.make_graphs('zinc', 32, seed=5)
+    b = collate(SpectralDesign(recfield=2, dv=2, nfreq=7).design_many(raw)).to(dev)
+    torch.manual_seed(4)
+    m = models.zinc_gnnml3().to(dev)
+    for _ in range(2):
+        models.zinc_loss(m(b), b.y).backward()
+    ref = {n: p.grad.clone() for n, p in m.named_parameters()}
+    m.zero_grad(set_to_none=True)
+    for k in range(2):
+        l = models.zinc_loss(m(b), b.y)
+        scope = Fn.deferred_folds(m.parameters())
+        assert scope.active == (k == 0)
+        with scope:
+            l.backward()
+    for n, p in m.named_parameters():
+        assert torch.equal(p.grad, ref[n]), 'accumulated gradient differs: ' + n
+    m.zero_grad(set_to_none=False)                                   # zeroed buffers kept: the scope must stand aside
+    l = models.zinc_loss(m(b), b.y)
+    with Fn.deferred_folds(m.parameters()) as scope:
+        assert not scope.active
+        l.backward()
+    for n, p in m.named_parameters():
+        assert torch.allclose(p.grad * 2, ref[n], rtol=0, atol=0) or torch.equal(p.grad + p.grad, ref[n]), n
+
+
+def test_gnnml1_block_bias_gradients_do_not_share_memory(dev):
+    """in the sum form (mode 0) fc_i1.bias and conv_i1.bias receive the same column sums; the two gradients autograd
+    adopts must not be one buffer (clip_grad_norm_ / accumulation would hit both).  Plus: two backward passes accumulate to twice one,
+    and an in-place scale of every gradient scales each bias gradient ONCE."""
+    from gnn_matlang_amd import SpectralDesign, collate, models, synthetic
+    raw = synthetic.make_graphs('counting', 12, seed=9)
+    b = collate(SpectralDesign(recfield=1, dv=1, nfreq=10, adddegree=True, laplacien=False, addadj=True).design_many(raw)).to(dev)
+    torch.manual_seed(1)
+    m = models.GNNML1(int(b.x.size(1)), nout=16, concat=False).to(dev)
+    m(b).square().sum().backward()
+    spans = {}
+    for n, p in m.named_parameters():
+        if p.grad is None:
+            continue
+        lo, hi = p.grad.data_ptr(), p.grad.data_ptr() + p.grad.numel() * 4
+        for n2, (lo2, hi2) in spans.items():
+            assert hi <= lo2 or hi2 <= lo, 'gradients of %s and %s overlap in memory' % (n, n2)
+        spans[n] = (lo, hi)
+    assert 'fc11.bias' in spans and 'conv11.bias' in spans
+    one = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    assert torch.equal(one['fc11.bias'], one['conv11.bias'])
+    for n, p in m.named_parameters():
+        if p.grad is not None:
+            p.grad.mul_(0.5)
+    for n, p in m.named_parameters():
+        if p.grad is not None:
+            assert torch.equal(p.grad, one[n] * 0.5), n
+            p.grad.mul_(2.0)
+    m(b).square().sum().backward()
+    for n, p in m.named_parameters():
+        if p.grad is not None:
+            assert torch.allclose(p.grad, 2 * one[n], rtol=1e-5, atol=1e-6 * float(one[n].abs().max())), n
+
+
+def test_one_launch_adam_checkpoint_resume_and_first_steps(dev):
+    """(1) OneLaunchAdam's state_dict carries the step count and the moments, and a fresh optimizer that loads it BEFORE
+    its first step continues exactly where the first one stopped (bias corrections included); loading into a running optimizer works
+    too.  (2) the bias corrections at t = 1 .. 3 are formed without cancellation: one step from zero moments moves every parameter by
+    lr * sign(g) to 2e-7 relative (|g| >> eps), which 1 - __powf(0.999, t) missed by 3e-5."""
+    from gnn_matlang_amd.optim import OneLaunchAdam
+    torch.manual_seed(3)
+    sizes = [7, 1024, 5000]
+    grads = [[torch.randn(n, device=dev) for n in sizes] for _ in range(6)]
+
+    def run(opt, ps, its):
+        for it in its:
+            for p, g in zip(ps, grads[it]):
+                p.grad = g.clone()
+            opt.step()
+    p0 = [torch.randn(n, device=dev) for n in sizes]
+    pa = [p.clone().requires_grad_(True) for p in p0]
+    oa = OneLaunchAdam(pa, lr=1e-2)
+    run(oa, pa, range(6))                                         # six uninterrupted steps
+    pb = [p.clone().requires_grad_(True) for p in p0]
+    ob = OneLaunchAdam(pb, lr=1e-2)
+    run(ob, pb, range(3))
+    sd = ob.state_dict()
+    assert all(float(torch.as_tensor(s['step']).reshape(-1)[0]) == 3.0 and 'exp_avg' in s and 'exp_avg_sq' in s for s in sd['state'].values())
+    import copy
+    sd = copy.deepcopy(sd)
+    pc = [p.detach().clone().requires_grad_(True) for p in pb]
+    oc = OneLaunchAdam(pc, lr=1e-2)
+    oc.load_state_dict(sd)                                        # before the first step
+    run(oc, pc, range(3, 6))
+    for a, c in zip(pa, pc):
+        assert torch.equal(a, c), 'resumed run differs from the uninterrupted one'
+    ob.load_state_dict(copy.deepcopy(sd))                         # into a running optimizer
+    run(ob, pb, range(3, 6))
+    for a, b in zip(pa, pb):
+        assert torch.equal(a, b)
+    # (2) first step: p - lr * g / (|g| + eps) exactly as torch computes it in double
+    for t in range(1, 4):
+        q = [torch.zeros(n, device=dev).requires_grad_(True) for n in sizes]
+        r = [torch.zeros(n, device=dev).requires_grad_(True) for n in sizes]
+        oq, orr = OneLaunchAdam(q, lr=1e-2), torch.optim.Adam(r, lr=1e-2)
+        for it in range(t):
+            for a, b, g in zip(q, r, grads[it]):
+                a.grad, b.grad = g.clone(), g.clone()
+            oq.step()
+            orr.step()
+        for a, b in zip(q, r):
+            err = float((a - b).abs().max() / b.abs().max())
+            assert err <= 3e-7, ('bias correction', t, err)

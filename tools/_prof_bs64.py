@@ -16,7 +16,7 @@ def step():
     b = dsd.batch_assembled(ids, bd)
     co.zero_grad(set_to_none=True)
     l = models.zinc_step_loss(cm, b, loss_sum=acc)
-    with Fn.deferred_folds():
+    with Fn.deferred_folds(None):
         l.backward(one_)
     co.step()
 for _ in range(3): step()

@@ -52,7 +52,7 @@ def main():
         if args.plain_head:
             l.backward()
         else:
-            with Fn.deferred_folds():
+            with Fn.deferred_folds(None):
                 l.backward(one_)
         co.step()
         if args.plain_head:
