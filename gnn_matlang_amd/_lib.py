@@ -47,6 +47,8 @@ SIGNATURES = {
     'gml_spectconv_bwd_mix': (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _i32,
                                              _i64, _i32, _i32, _i32, _i32, _i32, _u32, _p, _sz, _p]),
     'gml_edge_mlp_fwd_stack': (ctypes.c_int, [_p, _i32, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
+    'gml_edge_mlp_fwd_stack6': (ctypes.c_int, [_p, _i32, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
+    'gml_edge_mlp_fwd6': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
     'gml_spectconv_bwd_mix_relu': (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _i32, _i32,
                                                   _i64, _i32, _i32, _i32, _i32, _i32, _u32, _p, _sz, _p]),
     'gml_spectconv_bwd_mix_relu2': (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _i32, _p, _i32, _i32,
@@ -126,6 +128,7 @@ GML_OK, GML_E_BADARG, GML_E_UNSUPPORTED, GML_E_WORKSPACE = 0, -1, -2, -3
 GML_RELU, GML_ACCUM, GML_F32_MFMA, GML_GROUPS128, GML_GROUPS64R, GML_DMA_RING, GML_FWD_CHUNKED, GML_DVAL_ACCUM = 1, 2, 4, 8, 16, 32, 64, 128
 GML_POOL_SKIP_LAST = 2
 GML_FWD_ONEWIN = 256
+GML_F16X3 = 1024                # gml_spectconv_fwd / gml_ml3_fwd, ring kernel: f16 (hi, lo) pieces under power-of-two scales
 GML_NO_FOLD = 512               # gml_spectconv_bwd*: leave the dW partials in ws (gml_fold_many)
 GML_FOLD_MAX_JOBS = 16
 

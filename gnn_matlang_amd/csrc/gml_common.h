@@ -192,6 +192,43 @@ __device__ __forceinline__ void gml_split8(const float (&x)[8], bf16x8& hi, bf16
     }
 }
 
+// ---- "f16x3": the same three split products on f16 pieces (11 + 11 significant bits: hi + lo = x to 2^-24 -- fp32's own rounding --
+// where the bf16 pair stops at 2^-17), same MFMA rate, same operand layouts.  f16 has 5 exponent bits, so every operand goes through a
+// power-of-two scale (exact) that puts its tile's / column's largest magnitude just below 2^15; elements more than 2^17 below that
+// maximum lose relative (not absolute) precision gracefully: the absolute floor is 2^-39 of the maximum.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// scale s = 2^k with m * s in [2^14, 2^15) for a maximum m >= 0 (bits), and 1 / s; both kept inside the normal range
+__device__ __forceinline__ void gml_f16_scale_bits(uint32_t mbits, float& s, float& inv) {
+    const int e = (int)(mbits >> 23) & 0xff;
+    const int sb = min(268 - e, 253);
+    s = __uint_as_float((uint32_t)sb << 23);
+    inv = __uint_as_float((uint32_t)(254 - sb) << 23);
+}
+// maximum over the wave of a non-negative float's bits (non-negative floats order like their bit patterns); all 64 lanes active
+__device__ __forceinline__ uint32_t gml_wave_max_bits(uint32_t v) {
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true));     // quad_perm [1,0,3,2]
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true));     // quad_perm [2,3,0,1]
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true));    // row_half_mirror
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true));    // row_mirror
+    const uint32_t a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const uint32_t c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return max(max(a, b), max(c, d));
+}
+// x * s -> (hi, lo) f16 pairs
+__device__ __forceinline__ void gml_split8_f16(const float (&x)[8], float s, f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x2 v = f32x2{x[2 * i], x[2 * i + 1]} * s;
+        const f16x2 h = __builtin_convertvector(v, f16x2);
+        const f32x2 r = v - __builtin_convertvector(h, f32x2);
+        const f16x2 l = __builtin_convertvector(r, f16x2);
+        hi[2 * i] = h[0]; hi[2 * i + 1] = h[1];
+        lo[2 * i] = l[0]; lo[2 * i + 1] = l[1];
+    }
+}
+
 // sum of partial[w * n + j] over w = wl, wl + 16, ... < nparts in ascending order (the fixed order of every
 // partial fold), eight clamped, unconditional loads in flight per step instead of one dependent load per add
 __device__ __forceinline__ float gml_fold_column(const float* __restrict__ partial, int64_t nparts, int64_t n,

@@ -76,6 +76,12 @@ __device__ __forceinline__ void gml_quad_transpose(f32x4& v, int lane) {
     }
 }
 
+// operand piece type of the projection: bf16 pairs (bf16x3) or f16 pairs under power-of-two scales (f16x3, gml_common.h)
+template <bool F16> struct GmlPiece { using T = bf16x8; };
+template <> struct GmlPiece<true> { using T = f16x8; };
+__device__ __forceinline__ f32x4 gml_mfma_piece(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 gml_mfma_piece(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
 template <int S>
 struct GmlFwd3Cfg {
     static constexpr int ROWS = 128;
@@ -102,10 +108,14 @@ struct GmlFwd3Cfg {
 
 // MIX: the ML3Layer Hadamard branch (F2 <= 8) of the group's own rows rides along (see fwd2); EP: value rows through p.epos
 // EPL: epilogue (GmlFwdParams::epl): 0 sum over supports, 1 ConCat column blocks, 2 depthwise scale-then-one-projection
-template <int S, int NOB, bool MIX, bool EP, int EPL = 0>
+// F16: the projection (and the Hadamard branch) on f16 (hi, lo) pieces -- GML_F16X3: the aggregates of a 16-row tile share one
+// power-of-two scale (the tile's largest magnitude just below 2^15), every output column of W its own; undone in the epilogue
+template <int S, int NOB, bool MIX, bool EP, int EPL = 0, bool F16 = false>
 __global__ __launch_bounds__(GmlFwd3Cfg<S>::NT, 1) void gml_k_spectconv_fwd3(const GmlFwdParams p) {
     using C = GmlFwd3Cfg<S>;
+    using FT = typename GmlPiece<F16>::T;
     static_assert(S % 4 == 0, "float4 value rows");
+    static_assert(!F16 || EPL == 0, "f16 pieces: the sum-over-supports epilogue");
     static_assert(EPL == 0 || (!MIX && !EP), "epilogue variants: plain SpectConv calls");
     constexpr bool OWNX = MIX || EPL == 2;                     // the lane's own x row is needed (Hadamard branch / depthwise self term)
     constexpr int SW = EPL == 2 ? 1 : S;                       // W images (depthwise: one matrix)
@@ -127,14 +137,35 @@ __global__ __launch_bounds__(GmlFwd3Cfg<S>::NT, 1) void gml_k_spectconv_fwd3(con
     const bool loader = wave >= 8;
 
     // ---- once per workgroup: W image, zeroed X areas (chunks at or beyond Fin are never written by a DMA and stay zero)
+    // f16 pieces: first the largest magnitude of every output column (32 words of slot 0's column area, not yet in use)
+    uint32_t* cmax = reinterpret_cast<uint32_t*>(lds_raw + C::OFF_SLOT + C::OFF_COL);
+    if constexpr (F16) {
+        if (tid < 32) cmax[tid] = 0u;
+        __syncthreads();
+        for (int e = tid; e < SW * 32 * 32; e += C::NT) {
+            const int f = e & 31, o = (e >> 5) & 31, s = e >> 10;
+            if (f < p.Fin && o < p.Fout)
+                atomicMax(&cmax[o], __float_as_uint(fabsf(p.w[(int64_t)(p.s0 + s) * p.w_ss + (int64_t)f * p.w_si + (int64_t)o * p.w_so])));
+        }
+        __syncthreads();
+    }
     for (int e = tid; e < SW * 32 * 32; e += C::NT) {
         const int f = e & 31, o = (e >> 5) & 31, s = e >> 10;
         const float v = (f < p.Fin && o < p.Fout) ? p.w[(int64_t)(p.s0 + s) * p.w_ss + (int64_t)f * p.w_si + (int64_t)o * p.w_so] : 0.f;
-        const __bf16 h = (__bf16)v;
-        const __bf16 l = (__bf16)(v - (float)h);
         const int iof = (s * 32 + o) * 32 + ((((f >> 3) ^ gml_wkey(o)) & 3) << 3) + (f & 7);
-        Wof_h[iof] = h;
-        Wof_l[iof] = l;
+        if constexpr (F16) {
+            float sc, inv;
+            gml_f16_scale_bits(cmax[o], sc, inv);
+            const float vs = v * sc;
+            const _Float16 h = (_Float16)vs;
+            reinterpret_cast<_Float16*>(Wof_h)[iof] = h;
+            reinterpret_cast<_Float16*>(Wof_l)[iof] = (_Float16)(vs - (float)h);
+        } else {
+            const __bf16 h = (__bf16)v;
+            const __bf16 l = (__bf16)(v - (float)h);
+            Wof_h[iof] = h;
+            Wof_l[iof] = l;
+        }
     }
     // depthwise: [S + 1][32] scales right behind the single hi W image (bytes [0, 2048)); the lo image keeps its place at byte
     // W_HALF * 2 = S * 2048 (>= 8192), so [2048, 2048 + 128 (S + 1)) is free for S in {4, 8} (r03: it sat at byte 8192 -- ON the
@@ -280,8 +311,13 @@ __global__ __launch_bounds__(GmlFwd3Cfg<S>::NT, 1) void gml_k_spectconv_fwd3(con
         // Compute waves: one 16-row tile each
         // =====================================================================================================
         float bias_r[NOB];
+        float winv_r[NOB];                                     // f16 pieces: 1 / (scale of the lane's W column)
 #pragma unroll
-        for (int ob = 0; ob < NOB; ++ob) bias_r[ob] = (p.bias && ob * 16 + r16 < p.Fout) ? p.bias[ob * 16 + r16] : 0.f;
+        for (int ob = 0; ob < NOB; ++ob) {
+            bias_r[ob] = (p.bias && ob * 16 + r16 < p.Fout) ? p.bias[ob * 16 + r16] : 0.f;
+            winv_r[ob] = 1.f;
+            if constexpr (F16) { float sc; gml_f16_scale_bits(cmax[ob * 16 + r16], sc, winv_r[ob]); }
+        }
         // Wide output stores (one 16-byte store per lane and 16-column block instead of four 4-byte ones, the Hadamard columns
         // merged into the conv tile they complete): possible when the row is written in whole float4 chunks -- columns
         // [0, Fout (+ F2)) with mix_col = Fout, a multiple of 4 in total, float4-addressable rows.  ZINC: 30 + 2 = 32.
@@ -292,8 +328,8 @@ __global__ __launch_bounds__(GmlFwd3Cfg<S>::NT, 1) void gml_k_spectconv_fwd3(con
         // B[k = f][n = c] of the Hadamard product.  Narrow stores: c < F2 -> w11 row c, F2 <= c < 2 F2 -> w12 row c - F2 (partner
         // column c + F2).  Wide stores: w11 row i at column m0 + i -- where the product belongs in the conv tile -- and
         // w12 row i at column (m0 + i) ^ 8 (partner = lane ^ 8).
-        bf16x8 mwh, mwl;
-        float mbias = 0.f;
+        FT mwh, mwl;
+        float mbias = 0.f, mwinv = 1.f;
         if constexpr (MIX) {
             int r11 = -1, r12 = -1;                            // the w11 / w12 row this lane's column carries
             if (wide) {
@@ -309,7 +345,18 @@ __global__ __launch_bounds__(GmlFwd3Cfg<S>::NT, 1) void gml_k_spectconv_fwd3(con
                 const int f = 8 * kq + j;
                 v[j] = (f < p.Fin && r11 >= 0) ? p.w11[r11 * p.Fin + f] : ((f < p.Fin && r12 >= 0) ? p.w12[r12 * p.Fin + f] : 0.f);
             }
-            gml_split8(v, mwh, mwl);
+            if constexpr (F16) {                               // the column's scale: maximum over the four k groups of the lane's column
+                float m = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[j]));
+                m = fmaxf(m, __shfl_xor(m, 16));
+                m = fmaxf(m, __shfl_xor(m, 32));
+                float sc;
+                gml_f16_scale_bits(__float_as_uint(m), sc, mwinv);
+                gml_split8_f16(v, sc, mwh, mwl);
+            } else {
+                gml_split8(v, mwh, mwl);
+            }
             if (r11 >= 0) mbias = p.b11 ? p.b11[r11] : 0.f;
             else if (r12 >= 0) mbias = p.b12 ? p.b12[r12] : 0.f;
         }
@@ -423,8 +470,9 @@ __global__ __launch_bounds__(GmlFwd3Cfg<S>::NT, 1) void gml_k_spectconv_fwd3(con
 
             // ---- projection: out tile = sum_s acc_s W_s (acc split on the fly = A fragments, k = f = 8*kq + j)
             f32x4 oacc[NOB];
+            float oscale[NOB];
 #pragma unroll
-            for (int ob = 0; ob < NOB; ++ob) oacc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int ob = 0; ob < NOB; ++ob) { oacc[ob] = f32x4{0.f, 0.f, 0.f, 0.f}; oscale[ob] = 1.f; }
             if constexpr (EPL == 2) {
                 // depthwise (libs/spect_conv.py:81-91): scale the aggregates per feature, add the scaled own row, project ONCE
                 float hs[8];
@@ -477,30 +525,43 @@ __global__ __launch_bounds__(GmlFwd3Cfg<S>::NT, 1) void gml_k_spectconv_fwd3(con
                 }
                 continue;                                      // (every block is stored: nothing left for the common epilogue)
             } else {
-                bf16x8 wh[2][NOB], wl[2][NOB];
+                FT wh[2][NOB], wl[2][NOB];
                 auto frag = [&](int s, int st) {
 #pragma unroll
                     for (int ob = 0; ob < NOB; ++ob) {
                         const int o = ob * 16 + r16;           // B[k = f][n = o]: 8 consecutive f of column o
                         const int off = (s * 32 + o) * 32 + (((kq ^ gml_wkey(o)) & 3) << 3);
-                        wh[st][ob] = *reinterpret_cast<const bf16x8*>(Wof_h + off);
-                        wl[st][ob] = *reinterpret_cast<const bf16x8*>(Wof_l + off);
+                        wh[st][ob] = *reinterpret_cast<const FT*>(Wof_h + off);
+                        wl[st][ob] = *reinterpret_cast<const FT*>(Wof_l + off);
                     }
                 };
                 frag(0, 0);
+                float asc = 1.f;                               // f16 pieces: the tile's scale and the epilogue's factor per column block
+                if constexpr (F16) {
+                    float m = 0.f;
+#pragma unroll
+                    for (int s = 0; s < S; ++s)
+#pragma unroll
+                        for (int h = 0; h < 4; ++h) m = fmaxf(fmaxf(fabsf(acc[s][h].x), fabsf(acc[s][h].y)), m);
+                    float ainv;
+                    gml_f16_scale_bits(gml_wave_max_bits(__float_as_uint(m)), asc, ainv);
+#pragma unroll
+                    for (int ob = 0; ob < NOB; ++ob) oscale[ob] = ainv * winv_r[ob];
+                }
 #pragma unroll
                 for (int s = 0; s < ((GML_FWABL & 2) ? 0 : S); ++s) {
                     const int st = s & 1;
                     if (s + 1 < S) frag(s + 1, st ^ 1);
                     const float av[8] = {acc[s][0].x, acc[s][0].y, acc[s][1].x, acc[s][1].y, acc[s][2].x, acc[s][2].y, acc[s][3].x, acc[s][3].y};
-                    bf16x8 ah, al;
-                    gml_split8(av, ah, al);
+                    FT ah, al;
+                    if constexpr (F16) gml_split8_f16(av, asc, ah, al);
+                    else gml_split8(av, ah, al);
 #pragma unroll
-                    for (int ob = 0; ob < NOB; ++ob) oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wh[st][ob], oacc[ob], 0, 0, 0);
+                    for (int ob = 0; ob < NOB; ++ob) oacc[ob] = gml_mfma_piece(al, wh[st][ob], oacc[ob]);
 #pragma unroll
-                    for (int ob = 0; ob < NOB; ++ob) oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wl[st][ob], oacc[ob], 0, 0, 0);
+                    for (int ob = 0; ob < NOB; ++ob) oacc[ob] = gml_mfma_piece(ah, wl[st][ob], oacc[ob]);
 #pragma unroll
-                    for (int ob = 0; ob < NOB; ++ob) oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wh[st][ob], oacc[ob], 0, 0, 0);
+                    for (int ob = 0; ob < NOB; ++ob) oacc[ob] = gml_mfma_piece(ah, wh[st][ob], oacc[ob]);
                 }
                 __builtin_amdgcn_sched_group_barrier(0x100, 2 * NOB, 0);
 #pragma unroll
@@ -520,21 +581,32 @@ __global__ __launch_bounds__(GmlFwd3Cfg<S>::NT, 1) void gml_k_spectconv_fwd3(con
                 for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
-                        const float v = oacc[ob][reg] + bias_r[ob];
+                        const float v = F16 ? fmaf(oacc[ob][reg], oscale[ob], bias_r[ob]) : oacc[ob][reg] + bias_r[ob];
                         ov[ob][reg] = relu ? fmaxf(v, 0.f) : v;
                     }
                 if constexpr (MIX) {
                     // z[row][c] = x[row] . wmix[c]: A = the lane's row (k = f), D: lane (c = r16, kq) holds rows 4*kq + reg
-                    bf16x8 xh, xl;
-                    gml_split8(xrow, xh, xl);
+                    FT xh, xl;
+                    float zsc = 1.f;
+                    if constexpr (F16) {
+                        float m = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(xrow[j]));
+                        float xsc, xinv;
+                        gml_f16_scale_bits(gml_wave_max_bits(__float_as_uint(m)), xsc, xinv);
+                        gml_split8_f16(xrow, xsc, xh, xl);
+                        zsc = xinv * mwinv;
+                    } else {
+                        gml_split8(xrow, xh, xl);
+                    }
                     f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
-                    z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, mwh, z, 0, 0, 0);
-                    z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, mwl, z, 0, 0, 0);
-                    z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, mwh, z, 0, 0, 0);
+                    z = gml_mfma_piece(xl, mwh, z);
+                    z = gml_mfma_piece(xh, mwl, z);
+                    z = gml_mfma_piece(xh, mwh, z);
                     const bool mine = r16 >= m0 && r16 < m0 + p.F2;
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
-                        const float t = gml_tanh_short(z[reg] + mbias);
+                        const float t = F16 ? gml_tanh(fmaf(z[reg], zsc, mbias)) : gml_tanh_short(z[reg] + mbias);
                         const float u = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t), 0x128, 0xf, 0xf, true));   // row_ror:8 = lane ^ 8
                         if (mine) ov[NOB - 1][reg] = t * u;
                     }
@@ -555,7 +627,7 @@ __global__ __launch_bounds__(GmlFwd3Cfg<S>::NT, 1) void gml_k_spectconv_fwd3(con
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
                         const int lr = (int)((out_rows >> (8 * reg)) & 255u);
-                        float v = oacc[ob][reg] + bias_r[ob];
+                        float v = F16 ? fmaf(oacc[ob][reg], oscale[ob], bias_r[ob]) : oacc[ob][reg] + bias_r[ob];
                         if (relu) v = fmaxf(v, 0.f);
                         const int off = (o < p.Fout && lr < nr && !(GML_FWABL & 4)) ? (lr * (int)p.ldo + o) * 4 : 0x7fffff00;
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ors, off, 0, 0);
@@ -563,15 +635,26 @@ __global__ __launch_bounds__(GmlFwd3Cfg<S>::NT, 1) void gml_k_spectconv_fwd3(con
                 }
                 GML_TF3(7);
                 if constexpr (MIX) {
-                    bf16x8 xh, xl;
-                    gml_split8(xrow, xh, xl);
+                    FT xh, xl;
+                    float zsc = 1.f;
+                    if constexpr (F16) {
+                        float m = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(xrow[j]));
+                        float xsc, xinv;
+                        gml_f16_scale_bits(gml_wave_max_bits(__float_as_uint(m)), xsc, xinv);
+                        gml_split8_f16(xrow, xsc, xh, xl);
+                        zsc = xinv * mwinv;
+                    } else {
+                        gml_split8(xrow, xh, xl);
+                    }
                     f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
-                    z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, mwh, z, 0, 0, 0);
-                    z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, mwl, z, 0, 0, 0);
-                    z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, mwh, z, 0, 0, 0);
+                    z = gml_mfma_piece(xl, mwh, z);
+                    z = gml_mfma_piece(xh, mwl, z);
+                    z = gml_mfma_piece(xh, mwh, z);
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
-                        const float t = gml_tanh_short(z[reg] + mbias);
+                        const float t = F16 ? gml_tanh(fmaf(z[reg], zsc, mbias)) : gml_tanh_short(z[reg] + mbias);
                         const float u = __shfl(t, lane + p.F2);    // partner column c + F2 of the same 16-lane row group
                         const int lr = (int)((out_rows >> (8 * reg)) & 255u);
                         const int off = (r16 < p.F2 && lr < nr) ? (lr * (int)p.ldo + p.mix_col + r16) * 4 : 0x7fffff00;
@@ -601,7 +684,19 @@ int gml_launch_fwd3(const GmlFwdParams& p, dim3 grid, hipStream_t st, bool mix);
                            GmlFwd3Cfg<SV>::lds_bytes(), st, p);                                              \
         return gml_launch_status();                                                                          \
     }
-#define GML_FWD3_LAUNCH(SV, NOBV, MX, EPV) GML_FWD3_LAUNCH_L(SV, NOBV, MX, EPV, 0)
+#define GML_FWD3_LAUNCH_F(SV, NOBV, MX, EPV, F16V)                                                           \
+    {                                                                                                        \
+        GML_ALLOW_BIG_LDS(rc_, (&gml_k_spectconv_fwd3<SV, NOBV, MX, EPV, 0, F16V>), 160 * 1024)              \
+        if (rc_ != hipSuccess) return (int)rc_;                                                              \
+        hipLaunchKernelGGL((gml_k_spectconv_fwd3<SV, NOBV, MX, EPV, 0, F16V>), grid, dim3(GmlFwd3Cfg<SV>::NT), \
+                           GmlFwd3Cfg<SV>::lds_bytes(), st, p);                                              \
+        return gml_launch_status();                                                                          \
+    }
+#define GML_FWD3_LAUNCH(SV, NOBV, MX, EPV)                                                                   \
+    {                                                                                                        \
+        if (p.flags & GML_F16X3) GML_FWD3_LAUNCH_F(SV, NOBV, MX, EPV, true)                                  \
+        GML_FWD3_LAUNCH_F(SV, NOBV, MX, EPV, false)                                                          \
+    }
 #define GML_DEFINE_FWD3(SV, NOBV)                                                                            \
     template <>                                                                                              \
     int gml_launch_fwd3<SV, NOBV>(const GmlFwdParams& p, dim3 grid, hipStream_t st, bool mix) {              \

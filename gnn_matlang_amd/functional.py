@@ -35,12 +35,23 @@ import threading as _threading
 _TLS = _threading.local()
 
 
-def exact_mode():
+# Diagnostic switches (tools/precision_diag.py): EXACT_ONLY = None or a set of kernel families ('edge', 'conv') -- exact products are then
+# taken only by those families; FORCE_BWD_EXACT = None / True / False overrides the arithmetic a backward inherits from its forward.
+EXACT_ONLY = None
+FORCE_BWD_EXACT = None
+
+
+def _bwd_exact(ctx):
+    return ctx.exact if FORCE_BWD_EXACT is None else bool(FORCE_BWD_EXACT)
+
+
+def exact_mode(family='conv'):
     """True when the launches of THIS thread run on exact f32 products: the process-wide default F32_MFMA (environment, tests,
     bench) or an exact_products() scope of this thread.  The scope is thread-local: autograd runs a layer's backward on its own
     worker thread, and a scope entered there (ctx.exact) must not flip the arithmetic of a forward another thread is in the
     middle of."""
-    return bool(F32_MFMA) or getattr(_TLS, 'exact', 0) > 0
+    on = bool(F32_MFMA) or getattr(_TLS, 'exact', 0) > 0
+    return on and (EXACT_ONLY is None or family in EXACT_ONLY)
 
 
 class exact_products(object):
@@ -252,6 +263,18 @@ def rows4(x):
     return v
 
 
+# The FORWARD projection of the ring kernel (fwd3: every ML3Layer of the ZINC config) on f16 (hi, lo) pieces under power-of-two scales
+# (GML_F16X3, csrc/gml_common.h "f16x3": residual 2^-24 per operand instead of 2^-17, same matrix-pipe instruction count) -- the
+# default since round 6; GML_FWD_F16=0 restores the bf16 pairs.  With the three-piece edge forward (EDGE_FWD6) this makes the whole
+# forward pass fp32-class, which is what trained-state gradients need (profiles/r06_precision_diag.jsonl); the backward kernels
+# keep bf16x3 (measured not to matter).
+FWD_F16 = _os.environ.get('GML_FWD_F16', '1') not in ('0', '')
+
+
+def _fwd_arith_flags():
+    return _lib.GML_F32_MFMA if exact_mode() else (_lib.GML_F16X3 if FWD_F16 else 0)
+
+
 # ---------------------------------------------------------------------------- raw launches
 def fused_conv(rowptr, col, ginfo, epos, val, x, ldx, w, w_strides, bias, out, ldo, nrows, S, Fin, Fout, flags=0,
                out_off=0, tag='spectconv_fwd'):
@@ -266,7 +289,7 @@ def _fused_conv(rowptr, col, ginfo, epos, val, x, ldx, w, w_strides, bias, out, 
     _lib.call('gml_spectconv_fwd', _ptr(rowptr), _ptr(col), _ptr(ginfo), _ptr(epos), _ptr(val), _ptr(x), int(ldx),
               _ptr(w), int(w_strides[0]), int(w_strides[1]), int(w_strides[2]), _ptr(bias),
               _off(out, out_off), int(ldo), int(nrows), int(S), int(Fin), int(Fout),
-              int(flags) | (_lib.GML_F32_MFMA if exact_mode() else 0), _stream(x.device))
+              int(flags) | _fwd_arith_flags(), _stream(x.device))
 
 
 def conv_epilogue_applies(S, Fin, Fout):
@@ -461,16 +484,26 @@ def edge_mlp_fwd(ea, w1, w2, w3, w4, tpos=None, ea_split=None):
         return out[:, :So].contiguous(), (out_t[:, :So].contiguous() if out_t is not None else None)
     out = torch.empty(E, So, dtype=torch.float32, device=ea.device)
     out_t = torch.empty(E, So, dtype=torch.float32, device=ea.device) if tpos is not None else None
-    if exact_mode():                                      # exact arithmetic covers the edge branch too (round 5: it did not)
+    if exact_mode('edge'):                                # exact arithmetic covers the edge branch too (round 5: it did not)
         _lib.call('gml_edge_mlp_fwd_exact', _ptr(ea), _ptr(w1), _ptr(w2), _ptr(w3), _ptr(w4), _ptr(out), _ptr(tpos), _ptr(out_t),
                   int(E), int(S), int(So), _stream(ea.device))
         return out, out_t
+    if EDGE_FWD6 and 2 <= S <= 8 and not EDGE_VALU:       # three-piece products (fp32-class), reads the fp32 rows itself
+        rc = _lib.lib().gml_edge_mlp_fwd6(_ptr(ea), _ptr(w1), _ptr(w2), _ptr(w3), _ptr(w4), _ptr(out), _ptr(tpos), _ptr(out_t),
+                                          int(E), int(S), int(So), _stream(ea.device))
+        if rc != _lib.GML_E_UNSUPPORTED:
+            _lib.check(rc)
+            return out, out_t
     _lib.call('gml_edge_mlp_fwd', _ptr(ea), _ptr(ea_split), _ptr(w1), _ptr(w2), _ptr(w3), _ptr(w4), _ptr(out), _ptr(tpos),
               _ptr(out_t), int(E), int(S), int(So), _stream(ea.device))
     return out, out_t
 
 
 EDGE_STACK = not _os.environ.get('GML_NO_EDGE_STACK')     # A/B switch: edge branches of stacked layers in one launch
+# The edge-branch FORWARD on three-piece products ("bf16x6", csrc/gml_edge_chain6_impl.h: fp32-class learned supports) -- the default
+# since round 6; GML_EDGE_FWD6=0 restores the two-piece chain (bf16x3: ~5e-7 rms on the supports, which after training moved
+# parameter gradients to 1e-3 .. 1e-2 of their term sums: profiles/r06_precision_diag.jsonl).
+EDGE_FWD6 = _os.environ.get('GML_EDGE_FWD6', '1') not in ('0', '')
 
 
 def edge_mlp_fwd_stack(ea, ea_split, weights):
@@ -479,10 +512,20 @@ def edge_mlp_fwd_stack(ea, ea_split, weights):
     import ctypes
     E, S = ea.shape
     L = len(weights)
-    if exact_mode() or ea_split is None or not (2 <= L <= 4) or any(w[3].size(0) != S or w[0].size(1) != S for w in weights):
+    if exact_mode('edge') or not (2 <= L <= 4) or any(w[3].size(0) != S or w[0].size(1) != S for w in weights):
         return None                                       # (the stacked kernel is a matrix-core chain: not the exact arithmetic)
-    outs = [torch.empty(E, S, dtype=torch.float32, device=ea.device) for _ in range(L)]
     arr = lambda ts: (ctypes.c_void_p * L)(*[t.data_ptr() for t in ts])
+    if EDGE_FWD6 and not EDGE_VALU and S in (4, 8):
+        outs = [torch.empty(E, S, dtype=torch.float32, device=ea.device) for _ in range(L)]
+        rc = _lib.lib().gml_edge_mlp_fwd_stack6(_ptr(ea), L, arr([w[0] for w in weights]), arr([w[1] for w in weights]),
+                                                arr([w[2] for w in weights]), arr([w[3] for w in weights]), arr(outs), int(E), int(S),
+                                                int(S), _stream(ea.device))
+        if rc != _lib.GML_E_UNSUPPORTED:
+            _lib.check(rc)
+            return outs
+    if ea_split is None:
+        return None
+    outs = [torch.empty(E, S, dtype=torch.float32, device=ea.device) for _ in range(L)]
     rc = _lib.lib().gml_edge_mlp_fwd_stack(_ptr(ea_split), L, arr([w[0] for w in weights]), arr([w[1] for w in weights]),
                                            arr([w[2] for w in weights]), arr([w[3] for w in weights]), arr(outs), int(E), int(S),
                                            int(S), _stream(ea.device))
@@ -507,7 +550,7 @@ def edge_mlp_bwd(ea, w1, w2, w3, w4, gout, need_gin, ea_split=None):
     ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=dev)
     gin = torch.empty_like(ea) if need_gin else None
     dw1, dw2, dw3, dw4 = torch.empty_like(w1), torch.empty_like(w2), torch.empty_like(w3), torch.empty_like(w4)
-    if exact_mode():
+    if exact_mode('edge'):
         _lib.call('gml_edge_mlp_bwd_exact', _ptr(ea), _ptr(w1), _ptr(w2), _ptr(w3), _ptr(w4), _ptr(gout), _ptr(gin),
                   _ptr(dw1), _ptr(dw2), _ptr(dw3), _ptr(dw4), int(E), int(S), int(So), _ptr(ws), ws.numel(), _stream(dev))
         return gin, dw1, dw2, dw3, dw4
@@ -1091,7 +1134,7 @@ class SpectConvFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
-        with exact_products(ctx.exact):
+        with exact_products(_bwd_exact(ctx)):
             return SpectConvFunction._backward(ctx, gout)
 
     @staticmethod
@@ -1209,7 +1252,7 @@ class ML3LayerFunction(torch.autograd.Function):
                           Fin * nout1, nout1, 1, _ptr(cb_), _ptr(w11 if mixk else None),
                           _ptr(b11 if mixk else None), _ptr(w12 if mixk else None),
                           _ptr(b12 if mixk else None), _ptr(out), C, N, S, Fin, nout1, int(nout2) if mixk else 0,
-                          _lib.GML_RELU | gflag | (_lib.GML_F32_MFMA if exact_mode() else 0), _stream(x.device))
+                          _lib.GML_RELU | gflag | _fwd_arith_flags(), _stream(x.device))
             if nout2 > 0 and not mixk:
                 # ninp > 64 or nout2 > 24 (ptc.py:331-338 has ninp = 80): two plain library GEMMs + elementwise
                 out[:, nout1:] = torch.tanh(_linear(x, w11, b11)) * torch.tanh(_linear(x, w12, b12))
@@ -1230,7 +1273,7 @@ class ML3LayerFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
-        with exact_products(ctx.exact):
+        with exact_products(_bwd_exact(ctx)):
             return ML3LayerFunction._backward(ctx, gy)
 
     @staticmethod

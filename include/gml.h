@@ -63,6 +63,9 @@ enum {
                          edges per work item -- for batches whose groups need edge chunks (the caller knows the batch's largest group) */
     GML_DMA_RING = 32,  /* gml_spectconv_bwd / _bwd_mix: take the LDS-DMA landing-ring kernel (bwd4) where it applies; the
                          forward uses its ring kernel (fwd3) by default (GML_FWD_DMA=0 in the environment turns it off)   */
+    GML_F16X3 = 1024,   /* gml_spectconv_fwd / gml_ml3_fwd on the ring kernel (fwd3): project with f16 (hi, lo) pieces under per-tile /
+                         per-column power-of-two scales instead of bf16 pairs: residual 2^-24 instead of 2^-17 per operand, same
+                         instruction count on the matrix pipe (csrc/gml_common.h "f16x3").  Ignored by the other kernel families. */
     GML_NO_FOLD = 512   /* gml_spectconv_bwd / _bwd_mix / _bwd_mix_relu with dw != NULL: dw is NOT written -- the per-workgroup partial
                          sums stay in ws as [parts][S * Fin * Fout], parts = gml_spectconv_bwd_workspace_bytes(...) / (4 S Fin Fout) --
                          for a later gml_fold_many (the reference's batch 64: twelve fold launches of a step become one) */
@@ -322,6 +325,17 @@ int gml_edge_mlp_wide_fwd(const float* ea, const float* w1, const float* w2, con
 int gml_edge_mlp_fwd_stack(const void* ea_split, int32_t nlayers, const float* const* w1, const float* const* w2,
                            const float* const* w3, const float* const* w4, float* const* out,
                            int64_t num_edges, int32_t S, int32_t Sout, gml_stream_t stream);
+/* The edge-branch FORWARD with fp32-class products on the bf16 matrix cores ("bf16x6": every operand cut into three bf16 pieces, the
+ * products down to 2^-24 kept; csrc/gml_edge_chain6_impl.h; reference: libs/spect_conv.py:205-207, fp32 throughout).  Reads the fp32
+ * rows of ea itself (no pre-split image).  gml_edge_mlp_fwd6: one layer, 2 <= S = Sout <= 8, out / tpos / out_t as gml_edge_mlp_fwd.
+ * gml_edge_mlp_fwd_stack6: the layers of a stack in one pass (host pointer arrays as gml_edge_mlp_fwd_stack), S = Sout in {4, 8},
+ * 1 <= nlayers <= 4.  GML_E_UNSUPPORTED outside those shapes.  The default forward of the host side since round 6: the two-piece
+ * chain's ~5e-7 error on the learned supports is what moved trained-state gradients beyond 1e-4 of their term sums (DESIGN s6). */
+int gml_edge_mlp_fwd6(const float* ea, const float* w1, const float* w2, const float* w3, const float* w4, float* out,
+                      const int32_t* tpos, float* out_t, int64_t num_edges, int32_t S, int32_t Sout, gml_stream_t stream);
+int gml_edge_mlp_fwd_stack6(const float* ea, int32_t nlayers, const float* const* w1, const float* const* w2,
+                            const float* const* w3, const float* const* w4, float* const* out,
+                            int64_t num_edges, int32_t S, int32_t Sout, gml_stream_t stream);
 size_t gml_edge_mlp_bwd_workspace_bytes(int64_t num_edges, int32_t S, int32_t Sout);
 /* gout: dL/dout [E, Sout].  Writes dw1..dw4 (same shapes as the weights) and, if gin != NULL,
  * dL/dea [E, S].  Intermediates are recomputed from ea. */

@@ -23,18 +23,22 @@ def dev():
     return torch.device('cuda:0')
 
 
-@pytest.fixture(params=['bf16x3', 'f32', 'bf16x3-ring'])
+@pytest.fixture(params=['default', 'f32', 'default-ring', 'bf16x3'])
 def arith(request):
-    """projection arithmetic of the fused kernels: the default bf16 hi/lo split on the matrix cores (three products per
-    fp32 product, ~2^-17 operand residual) and the exact f32-input MFMA (GML_F32_MFMA).  The golden suites run in both --
-    and a third time with the fused backward on its LDS-DMA landing-ring kernel (bwd4, opt-in: GML_DMA_RING), so that the
-    non-default kernel stays parity-checked (the forward's ring kernel, fwd3, is the default wherever it applies)."""
+    """arithmetic of the fused kernels.  'default' (round 6): the FORWARD pass fp32-class -- edge branch on three-piece bf16 products
+    (gml_edge_mlp_fwd6), conv projection + Hadamard branch on f16 (hi, lo) pieces under power-of-two scales (GML_F16X3) -- and the
+    backward kernels on the bf16 hi/lo split (three products per fp32 product, ~2^-17 operand residual); 'f32': the exact f32-input
+    MFMA family everywhere (GML_F32_MFMA); 'bf16x3': the bf16 pairs in the forward too (rounds 1-5's default: GML_EDGE_FWD6=0
+    GML_FWD_F16=0).  The golden suites run in all of them -- and once more with the fused backward on its LDS-DMA landing-ring kernel
+    (bwd4, opt-in: GML_DMA_RING), so that the non-default kernel stays parity-checked."""
     from gnn_matlang_amd import functional as Fn
-    old, old_ring = Fn.F32_MFMA, Fn.BWD_DMA
+    old = Fn.F32_MFMA, Fn.BWD_DMA, Fn.EDGE_FWD6, Fn.FWD_F16
     Fn.F32_MFMA = request.param == 'f32'
     Fn.BWD_DMA = request.param.endswith('-ring')
+    if request.param == 'bf16x3':
+        Fn.EDGE_FWD6 = Fn.FWD_F16 = False
     yield request.param.split('-')[0]
-    Fn.F32_MFMA, Fn.BWD_DMA = old, old_ring
+    Fn.F32_MFMA, Fn.BWD_DMA, Fn.EDGE_FWD6, Fn.FWD_F16 = old
 
 
 def cu(a, dev):
@@ -2079,3 +2083,47 @@ def test_one_launch_adam_checkpoint_resume_and_first_steps(dev):
         for a, b in zip(q, r):
             err = float((a - b).abs().max() / b.abs().max())
             assert err <= 3e-7, ('bias correction', t, err)
+
+
+@pytest.mark.parametrize('cx,cw', [(0, 0), (40, 20), (-40, -20), (60, -50), (-90, 30)])
+def test_f16_forward_is_scale_invariant(dev, cx, cw):
+    """GML_F16X3 (the forward projection on f16 pieces): the per-tile / per-column power-of-two scales make the arithmetic
+    independent of the operands' magnitude -- x * 2^cx and W * 2^cw give EXACTLY 2^(cx + cw) times the unscaled output (no overflow
+    to inf at 2^60, no flush at 2^-90, bit for bit), for the conv columns and, with the Hadamard branch's weights scaled too, for
+    its pre-activations (checked through the conv columns only: tanh is not homogeneous).  And the result sits at fp32 level
+    against float64: 3e-6 of the term sum where the bf16 pairs sit at 1e-5."""
+    from gnn_matlang_amd import ML3Layer, SpectralDesign, collate, synthetic, functional as Fn
+    raw = synthetic.make_graphs('zinc', 64, seed=11)
+    b = collate(SpectralDesign(recfield=2, dv=2, nfreq=7).design_many(raw)).to(dev)
+    torch.manual_seed(5)
+    layer = ML3Layer(False, 8, 8, 32, 30, 2).to(dev)
+    x = torch.randn(b.x.size(0), 32, device=dev)
+    csr = b.csr('edge_index2')
+    old = Fn.FWD_F16
+    Fn.FWD_F16 = True
+    try:
+        with torch.no_grad():
+            y0 = layer(x, csr, b.edge_attr2)
+            layer.conv1.bias.zero_()
+            y1 = layer(x, csr, b.edge_attr2)[:, :30]
+            layer.conv1.weight.mul_(2.0 ** cw)
+            y2 = layer(x * 2.0 ** cx, csr, b.edge_attr2)[:, :30]
+    finally:
+        Fn.FWD_F16 = old
+    assert torch.isfinite(y2).all()
+    assert torch.equal(y2, y1 * 2.0 ** (cx + cw)), float((y2 / 2.0 ** (cx + cw) - y1).abs().max())
+    if cx == 0 and cw == 0:
+        # against float64 under the term-sum criterion (relu = the device's own mask where the two disagree near zero)
+        xd, vd, wd = x.double().cpu(), b.edge_attr2.double().cpu(), layer.conv1.weight.double().cpu()
+        ei = b.edge_index2.cpu()
+        ref = torch.zeros(x.size(0), 30, dtype=torch.float64)
+        tsum = torch.zeros_like(ref)
+        for s_ in range(8):
+            h = torch.zeros(x.size(0), 32, dtype=torch.float64).index_add_(0, ei[1], vd[:, s_:s_ + 1] * xd[ei[0]])
+            ha = torch.zeros(x.size(0), 32, dtype=torch.float64).index_add_(0, ei[1], vd[:, s_:s_ + 1].abs() * xd[ei[0]].abs())
+            ref += h @ wd[s_]
+            tsum += ha @ wd[s_].abs()
+        got = y1.double().cpu()
+        err = ((got - ref.clamp(min=0)).abs() / tsum.clamp(min=1e-300))
+        err[(ref.abs() < 1e-5 * tsum)] = 0                      # units at the kink
+        assert float(err.max()) <= 3e-6, float(err.max())
