@@ -7,8 +7,10 @@ A step = forward + L1-sum loss + backward + (N>1: one flat SUM all-reduce of the
 of the reference's ZINC GNNML3 (Zinc12k.py:310-371: 4 x ML3Layer 30+2, S = 8 supports, 25 input
 features, add-pool, fc 32 -> 1, lr 1e-3) over one batch of synthetic ZINC-like graphs per GPU (weak
 scaling: graphs per GPU fixed; --global-batch: strong scaling).  Inputs are resident in HBM before the
-timed region.  Storage and accumulation are fp32; the projections run as bf16 hi/lo splits on the matrix
-cores (``value_exact_fp32`` is the same step with exact fp32 products).
+timed region.  Storage and accumulation are fp32; the products run as split pieces on the matrix cores: the forward
+pass fp32-class (edge branch three bf16 pieces / six products, conv projection f16 hi/lo under power-of-two scales), the
+backward on bf16 hi/lo (``value_bf16x3`` is the same step with bf16 hi/lo in the forward too -- rounds 1-5's headline
+arithmetic, whose trained-state gradients miss 1e-4; ``value_exact_fp32`` the step with exact fp32 products everywhere).
 
 With --gpus N > 1 and no WORLD_SIZE in the environment bench.py starts the N ranks itself
 (python -m torch.distributed.run ...) before touching the GPU and relays rank 0's line.
@@ -37,7 +39,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 measured achievable
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32-in MFMA (= fp32 vector) peak
-DTYPE = 'f32 storage/accumulate, bf16x3-split products'
+DTYPE = 'f32 storage/accumulate; forward products fp32-class (edge branch bf16x6, conv f16x3 split), backward products bf16x3 split'
 
 
 LINE_BUDGET = 6000           # characters: the driver's capture keeps only the tail of stdout (8,000 characters in round 5)
@@ -254,21 +256,27 @@ def parity_vs_oracle(model, data, base, log):
                criterion='|got - ref| <= 1e-4 * T per element; T = sum of |terms| at product level, per layer from the float64 activations and output gradients (oracle/parity_at_size.py, oracle/termsums.py), ref = oracle in float64',
                modes={})
     T = None
-    for mode in ('bf16x3', 'f32'):
+    for mode in ('default', 'bf16x3', 'f32'):
         for p_ in model.parameters():
             p_.grad = None
         outs, n0_ = {}, int(base.x.size(0))
         hooks = [getattr(model, 'conv%d' % i).register_forward_hook(lambda mod, inp, o, i=i: outs.__setitem__(i, o.detach()))
                  for i in range(1, model.nlayers)]
-        with Fn.exact_products(mode == 'f32'):
-            cap = {}
-            pre = model(data, _capture=cap)
-            models.zinc_loss(pre, data.y).backward()
-            for h_ in hooks:
-                h_.remove()
-            with torch.no_grad():                          # the last layer's per-node output (inside the model it is pooled in its own
-                L_ = model.nlayers                         # autograd node): the same kernels on the same input -- the same values
-                outs[L_] = getattr(model, 'conv%d' % L_)(outs[L_ - 1], data.csr('edge_index2'), data.edge_attr2)
+        keep = Fn.EDGE_FWD6, Fn.FWD_F16
+        if mode == 'bf16x3':                               # bf16 hi/lo pieces in the forward too (rounds 1-5's default)
+            Fn.EDGE_FWD6 = Fn.FWD_F16 = False
+        try:
+            with Fn.exact_products(mode == 'f32'):
+                cap = {}
+                pre = model(data, _capture=cap)
+                models.zinc_loss(pre, data.y).backward()
+                for h_ in hooks:
+                    h_.remove()
+                with torch.no_grad():                      # the last layer's per-node output (inside the model it is pooled in its own
+                    L_ = model.nlayers                     # autograd node): the same kernels on the same input -- the same values
+                    outs[L_] = getattr(model, 'conv%d' % L_)(outs[L_ - 1], data.csr('edge_index2'), data.edge_attr2)
+        finally:
+            Fn.EDGE_FWD6, Fn.FWD_F16 = keep
         outs = {i: o[:n0_].clone() for i, o in outs.items()}      # first copy (the copies are bit-identical on the device: tools/parity_diag.py)
         grads_dev = {n: p_.grad.detach().cpu().numpy() for n, p_ in model.named_parameters()}
         ref = PS.reference(host, model.state_dict(), data.y, pre_dev=pre[:, 0], T=T, head_pre_dev=cap['head_pre'])
@@ -289,7 +297,7 @@ def parity_vs_oracle(model, data, base, log):
                                   oracle_seconds=round(ref['seconds'], 2))
         nflip = sum(v['differing'] for v in flips.values())
         log('parity at bench size, %s: logits %.2e, gradients %.2e of their term sums (worst: %s), %s; %d of %d relu units on the other side of zero' % (
-            mode, rep['logits_rel_err'], rep['worst_termsum'], worst[0], 'within 1e-4' if rep['ok'] else 'beyond 1e-4 (forward error of the bf16 splits: relu flips / small activations, DESIGN s6)',
+            mode, rep['logits_rel_err'], rep['worst_termsum'], worst[0], 'within 1e-4' if rep['ok'] else 'beyond 1e-4 (forward error of the bf16 pairs: relu units downstream decide differently, DESIGN s6)',
             nflip, sum(v['units'] for v in flips.values())) + '; with the float64 pass on the device\'s activation pattern: %.2e' % rep_m['worst_termsum'])
         wm = max(rep_m['tensors'].items(), key=lambda kv: kv[1]['termsum'])
         log('   worst element on the device pattern: %s%s got %.6e ref %.6e T %.3e (tensor max %.3e)' % (wm[0], wm[1]['worst_index'], wm[1]['worst_got'], wm[1]['worst_ref'], wm[1]['worst_T'], wm[1]['tensor_max_abs']))
@@ -716,6 +724,16 @@ def main():
             res['roofline_exact_fp32'] = candx[0]
             res['roofline_exact_fp32_other'] = candx[1:]
             log('exact fp32: %.3f ms/step' % (dtx / args.steps * 1e3))
+            # ---- the same step with bf16 hi/lo pieces in the forward too (rounds 1-5's headline arithmetic)
+            keep_ = Fn.EDGE_FWD6, Fn.FWD_F16
+            Fn.EDGE_FWD6 = Fn.FWD_F16 = False
+            for _ in range(2):
+                step()
+            dt3, _ = timed_block(step, args.steps)
+            Fn.EDGE_FWD6, Fn.FWD_F16 = keep_
+            res['value_bf16x3'] = dict(value=data.num_graphs * args.steps / dt3, unit='graphs/s', ms_per_step=dt3 / args.steps * 1e3,
+                                       arithmetic='bf16 hi/lo pieces (three products per fp32 product) in every kernel, short tanh in the edge chain: GML_EDGE_FWD6=0 GML_FWD_F16=0')
+            log('bf16x3 everywhere: %.3f ms/step' % (dt3 / args.steps * 1e3))
             # ---- a NEW batch every step: the per-batch index work inside the timed region
             fields = {k: v for k, v in data.__dict__.items() if not k.startswith('_')}
 

@@ -45,11 +45,45 @@ __device__ __forceinline__ GmlOp3 gml_wop3(const float (&v)[8]) {
     return o;
 }
 
+// tanh of two arguments that arrive pre-scaled by 2 log2(e) (z = x / k, k = ln(2) / 2).  TA: relative-accurate -- below |x| = 1/4 the odd
+// series of gml_tanh_small in the scaled argument, x + x^3 P(x^2) = z (k + w (b0 + w (b1 + w (b2 + w b3)))), w = z^2,
+// b_i = k^(2 i + 3) a_i, both values at once on the packed fp32 pipe (6 packed operations per pair; series error 8e-9 relative);
+// otherwise (and above 1/4) the short form 1 - 2 / (e^2x + 1), ~2e-7 ABSOLUTE
+template <bool TA>
+__device__ __forceinline__ void gml_tanh_pair_scaled(float z2, float z3, float& t2, float& t3) {
+    t2 = fmaf(-2.f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(z2) + 1.f), 1.f);
+    t3 = fmaf(-2.f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(z3) + 1.f), 1.f);
+    if constexpr (TA) {
+        const f32x2 zz = f32x2{z2, z3};
+        const f32x2 w = zz * zz;
+        f32x2 q = w * 1.5776033314321529e-06f - 3.241205933362716e-05f;     // b3 = k^9 62/2835, b2 = -k^7 17/315
+        q = q * w + 6.666779073214221e-04f;                               // b1 = k^5 2/15
+        q = q * w - 1.3876027166205392e-02f;                              // b0 = -k^3 / 3
+        q = q * w + 0.34657359027997264f;                                 // k
+        q = q * zz;
+        t2 = fabsf(z2) < 0.7213475f ? q.x : t2;
+        t3 = fabsf(z3) < 0.7213475f ? q.y : t3;
+    }
+}
+
 template <int S>
 struct GmlChain6W {           // weight operands of one wave and one layer (36 registers)
     bf16x8 a1A[3], a1B[3];    // layer 1: W1, W2, W3 rows (k = in-channel); piece per lane group: A (h, h, m, m), B (h, l, m, l)
     bf16x8 a2[3];             // layer 2: W4 pieces h, m, l (k = [h1 4g..4g+3 | h23 4g..4g+3]); rows 8..15 repeat rows 0..7
 };
+
+// (xa, xb) in D layout -> the three piece tuples (a01, a23, b01, b23); the two residual subtractions run on the matrix pipe
+// (x - h = [-I | 0] H + x, gml_split_pair: exact) -- the kernel is VALU-issue-bound, an MFMA costs two VALU slots, the 24 unpack /
+// subtract operations it replaces cost 24
+__device__ __forceinline__ void gml_split3_tiles(const GmlNegI& N, const f32x4 xa, const f32x4 xb, u32x4& ph, u32x4& pm, u32x4& pl) {
+    ph = u32x4{gml_pack2(xa[0], xa[1]), gml_pack2(xa[2], xa[3]), gml_pack2(xb[0], xb[1]), gml_pack2(xb[2], xb[3])};
+    const bf16x8 H = __builtin_bit_cast(bf16x8, ph);
+    const f32x4 ra = GML_MFMA(N.first, H, xa), rb = GML_MFMA(N.second, H, xb);
+    pm = u32x4{gml_pack2(ra[0], ra[1]), gml_pack2(ra[2], ra[3]), gml_pack2(rb[0], rb[1]), gml_pack2(rb[2], rb[3])};
+    const bf16x8 M = __builtin_bit_cast(bf16x8, pm);
+    const f32x4 sa = GML_MFMA(N.first, M, ra), sb = GML_MFMA(N.second, M, rb);
+    pl = u32x4{gml_pack2(sa[0], sa[1]), gml_pack2(sa[2], sa[3]), gml_pack2(sb[0], sb[1]), gml_pack2(sb[2], sb[3])};
+}
 
 template <int S>
 __device__ __forceinline__ void gml_chain6_load_weights(GmlChain6W<S>& W, const float* __restrict__ w1, const float* __restrict__ w2,
@@ -98,8 +132,8 @@ __device__ __forceinline__ void gml_chain6_b1(const float (&e)[8], int g, bf16x8
 
 // out (pre-activation, rows q = 4 (g & 1) + r) of one tile.  TA: relative-accurate tanh (series below 1/4, as gml_tanh) instead of the
 // short form 1 - 2 / (e^2x + 1), whose ~2e-7 ABSOLUTE error is what is left of the branch's error once the products are exact
-template <int S, bool TA>
-__device__ __forceinline__ f32x4 gml_chain6_forward(const GmlChain6W<S>& W, const bf16x8 BA, const bf16x8 BB) {
+template <int S, bool TA, bool RES>
+__device__ __forceinline__ f32x4 gml_chain6_forward(const GmlChain6W<S>& W, const GmlNegI& negI, const bf16x8 BA, const bf16x8 BB) {
     const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 z[3];
 #pragma unroll
@@ -107,28 +141,22 @@ __device__ __forceinline__ f32x4 gml_chain6_forward(const GmlChain6W<S>& W, cons
     float h[8];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {                            // z[1], z[2] arrive pre-scaled by 2 log2(e): z = x / k, k = ln(2) / 2
-        float t2 = fmaf(-2.f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(z[1][r]) + 1.f), 1.f);
-        float t3 = fmaf(-2.f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(z[2][r]) + 1.f), 1.f);
-        if constexpr (TA) {
-            // |x| < 1/4: the odd series of gml_tanh_small in the scaled argument, x + x^3 P(x^2) = z (k + w (b0 + w (b1 + w (b2 + w b3)))),
-            // w = z^2, b_i = k^(2 i + 3) a_i -- both tanh of a row at once on the packed fp32 pipe (6 packed operations per pair)
-            const f32x2 zz = f32x2{z[1][r], z[2][r]};
-            const f32x2 w = zz * zz;
-            f32x2 q = w * 1.5776033314321529e-06f - 3.241205933362716e-05f;     // b3 = k^9 62/2835, b2 = -k^7 17/315
-            q = q * w + 6.666779073214221e-04f;                               // b1 = k^5 2/15
-            q = q * w - 1.3876027166205392e-02f;                              // b0 = -k^3 / 3
-            q = q * w + 0.34657359027997264f;                                 // k      (series error 8e-9 relative below |x| = 1/4)
-            q = q * zz;
-            t2 = fabsf(z[1][r]) < 0.7213475f ? q.x : t2;
-            t3 = fabsf(z[2][r]) < 0.7213475f ? q.y : t3;
-        }
+        float t2, t3;
+        gml_tanh_pair_scaled<TA>(z[1][r], z[2][r], t2, t3);
         h[r] = gml_relu1(z[0][r]);
         h[4 + r] = t2 * t3;
     }
-    uint32_t hh[4], hm[4], hl[4];                            // (h1 pair, h1 pair, h23 pair, h23 pair)
+    bf16x8 Bh, Bm, Bl;                                       // (h1 pair, h1 pair, h23 pair, h23 pair) of each piece
+    if constexpr (RES) {
+        u32x4 ph, pm, pl;
+        gml_split3_tiles(negI, f32x4{h[0], h[1], h[2], h[3]}, f32x4{h[4], h[5], h[6], h[7]}, ph, pm, pl);
+        Bh = __builtin_bit_cast(bf16x8, ph); Bm = __builtin_bit_cast(bf16x8, pm); Bl = __builtin_bit_cast(bf16x8, pl);
+    } else {
+        uint32_t hh[4], hm[4], hl[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) gml_split3_pair(h[2 * j], h[2 * j + 1], hh[j], hm[j], hl[j]);
-    const bf16x8 Bh = gml_op(hh[0], hh[1], hh[2], hh[3]), Bm = gml_op(hm[0], hm[1], hm[2], hm[3]), Bl = gml_op(hl[0], hl[1], hl[2], hl[3]);
+        for (int j = 0; j < 4; ++j) gml_split3_pair(h[2 * j], h[2 * j + 1], hh[j], hm[j], hl[j]);
+        Bh = gml_op(hh[0], hh[1], hh[2], hh[3]); Bm = gml_op(hm[0], hm[1], hm[2], hm[3]); Bl = gml_op(hl[0], hl[1], hl[2], hl[3]);
+    }
     f32x4 o = GML_MFMA(W.a2[2], Bh, zero);
     o = GML_MFMA(W.a2[1], Bm, o);
     o = GML_MFMA(W.a2[0], Bl, o);
@@ -136,6 +164,10 @@ __device__ __forceinline__ f32x4 gml_chain6_forward(const GmlChain6W<S>& W, cons
     o = GML_MFMA(W.a2[0], Bm, o);
     return GML_MFMA(W.a2[0], Bh, o);
 }
+
+#ifndef GML_CHAIN6_RES
+#define GML_CHAIN6_RES true
+#endif
 
 template <int L>
 struct GmlChain6Stack {
@@ -155,6 +187,8 @@ __global__ __launch_bounds__(256, 2) void gml_k_edge_chain6_fwd(const float* __r
     GmlChain6W<S> W[L];
 #pragma unroll
     for (int l = 0; l < L; ++l) gml_chain6_load_weights<S>(W[l], a.w1[l], a.w2[l], a.w3[l], a.w4[l], c16, g);
+    GmlNegI negI;
+    gml_chain_make_negI(negI, c16, g);
     const int q0 = 4 * (g & 1);
     const int64_t stride = (int64_t)gridDim.x * 8;
     int64_t t = ((int64_t)blockIdx.x * 4 + wave) * 2;
@@ -213,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void gml_k_edge_chain6_fwd(const float* __r
         for (int l = 0; l < L; ++l) {
             f32x4 o[2];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) o[u] = gml_chain6_forward<S, TA>(W[l], BA[u], BB[u]);
+            for (int u = 0; u < 2; ++u) o[u] = gml_chain6_forward<S, TA, GML_CHAIN6_RES>(W[l], negI, BA[u], BB[u]);
             // lane groups 0,1 hold q = 0..3 / 4..7 and write `out`; groups 2,3 hold the same rows again and (DUAL) write the second,
             // source-sorted copy at tpos[e]; the range check of the descriptor drops edges past E
             const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.out[l]) + (((uint64_t)thi << 32) | tlo), 0, nrec, 0x00020000);

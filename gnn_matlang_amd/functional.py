@@ -488,7 +488,7 @@ def edge_mlp_fwd(ea, w1, w2, w3, w4, tpos=None, ea_split=None):
         _lib.call('gml_edge_mlp_fwd_exact', _ptr(ea), _ptr(w1), _ptr(w2), _ptr(w3), _ptr(w4), _ptr(out), _ptr(tpos), _ptr(out_t),
                   int(E), int(S), int(So), _stream(ea.device))
         return out, out_t
-    if EDGE_FWD6 and 2 <= S <= 8 and not EDGE_VALU:       # three-piece products (fp32-class), reads the fp32 rows itself
+    if EDGE_FWD6 and 2 <= S <= 16 and not EDGE_VALU:      # three-piece products (fp32-class), reads the fp32 rows itself
         rc = _lib.lib().gml_edge_mlp_fwd6(_ptr(ea), _ptr(w1), _ptr(w2), _ptr(w3), _ptr(w4), _ptr(out), _ptr(tpos), _ptr(out_t),
                                           int(E), int(S), int(So), _stream(ea.device))
         if rc != _lib.GML_E_UNSUPPORTED:

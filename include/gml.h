@@ -327,7 +327,7 @@ int gml_edge_mlp_fwd_stack(const void* ea_split, int32_t nlayers, const float* c
                            int64_t num_edges, int32_t S, int32_t Sout, gml_stream_t stream);
 /* The edge-branch FORWARD with fp32-class products on the bf16 matrix cores ("bf16x6": every operand cut into three bf16 pieces, the
  * products down to 2^-24 kept; csrc/gml_edge_chain6_impl.h; reference: libs/spect_conv.py:205-207, fp32 throughout).  Reads the fp32
- * rows of ea itself (no pre-split image).  gml_edge_mlp_fwd6: one layer, 2 <= S = Sout <= 8, out / tpos / out_t as gml_edge_mlp_fwd.
+ * rows of ea itself (no pre-split image).  gml_edge_mlp_fwd6: one layer, 2 <= S = Sout <= 16, out / tpos / out_t as gml_edge_mlp_fwd.
  * gml_edge_mlp_fwd_stack6: the layers of a stack in one pass (host pointer arrays as gml_edge_mlp_fwd_stack), S = Sout in {4, 8},
  * 1 <= nlayers <= 4.  GML_E_UNSUPPORTED outside those shapes.  The default forward of the host side since round 6: the two-piece
  * chain's ~5e-7 error on the learned supports is what moved trained-state gradients beyond 1e-4 of their term sums (DESIGN s6). */

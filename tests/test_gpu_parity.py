@@ -876,13 +876,18 @@ def test_full_size_properties(dev):
 
 
 def test_bench_size_train_step_vs_fp64_oracle(dev):
-    """the HEADLINE mode (bf16x3 products) at the HEADLINE size -- bench.py's own batch, 131,072 ZINC-like
-    graphs = 2,048 distinct graphs x 64 copies with a target each -- one train step, logits and EVERY parameter gradient against the
-    oracle in float64 under the term-sum criterion (oracle/parity_at_size.py: the copies make one float64 pass over the pool
-    the exact reference for the whole batch; T = the layer-local sums of |x| |val| |g| |w| products over all copies).  At the initial
-    parameters AND after 100 Adam steps on the batch (weights grown, sums cancelling harder: the state bench.py's own parity block
-    is in after its timed steps).  The exact-product mode runs through the same check (its own numbers are what bench.py prints as
-    max_rel_err_vs_oracle).  sign(pre - y) and the head's relu mask are the device's own (see PS.reference)."""
+    """The HEADLINE arithmetic at the HEADLINE size -- bench.py's own batch, 131,072 ZINC-like graphs = 2,048 distinct graphs x 64 copies
+    with a target each -- one train step, logits and EVERY parameter gradient against the oracle in float64 under the term-sum
+    criterion (oracle/parity_at_size.py: the copies make one float64 pass over the pool the exact reference for the whole batch;
+    T = the layer-local sums of |x| |val| |g| |w| products over all copies).  At the initial parameters AND after 100 Adam steps on
+    the batch (weights grown, sums cancelling harder, nearly dead relu units: the state bench.py's own parity block is in after its
+    timed steps).  sign(pre - y) and the head's relu mask are the device's own (see PS.reference).
+
+    Round 6: the trained state is held to 1e-4 ON EVERY GRADIENT in the default arithmetic -- the carve-out
+    of round 5 is gone.  What it took (tools/precision_diag.py, profiles/r06_precision_diag.jsonl): the FORWARD pass fp32-class
+    (edge branch: three bf16 pieces + relative-accurate tanh; conv projection / Hadamard branch: f16 pieces under power-of-two
+    scales); the backward kernels' bf16 pairs were measured not to matter.  The old all-bf16x3 arithmetic runs through the same
+    check: held at the initial state and on the logits, its trained-state gradients (8.5e-3 of their term sums here) are printed."""
     import bench
     from gnn_matlang_amd import functional as Fn, models
     from oracle import parity_at_size as PS
@@ -900,28 +905,29 @@ def test_bench_size_train_step_vs_fp64_oracle(dev):
                 models.zinc_loss(m(full), full.y).backward()
                 opt.step()
         T = None
-        for mode in ('bf16x3', 'f32'):
+        for mode in ('default', 'bf16x3', 'f32'):
             m.zero_grad()
-            with Fn.exact_products(mode == 'f32'):
-                cap = {}
-                pre = m(full, _capture=cap)
-                models.zinc_loss(pre, full.y).backward()
+            keep = Fn.EDGE_FWD6, Fn.FWD_F16
+            if mode == 'bf16x3':
+                Fn.EDGE_FWD6 = Fn.FWD_F16 = False
+            try:
+                with Fn.exact_products(mode == 'f32'):
+                    cap = {}
+                    pre = m(full, _capture=cap)
+                    models.zinc_loss(pre, full.y).backward()
+            finally:
+                Fn.EDGE_FWD6, Fn.FWD_F16 = keep
             ref = PS.reference(host, m.state_dict(), full.y, pre_dev=pre[:, 0], T=T, head_pre_dev=cap['head_pre'])
             T = ref['T']
             rep = PS.compare(ref, pre[:, 0].detach().cpu().numpy(), {n: p.grad.detach().cpu().numpy() for n, p in m.named_parameters()}, tol=TOL)
             worst[state, mode] = (rep['logits_rel_err'], rep['worst_termsum'], rep['worst_maxnorm'], ref['head_units_flipped'])
-            # The INITIAL state is held to the bar on every tensor.  The trained state is held on the LOGITS in both modes and on every
-            # gradient in the exact mode only: after 100 steps on random targets some relu units of the layers are nearly dead, and the
-            # headline mode's forward error (1e-5 of a layer's scale) then flips a relu unit here and there (in all 64 copies together) and
-            # gives small activations large relative errors -- single elements of such units' gradients sit at 1e-3 .. 1e-2 of their own
-            # term sums, differently after every change of a summation order (3e-5 .. 8e-3 over this round's builds for one seed;
-            # tools/parity_diag.py and bench.py show the units and the worst element).  Properties of an fp32-class vs a 1e-5-class
-            # forward, not errors of a backward kernel -- so no bound is asserted on those gradients there, they are printed.
             bad = {n: v for n, v in rep['tensors'].items() if v['termsum'] > TOL}
             assert rep['logits_rel_err'] <= TOL, (state, mode, rep['logits_rel_err'])
-            # (the exact mode -- fp32-class forward since round 5 -- is held to the bar in the trained state too: its flips are fp32's)
-            assert not (state == 'init' or mode == 'f32') or not bad, (state, mode, bad)
+            # every tensor, both states, in the default and the exact arithmetic; the all-bf16x3 arithmetic at the initial state only
+            assert not (state == 'init' or mode != 'bf16x3') or not bad, (state, mode, bad)
     print('bench-size parity (logits, worst term-sum, worst max-norm, head units taken from the device):', worst)
+    # the default arithmetic's trained-state gradients are fp32-class, not merely inside the bar
+    assert worst['trained', 'default'][1] <= 3e-5, worst
 
 
 # ------------------------------------------------------------------------------------------ randomised sweeps (short)
