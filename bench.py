@@ -103,11 +103,20 @@ def compact_line(res):
     for k in ('final_loss', 'blocks', 'n_ranks_seen', 'rccl_version', 'hbm_copy_GBps', 'per_rank_ms_per_step', 'extras'):
         if k in res:
             out[k] = res[k]
+    def cut_all(v, n=120):
+        if isinstance(v, dict):
+            return {k: cut_all(x, n) for k, x in v.items()}
+        if isinstance(v, (list, tuple)):
+            return [cut_all(x, n) for x in v[:16]]
+        return cut(v, n)
+    for k in ('sharding', 'data_parallel'):                      # N > 1 / --global-batch: per-rank cut and times, all-reduce cost
+        if k in res:
+            out[k] = cut_all(res[k])
     out = _sig(out)
     line = json.dumps(out, separators=(',', ':'))
     # never exceed the budget: drop the side figures, least important first (the contract fields, config, roofline and
     # cpu_baseline are never dropped)
-    for k in ('per_rank_ms_per_step', 'max_rel_err_vs_oracle', 'kernels_ms_per_step', 'ref_batch', 'distinct_graphs', 'fresh_batch',
+    for k in ('per_rank_ms_per_step', 'max_rel_err_vs_oracle', 'data_parallel', 'sharding', 'kernels_ms_per_step', 'ref_batch', 'distinct_graphs', 'fresh_batch',
               'roofline_step', 'epoch_bs64', 'max_rel_err_vs_oracle_after_training', 'spmm', 'value_exact_fp32',
               'roofline_step_compulsory'):
         if len(line) <= LINE_BUDGET:

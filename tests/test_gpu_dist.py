@@ -89,3 +89,26 @@ def test_bench_two_gpus_over_rccl():
     d = _run_bench(['--gpus', '2', '--global-batch', '8192'])
     assert d['n_ranks_seen'] == 2 and d['scaling'] == 'strong' and sum(d['sharding']['graphs_per_rank']) == 8192
     assert d['sharding']['max_over_mean'] < 1.02
+
+
+def test_bench_strong_scaling_four_ranks_share_the_device():
+    """--global-batch (strong scaling) with FOUR spawned ranks on cuda:0 over gloo (GML_BENCH_SHARE_DEVICE=1): ONE
+    global data set cut by shard_graphs_balanced into four shards balanced by support edges, one flat all-reduce per step, per-rank
+    times -- and the captured batch-64 step records an error string instead of hanging where the collective cannot be captured (gloo)."""
+    import json
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '1', '--no-cpu', '--no-extras', '--ref-batch', '0',
+           '--min-seconds', '0', '--gpus', '4', '--global-batch', '4096']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', GML_BENCH_SHARE_DEVICE='1'))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = r.stdout.strip().splitlines()[-1]
+    assert len(line) < 8000
+    d = json.loads(line)
+    assert d['n_gpus'] == 4 and d['n_ranks_seen'] == 4 and d['scaling'] == 'strong' and d['config']['global_batch'] == 4096
+    sh = d['sharding']
+    assert len(sh['graphs_per_rank']) == 4 and sum(sh['graphs_per_rank']) == 4096 and sh['max_over_mean'] < 1.05
+    dp = d['data_parallel']
+    assert len(dp['per_rank_ms_per_step']) == 4 and dp['allreduce_ms'] > 0 and dp['allreduce_bytes'] == 4 * d['config']['params']
+    cap = dp['captured_bs64_per_rank']
+    assert ('error' in cap) or (cap.get('ms_per_step', 0) > 0), cap          # gloo: an error string; RCCL: the captured step's time
+    assert np.isfinite(d['final_loss'])
