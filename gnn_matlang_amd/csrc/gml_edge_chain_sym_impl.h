@@ -1,0 +1,180 @@
+// ML3Layer edge branch over the UNIQUE support rows of a batch (round 6).
+//
+// The supports SpectralDesign produces are samples of symmetric matrices (U f(L) U^T, powers of A: libs/utils.py:546-610), so the rows
+// of edge (i, j) and of its mirror (j, i) are -- for 92 % of ZINC-like edges bit for bit -- the same 32 bytes, and the edge branch
+//
+//   out = relu( W4 . [ relu(W1 e) ; tanh(W2 e) * tanh(W3 e) ] )                         libs/spect_conv.py:205-207
+//
+// gives both the same output row.  Common-subexpression elimination on the DATA: gml_edge_sym_flags marks, per batch, the edges whose
+// mirror row is bitwise identical (flag 2 on the copy with src < dst, 0 on the other; 1 = evaluate alone: self loops, rows that differ
+// -- the +-1e-17 noise of structurally-zero entries --, edges without a mirror).  The forward evaluates the unique rows (62 % of the
+// edges) and stores each result to the edge's row and to its mirror's; the backward adds the mirror's output gradient to the edge's
+// before ONE pass of the chain -- sum_e go_e (x) h_e with h_e = h_mirror is (go_e + go_mirror) (x) h_e.  Nothing is approximated: an
+// edge whose mirror differs in one bit is evaluated on its own, asymmetric inputs simply find no pairs.  Both kernels are
+// instruction-issue-bound (DESIGN s4.3), so the skipped evaluations are time saved; the bytes are the same (every output row is
+// still written, every gradient row still read).  S = Sout in {4, 8}; the raw supports carry no gradient on this road.
+#pragma once
+#include "gml_edge_chain6_impl.h"
+
+// cache policy of the forward's output stores: 0 = default (write-back).  The plain forward streams its rows out with nt (2); here the
+// mirror's row is a second, scattered 32-byte store into a line a later entry completes -- keeping the lines in the L2 until they are
+// full measured 1.15 vs 1.28 ms per step for the four-layer forward (profiles/r06_d_edge_sym_ab.log)
+#ifndef GML_SYM_ST_AUX
+#define GML_SYM_ST_AUX 0
+#endif
+// workgroups per CU of the backward (launch bound): 3 = 150 VGPRs, no spills; 4 = 128 VGPRs + 8 spilled: 1.83 vs 1.45 ms per step
+#ifndef GML_SYM_BWD_WGS
+#define GML_SYM_BWD_WGS 3
+#endif
+template <int S>
+__global__ __launch_bounds__(256, GML_SYM_BWD_WGS) void gml_k_edge_chain_bwd_sym(
+    const uint32_t* __restrict__ es, const int32_t* __restrict__ uid, const int32_t* __restrict__ mir, const float* __restrict__ w1,
+    const float* __restrict__ w2, const float* __restrict__ w3, const float* __restrict__ w4, const float* __restrict__ gout,
+    float* __restrict__ partial, int64_t U, int64_t ntiles) {
+    static_assert(S % 4 == 0, "float4 rows");
+    constexpr int H2 = 2 * S, H4 = 4 * S;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 12 * 512];
+    float (*red)[20][64] = reinterpret_cast<float (*)[20][64]>(smem);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c16 = lane & 15, g = lane >> 4;
+    const int q0 = 4 * (g & 1);
+    unsigned char* trw = smem + wave * (12 * 512);
+    const int tr_wo = g * 128 + ((c16 ^ ((g >> 1) << 3)) << 3);
+    const int tr_ro = (c16 & 3) * 128 + (((4 * g + (c16 >> 2)) ^ (((c16 & 3) >> 1) << 3)) << 3);
+    GmlChainW<S> W;
+    gml_chain_load_fwd_weights<S>(W, w1, w2, w3, w4, c16, g);
+    bf16x8 a3[2], aE;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = q0 + j;
+            v[j] = v[4 + j] = (c16 < H2 && q < S) ? w4[q * H4 + blk * H2 + c16] : 0.f;
+        }
+        a3[blk] = gml_wop(v, g >= 2);
+    }
+    {
+        float ve[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ve[j] = (g >= 2 && c16 == 4 * g + (j & 3)) ? 1.f : 0.f;
+        aE = gml_wop(ve, false);
+    }
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[5];
+#pragma unroll
+    for (int b = 0; b < 5; ++b) acc[b] = zero;
+
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t t = (int64_t)blockIdx.x * 4 + wave;
+    struct Idx { int32_t e, m; bool ok; };
+    auto fetch_idx = [&](int64_t tt) -> Idx {
+        const int64_t u = tt * 16 + c16;
+        const int64_t uc = u < U ? u : U - 1;
+        Idx r;
+        r.e = uid[uc]; r.m = mir[uc]; r.ok = u < U;
+        return r;
+    };
+    u32x4 b1_n;
+    uint2 eh_n, el_n;
+    f32x4 g_n, g2_n;
+    auto fetch_rows = [&](const Idx& ix) {
+        const int64_t e = ix.e, m = ix.m >= 0 ? ix.m : ix.e;
+        b1_n = *reinterpret_cast<const u32x4*>(es + e * 8 + 4 * (g & 1));
+        eh_n = *reinterpret_cast<const uint2*>(es + e * 8 + 2 * (g & 1));
+        el_n = *reinterpret_cast<const uint2*>(es + e * 8 + 4 + 2 * (g & 1));
+        const int qq = q0 < S ? q0 : 0;
+        g_n = *reinterpret_cast<const f32x4*>(gout + e * S + qq);
+        g2_n = *reinterpret_cast<const f32x4*>(gout + m * S + qq);
+    };
+    float gq[4], ye[4];
+    bf16x8 B1, BE;
+    auto take = [&](const Idx& ix) {
+        asm volatile("" : "+v"(b1_n), "+v"(eh_n), "+v"(el_n), "+v"(g_n), "+v"(g2_n));
+        B1 = __builtin_bit_cast(bf16x8, b1_n);
+        BE = __builtin_bit_cast(bf16x8, u32x4{eh_n.x, eh_n.y, el_n.x, el_n.y});
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float gm = ix.m >= 0 ? g2_n[r] : 0.f;
+            gq[r] = (ix.ok && q0 + r < S) ? g_n[r] + gm : 0.f;
+        }
+    };
+    Idx ix_c = fetch_idx(t), ix_n = fetch_idx(t + stride);
+    fetch_rows(ix_c);
+    take(ix_c);
+    for (; t < ntiles; t += stride) {
+        GmlChainT T;
+        fetch_rows(ix_n);                                      // next tile's rows are in flight while this one is computed
+        const Idx ix_nn = fetch_idx(t + 2 * stride);
+        __builtin_amdgcn_sched_barrier(0);
+        gml_chain_forward<S, true>(W, T, B1, g);
+        {
+            const f32x4 ef = GML_MFMA(aE, BE, zero);          // rows 8..15 (lane groups 2, 3): e = hi + lo, exact
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ye[r] = ef[r];
+        }
+        f32x4 go;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) go[r] = (T.out[r] > 0.f) ? gq[r] : 0.f;
+        const bf16x8 B3 = __builtin_bit_cast(bf16x8, gml_split_one(W.negI, go));      // [go hi | go lo]
+        const f32x4 dh1 = GML_MFMA(a3[0], B3, zero);
+        const f32x4 dh23 = GML_MFMA(a3[1], B3, zero);
+        f32x4 gz1, gz2, gz3, y;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            gz1[r] = (T.z1[r] > 0.f) ? dh1[r] : 0.f;
+            gz2[r] = dh23[r] * T.t3[r] * fmaf(-T.t2[r], T.t2[r], 1.f);
+            gz3[r] = dh23[r] * T.t2[r] * fmaf(-T.t3[r], T.t3[r], 1.f);
+            y[r] = (g < 2) ? go[r] : ye[r];
+        }
+        u32x4 g12h, g12l, g3yh, g3yl;
+        gml_split_pair(W.negI, gz1, gz2, g12h, g12l);
+        gml_split_pair(W.negI, gz3, y, g3yh, g3yl);
+        bf16x8 XT[5], YTb;
+        {
+            const u32x4 im[6] = {T.hh, T.hl, g12h, g12l, g3yh, g3yl};
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                *reinterpret_cast<uint2*>(trw + (4 * i + 0) * 512 + tr_wo) = uint2{im[2 * i].x, im[2 * i].y};
+                *reinterpret_cast<uint2*>(trw + (4 * i + 1) * 512 + tr_wo) = uint2{im[2 * i + 1].x, im[2 * i + 1].y};
+                *reinterpret_cast<uint2*>(trw + (4 * i + 2) * 512 + tr_wo) = uint2{im[2 * i].z, im[2 * i].w};
+                *reinterpret_cast<uint2*>(trw + (4 * i + 3) * 512 + tr_wo) = uint2{im[2 * i + 1].z, im[2 * i + 1].w};
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int b = 0; b < 5; ++b) XT[b] = gml_tr_frag(trw + (2 * b) * 512 + tr_ro, trw + (2 * b + 1) * 512 + tr_ro);
+            YTb = gml_tr_frag(trw + 10 * 512 + tr_ro, trw + 11 * 512 + tr_ro);
+            __builtin_amdgcn_wave_barrier();
+        }
+        const u32x4 YT = __builtin_bit_cast(u32x4, YTb);
+        const bf16x8 Bhh = gml_op(YT.x, YT.y, YT.x, YT.y);
+        const bf16x8 Bl0 = gml_op(YT.z, YT.w, 0u, 0u);
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+            acc[b] = GML_MFMA(XT[b], Bl0, acc[b]);
+            acc[b] = GML_MFMA(XT[b], Bhh, acc[b]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        take(ix_n);
+        ix_n = ix_nn;
+    }
+
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 5; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][4 * b + r][lane] = acc[b][r];
+    __syncthreads();
+    float* P = partial + (int64_t)blockIdx.x * GML_CHAIN_NW(S);
+    for (int it = threadIdx.x; it < 20 * 64; it += 256) {
+        const int br = it >> 6, ln = it & 63;
+        const float v = ((red[0][br][ln] + red[1][br][ln]) + red[2][br][ln]) + red[3][br][ln];
+        const int b = br >> 2, row = 4 * (ln >> 4) + (br & 3), col = ln & 15;
+        if (row >= H2) continue;
+        if (b < 2) {
+            if (col < S) P[6 * S * S + col * H4 + b * H2 + row] = v;
+        } else {
+            if (col >= 8 && col < 8 + S) P[(b - 2) * H2 * S + row * S + (col - 8)] = v;
+        }
+    }
+}

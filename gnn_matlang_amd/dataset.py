@@ -216,6 +216,7 @@ class DeviceDataset(object):
             _lib.call('gml_batch_assemble', ctypes.addressof(d), st)
         g.gmax_t128 = g.gmax128 = (int(bounds['caps'][0]), int(bounds['caps'][1]))
         g.src_sorted = True
+        g.static_shape = True
         if es is not None:                                                # the pre-split supports travel with the batch (functional.presplit_of)
             g._val_cache[('p', ea.data_ptr(), ea._version, tuple(ea.shape))] = (ea, es)
         b = Batch(x=x, edge_attr2=ea, batch=batch, ptr=ptr, y=y, graph_valid=valid)

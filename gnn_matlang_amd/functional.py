@@ -504,17 +504,29 @@ EDGE_STACK = not _os.environ.get('GML_NO_EDGE_STACK')     # A/B switch: edge bra
 # since round 6; GML_EDGE_FWD6=0 restores the two-piece chain (bf16x3: ~5e-7 rms on the supports, which after training moved
 # parameter gradients to 1e-3 .. 1e-2 of their term sums: profiles/r06_precision_diag.jsonl).
 EDGE_FWD6 = _os.environ.get('GML_EDGE_FWD6', '1') not in ('0', '')
+# The edge branch over a batch's UNIQUE support rows (csrc/gml_edge_chain_sym_impl.h: an edge and its mirror mostly carry bitwise the
+# same row -- the supports sample symmetric matrices -- and then get the same output; exact, no tolerance): GML_EDGE_SYM=0 turns it off.
+EDGE_SYM = _os.environ.get('GML_EDGE_SYM', '1') not in ('0', '')
 
 
-def edge_mlp_fwd_stack(ea, ea_split, weights):
+def edge_mlp_fwd_stack(ea, ea_split, weights, sym=None):
     """The edge branches of several layers on the SAME supports in one pass (gml_edge_mlp_fwd_stack): weights = [(w1, w2, w3, w4)]
     per layer; returns the list of outputs [E, S] (edge order of ea), or None when the library has no stacked kernel for the shape."""
     import ctypes
     E, S = ea.shape
     L = len(weights)
-    if exact_mode('edge') or not (2 <= L <= 4) or any(w[3].size(0) != S or w[0].size(1) != S for w in weights):
+    if exact_mode('edge') or not ((1 if sym is not None else 2) <= L <= 4) or any(w[3].size(0) != S or w[0].size(1) != S for w in weights):
         return None                                       # (the stacked kernel is a matrix-core chain: not the exact arithmetic)
     arr = lambda ts: (ctypes.c_void_p * L)(*[t.data_ptr() for t in ts])
+    if EDGE_FWD6 and not EDGE_VALU and S in (4, 8) and sym is not None and EDGE_SYM:
+        # the unique support rows only (gml_edge_chain_sym_impl.h): every output row is written, by its own entry or by its mirror's
+        outs = [torch.empty(E, S, dtype=torch.float32, device=ea.device) for _ in range(L)]
+        rc = _lib.lib().gml_edge_mlp_fwd_stack6_sym(_ptr(ea), _ptr(sym[0]), _ptr(sym[1]), int(sym[0].numel()), L, arr([w[0] for w in weights]),
+                                                    arr([w[1] for w in weights]), arr([w[2] for w in weights]), arr([w[3] for w in weights]),
+                                                    arr(outs), int(E), int(S), int(S), _stream(ea.device))
+        if rc != _lib.GML_E_UNSUPPORTED:
+            _lib.check(rc)
+            return outs
     if EDGE_FWD6 and not EDGE_VALU and S in (4, 8):
         outs = [torch.empty(E, S, dtype=torch.float32, device=ea.device) for _ in range(L)]
         rc = _lib.lib().gml_edge_mlp_fwd_stack6(_ptr(ea), L, arr([w[0] for w in weights]), arr([w[1] for w in weights]),
@@ -535,7 +547,7 @@ def edge_mlp_fwd_stack(ea, ea_split, weights):
     return outs
 
 
-def edge_mlp_bwd(ea, w1, w2, w3, w4, gout, need_gin, ea_split=None):
+def edge_mlp_bwd(ea, w1, w2, w3, w4, gout, need_gin, ea_split=None, sym=None):
     E, S = ea.shape
     So = w4.size(0)
     dev = ea.device
@@ -555,6 +567,21 @@ def edge_mlp_bwd(ea, w1, w2, w3, w4, gout, need_gin, ea_split=None):
                   _ptr(dw1), _ptr(dw2), _ptr(dw3), _ptr(dw4), int(E), int(S), int(So), _ptr(ws), ws.numel(), _stream(dev))
         return gin, dw1, dw2, dw3, dw4
     fq = _fold_queue()
+    if sym is not None and EDGE_SYM and not need_gin and ea_split is not None and S in (4, 8) and not EDGE_VALU and E > 0:
+        # unique support rows only: entry u runs the chain once on gout[uid[u]] + gout[mir[u]]
+        U = int(sym[0].numel())
+        nofold = fq is not None
+        d = [_ptr(None)] * 4 if nofold else [_ptr(dw1), _ptr(dw2), _ptr(dw3), _ptr(dw4)]
+        rc = _lib.lib().gml_edge_mlp_bwd_sym(_ptr(ea_split), _ptr(sym[0]), _ptr(sym[1]), U, _ptr(w1), _ptr(w2), _ptr(w3), _ptr(w4), _ptr(gout),
+                                             d[0], d[1], d[2], d[3], int(E), int(S), int(So), _ptr(ws), ws.numel(), _stream(dev))
+        if rc != _lib.GML_E_UNSUPPORTED:
+            _lib.check(rc)
+            if not nofold:
+                return None, dw1, dw2, dw3, dw4
+            n1, n4 = 2 * S * S, 4 * S * So
+            flat = torch.empty(3 * n1 + n4, dtype=torch.float32, device=dev)
+            fq.append((ws, int(_lib.lib().gml_edge_mlp_bwd_sym_parts(U)), 3 * n1 + n4, [(flat, 3 * n1 + n4)]))
+            return (None, flat[:n1].view_as(w1), flat[n1:2 * n1].view_as(w2), flat[2 * n1:3 * n1].view_as(w3), flat[3 * n1:].view_as(w4))
     if fq is not None and E > 0:
         nparts = int(_lib.lib().gml_edge_mlp_bwd_parts(int(E), int(S), int(So), 1 if ea_split is not None else 0, 1 if need_gin else 0))
         _lib.call('gml_edge_mlp_bwd', _ptr(ea), _ptr(ea_split), _ptr(w1), _ptr(w2), _ptr(w3), _ptr(w4), _ptr(gout), _ptr(gin),
@@ -1221,14 +1248,16 @@ class ML3LayerFunction(torch.autograd.Function):
                     if ea_t is None and stack is not None and val_is_source:
                         ws_ = [(w1, w2, w3, w4)] + [tuple(_f32c(t, 'edge branch weight') for t in w) for w in stack[0]]
                         with _Timed('edge_mlp_fwd', 4 * val.numel() * (1 + len(ws_)), 20 * val.size(0) * val.size(1) ** 2 * len(ws_)):
-                            outs = edge_mlp_fwd_stack(val_s, csr.presplit(val_s), ws_)
+                            outs = edge_mlp_fwd_stack(val_s, csr.presplit(val_s), ws_, csr.sym_index(val_s) if EDGE_SYM else None)
                         if outs is not None:
                             _path('edge', 'stack of %d layers in one pass' % len(ws_), val.size(1), '-', w4.size(0))
                             ea_t = outs[0]
                             stack[1].extend(outs[1:])
                     if ea_t is None:
                         with _Timed('edge_mlp_fwd', 4 * val.numel() * 2, 20 * val.size(0) * val.size(1) ** 2):
-                            ea_t, _ = edge_mlp_fwd(val_s, w1, w2, w3, w4, None, csr.presplit(val_s))
+                            sym_ = csr.sym_index(val_s) if (EDGE_SYM and not val.requires_grad) else None
+                            one = edge_mlp_fwd_stack(val_s, None, [(w1, w2, w3, w4)], sym_) if sym_ is not None else None
+                            ea_t = one[0] if one is not None else edge_mlp_fwd(val_s, w1, w2, w3, w4, None, csr.presplit(val_s))[0]
                     ea, epos = ea_t, csr.tpos
                 else:
                     with _Timed('edge_mlp_fwd', 4 * val.numel() * (3 if dual else 2), 20 * val.size(0) * val.size(1) ** 2):
@@ -1365,8 +1394,8 @@ class ML3LayerFunction(torch.autograd.Function):
                     # the edge MLP is per-edge, so it can run in whichever order dea arrived in
                     val_in = val if ctx.val_is_source else (csr.to_source_order(val, cache=not val.requires_grad) if dea_src else val)
                     with _Timed('edge_mlp_bwd', 4 * val.numel() * 2, 60 * val.size(0) * val.size(1) ** 2):
-                        gin, g[2], g[3], g[4], g[5] = edge_mlp_bwd(val_in, w1, w2, w3, w4, dea, need[1],
-                                                                   csr.presplit(val_in))
+                        gin, g[2], g[3], g[4], g[5] = edge_mlp_bwd(val_in, w1, w2, w3, w4, dea, need[1], csr.presplit(val_in),
+                                                                   csr.sym_index(val_in) if (EDGE_SYM and dea_src and not need[1]) else None)
                     if gin is not None and dea_src:
                         gin = csr.from_source_order(gin)
                     g[1] = gin

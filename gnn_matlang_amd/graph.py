@@ -37,7 +37,7 @@ def _require_cuda(t, name):
 class GraphCSR(object):
     __slots__ = ('N', 'E', 'device', 'rowptr', 'col', 'perm', 'rowptr_t', 'col_t', 'pos_t', 'perm_t', 'src_sorted',
                  '_ginfo', '_ginfo_t', '_gmax', '_gmax_t', 'ginfo_t128', 'gmax_t128', 'ginfo128', 'gmax128', 'tpos', '_val_cache', '_keep', '_r64',
-                 '_r64t', '_bad')
+                 '_r64t', '_bad', 'static_shape')
 
     def __init__(self):
         self._val_cache = OrderedDict()
@@ -46,6 +46,7 @@ class GraphCSR(object):
         self._r64 = None
         self._ginfo = self._ginfo_t = self._gmax = self._gmax_t = None
         self._bad = None
+        self.static_shape = False                              # True: a static-shape batch whose tensors are refilled in place (dataset.py)
 
     @staticmethod
     def from_edge_index(edge_index, num_nodes, assume_source_sorted=True, static_caps=None):
@@ -97,6 +98,7 @@ class GraphCSR(object):
             # clamped there, so nothing was written out of bounds: raise like the reference's scatter does)
             if static_caps is not None:
                 g.gmax_t128 = (int(static_caps[0]), int(static_caps[1]))
+                g.static_shape = True                          # contents change under the same tensors (HIP-graph replays): no data-dependent caches
                 g.gmax128 = g.gmax_t128                        # (the caller bounds both views: symmetric masks)
                 g.src_sorted = bool(assume_source_sorted)
                 g._bad = bad.clone()                           # not read here (no host read): see check()
@@ -239,6 +241,32 @@ class GraphCSR(object):
             self._val_cache[key] = (val, out)
             while len(self._val_cache) > 12:
                 self._val_cache.popitem(last=False)
+        return out
+
+    def sym_index(self, val_s):
+        """(uid, mir) int32 [U] for per-batch supports in SOURCE order: the edges the edge branch has to evaluate and, per entry, the
+        mirror edge (j, i) that carries bitwise the same row (-1: none) -- include/gml.h gml_edge_sym_flags.  Cached on the tensor's
+        identity like the other derived arrays; None when nothing can be shared (S not in {4, 8}, supports that carry a gradient,
+        fewer than 10 % of the evaluations saved), for static-shape batches (their tensors are refilled in place by every replay of a
+        captured step) or while a HIP graph is being captured (the list's length is data)."""
+        S = int(val_s.size(1))
+        if S not in (4, 8) or val_s.requires_grad or self.E == 0 or self.E * S * 4 >= 0x7fffff00 or getattr(self, 'static_shape', False):
+            return None
+        key = ('y', val_s.data_ptr(), val_s._version, tuple(val_s.shape))
+        hit = self._val_cache.get(key)
+        if hit is not None:
+            return hit[1]
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        flag = torch.empty(self.E, dtype=torch.int32, device=val_s.device)
+        mirror = torch.empty(self.E, dtype=torch.int32, device=val_s.device)
+        _lib.call('gml_edge_sym_flags', _ptr(self.rowptr_t), _ptr(self.col_t), _ptr(val_s), self.N, self.E, S, _ptr(flag), _ptr(mirror),
+                  _stream(val_s.device))
+        uid = torch.nonzero(flag, as_tuple=False).view(-1).to(torch.int32)
+        out = (uid, mirror[uid.long()].contiguous()) if uid.numel() <= 0.9 * self.E else None
+        self._val_cache[key] = (val_s, out)
+        while len(self._val_cache) > 12:
+            self._val_cache.popitem(last=False)
         return out
 
     def from_source_order(self, val_t):

@@ -336,6 +336,26 @@ int gml_edge_mlp_fwd6(const float* ea, const float* w1, const float* w2, const f
 int gml_edge_mlp_fwd_stack6(const float* ea, int32_t nlayers, const float* const* w1, const float* const* w2,
                             const float* const* w3, const float* const* w4, float* const* out,
                             int64_t num_edges, int32_t S, int32_t Sout, gml_stream_t stream);
+/* The edge branch over a batch's UNIQUE support rows (csrc/gml_edge_chain_sym_impl.h).  SpectralDesign's supports sample symmetric
+ * matrices (libs/utils.py:546-610), so edge (i, j) and its mirror (j, i) mostly carry bitwise the same row and the branch
+ * (libs/spect_conv.py:205-207) gives both the same output.  gml_edge_sym_flags: per edge of the SOURCE-keyed view (rowptr_t, col_t of
+ * gml_csr_from_coo; val_s [num_edges, S] in that order) flag = 2 (evaluate, and the mirror at position mirror[k] takes the same
+ * row: src < dst, rows bitwise equal), 0 (covered by its mirror) or 1 (evaluate alone); mirror = -1 unless flag = 2.  The caller
+ * compacts the edges with flag > 0 into uid / mir [num_unique] (int32).  gml_edge_mlp_fwd_stack6_sym: gml_edge_mlp_fwd_stack6 over
+ * those entries, out[l][uid[u]] and out[l][mir[u]] written (every row of out is written exactly once when uid / mir come from the flags).
+ * gml_edge_mlp_bwd_sym: gml_edge_mlp_bwd (no gin) with gout[uid[u]] + gout[mir[u]] as the entry's output gradient; partial rows in ws:
+ * gml_edge_mlp_bwd_sym_parts(num_unique) (ws sized by gml_edge_mlp_bwd_workspace_bytes(num_edges, ..) is large enough); dw1 .. dw4
+ * all NULL leaves the partials for gml_fold_many.  S = Sout in {4, 8}; GML_E_UNSUPPORTED otherwise.  Exact: no tolerance is involved --
+ * rows that differ in one bit are evaluated separately. */
+int gml_edge_sym_flags(const int32_t* rowptr_t, const int32_t* col_t, const float* val_s, int64_t num_rows, int64_t num_edges,
+                       int32_t S, int32_t* flag, int32_t* mirror, gml_stream_t stream);
+int gml_edge_mlp_fwd_stack6_sym(const float* ea, const int32_t* uid, const int32_t* mir, int64_t num_unique, int32_t nlayers,
+                                const float* const* w1, const float* const* w2, const float* const* w3, const float* const* w4,
+                                float* const* out, int64_t num_edges, int32_t S, int32_t Sout, gml_stream_t stream);
+int64_t gml_edge_mlp_bwd_sym_parts(int64_t num_unique);
+int gml_edge_mlp_bwd_sym(const void* ea_split, const int32_t* uid, const int32_t* mir, int64_t num_unique, const float* w1,
+                         const float* w2, const float* w3, const float* w4, const float* gout, float* dw1, float* dw2, float* dw3,
+                         float* dw4, int64_t num_edges, int32_t S, int32_t Sout, void* ws, size_t ws_bytes, gml_stream_t stream);
 size_t gml_edge_mlp_bwd_workspace_bytes(int64_t num_edges, int32_t S, int32_t Sout);
 /* gout: dL/dout [E, Sout].  Writes dw1..dw4 (same shapes as the weights) and, if gin != NULL,
  * dL/dea [E, S].  Intermediates are recomputed from ea. */

@@ -2133,3 +2133,114 @@ def test_f16_forward_is_scale_invariant(dev, cx, cw):
         err = ((got - ref.clamp(min=0)).abs() / tsum.clamp(min=1e-300))
         err[(ref.abs() < 1e-5 * tsum)] = 0                      # units at the kink
         assert float(err.max()) <= 3e-6, float(err.max())
+
+
+# ------------------------------------------------------------------------------------------ the edge branch over unique support rows (round 6)
+def _sym_batch(dev, ngraphs=96, perturb=0.0, seed=21):
+    from gnn_matlang_amd import SpectralDesign, collate, synthetic
+    raw = synthetic.make_graphs('zinc', ngraphs, seed=seed)
+    b = collate(SpectralDesign(recfield=2, dv=2, nfreq=7).design_many(raw)).to(dev)
+    if perturb > 0:                                        # break the symmetry of a share of the rows by one ulp of one channel
+        g = torch.Generator().manual_seed(seed)
+        pick = (torch.rand(b.edge_attr2.size(0), generator=g) < perturb).to(dev)
+        ch = torch.randint(0, 8, (b.edge_attr2.size(0),), generator=g).to(dev)
+        bits = b.edge_attr2.view(torch.int32).clone()
+        bits[pick, ch[pick]] ^= 1
+        b.edge_attr2 = bits.view(torch.float32)
+    return b
+
+
+@pytest.mark.parametrize('perturb', [0.0, 0.3])
+def test_edge_sym_flags_match_a_numpy_pairing(dev, perturb):
+    """gml_edge_sym_flags: flag 2 = the edge (src < dst) whose mirror carries bitwise the same row, 0 = that mirror, 1 = alone; every
+    edge is covered exactly once by the compacted (uid, mir) list; rows that differ in ONE BIT are not paired."""
+    b = _sym_batch(dev, perturb=perturb)
+    csr = b.csr('edge_index2')
+    vals = csr.to_source_order(csr.sort_values(b.edge_attr2))
+    sym = csr.sym_index(vals)
+    rp, col = csr.rowptr_t.cpu().numpy().astype(np.int64), csr.col_t.cpu().numpy().astype(np.int64)
+    v = vals.cpu().numpy().view(np.uint32)
+    E, N = col.size, rp.size - 1
+    src = np.repeat(np.arange(N), np.diff(rp))
+    key = src * N + col
+    pos = np.searchsorted(key, col * N + src)
+    has = (pos < E) & (key[np.minimum(pos, E - 1)] == col * N + src)
+    same = has & (v == v[np.minimum(pos, E - 1)]).all(axis=1) & (src != col)
+    flag = np.where(same & (src < col), 2, np.where(same, 0, 1))
+    assert sym is not None
+    uid, mir = sym[0].cpu().numpy(), sym[1].cpu().numpy()
+    np.testing.assert_array_equal(uid, np.nonzero(flag)[0])
+    np.testing.assert_array_equal(mir, np.where(flag[uid] == 2, pos[uid], -1))
+    covered = np.zeros(E, dtype=np.int64)
+    np.add.at(covered, uid, 1)
+    np.add.at(covered, mir[mir >= 0], 1)
+    assert (covered == 1).all()
+    share = uid.size / E
+    assert (share < 0.66) if perturb == 0 else (0.66 < share < 0.9), share
+
+
+@pytest.mark.parametrize('perturb,layers', [(0.0, 4), (0.3, 4), (0.0, 1), (0.0, 2)])
+def test_edge_branch_over_unique_rows_equals_the_plain_kernels(dev, perturb, layers):
+    """the edge branch over the batch's unique support rows (gml_edge_mlp_fwd_stack6_sym / gml_edge_mlp_bwd_sym): the forward is BITWISE
+    the plain forward (an edge and its mirror get the same row either way), the weight gradients equal the plain backward's to
+    summation order (1e-5 of the tensor's scale, and 1e-4 of the term sums against float64)."""
+    from gnn_matlang_amd import functional as Fn
+    b = _sym_batch(dev, perturb=perturb)
+    csr = b.csr('edge_index2')
+    vals = csr.to_source_order(csr.sort_values(b.edge_attr2), cache=True)
+    sym = csr.sym_index(vals)
+    assert sym is not None
+    torch.manual_seed(3)
+    ws = [tuple(torch.randn(*shp, device=dev) * 0.4 for shp in ((16, 8), (16, 8), (16, 8), (8, 32))) for _ in range(layers)]
+    plain = Fn.edge_mlp_fwd_stack(vals, csr.presplit(vals), ws, None) if layers > 1 else [Fn.edge_mlp_fwd(vals, *ws[0], None, csr.presplit(vals))[0]]
+    shared = Fn.edge_mlp_fwd_stack(vals, csr.presplit(vals), ws, sym)
+    assert shared is not None and len(shared) == layers
+    for l in range(layers):
+        assert torch.equal(plain[l], shared[l]), 'layer %d: forward over unique rows differs' % l
+    gout = torch.randn_like(vals)
+    w1, w2, w3, w4 = ws[0]
+    ref = Fn.edge_mlp_bwd(vals, w1, w2, w3, w4, gout, False, csr.presplit(vals), None)
+    got = Fn.edge_mlp_bwd(vals, w1, w2, w3, w4, gout, False, csr.presplit(vals), sym)
+    assert got[0] is None
+    for name, a, r in zip(('dw1', 'dw2', 'dw3', 'dw4'), got[1:], ref[1:]):
+        close(a, r, tol=1e-5, what='unique-row backward ' + name)
+    # against float64 autograd
+    e64 = vals.double().cpu()
+    p64 = [t.double().cpu().requires_grad_(True) for t in (w1, w2, w3, w4)]
+    h = torch.cat([torch.relu(e64 @ p64[0].t()), torch.tanh(e64 @ p64[1].t()) * torch.tanh(e64 @ p64[2].t())], 1)
+    out = torch.relu(h @ p64[3].t())
+    close(shared[0], out.float(), tol=2e-6, what='forward over unique rows vs float64')
+    out.backward(gout.double().cpu())
+    for name, a, p in zip(('dw1', 'dw2', 'dw3', 'dw4'), got[1:], p64):
+        close(a, p.grad.float(), what='unique-row backward vs float64 ' + name)
+
+
+def test_model_step_with_and_without_unique_row_sharing(dev):
+    """the ZINC GNNML3 step with GML_EDGE_SYM on / off: logits bitwise equal, every parameter gradient within 1e-5 of its scale; static
+    (captured-epoch) batches never take the shared road (their tensors are refilled in place: a cached pairing would go stale)."""
+    from gnn_matlang_amd import functional as Fn, models
+    b = _sym_batch(dev, ngraphs=128)
+    torch.manual_seed(0)
+    m = models.zinc_gnnml3().to(dev)
+    res = {}
+    for on in (True, False):
+        old = Fn.EDGE_SYM
+        Fn.EDGE_SYM = on
+        try:
+            m.zero_grad()
+            pre = m(b)
+            models.zinc_loss(pre, b.y).backward()
+            res[on] = (pre.detach().clone(), {n: p.grad.clone() for n, p in m.named_parameters()})
+        finally:
+            Fn.EDGE_SYM = old
+    assert torch.equal(res[True][0], res[False][0])
+    for n in res[True][1]:
+        close(res[True][1][n], res[False][1][n], tol=1e-5, what='shared vs plain ' + n)
+    from gnn_matlang_amd.dataset import DeviceDataset
+    from gnn_matlang_amd import SpectralDesign, synthetic
+    raw = synthetic.make_graphs('zinc', 64, seed=4)
+    dsd = DeviceDataset.from_graphs(SpectralDesign(recfield=2, dv=2, nfreq=7).design_many(raw), dev)
+    dsd.prepare()
+    sb = dsd.batch_assembled(torch.arange(16, device=dev), dsd.bounds(16))
+    c = sb.csr('edge_index2')
+    assert c.sym_index(c.to_source_order(c.sort_values(sb.edge_attr2))) is None
