@@ -89,7 +89,7 @@ def compact_line(res):
         out['spmm'] = _pick(res['spmm'], ['bound', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_ms', 'algorithmic_bytes_per_launch', 'S', 'Fin'])
     if 'kernels_ms_per_step' in res:
         out['kernels_ms_per_step'] = res['kernels_ms_per_step']
-    for k in ('value_exact_fp32', 'value_bf16x3', 'value_bf16x6'):
+    for k in ('value_exact_fp32', 'value_bf16x3', 'value_all_rows'):
         if k in res:
             out[k] = _pick(res[k], ['value', 'unit', 'ms_per_step'])
     for k in ('fresh_batch', 'distinct_graphs', 'ref_batch'):
@@ -103,6 +103,8 @@ def compact_line(res):
     for k in ('final_loss', 'blocks', 'n_ranks_seen', 'rccl_version', 'hbm_copy_GBps', 'per_rank_ms_per_step', 'extras'):
         if k in res:
             out[k] = res[k]
+    if 'edge_unique_rows' in res:
+        out['edge_unique_rows'] = _pick(res['edge_unique_rows'], ['share', 'enabled'])
     def cut_all(v, n=120):
         if isinstance(v, dict):
             return {k: cut_all(x, n) for k, x in v.items()}
@@ -582,6 +584,14 @@ def main():
                    final_loss=lossv, blocks=len(blocks), block_seconds=[round(b, 4) for b in blocks],
                    n_ranks_seen=dist.get_world_size() if world > 1 else 1,
                    rccl_version='.'.join(str(v) for v in torch.cuda.nccl.version()) if (world > 1 and not share) else None)
+        try:                                                   # share of the support rows the edge branch evaluates (the rest: bitwise mirrors)
+            csr_ = data.csr('edge_index2')
+            sym_ = csr_.sym_index(data.edge_attr2) if (Fn.EDGE_SYM and csr_.src_sorted) else None
+            res['edge_unique_rows'] = dict(share=(sym_[0].numel() / csr_.E) if sym_ is not None else 1.0, enabled=bool(Fn.EDGE_SYM),
+                                           note='edge (i, j) and its mirror (j, i) carry bitwise the same supports (symmetric spectral matrices): the edge '
+                                                'branch runs once per unique row, exact (csrc/gml_edge_chain_sym_impl.h); GML_EDGE_SYM=0 evaluates every row')
+        except Exception as e_:                                # noqa: BLE001 (a context figure: never fatal)
+            res['edge_unique_rows'] = dict(error=repr(e_)[:200])
         if shard_imb is not None:
             res['sharding'] = shard_imb
         if dp is not None:
@@ -743,6 +753,16 @@ def main():
             res['value_bf16x3'] = dict(value=data.num_graphs * args.steps / dt3, unit='graphs/s', ms_per_step=dt3 / args.steps * 1e3,
                                        arithmetic='bf16 hi/lo pieces (three products per fp32 product) in every kernel, short tanh in the edge chain: GML_EDGE_FWD6=0 GML_FWD_F16=0')
             log('bf16x3 everywhere: %.3f ms/step' % (dt3 / args.steps * 1e3))
+            # ---- the default arithmetic with EVERY support row evaluated (no sharing between an edge and its mirror)
+            keep_s = Fn.EDGE_SYM
+            Fn.EDGE_SYM = False
+            for _ in range(2):
+                step()
+            dts, _ = timed_block(step, args.steps)
+            Fn.EDGE_SYM = keep_s
+            res['value_all_rows'] = dict(value=data.num_graphs * args.steps / dts, unit='graphs/s', ms_per_step=dts / args.steps * 1e3,
+                                         note='GML_EDGE_SYM=0: the edge branch evaluates every support row, mirrors included')
+            log('every support row evaluated: %.3f ms/step' % (dts / args.steps * 1e3))
             # ---- a NEW batch every step: the per-batch index work inside the timed region
             fields = {k: v for k, v in data.__dict__.items() if not k.startswith('_')}
 

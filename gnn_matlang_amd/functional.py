@@ -141,7 +141,8 @@ def flush_folds(jobs):
                     t, c = dsts[k] if k < len(dsts) else (None, 0)
                     a.dst[k] = t.data_ptr() if t is not None else None
                     a.ndst[k] = int(c)
-            _lib.call('gml_fold_many', ctypes.addressof(arr), len(chunk), _stream(dev))
+            with _Timed('fold'):
+                _lib.call('gml_fold_many', ctypes.addressof(arr), len(chunk), _stream(dev))
 
 
 EDGE_VALU = _os.environ.get('GML_EDGE_VALU', '0') == '1'
@@ -669,8 +670,9 @@ def xty(a, b):
         return None
     out = torch.empty(p, q, dtype=torch.float32, device=a.device)
     ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=a.device)
-    _lib.call('gml_xty', _ptr(a), int(a.stride(0)), _ptr(b), int(b.stride(0)), _ptr(out), n, p, q, _ptr(ws), ws.numel(),
-              _stream(a.device))
+    with _Timed('xty'):
+        _lib.call('gml_xty', _ptr(a), int(a.stride(0)), _ptr(b), int(b.stride(0)), _ptr(out), n, p, q, _ptr(ws), ws.numel(),
+                  _stream(a.device))
     return out
 
 
@@ -779,12 +781,14 @@ class BatchNormFunction(torch.autograd.Function):
             st = _stream(dev)
             stats = torch.empty(3, C, dtype=torch.float32, device=dev)
             ws = torch.empty(max(int(L.gml_bn_workspace_bytes(N)), 4), dtype=torch.uint8, device=dev)
-            rc = L.gml_bn_stats(_ptr(x), int(x.stride(0)), N, C, float(eps), _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]), _ptr(ws), ws.numel(), st)
+            with _Timed('bn_fwd'):
+                rc = L.gml_bn_stats(_ptr(x), int(x.stride(0)), N, C, float(eps), _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]), _ptr(ws), ws.numel(), st)
             if rc == _lib.GML_E_UNSUPPORTED:
                 raise NotImplementedError('shape')
             _lib.check(rc)
             y = torch.empty(N, C, dtype=torch.float32, device=dev)
-            _lib.call('gml_bn_apply', _ptr(x), int(x.stride(0)), N, C, _ptr(stats[0]), _ptr(stats[2]), _ptr(weight), _ptr(bias), _ptr(y), C, st)
+            with _Timed('bn_fwd'):
+                _lib.call('gml_bn_apply', _ptr(x), int(x.stride(0)), N, C, _ptr(stats[0]), _ptr(stats[2]), _ptr(weight), _ptr(bias), _ptr(y), C, st)
         ctx.save_for_backward(x, weight, stats)
         ctx.has_bias = bias is not None
         ctx.mark_non_differentiable(stats)
@@ -800,13 +804,15 @@ class BatchNormFunction(torch.autograd.Function):
             st = _stream(dev)
             sums = torch.empty(2, C, dtype=torch.float32, device=dev)
             ws = torch.empty(max(int(_lib.lib().gml_bn_workspace_bytes(N)), 4), dtype=torch.uint8, device=dev)
-            _lib.call('gml_bn_bwd_sums', _ptr(dy), int(dy.stride(0)), _ptr(x), int(x.stride(0)), N, C, _ptr(stats[0]), _ptr(stats[2]),
-                      _ptr(sums[0]), _ptr(sums[1]), _ptr(ws), ws.numel(), st)
+            with _Timed('bn_bwd'):
+                _lib.call('gml_bn_bwd_sums', _ptr(dy), int(dy.stride(0)), _ptr(x), int(x.stride(0)), N, C, _ptr(stats[0]), _ptr(stats[2]),
+                          _ptr(sums[0]), _ptr(sums[1]), _ptr(ws), ws.numel(), st)
             dx = None
             if ctx.needs_input_grad[0]:
                 dx = torch.empty(N, C, dtype=torch.float32, device=dev)
-                _lib.call('gml_bn_bwd_apply', _ptr(dy), int(dy.stride(0)), _ptr(x), int(x.stride(0)), N, C, _ptr(stats[0]), _ptr(stats[2]),
-                          _ptr(weight), _ptr(sums[0]), _ptr(sums[1]), _ptr(dx), C, st)
+                with _Timed('bn_bwd'):
+                    _lib.call('gml_bn_bwd_apply', _ptr(dy), int(dy.stride(0)), _ptr(x), int(x.stride(0)), N, C, _ptr(stats[0]), _ptr(stats[2]),
+                              _ptr(weight), _ptr(sums[0]), _ptr(sums[1]), _ptr(dx), C, st)
         return dx, (sums[1] if weight is not None else None), (sums[0] if ctx.has_bias else None), None
 
 
@@ -849,8 +855,9 @@ class HeadL1Function(torch.autograd.Function):
         loss = torch.empty((), dtype=torch.float32, device=p.device)
         with torch.cuda.device(p.device):
             # loss_sum (optional, a float32 scalar on the device): += loss inside the same launch -- an epoch's running loss
-            _lib.call('gml_head_l1_fwd_acc', _ptr(p), int(p.stride(0)), _ptr(y), _ptr(valid), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2),
-                      int(R), int(y.numel()), int(nin), int(w1.size(0)), _ptr(loss), _ptr(loss_sum), _ptr(None), _stream(p.device))
+            with _Timed('head'):
+                _lib.call('gml_head_l1_fwd_acc', _ptr(p), int(p.stride(0)), _ptr(y), _ptr(valid), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2),
+                          int(R), int(y.numel()), int(nin), int(w1.size(0)), _ptr(loss), _ptr(loss_sum), _ptr(None), _stream(p.device))
         ctx.save_for_backward(p, y, valid, w1, b1, w2, b2)
         return loss
 
@@ -865,9 +872,10 @@ class HeadL1Function(torch.autograd.Function):
         db2 = torch.empty_like(b2) if b2 is not None else None
         g = g.contiguous()
         with torch.cuda.device(p.device):
-            _lib.call('gml_head_l1_bwd', _ptr(p), int(p.stride(0)), _ptr(y), _ptr(valid), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2),
-                      int(R), int(y.numel()), int(nin), nh, _ptr(g), _ptr(gp), nin, _ptr(dw1), _ptr(db1), _ptr(dw2), _ptr(db2),
-                      _stream(p.device))
+            with _Timed('head'):
+                _lib.call('gml_head_l1_bwd', _ptr(p), int(p.stride(0)), _ptr(y), _ptr(valid), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2),
+                          int(R), int(y.numel()), int(nin), nh, _ptr(g), _ptr(gp), nin, _ptr(dw1), _ptr(db1), _ptr(dw2), _ptr(db2),
+                          _stream(p.device))
         return gp, None, None, dw1, db1, dw2, db2, None
 
 
@@ -895,8 +903,9 @@ def segment_bcast(g, ptr, nrows, mean=False):
     ptr = _ptr32(ptr)
     B, F = int(ptr.numel() - 1), int(g.size(1))
     out = torch.empty(nrows, F, dtype=torch.float32, device=g.device)
-    _lib.call('gml_segment_bcast', _ptr(g), int(g.stride(0)), _ptr(ptr), _ptr(out), F, B, F, 1 if mean else 0,
-              _stream(g.device))
+    with _Timed('pool'):
+        _lib.call('gml_segment_bcast', _ptr(g), int(g.stride(0)), _ptr(ptr), _ptr(out), F, B, F, 1 if mean else 0,
+                  _stream(g.device))
     return out
 
 
@@ -923,8 +932,9 @@ def segment_sum(x, ptr, mean=False):
     ptr = _ptr32(ptr)
     B, F = int(ptr.numel() - 1), int(x.size(1))
     out = torch.empty(B, F, dtype=torch.float32, device=x.device)
-    _lib.call('gml_segment_sum', _ptr(x), int(x.stride(0)), _ptr(ptr), _ptr(out), F, B, F, int(mean),
-              _stream(x.device))
+    with _Timed('pool'):
+        _lib.call('gml_segment_sum', _ptr(x), int(x.stride(0)), _ptr(ptr), _ptr(out), F, B, F, int(mean),
+                  _stream(x.device))
     return out
 
 
@@ -934,7 +944,8 @@ def segment_max(x, ptr):
     B, F = int(ptr.numel() - 1), int(x.size(1))
     out = torch.empty(B, F, dtype=torch.float32, device=x.device)
     arg = torch.empty(B, F, dtype=torch.int32, device=x.device)
-    _lib.call('gml_segment_max', _ptr(x), int(x.stride(0)), _ptr(ptr), _ptr(out), F, _ptr(arg), B, F, _stream(x.device))
+    with _Timed('pool'):
+        _lib.call('gml_segment_max', _ptr(x), int(x.stride(0)), _ptr(ptr), _ptr(out), F, _ptr(arg), B, F, _stream(x.device))
     return out, arg
 
 
@@ -942,7 +953,8 @@ def segment_max_bwd(g, ptr, arg, nrows):
     ptr = _ptr32(ptr)
     B, F = int(ptr.numel() - 1), int(g.size(1))
     out = torch.empty(nrows, F, dtype=torch.float32, device=g.device)
-    _lib.call('gml_segment_max_bwd', _ptr(g), int(g.stride(0)), _ptr(ptr), _ptr(arg), _ptr(out), F, B, F, _stream(g.device))
+    with _Timed('pool'):
+        _lib.call('gml_segment_max_bwd', _ptr(g), int(g.stride(0)), _ptr(ptr), _ptr(arg), _ptr(out), F, B, F, _stream(g.device))
     return out
 
 

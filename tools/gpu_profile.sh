@@ -9,6 +9,7 @@ mkdir -p $out
 export TMPDIR=/tmp
 BENCH="python3 bench.py --steps 4 --warmup 2 --batch $batch --no-cpu --no-profile --ref-batch 0 --min-seconds 0"
 python3 bench.py --batch $batch > $out/${tag}_bench.json 2> $out/${tag}_bench.log
+cp bench_extras.json $out/${tag}_bench_extras.json   # the full record of THIS run (the later runs overwrite bench_extras.json)
 rocprofv3 --kernel-trace --stats -d $out/${tag}_stats -o ${tag}_stats -- python3 bench.py --steps 20 --warmup 5 --batch $batch --no-cpu --no-profile --ref-batch 0 --min-seconds 0 > $out/${tag}_stats.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $out/${tag}_pmcA -o ${tag}_pmcA --output-format csv -- $BENCH > $out/${tag}_pmcA.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES -d $out/${tag}_pmcB -o ${tag}_pmcB --output-format csv -- $BENCH > $out/${tag}_pmcB.log 2>&1

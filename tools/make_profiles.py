@@ -21,6 +21,9 @@ for ext in ('json', 'log'):
     src = os.path.join(G, '%s_bench.%s' % (tag, ext))
     if os.path.exists(src):
         open(os.path.join(P, '%s_bench_default.%s' % (pre, ext)), 'w').write(open(src).read())
+src = os.path.join(G, '%s_bench_extras.json' % tag)                 # the full record behind the compact line (round 6)
+if os.path.exists(src):
+    open(os.path.join(P, '%s_bench_extras.json' % pre), 'w').write(open(src).read())
 run('tools/rocprof_summary.py', os.path.join(G, '%s_stats' % tag, '%s_stats_results.db' % tag),
     os.path.join(P, '%s_kernel_stats_b131072.md' % pre))
 run('tools/hbm_traffic.py', os.path.join(G, '%s_fetch' % tag, '%s_fetch_counter_collection.csv' % tag),
@@ -60,9 +63,9 @@ for name in ('spmm.json', 'sr25_sweep.jsonl'):
 b = json.load(open(os.path.join(P, '%s_bench_default.json' % pre)))
 print('commit', commit, 'value', b['value'], 'ms/step', b['ms_per_step'])
 print(b['kernels_ms_per_step'])
-print('roofline', b['roofline']['frac'], b['roofline']['avg_launch_ms'], b['roofline'].get('traffic'), '| fwd', b['roofline_other'][0]['frac'],
-      b['roofline_other'][0].get('traffic'))
+print('roofline', b['roofline']['frac'], b['roofline']['avg_launch_ms'], b['roofline'].get('traffic'))
 for k in ('value_exact_fp32', 'fresh_batch', 'ref_batch', 'epoch_bs64'):
-    print(k, {kk: vv for kk, vv in b[k].items() if kk in ('value', 'ms_per_step', 'index_build_ms_per_batch')})
+    if k in b:
+        print(k, {kk: vv for kk, vv in b[k].items() if kk in ('value', 'ms_per_step', 'index_build_ms_per_batch')})
 for k, v in list(tj['kernels'].items())[:8]:
     print('%-50s %8.1f MB x %d' % (k[:50], v['hbm_bytes_per_launch'] / 1e6, v['launches']))
