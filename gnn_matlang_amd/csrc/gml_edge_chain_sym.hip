@@ -7,7 +7,7 @@ extern "C" int gml_edge_sym_flags(const int32_t* rowptr_t, const int32_t* col_t,
     if (num_rows < 0 || num_edges < 0 || S <= 0) return GML_E_BADARG;
     if (num_edges == 0) return GML_OK;
     if (!rowptr_t || !col_t || !val_s || !flag || !mirror || num_rows == 0) return GML_E_BADARG;
-    hipLaunchKernelGGL(gml_k_edge_sym_flags, dim3((unsigned)gml_cdiv(num_edges, 256)), dim3(256), 0, (hipStream_t)stream, rowptr_t,
+    hipLaunchKernelGGL(gml_k_edge_sym_flags, dim3((unsigned)gml_cdiv(num_rows * 16, 256)), dim3(256), 0, (hipStream_t)stream, rowptr_t,
                        col_t, reinterpret_cast<const uint32_t*>(val_s), num_rows, num_edges, (int)S, flag, mirror);
     return gml_launch_status();
 }

@@ -26,6 +26,132 @@
 #ifndef GML_SYM_BWD_WGS
 #define GML_SYM_BWD_WGS 3
 #endif
+
+// flag / mirror of every edge of the SOURCE-keyed view (row r = source, col_t = targets ascending inside a row).  16 lanes share a
+// source row and deal its edges: the row is known without a search, the mirror is found by bisection in the target's row
+__global__ __launch_bounds__(256) void gml_k_edge_sym_flags(const int32_t* __restrict__ rowptr_t, const int32_t* __restrict__ col_t,
+                                                           const uint32_t* __restrict__ val, int64_t N, int64_t E, int S,
+                                                           int32_t* __restrict__ flag, int32_t* __restrict__ mirror) {
+    const int64_t src = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    if (src >= N) return;
+    const int k1 = rowptr_t[src + 1];
+    for (int k = rowptr_t[src] + (threadIdx.x & 15); k < k1; k += 16) {
+        const int dst = col_t[k];
+        int f = 1, m = -1;
+        if (src != dst) {
+            const int e1 = rowptr_t[dst + 1];
+            int a = rowptr_t[dst], b = e1;                     // find src among the targets of row dst
+            while (a < b) {
+                const int mid = (a + b) >> 1;
+                if (col_t[mid] < (int)src) a = mid + 1; else b = mid;
+            }
+            if (a < e1 && col_t[a] == (int)src) {
+                bool same = true;
+                for (int s = 0; s < S; ++s) same = same && (val[(int64_t)k * S + s] == val[(int64_t)a * S + s]);
+                if (same) { f = src < dst ? 2 : 0; m = a; }
+            }
+        }
+        flag[k] = f;
+        mirror[k] = f == 2 ? m : -1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ forward over the unique rows
+// entry u: uid[u] = the edge to evaluate, mir[u] = its mirror (-1: none).  out[l][uid] and out[l][mir] receive the row.
+template <int S, int L, bool TA>
+__global__ __launch_bounds__(256, 2) void gml_k_edge_chain6_fwd_sym(const float* __restrict__ ea, const int32_t* __restrict__ uid,
+                                                                   const int32_t* __restrict__ mir, const GmlChain6Stack<L> a,
+                                                                   int64_t E, int64_t U, int64_t ntiles) {
+    static_assert(S % 4 == 0, "float4 rows");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c16 = lane & 15, g = lane >> 4;
+    GmlChain6W<S> W[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) gml_chain6_load_weights<S>(W[l], a.w1[l], a.w2[l], a.w3[l], a.w4[l], c16, g);
+    GmlNegI negI;
+    gml_chain_make_negI(negI, c16, g);
+    const int q0 = 4 * (g & 1);
+    const int64_t stride = (int64_t)gridDim.x * 8;
+    int64_t t = ((int64_t)blockIdx.x * 4 + wave) * 2;
+    constexpr int OOB = 0x7ffffff0;
+    // the lane's store row: lane groups 0, 1 write the edge's own row, groups 2, 3 its mirror's; < 0: nothing to store
+    auto fetch_idx = [&](int64_t tt, int32_t (&el)[2], int32_t (&st)[2]) {
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int64_t u = (tt + v) * 16 + c16;
+            const int64_t uc = u < U ? u : U - 1;
+            const int32_t e = uid[uc], m = mir[uc];
+            el[v] = e;
+            st[v] = u < U ? (g < 2 ? e : m) : -1;
+        }
+    };
+    auto fetch_rows = [&](const int32_t (&el)[2], float (&r)[2][8]) {
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const float* p = ea + (int64_t)el[v] * S;
+#pragma unroll
+            for (int j = 0; j < S / 4; ++j) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(p + 4 * j);
+                r[v][4 * j] = x.x; r[v][4 * j + 1] = x.y; r[v][4 * j + 2] = x.z; r[v][4 * j + 3] = x.w;
+            }
+#pragma unroll
+            for (int j = S; j < 8; ++j) r[v][j] = 0.f;
+        }
+    };
+    int32_t el_c[2], st_c[2], el_n[2], st_n[2], el_nn[2], st_nn[2];
+    float ec[2][8], en[2][8];
+    fetch_idx(t, el_c, st_c);
+    fetch_idx(t + stride, el_n, st_n);
+    fetch_rows(el_c, ec);
+    for (; t < ntiles; t += stride) {
+        bf16x8 BA[2], BB[2];
+#pragma unroll
+        for (int v = 0; v < 2; ++v) gml_chain6_b1(ec[v], g, BA[v], BB[v]);
+        fetch_rows(el_n, en);                                  // next pair's rows (their indices arrived a trip ago)
+        fetch_idx(t + 2 * stride, el_nn, st_nn);               // and the indices of the pair after it
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            f32x4 o[2];
+#pragma unroll
+            for (int v = 0; v < 2; ++v) o[v] = gml_chain6_forward<S, TA, GML_CHAIN6_RES>(W[l], negI, BA[v], BB[v]);
+            const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(a.out[l], 0, (int)(uint32_t)(E * S * 4), 0x00020000);
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const f32x4 x = f32x4{gml_relu1(o[v][0]), gml_relu1(o[v][1]), gml_relu1(o[v][2]), gml_relu1(o[v][3])};
+                const int off = (st_c[v] >= 0 && q0 < S) ? (st_c[v] * S + q0) * 4 : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), rs_o, off, 0, GML_SYM_ST_AUX);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+#pragma unroll
+            for (int j = 0; j < S; ++j) { asm volatile("" : "+v"(en[v][j])); ec[v][j] = en[v][j]; }
+            asm volatile("" : "+v"(el_nn[v]), "+v"(st_nn[v]));
+            el_c[v] = el_n[v]; st_c[v] = st_n[v];
+            el_n[v] = el_nn[v]; st_n[v] = st_nn[v];
+        }
+    }
+}
+
+template <int S, int L>
+int gml_launch_edge_chain6_fwd_sym(const float* ea, const int32_t* uid, const int32_t* mir, const GmlChain6Stack<L>& a, int64_t E,
+                                   int64_t U, hipStream_t st) {
+    const int64_t ntiles = gml_cdiv(U, 16);
+    int64_t grid = gml_cdiv(ntiles, 8);
+    if (grid > 4 * GML_NUM_CU) grid = 4 * GML_NUM_CU;
+    if (gml_chain6_accurate_tanh())
+        hipLaunchKernelGGL((gml_k_edge_chain6_fwd_sym<S, L, true>), dim3((unsigned)grid), dim3(256), 0, st, ea, uid, mir, a, E, U, ntiles);
+    else
+        hipLaunchKernelGGL((gml_k_edge_chain6_fwd_sym<S, L, false>), dim3((unsigned)grid), dim3(256), 0, st, ea, uid, mir, a, E, U, ntiles);
+    return gml_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------ backward over the unique rows
+// gml_k_edge_chain_bwd<S, GIN = false, PRE = true> (gml_edge_chain_impl.h) with the index indirection: tile entry u evaluates edge
+// uid[u] on the output gradient gout[uid[u]] + gout[mir[u]].  Same arithmetic (two-piece chain, recomputed intermediates), same
+// partial-sum layout [dw1 | dw2 | dw3 | dw4] per workgroup.
 template <int S>
 __global__ __launch_bounds__(256, GML_SYM_BWD_WGS) void gml_k_edge_chain_bwd_sym(
     const uint32_t* __restrict__ es, const int32_t* __restrict__ uid, const int32_t* __restrict__ mir, const float* __restrict__ w1,

@@ -262,8 +262,8 @@ class GraphCSR(object):
         mirror = torch.empty(self.E, dtype=torch.int32, device=val_s.device)
         _lib.call('gml_edge_sym_flags', _ptr(self.rowptr_t), _ptr(self.col_t), _ptr(val_s), self.N, self.E, S, _ptr(flag), _ptr(mirror),
                   _stream(val_s.device))
-        uid = torch.nonzero(flag, as_tuple=False).view(-1).to(torch.int32)
-        out = (uid, mirror[uid.long()].contiguous()) if uid.numel() <= 0.9 * self.E else None
+        idx = torch.nonzero(flag, as_tuple=False).view(-1)
+        out = (idx.to(torch.int32), mirror[idx]) if idx.numel() <= 0.9 * self.E else None
         self._val_cache[key] = (val_s, out)
         while len(self._val_cache) > 12:
             self._val_cache.popitem(last=False)
