@@ -496,7 +496,7 @@ def main():
     prof, Fn.PROFILE = Fn.PROFILE, None
     if os.environ.get('GML_BENCH_DUMP') and prof:            # debugging aid: per-launch HIP-event times of the profiled block
         for tag, recs in prof.items():
-            ms = [a.elapsed_time(b) for a, b, _, _ in recs]
+            ms = [r_[0].elapsed_time(r_[1]) for r_ in recs]
             n = max(len(ms) // args.steps, 1)
             log('launches of %s: %s' % (tag, [round(sum(ms[i::n]) / args.steps, 3) for i in range(n)]))
             log('   first launch of every step: %s' % [round(v, 2) for v in ms[0::n]])

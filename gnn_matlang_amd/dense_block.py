@@ -157,7 +157,8 @@ class _DenseConv(torch.autograd.Function):
         Fn._path('dense', 'support product + projection chained (bf16x3 HIP)', S, Fin, Fout)
         # algorithmic bytes: the packed support images (bf16 hi + lo), x, out, and Hcat when the weight gradient wants it
         q_img = sup.B * S * 2 * sup.n * sup.KP * 2
-        with Fn._Timed('dense_conv_fwd', q_img + 4 * rows * (Fin + Fout + (S * Fin if need_h else 0)), 2 * sup.B * S * sup.n * sup.n * Fin + 2 * rows * S * Fin * Fout):
+        with Fn._Timed('dense_conv_fwd', q_img + 4 * rows * (Fin + Fout + (S * Fin if need_h else 0)), 2 * sup.B * S * sup.n * sup.n * Fin + 2 * rows * S * Fin * Fout,
+                       q2=q_img + 4 * rows * (Fin + Fout)):                 # compulsory: without the Hcat this design writes for its own dW
             _lib.call('gml_dense_conv_fwd', _ptr(sup.fwd), _ptr(x), int(x.stride(0)), _ptr(wimg), _ptr(bias), _ptr(out), Fout,
                       _ptr(hcat), sup.B, S, sup.n, sup.KP, Fin, Fout, 1 if relu else 0, _stream(dev))
         # relu (round 5): applied in the kernel's epilogue (libs/layers_tf.py:238: act(output)); the backward's mask and the bias
@@ -212,7 +213,7 @@ class _DenseConv(torch.autograd.Function):
             P = _splits(rows)
             dw = None
             if not DW_GEMM_LIB:                                   # round 5: Hcat^T g on the bf16 matrix cores (gml_xty_wide), not a library GEMM
-                with Fn._Timed('dense_dw_xty_wide', 4 * rows * (S * Fin + Fout), 2 * rows * S * Fin * Fout):
+                with Fn._Timed('dense_dw_xty_wide', 4 * rows * (S * Fin + Fout), 2 * rows * S * Fin * Fout, q2=4 * rows * (Fin + Fout)):
                     dw = Fn.xty_wide(hcat, g)
                 dw = dw.view(S, Fin, Fout) if dw is not None else None
             if dw is None:

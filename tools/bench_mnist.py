@@ -51,15 +51,27 @@ for name, dn in (('sparse', 0), ('dense_lib', 75), ('dense', 75)):
         torch.cuda.synchronize()
         summ = Fn.profile_summary(Fn.PROFILE)
         Fn.PROFILE = None
+        BF16_PEAK = 2500.0                                        # dense bf16 MFMA TFLOP/s (MI355X_MICROARCH.md); bf16x3 = 3 products per fp32 product
         kern = {k: dict(launches_per_step=v['launches'] / n, avg_launch_ms=round(v['ms'], 4), ms_per_step=round(v['ms'] * v['launches'] / n, 4),
-                        GBps=round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1), TFLOPs=round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2))
+                        GBps=round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1), GBps_compulsory=round(v['bytes_compulsory'] / (v['ms'] * 1e-3) / 1e9, 1),
+                        TFLOPs=round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2))
                 for k, v in summ.items() if v['bytes'] > 0}
         top = max((k for k in kern if k.startswith('dense_conv')), key=lambda k: kern[k]['ms_per_step'], default=None)
         if top is not None:
+            # priced against the COMPULSORY bytes (no Hcat -- an array this design writes for its own weight gradient) and
+            # against the bf16 matrix roof at three products per fp32 product; whichever takes longer binds
             v = summ[top]
-            gbs = v['bytes'] / (v['ms'] * 1e-3) / 1e9
-            out[name]['roofline'] = dict(bound='hbm', kernel=top, achieved=gbs, peak=8000.0, unit='GB/s', frac=gbs / 8000.0, traffic=None,
-                                         avg_launch_ms=v['ms'], algorithmic_bytes_per_launch=v['bytes'],
-                                         note='mean over the three layers of the model; the same kernel on the matrix pipe: %.1f TFLOP/s' % (v['flops'] / (v['ms'] * 1e-3) / 1e12))
+            t = v['ms'] * 1e-3
+            t_hbm, t_mat = v['bytes_compulsory'] / 8000e9, 3 * v['flops'] / (BF16_PEAK * 1e12)
+            if t_mat > t_hbm:
+                roof = dict(bound='mfma', achieved=3 * v['flops'] / t / 1e12, peak=BF16_PEAK, unit='TFLOP/s', frac=t_mat / t)
+            else:
+                roof = dict(bound='hbm', achieved=v['bytes_compulsory'] / t / 1e9, peak=8000.0, unit='GB/s', frac=t_hbm / t)
+            roof.update(kernel=top, traffic=None, avg_launch_ms=v['ms'], algorithmic_bytes_per_launch=v['bytes_compulsory'],
+                        bytes_per_launch_with_Hcat=v['bytes'], frac_with_Hcat_bytes=v['bytes'] / t / 1e9 / 8000.0,
+                        frac_of_bf16_matrix_roof=t_mat / t,
+                        note='mean over the three layers of the model; compulsory bytes = packed support images + x + out (Hcat, written for this '
+                             'design\'s own dW, is NOT counted; with it: frac_with_Hcat_bytes); 3 bf16 products per fp32 product on the matrix pipe')
+            out[name]['roofline'] = roof
         out[name]['kernels'] = kern
 print(json.dumps(dict(graphs=B, nodes=int(data.x.size(0)), support_edges=int(data.edge_index2.size(1)), **out)))
