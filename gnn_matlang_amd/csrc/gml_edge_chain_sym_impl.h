@@ -34,18 +34,20 @@ __global__ __launch_bounds__(256) void gml_k_edge_sym_flags(const int32_t* __res
                                                            int32_t* __restrict__ flag, int32_t* __restrict__ mirror) {
     const int64_t src = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     if (src >= N) return;
-    const int k1 = rowptr_t[src + 1];
-    for (int k = rowptr_t[src] + (threadIdx.x & 15); k < k1; k += 16) {
+    const int k0 = rowptr_t[src], k1 = rowptr_t[src + 1];
+    for (int k = k0 + (threadIdx.x & 15); k < k1; k += 16) {
         const int dst = col_t[k];
         int f = 1, m = -1;
-        if (src != dst) {
+        // (a multigraph's repeated edge (i, j) has no unique mirror: such edges -- on either side -- are evaluated alone)
+        const bool dup = (k > k0 && col_t[k - 1] == dst) || (k + 1 < k1 && col_t[k + 1] == dst);
+        if (src != dst && !dup) {
             const int e1 = rowptr_t[dst + 1];
-            int a = rowptr_t[dst], b = e1;                     // find src among the targets of row dst
+            int a = rowptr_t[dst], b = e1;                     // find src among the targets of row dst (first occurrence)
             while (a < b) {
                 const int mid = (a + b) >> 1;
                 if (col_t[mid] < (int)src) a = mid + 1; else b = mid;
             }
-            if (a < e1 && col_t[a] == (int)src) {
+            if (a < e1 && col_t[a] == (int)src && !(a + 1 < e1 && col_t[a + 1] == (int)src)) {
                 bool same = true;
                 for (int s = 0; s < S; ++s) same = same && (val[(int64_t)k * S + s] == val[(int64_t)a * S + s]);
                 if (same) { f = src < dst ? 2 : 0; m = a; }

@@ -2244,3 +2244,45 @@ def test_model_step_with_and_without_unique_row_sharing(dev):
     sb = dsd.batch_assembled(torch.arange(16, device=dev), dsd.bounds(16))
     c = sb.csr('edge_index2')
     assert c.sym_index(c.to_source_order(c.sort_values(sb.edge_attr2))) is None
+
+
+def test_edge_sym_pairing_with_repeated_and_one_sided_edges(dev):
+    """multigraph input (an edge repeated, on one side or on both) and one-sided edges (no mirror at all): such edges are evaluated
+    alone; every row of the output is still written exactly once and equals the plain kernels' bit for bit."""
+    from gnn_matlang_amd import functional as Fn
+    from gnn_matlang_amd.graph import GraphCSR
+    g = torch.Generator().manual_seed(5)
+    N = 300
+    a = torch.randint(0, N, (2, 1500), generator=g)
+    und = torch.cat([a, a.flip(0)], 1)                              # symmetric structure
+    und = torch.unique(und, dim=1)
+    extra = torch.cat([und[:, :200], und[:, :200], und[:, 300:350].flip(0)[:, :0]], 1)      # 200 edges repeated twice more (one side only)
+    both = torch.cat([und[:, 400:450], und[:, 400:450].flip(0)], 1)                         # 50 pairs repeated on both sides
+    oneside = torch.stack([torch.randint(0, N, (120,), generator=g), torch.randint(0, N, (120,), generator=g)])
+    ei = torch.cat([und, extra, both, oneside, torch.arange(N).repeat(2, 1)], 1)
+    order = torch.argsort(ei[0] * N + ei[1], stable=True)
+    ei = ei[:, order].to(dev)
+    # symmetric values: a function of the unordered pair, so mirrors are bitwise equal
+    lo, hi = torch.minimum(ei[0], ei[1]), torch.maximum(ei[0], ei[1])
+    base = torch.randn(N * N // 64 + 8, 8, generator=g).to(dev)
+    vals = base[(lo * 7 + hi * 13) % base.size(0)].contiguous()
+    csr = GraphCSR.from_edge_index(ei, N)
+    vs = csr.to_source_order(csr.sort_values(vals))
+    sym = csr.sym_index(vs)
+    assert sym is not None
+    uid, mir = sym[0].cpu().numpy(), sym[1].cpu().numpy()
+    covered = np.zeros(csr.E, dtype=np.int64)
+    np.add.at(covered, uid, 1)
+    np.add.at(covered, mir[mir >= 0], 1)
+    assert (covered == 1).all(), 'rows written %s times' % np.unique(covered)
+    torch.manual_seed(1)
+    ws = [tuple(torch.randn(*shp, device=dev) * 0.4 for shp in ((16, 8), (16, 8), (16, 8), (8, 32))) for _ in range(2)]
+    plain = Fn.edge_mlp_fwd_stack(vs, csr.presplit(vs), ws, None)
+    shared = Fn.edge_mlp_fwd_stack(vs, csr.presplit(vs), ws, sym)
+    for l in range(2):
+        assert torch.equal(plain[l], shared[l])
+    gout = torch.randn_like(vs)
+    ref = Fn.edge_mlp_bwd(vs, *ws[0], gout, False, csr.presplit(vs), None)
+    got = Fn.edge_mlp_bwd(vs, *ws[0], gout, False, csr.presplit(vs), sym)
+    for a_, r_ in zip(got[1:], ref[1:]):
+        close(a_, r_, tol=1e-5, what='unique-row backward on a multigraph')
