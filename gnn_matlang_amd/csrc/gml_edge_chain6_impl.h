@@ -260,6 +260,11 @@ __global__ __launch_bounds__(256, 2) void gml_k_edge_chain6_fwd(const float* __r
                     const bool q_ok = q0 < S;
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_o, q_ok ? off_o : (int)0xffffff00, 0, 2);
                     if constexpr (DUAL) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_t, q_ok ? off_t : (int)0xffffff00, 0, 0);
+                } else if constexpr (S == 6 && !DUAL) {         // rows of 24 bytes: columns 0..3 as one 16-byte store, 4, 5 as one 8-byte store
+                    typedef uint32_t u32x2_ __attribute__((ext_vector_type(2)));
+                    const f32x4 v = f32x4{gml_relu1(o[u][0]), gml_relu1(o[u][1]), gml_relu1(o[u][2]), gml_relu1(o[u][3])};
+                    if (q0 == 0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_o, off_o, 0, 2);
+                    else __builtin_amdgcn_raw_buffer_store_b64(u32x2_{__float_as_uint(v[0]), __float_as_uint(v[1])}, rs_o, off_o, 0, 2);
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {

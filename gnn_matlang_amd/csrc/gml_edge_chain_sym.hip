@@ -1,5 +1,5 @@
 // C-ABI of the edge branch over a batch's UNIQUE support rows (gml_edge_chain_sym_impl.h): the pairing pass, the forward of a layer
-// stack (three-piece products) and the backward (two-piece chain), S = Sout in {4, 8}
+// stack (three-piece products; stacks: S in {4, 8}, single layers: 2 <= S <= 8) and the backward (two-piece chain), 2 <= S = Sout <= 8
 #include "gml_edge_chain_sym_impl.h"
 
 extern "C" int gml_edge_sym_flags(const int32_t* rowptr_t, const int32_t* col_t, const float* val_s, int64_t num_rows,
@@ -26,16 +26,17 @@ extern "C" int gml_edge_mlp_fwd_stack6_sym(const float* ea, const int32_t* uid, 
                                            gml_stream_t stream) {
     if (num_edges < 0 || num_unique < 0 || num_unique > num_edges || S <= 0 || Sout <= 0 || nlayers <= 0 || !w1 || !w2 || !w3 || !w4 || !out)
         return GML_E_BADARG;
-    if (S != Sout || (S != 8 && S != 4) || nlayers > 4) return GML_E_UNSUPPORTED;
+    if (S != Sout || S < 2 || S > 8 || nlayers > 4 || (S != 8 && S != 4 && nlayers > 1)) return GML_E_UNSUPPORTED;
     if ((uint64_t)num_edges * (uint64_t)S * 4u >= 0x7fffff00ull) return GML_E_UNSUPPORTED;      /* 32-bit store offsets */
     if (num_edges == 0) return GML_OK;
-    if (num_unique == 0 || !ea || !uid || !mir || (((uintptr_t)ea) & 15) != 0) return GML_E_BADARG;
+    if (num_unique == 0 || !ea || !uid || !mir || (S % 4 == 0 && (((uintptr_t)ea) & 15) != 0)) return GML_E_BADARG;
     for (int l = 0; l < nlayers; ++l)
-        if (!w1[l] || !w2[l] || !w3[l] || !w4[l] || !out[l] || (((uintptr_t)out[l]) & 15) != 0) return GML_E_BADARG;
+        if (!w1[l] || !w2[l] || !w3[l] || !w4[l] || !out[l] || (S % 4 == 0 && (((uintptr_t)out[l]) & 15) != 0)) return GML_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
 #define GML_SYM_GO(SV, LV) if (S == SV && nlayers == LV) return sym_fwd_go<SV, LV>(ea, uid, mir, num_unique, w1, w2, w3, w4, out, num_edges, st);
     GML_SYM_GO(8, 1) GML_SYM_GO(8, 2) GML_SYM_GO(8, 3) GML_SYM_GO(8, 4)
     GML_SYM_GO(4, 1) GML_SYM_GO(4, 2) GML_SYM_GO(4, 3) GML_SYM_GO(4, 4)
+    GML_SYM_GO(2, 1) GML_SYM_GO(3, 1) GML_SYM_GO(5, 1) GML_SYM_GO(6, 1) GML_SYM_GO(7, 1)
     return GML_E_UNSUPPORTED;
 }
 
@@ -68,10 +69,13 @@ extern "C" int gml_edge_mlp_bwd_sym(const void* ea_split, const int32_t* uid, co
     if (num_edges <= 0 || num_unique <= 0 || num_unique > num_edges || S <= 0 || Sout <= 0) return GML_E_BADARG;
     const bool nofold = !dw1 && !dw2 && !dw3 && !dw4;
     if (!w1 || !w2 || !w3 || !w4 || (!nofold && (!dw1 || !dw2 || !dw3 || !dw4))) return GML_E_BADARG;
-    if (S != Sout || (S != 8 && S != 4)) return GML_E_UNSUPPORTED;
-    if (!ea_split || !uid || !mir || !gout || !ws || ((((uintptr_t)ea_split) | ((uintptr_t)gout)) & 15) != 0) return GML_E_BADARG;
+    if (S != Sout || S < 2 || S > 8) return GML_E_UNSUPPORTED;
+    if (!ea_split || !uid || !mir || !gout || !ws || (((uintptr_t)ea_split) & 15) != 0 || (S % 4 == 0 && (((uintptr_t)gout) & 15) != 0)) return GML_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     const uint32_t* es = (const uint32_t*)ea_split;
-    if (S == 8) return sym_bwd_go<8>(es, uid, mir, num_unique, w1, w2, w3, w4, gout, dw1, dw2, dw3, dw4, ws, ws_bytes, st);
-    return sym_bwd_go<4>(es, uid, mir, num_unique, w1, w2, w3, w4, gout, dw1, dw2, dw3, dw4, ws, ws_bytes, st);
+    switch (S) {
+#define GML_SYM_BWD(SV) case SV: return sym_bwd_go<SV>(es, uid, mir, num_unique, w1, w2, w3, w4, gout, dw1, dw2, dw3, dw4, ws, ws_bytes, st);
+        GML_SYM_BWD(2) GML_SYM_BWD(3) GML_SYM_BWD(4) GML_SYM_BWD(5) GML_SYM_BWD(6) GML_SYM_BWD(7) GML_SYM_BWD(8)
+    }
+    return GML_E_UNSUPPORTED;
 }

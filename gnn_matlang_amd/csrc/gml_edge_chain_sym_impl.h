@@ -12,7 +12,7 @@
 // before ONE pass of the chain -- sum_e go_e (x) h_e with h_e = h_mirror is (go_e + go_mirror) (x) h_e.  Nothing is approximated: an
 // edge whose mirror differs in one bit is evaluated on its own, asymmetric inputs simply find no pairs.  Both kernels are
 // instruction-issue-bound (DESIGN s4.3), so the skipped evaluations are time saved; the bytes are the same (every output row is
-// still written, every gradient row still read).  S = Sout in {4, 8}; the raw supports carry no gradient on this road.
+// still written, every gradient row still read).  2 <= S = Sout <= 8; the raw supports carry no gradient on this road.
 #pragma once
 #include "gml_edge_chain6_impl.h"
 
@@ -64,7 +64,6 @@ template <int S, int L, bool TA>
 __global__ __launch_bounds__(256, 2) void gml_k_edge_chain6_fwd_sym(const float* __restrict__ ea, const int32_t* __restrict__ uid,
                                                                    const int32_t* __restrict__ mir, const GmlChain6Stack<L> a,
                                                                    int64_t E, int64_t U, int64_t ntiles) {
-    static_assert(S % 4 == 0, "float4 rows");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c16 = lane & 15, g = lane >> 4;
     GmlChain6W<S> W[L];
@@ -91,10 +90,21 @@ __global__ __launch_bounds__(256, 2) void gml_k_edge_chain6_fwd_sym(const float*
 #pragma unroll
         for (int v = 0; v < 2; ++v) {
             const float* p = ea + (int64_t)el[v] * S;
+            if constexpr (S % 4 == 0) {
 #pragma unroll
-            for (int j = 0; j < S / 4; ++j) {
-                const f32x4 x = *reinterpret_cast<const f32x4*>(p + 4 * j);
-                r[v][4 * j] = x.x; r[v][4 * j + 1] = x.y; r[v][4 * j + 2] = x.z; r[v][4 * j + 3] = x.w;
+                for (int j = 0; j < S / 4; ++j) {
+                    const f32x4 x = *reinterpret_cast<const f32x4*>(p + 4 * j);
+                    r[v][4 * j] = x.x; r[v][4 * j + 1] = x.y; r[v][4 * j + 2] = x.z; r[v][4 * j + 3] = x.w;
+                }
+            } else if constexpr (S % 2 == 0) {
+#pragma unroll
+                for (int j = 0; j < S / 2; ++j) {
+                    const f32x2 x = *reinterpret_cast<const f32x2*>(p + 2 * j);
+                    r[v][2 * j] = x.x; r[v][2 * j + 1] = x.y;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < S; ++j) r[v][j] = p[j];
             }
 #pragma unroll
             for (int j = S; j < 8; ++j) r[v][j] = 0.f;
@@ -122,7 +132,17 @@ __global__ __launch_bounds__(256, 2) void gml_k_edge_chain6_fwd_sym(const float*
             for (int v = 0; v < 2; ++v) {
                 const f32x4 x = f32x4{gml_relu1(o[v][0]), gml_relu1(o[v][1]), gml_relu1(o[v][2]), gml_relu1(o[v][3])};
                 const int off = (st_c[v] >= 0 && q0 < S) ? (st_c[v] * S + q0) * 4 : OOB;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), rs_o, off, 0, GML_SYM_ST_AUX);
+                if constexpr (S % 4 == 0) {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), rs_o, off, 0, GML_SYM_ST_AUX);
+                } else if constexpr (S == 6) {                   // rows of 24 bytes: columns 0..3 as one 16-byte store (dword-aligned: enough for a
+                    typedef uint32_t u32x2_ __attribute__((ext_vector_type(2)));                      // buffer store), columns 4, 5 as one 8-byte store
+                    if (q0 == 0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), rs_o, off, 0, GML_SYM_ST_AUX);
+                    else __builtin_amdgcn_raw_buffer_store_b64(u32x2_{__float_as_uint(x[0]), __float_as_uint(x[1])}, rs_o, off, 0, GML_SYM_ST_AUX);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x[r]), rs_o, (q0 + r < S && off != OOB) ? off + 4 * r : OOB, 0, GML_SYM_ST_AUX);
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -159,7 +179,6 @@ __global__ __launch_bounds__(256, GML_SYM_BWD_WGS) void gml_k_edge_chain_bwd_sym
     const uint32_t* __restrict__ es, const int32_t* __restrict__ uid, const int32_t* __restrict__ mir, const float* __restrict__ w1,
     const float* __restrict__ w2, const float* __restrict__ w3, const float* __restrict__ w4, const float* __restrict__ gout,
     float* __restrict__ partial, int64_t U, int64_t ntiles) {
-    static_assert(S % 4 == 0, "float4 rows");
     constexpr int H2 = 2 * S, H4 = 4 * S;
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 12 * 512];
     float (*red)[20][64] = reinterpret_cast<float (*)[20][64]>(smem);
@@ -211,9 +230,18 @@ __global__ __launch_bounds__(256, GML_SYM_BWD_WGS) void gml_k_edge_chain_bwd_sym
         b1_n = *reinterpret_cast<const u32x4*>(es + e * 8 + 4 * (g & 1));
         eh_n = *reinterpret_cast<const uint2*>(es + e * 8 + 2 * (g & 1));
         el_n = *reinterpret_cast<const uint2*>(es + e * 8 + 4 + 2 * (g & 1));
-        const int qq = q0 < S ? q0 : 0;
-        g_n = *reinterpret_cast<const f32x4*>(gout + e * S + qq);
-        g2_n = *reinterpret_cast<const f32x4*>(gout + m * S + qq);
+        if constexpr (S % 4 == 0) {
+            const int qq = q0 < S ? q0 : 0;
+            g_n = *reinterpret_cast<const f32x4*>(gout + e * S + qq);
+            g2_n = *reinterpret_cast<const f32x4*>(gout + m * S + qq);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qq = q0 + r < S ? q0 + r : S - 1;    // clamped: always a readable element (masked in take)
+                g_n[r] = gout[e * S + qq];
+                g2_n[r] = gout[m * S + qq];
+            }
+        }
     };
     float gq[4], ye[4];
     bf16x8 B1, BE;

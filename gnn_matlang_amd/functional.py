@@ -521,7 +521,7 @@ def edge_mlp_fwd_stack(ea, ea_split, weights, sym=None):
     if exact_mode('edge') or not ((1 if sym is not None else 2) <= L <= 4) or any(w[3].size(0) != S or w[0].size(1) != S for w in weights):
         return None                                       # (the stacked kernel is a matrix-core chain: not the exact arithmetic)
     arr = lambda ts: (ctypes.c_void_p * L)(*[t.data_ptr() for t in ts])
-    if EDGE_FWD6 and not EDGE_VALU and S in (4, 8) and sym is not None and EDGE_SYM:
+    if EDGE_FWD6 and not EDGE_VALU and (S in (4, 8) or (L == 1 and 2 <= S <= 8)) and sym is not None and EDGE_SYM:
         # the unique support rows only (gml_edge_chain_sym_impl.h): every output row is written, by its own entry or by its mirror's
         outs = [torch.empty(E, S, dtype=torch.float32, device=ea.device) for _ in range(L)]
         rc = _lib.lib().gml_edge_mlp_fwd_stack6_sym(_ptr(ea), _ptr(sym[0]), _ptr(sym[1]), int(sym[0].numel()), L, arr([w[0] for w in weights]),
@@ -570,7 +570,7 @@ def edge_mlp_bwd(ea, w1, w2, w3, w4, gout, need_gin, ea_split=None, sym=None):
                   _ptr(dw1), _ptr(dw2), _ptr(dw3), _ptr(dw4), int(E), int(S), int(So), _ptr(ws), ws.numel(), _stream(dev))
         return gin, dw1, dw2, dw3, dw4
     fq = _fold_queue()
-    if sym is not None and EDGE_SYM and not need_gin and ea_split is not None and S in (4, 8) and not EDGE_VALU and E > 0:
+    if sym is not None and EDGE_SYM and not need_gin and ea_split is not None and 2 <= S <= 8 and not EDGE_VALU and E > 0:
         # unique support rows only: entry u runs the chain once on gout[uid[u]] + gout[mir[u]]
         U = int(sym[0].numel())
         nofold = fq is not None
@@ -1275,7 +1275,13 @@ class ML3LayerFunction(torch.autograd.Function):
                     ea, epos = ea_t, csr.tpos
                 else:
                     with _Timed('edge_mlp_fwd', 4 * val.numel() * (3 if dual else 2), 20 * val.size(0) * val.size(1) ** 2):
-                        ea, ea_t = edge_mlp_fwd(val, w1, w2, w3, w4, csr.tpos if dual else None, csr.presplit(val))
+                        # (inference / unfused training: target order; unique support rows only where the batch pairs up)
+                        sym_ = csr.sym_index(val, 'target') if (EDGE_SYM and not dual and not val.requires_grad and w4.size(0) == val.size(1)) else None
+                        one = edge_mlp_fwd_stack(val, None, [(w1, w2, w3, w4)], sym_) if sym_ is not None else None
+                        if one is not None:
+                            ea, ea_t = one[0], None
+                        else:
+                            ea, ea_t = edge_mlp_fwd(val, w1, w2, w3, w4, csr.tpos if dual else None, csr.presplit(val))
             else:
                 ea, ea_t = val, None
             if ea.size(1) != S:

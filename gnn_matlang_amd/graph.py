@@ -243,28 +243,29 @@ class GraphCSR(object):
                 self._val_cache.popitem(last=False)
         return out
 
-    def sym_index(self, val_s):
-        """(uid, mir) int32 [U] for per-batch supports in SOURCE order: the edges the edge branch has to evaluate and, per entry, the
-        mirror edge (j, i) that carries bitwise the same row (-1: none) -- include/gml.h gml_edge_sym_flags.  Cached on the tensor's
-        identity like the other derived arrays; None when nothing can be shared (S not in {4, 8}, supports that carry a gradient,
-        fewer than 10 % of the evaluations saved), for static-shape batches (their tensors are refilled in place by every replay of a
-        captured step) or while a HIP graph is being captured (the list's length is data)."""
-        S = int(val_s.size(1))
-        if S not in (4, 8) or val_s.requires_grad or self.E == 0 or self.E * S * 4 >= 0x7fffff00 or getattr(self, 'static_shape', False):
+    def sym_index(self, val, view='source'):
+        """(uid, mir) int32 [U] for per-batch supports in SOURCE order (view='source': the order the training edge branch runs in) or in
+        target-sorted order (view='target': inference): the edges the edge branch has to evaluate and, per entry, the mirror edge (j, i)
+        that carries bitwise the same row (-1: none) -- include/gml.h gml_edge_sym_flags.  Cached on the tensor's identity like the
+        other derived arrays; None when nothing can be shared (S outside 2 .. 8, supports that carry a gradient, fewer than 10 % of the
+        evaluations saved), for static-shape batches (their tensors are refilled in place by every replay of a captured step) or
+        while a HIP graph is being captured (the list's length is data)."""
+        S = int(val.size(1))
+        if not (2 <= S <= 8) or val.requires_grad or self.E == 0 or self.E * S * 4 >= 0x7fffff00 or getattr(self, 'static_shape', False):
             return None
-        key = ('y', val_s.data_ptr(), val_s._version, tuple(val_s.shape))
+        key = ('y' + view[0], val.data_ptr(), val._version, tuple(val.shape))
         hit = self._val_cache.get(key)
         if hit is not None:
             return hit[1]
         if torch.cuda.is_current_stream_capturing():
             return None
-        flag = torch.empty(self.E, dtype=torch.int32, device=val_s.device)
-        mirror = torch.empty(self.E, dtype=torch.int32, device=val_s.device)
-        _lib.call('gml_edge_sym_flags', _ptr(self.rowptr_t), _ptr(self.col_t), _ptr(val_s), self.N, self.E, S, _ptr(flag), _ptr(mirror),
-                  _stream(val_s.device))
+        rp, cl = (self.rowptr_t, self.col_t) if view == 'source' else (self.rowptr, self.col)
+        flag = torch.empty(self.E, dtype=torch.int32, device=val.device)
+        mirror = torch.empty(self.E, dtype=torch.int32, device=val.device)
+        _lib.call('gml_edge_sym_flags', _ptr(rp), _ptr(cl), _ptr(val), self.N, self.E, S, _ptr(flag), _ptr(mirror), _stream(val.device))
         idx = torch.nonzero(flag, as_tuple=False).view(-1)
         out = (idx.to(torch.int32), mirror[idx]) if idx.numel() <= 0.9 * self.E else None
-        self._val_cache[key] = (val_s, out)
+        self._val_cache[key] = (val, out)
         while len(self._val_cache) > 12:
             self._val_cache.popitem(last=False)
         return out

@@ -345,7 +345,7 @@ int gml_edge_mlp_fwd_stack6(const float* ea, int32_t nlayers, const float* const
  * those entries, out[l][uid[u]] and out[l][mir[u]] written (every row of out is written exactly once when uid / mir come from the flags).
  * gml_edge_mlp_bwd_sym: gml_edge_mlp_bwd (no gin) with gout[uid[u]] + gout[mir[u]] as the entry's output gradient; partial rows in ws:
  * gml_edge_mlp_bwd_sym_parts(num_unique) (ws sized by gml_edge_mlp_bwd_workspace_bytes(num_edges, ..) is large enough); dw1 .. dw4
- * all NULL leaves the partials for gml_fold_many.  S = Sout in {4, 8}; GML_E_UNSUPPORTED otherwise.  Exact: no tolerance is involved --
+ * all NULL leaves the partials for gml_fold_many.  2 <= S = Sout <= 8 (layer stacks: S in {4, 8}); GML_E_UNSUPPORTED otherwise.  Exact: no tolerance --
  * rows that differ in one bit are evaluated separately. */
 int gml_edge_sym_flags(const int32_t* rowptr_t, const int32_t* col_t, const float* val_s, int64_t num_rows, int64_t num_edges,
                        int32_t S, int32_t* flag, int32_t* mirror, gml_stream_t stream);

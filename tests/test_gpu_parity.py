@@ -2286,3 +2286,30 @@ def test_edge_sym_pairing_with_repeated_and_one_sided_edges(dev):
     got = Fn.edge_mlp_bwd(vs, *ws[0], gout, False, csr.presplit(vs), sym)
     for a_, r_ in zip(got[1:], ref[1:]):
         close(a_, r_, tol=1e-5, what='unique-row backward on a multigraph')
+
+
+@pytest.mark.parametrize('view', ['source', 'target'])
+def test_edge_branch_over_unique_rows_six_supports(dev, view):
+    """sr25.py's six supports (rows of 24 bytes: 8-byte vector accesses, scalar stores) on the unique-row kernels, in the training
+    order (source view) and the inference order (target view): forward bitwise the plain forward, backward to summation order."""
+    from gnn_matlang_amd import SpectralDesign, collate, synthetic, functional as Fn
+    raw = synthetic.make_graphs('zinc', 80, seed=8)
+    b = collate(SpectralDesign(recfield=1, dv=2, nfreq=5, adddegree=True).design_many(raw)).to(dev)
+    assert b.edge_attr2.size(1) == 6
+    csr = b.csr('edge_index2')
+    vals = csr.sort_values(b.edge_attr2)
+    if view == 'source':
+        vals = csr.to_source_order(vals, cache=True)
+    sym = csr.sym_index(vals, view)
+    assert sym is not None and sym[0].numel() < 0.8 * csr.E
+    torch.manual_seed(6)
+    w = tuple(torch.randn(*shp, device=dev) * 0.4 for shp in ((12, 6), (12, 6), (12, 6), (6, 24)))
+    plain = Fn.edge_mlp_fwd(vals, *w, None, csr.presplit(vals))[0]
+    shared = Fn.edge_mlp_fwd_stack(vals, None, [w], sym)
+    assert shared is not None and torch.equal(plain, shared[0])
+    if view == 'source':
+        gout = torch.randn_like(vals)
+        ref = Fn.edge_mlp_bwd(vals, *w, gout, False, csr.presplit(vals), None)
+        got = Fn.edge_mlp_bwd(vals, *w, gout, False, csr.presplit(vals), sym)
+        for a_, r_ in zip(got[1:], ref[1:]):
+            close(a_, r_, tol=1e-5, what='unique-row backward, six supports')
