@@ -50,7 +50,7 @@ SIGNATURES = {
     'gml_edge_mlp_fwd_stack6': (ctypes.c_int, [_p, _i32, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
     'gml_edge_sym_flags': (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i32, _p, _p, _p]),
     'gml_edge_mlp_fwd_stack6_sym': (ctypes.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
-    'gml_edge_mlp_bwd_sym_parts': (ctypes.c_int64, [_i64]),
+    'gml_edge_mlp_bwd_sym_parts': (ctypes.c_int64, [_i64, _i32]),
     'gml_edge_mlp_bwd_sym': (ctypes.c_int, [_p, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p, ctypes.c_size_t, _p]),
     'gml_edge_mlp_fwd6': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
     'gml_spectconv_bwd_mix_relu': (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _i32, _i32,

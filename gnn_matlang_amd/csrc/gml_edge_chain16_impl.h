@@ -167,11 +167,15 @@ struct GmlChain16WB {
 
 #define GML_CHAIN16_NW(S) (10 * (S) * (S))
 
-template <int S>
+// SYM (round 6, gml_edge_chain_sym_impl.h): tile entry u evaluates edge uid[u] on gout[uid[u]] + gout[mir[u]] (mir < 0: alone); E is
+// then the number of entries
+template <int S, bool SYM = false>
 __global__ __launch_bounds__(256, 2) void gml_k_edge_chain16_bwd(const uint32_t* __restrict__ es, const float* __restrict__ w1,
                                                                 const float* __restrict__ w2, const float* __restrict__ w3,
                                                                 const float* __restrict__ w4, const float* __restrict__ gout,
-                                                                float* __restrict__ partial, int64_t E, int64_t ntiles) {
+                                                                float* __restrict__ partial, int64_t E, int64_t ntiles,
+                                                                const int32_t* __restrict__ uid = nullptr,
+                                                                const int32_t* __restrict__ mir = nullptr) {
     constexpr int H2 = 2 * S, H4 = 4 * S;
     // 4 waves x 12 bf16 tile images (the transposition scratch, see gml_edge_chain_impl.h); the same bytes hold the
     // workgroup's partial sums at the end (5 accumulator tiles at a time)
@@ -214,9 +218,20 @@ __global__ __launch_bounds__(256, 2) void gml_k_edge_chain16_bwd(const uint32_t*
     const int qc = 4 * g < S ? 4 * g : 0;                       // (lanes with no gout column read a valid one, zeroed below)
     u32x4 b1_n;
     uint2 eh_n, el_n;
-    f32x4 g_n;
+    f32x4 g_n, g2_n = f32x4{0.f, 0.f, 0.f, 0.f};
     auto fetch = [&](int64_t tt) {                              // unconditional, clamped
-        const int64_t e = min(tt * 16 + c16, E - 1);
+        int64_t e = min(tt * 16 + c16, E - 1);
+        if constexpr (SYM) {
+            const int32_t m = mir[e];
+            e = uid[e];
+            const int64_t mm = m >= 0 ? m : e;                  // (no mirror: a readable row, dropped below)
+            if constexpr (S % 4 == 0) g2_n = *reinterpret_cast<const f32x4*>(gout + mm * S + qc);
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) g2_n[r] = gout[mm * S + (qc + r < S ? qc + r : S - 1)];
+            }
+            if (m < 0) g2_n = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         const uint32_t* row = es + e * 16;
         b1_n = *reinterpret_cast<const u32x4*>(row + 4 * g);
         eh_n = *reinterpret_cast<const uint2*>(row + 2 * g);        // hi[4g .. 4g+3]
@@ -234,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void gml_k_edge_chain16_bwd(const uint32_t*
         const bool ok = t * 16 + c16 < E;
         f32x4 gq;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) gq[r] = (ok && 4 * g + r < S) ? g_n[r] : 0.f;
+        for (int r = 0; r < 4; ++r) gq[r] = (ok && 4 * g + r < S) ? (SYM ? g_n[r] + g2_n[r] : g_n[r]) : 0.f;
         fetch(t + stride < ntiles ? t + stride : t);
         GmlChain16T T;
         gml_chain16_forward<S, true>(W, T, B1);

@@ -56,13 +56,15 @@ __device__ __forceinline__ void gml_chain16x6_load_weights(GmlChain16W6<S>& W, c
     }
 }
 
-// out [E, S]; out_t (optional): the same rows at tpos[e]
-template <int S, bool TA>
+// out [E, S]; out_t (optional): the same rows at tpos[e].  SYM (gml_edge_chain_sym_impl.h): tile entry u evaluates edge uid[u] and
+// stores the row to out[uid[u]] and out[mir[u]] (mir < 0: none); E is then the number of entries (tpos / out_t unused)
+template <int S, bool TA, bool SYM = false>
 __global__ __launch_bounds__(256, 2) void gml_k_edge_chain16x6_fwd(const float* __restrict__ ea, const float* __restrict__ w1,
                                                                   const float* __restrict__ w2, const float* __restrict__ w3,
                                                                   const float* __restrict__ w4, float* __restrict__ out,
                                                                   const int32_t* __restrict__ tpos, float* __restrict__ out_t,
-                                                                  int64_t E, int64_t ntiles) {
+                                                                  int64_t E, int64_t ntiles, const int32_t* __restrict__ uid = nullptr,
+                                                                  const int32_t* __restrict__ mir = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c16 = lane & 15, g = lane >> 4;
     GmlChain16W6<S> W;
@@ -73,8 +75,13 @@ __global__ __launch_bounds__(256, 2) void gml_k_edge_chain16x6_fwd(const float* 
     const int64_t stride = (int64_t)gridDim.x * 4;
     int64_t t = (int64_t)blockIdx.x * 4 + wave;
     const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+    int32_t sid_n = 0;                                          // SYM: the entry's own edge (its store row)
     auto fetch = [&](int64_t tt, float (&e)[8], int32_t& tp) {  // clamped: always a readable edge
-        const int64_t ed = min(tt * 16 + c16, E - 1);
+        int64_t ed = min(tt * 16 + c16, E - 1);
+        if constexpr (SYM) {
+            tp = mir[ed];
+            ed = sid_n = uid[ed];
+        }
         const float* p = ea + ed * S;
         if constexpr (S % 4 == 0) {
 #pragma unroll
@@ -87,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void gml_k_edge_chain16x6_fwd(const float* 
 #pragma unroll
             for (int j = 0; j < 8; ++j) e[j] = c0 + j < S ? p[c0 + j] : 0.f;
         }
-        tp = out_t != nullptr ? tpos[ed] : 0;
+        if constexpr (!SYM) tp = out_t != nullptr ? tpos[ed] : 0;
     };
     float en[8];
     int32_t tpn;
@@ -96,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void gml_k_edge_chain16x6_fwd(const float* 
         float e[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) e[j] = en[j];
-        const int32_t tp = tpn;
+        const int32_t tp = tpn, sid = sid_n;
         fetch(t + stride < ntiles ? t + stride : t, en, tpn);   // next tile's rows in flight during this chain
         // layer-1 operands: BA = [e_h | e_m], BB = [e_l | e_h] over the lane groups (0, 1 | 2, 3)
         uint32_t a[4], b[4];
@@ -139,8 +146,8 @@ __global__ __launch_bounds__(256, 2) void gml_k_edge_chain16x6_fwd(const float* 
         const int64_t eid = t * 16 + c16;
         if (eid < E && q0 < S) {
             const f32x4 v = f32x4{gml_relu1(o[0]), gml_relu1(o[1]), gml_relu1(o[2]), gml_relu1(o[3])};
-            float* op = out + eid * S + q0;
-            float* ot = out_t != nullptr ? out_t + (int64_t)tp * S + q0 : nullptr;
+            float* op = out + (SYM ? (int64_t)sid : eid) * S + q0;
+            float* ot = SYM ? (tp >= 0 ? out + (int64_t)tp * S + q0 : nullptr) : (out_t != nullptr ? out_t + (int64_t)tp * S + q0 : nullptr);
             if constexpr (S % 4 == 0) {
                 __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(op));
                 if (ot != nullptr) *reinterpret_cast<f32x4*>(ot) = v;
@@ -154,6 +161,19 @@ __global__ __launch_bounds__(256, 2) void gml_k_edge_chain16x6_fwd(const float* 
             }
         }
     }
+}
+
+template <int S>
+int gml_launch_edge_chain16x6_fwd_sym(const float* ea, const int32_t* uid, const int32_t* mir, int64_t U, const float* w1, const float* w2,
+                                      const float* w3, const float* w4, float* out, hipStream_t st) {
+    const int64_t ntiles = gml_cdiv(U, 16);
+    int64_t grid = gml_cdiv(ntiles, 4);
+    if (grid > 4 * GML_NUM_CU) grid = 4 * GML_NUM_CU;
+    if (gml_chain6_accurate_tanh())
+        hipLaunchKernelGGL((gml_k_edge_chain16x6_fwd<S, true, true>), dim3((unsigned)grid), dim3(256), 0, st, ea, w1, w2, w3, w4, out, nullptr, nullptr, U, ntiles, uid, mir);
+    else
+        hipLaunchKernelGGL((gml_k_edge_chain16x6_fwd<S, false, true>), dim3((unsigned)grid), dim3(256), 0, st, ea, w1, w2, w3, w4, out, nullptr, nullptr, U, ntiles, uid, mir);
+    return gml_launch_status();
 }
 
 template <int S>

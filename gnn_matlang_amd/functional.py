@@ -521,7 +521,7 @@ def edge_mlp_fwd_stack(ea, ea_split, weights, sym=None):
     if exact_mode('edge') or not ((1 if sym is not None else 2) <= L <= 4) or any(w[3].size(0) != S or w[0].size(1) != S for w in weights):
         return None                                       # (the stacked kernel is a matrix-core chain: not the exact arithmetic)
     arr = lambda ts: (ctypes.c_void_p * L)(*[t.data_ptr() for t in ts])
-    if EDGE_FWD6 and not EDGE_VALU and (S in (4, 8) or (L == 1 and 2 <= S <= 8)) and sym is not None and EDGE_SYM:
+    if EDGE_FWD6 and not EDGE_VALU and (S in (4, 8) or (L == 1 and 2 <= S <= 16)) and sym is not None and EDGE_SYM:
         # the unique support rows only (gml_edge_chain_sym_impl.h): every output row is written, by its own entry or by its mirror's
         outs = [torch.empty(E, S, dtype=torch.float32, device=ea.device) for _ in range(L)]
         rc = _lib.lib().gml_edge_mlp_fwd_stack6_sym(_ptr(ea), _ptr(sym[0]), _ptr(sym[1]), int(sym[0].numel()), L, arr([w[0] for w in weights]),
@@ -570,7 +570,7 @@ def edge_mlp_bwd(ea, w1, w2, w3, w4, gout, need_gin, ea_split=None, sym=None):
                   _ptr(dw1), _ptr(dw2), _ptr(dw3), _ptr(dw4), int(E), int(S), int(So), _ptr(ws), ws.numel(), _stream(dev))
         return gin, dw1, dw2, dw3, dw4
     fq = _fold_queue()
-    if sym is not None and EDGE_SYM and not need_gin and ea_split is not None and 2 <= S <= 8 and not EDGE_VALU and E > 0:
+    if sym is not None and EDGE_SYM and not need_gin and ea_split is not None and 2 <= S <= 16 and not EDGE_VALU and E > 0:
         # unique support rows only: entry u runs the chain once on gout[uid[u]] + gout[mir[u]]
         U = int(sym[0].numel())
         nofold = fq is not None
@@ -583,7 +583,7 @@ def edge_mlp_bwd(ea, w1, w2, w3, w4, gout, need_gin, ea_split=None, sym=None):
                 return None, dw1, dw2, dw3, dw4
             n1, n4 = 2 * S * S, 4 * S * So
             flat = torch.empty(3 * n1 + n4, dtype=torch.float32, device=dev)
-            fq.append((ws, int(_lib.lib().gml_edge_mlp_bwd_sym_parts(U)), 3 * n1 + n4, [(flat, 3 * n1 + n4)]))
+            fq.append((ws, int(_lib.lib().gml_edge_mlp_bwd_sym_parts(U, int(S))), 3 * n1 + n4, [(flat, 3 * n1 + n4)]))
             return (None, flat[:n1].view_as(w1), flat[n1:2 * n1].view_as(w2), flat[2 * n1:3 * n1].view_as(w3), flat[3 * n1:].view_as(w4))
     if fq is not None and E > 0:
         nparts = int(_lib.lib().gml_edge_mlp_bwd_parts(int(E), int(S), int(So), 1 if ea_split is not None else 0, 1 if need_gin else 0))

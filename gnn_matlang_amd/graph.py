@@ -247,11 +247,11 @@ class GraphCSR(object):
         """(uid, mir) int32 [U] for per-batch supports in SOURCE order (view='source': the order the training edge branch runs in) or in
         target-sorted order (view='target': inference): the edges the edge branch has to evaluate and, per entry, the mirror edge (j, i)
         that carries bitwise the same row (-1: none) -- include/gml.h gml_edge_sym_flags.  Cached on the tensor's identity like the
-        other derived arrays; None when nothing can be shared (S outside 2 .. 8, supports that carry a gradient, fewer than 10 % of the
+        other derived arrays; None when nothing can be shared (S outside 2 .. 16, supports that carry a gradient, fewer than 10 % of the
         evaluations saved), for static-shape batches (their tensors are refilled in place by every replay of a captured step) or
         while a HIP graph is being captured (the list's length is data)."""
         S = int(val.size(1))
-        if not (2 <= S <= 8) or val.requires_grad or self.E == 0 or self.E * S * 4 >= 0x7fffff00 or getattr(self, 'static_shape', False):
+        if not (2 <= S <= 16) or val.requires_grad or self.E == 0 or self.E * S * 4 >= 0x7fffff00 or getattr(self, 'static_shape', False):
             return None
         key = ('y' + view[0], val.data_ptr(), val._version, tuple(val.shape))
         hit = self._val_cache.get(key)

@@ -344,15 +344,15 @@ int gml_edge_mlp_fwd_stack6(const float* ea, int32_t nlayers, const float* const
  * compacts the edges with flag > 0 into uid / mir [num_unique] (int32).  gml_edge_mlp_fwd_stack6_sym: gml_edge_mlp_fwd_stack6 over
  * those entries, out[l][uid[u]] and out[l][mir[u]] written (every row of out is written exactly once when uid / mir come from the flags).
  * gml_edge_mlp_bwd_sym: gml_edge_mlp_bwd (no gin) with gout[uid[u]] + gout[mir[u]] as the entry's output gradient; partial rows in ws:
- * gml_edge_mlp_bwd_sym_parts(num_unique) (ws sized by gml_edge_mlp_bwd_workspace_bytes(num_edges, ..) is large enough); dw1 .. dw4
- * all NULL leaves the partials for gml_fold_many.  2 <= S = Sout <= 8 (layer stacks: S in {4, 8}); GML_E_UNSUPPORTED otherwise.  Exact: no tolerance --
+ * gml_edge_mlp_bwd_sym_parts(num_unique, S) (ws sized by gml_edge_mlp_bwd_workspace_bytes(num_edges, ..) is large enough); dw1 .. dw4
+ * all NULL leaves the partials for gml_fold_many.  2 <= S = Sout <= 16 (layer stacks: S in {4, 8}; S > 8: ea_split = the 64-byte rows of gml_edge_presplit); GML_E_UNSUPPORTED otherwise.  Exact: no tolerance --
  * rows that differ in one bit are evaluated separately. */
 int gml_edge_sym_flags(const int32_t* rowptr_t, const int32_t* col_t, const float* val_s, int64_t num_rows, int64_t num_edges,
                        int32_t S, int32_t* flag, int32_t* mirror, gml_stream_t stream);
 int gml_edge_mlp_fwd_stack6_sym(const float* ea, const int32_t* uid, const int32_t* mir, int64_t num_unique, int32_t nlayers,
                                 const float* const* w1, const float* const* w2, const float* const* w3, const float* const* w4,
                                 float* const* out, int64_t num_edges, int32_t S, int32_t Sout, gml_stream_t stream);
-int64_t gml_edge_mlp_bwd_sym_parts(int64_t num_unique);
+int64_t gml_edge_mlp_bwd_sym_parts(int64_t num_unique, int32_t S);
 int gml_edge_mlp_bwd_sym(const void* ea_split, const int32_t* uid, const int32_t* mir, int64_t num_unique, const float* w1,
                          const float* w2, const float* w3, const float* w4, const float* gout, float* dw1, float* dw2, float* dw3,
                          float* dw4, int64_t num_edges, int32_t S, int32_t Sout, void* ws, size_t ws_bytes, gml_stream_t stream);

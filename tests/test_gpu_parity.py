@@ -2313,3 +2313,54 @@ def test_edge_branch_over_unique_rows_six_supports(dev, view):
         got = Fn.edge_mlp_bwd(vals, *w, gout, False, csr.presplit(vals), sym)
         for a_, r_ in zip(got[1:], ref[1:]):
             close(a_, r_, tol=1e-5, what='unique-row backward, six supports')
+
+
+def test_edge_branch_over_unique_rows_twelve_supports(dev):
+    """counting.py's twelve supports (the 9 .. 16-support kernel family) on the unique-row road: forward bitwise the plain three-piece
+    forward, weight gradients equal to the plain backward's to summation order, and the counting model's step with the road on / off."""
+    from gnn_matlang_amd import SpectralDesign, collate, synthetic, functional as Fn, models
+    raw = synthetic.make_graphs('counting', 96, seed=12)
+    b = collate(SpectralDesign(recfield=1, dv=1, nfreq=10, adddegree=True, laplacien=False, addadj=True).design_many(raw)).to(dev)
+    assert b.edge_attr2.size(1) == 12
+    # counting.py's design (laplacien=False) computes its supports in a way that leaves mirrored rows one fp32 ulp apart (14 % of the
+    # pairs are bitwise equal): the pairing pass then finds nothing to share and the plain kernels run -- checked first.  The rest of
+    # the test runs on the same supports made bitwise symmetric (every edge takes the row of its src < dst orientation).
+    csr = b.csr('edge_index2')
+    assert csr.sym_index(csr.to_source_order(csr.sort_values(b.edge_attr2))) is None
+    ei = b.edge_index2.cpu().numpy()
+    N = int(b.x.size(0))
+    key, rkey = ei[0].astype(np.int64) * N + ei[1], ei[1].astype(np.int64) * N + ei[0]
+    order = np.argsort(key)
+    rev = order[np.searchsorted(key[order], rkey)]
+    ea = b.edge_attr2.cpu().numpy()
+    b.edge_attr2 = torch.from_numpy(np.where((ei[0] <= ei[1])[:, None], ea, ea[rev])).to(dev)
+    vals = csr.to_source_order(csr.sort_values(b.edge_attr2), cache=True)
+    sym = csr.sym_index(vals)
+    assert sym is not None and sym[0].numel() < 0.75 * csr.E
+    torch.manual_seed(7)
+    w = tuple(torch.randn(*shp, device=dev) * 0.3 for shp in ((24, 12), (24, 12), (24, 12), (12, 48)))
+    plain = Fn.edge_mlp_fwd(vals, *w, None, csr.presplit(vals))[0]
+    shared = Fn.edge_mlp_fwd_stack(vals, None, [w], sym)
+    assert shared is not None and torch.equal(plain, shared[0])
+    gout = torch.randn_like(vals)
+    ref = Fn.edge_mlp_bwd(vals, *w, gout, False, csr.presplit(vals), None)
+    got = Fn.edge_mlp_bwd(vals, *w, gout, False, csr.presplit(vals), sym)
+    for a_, r_ in zip(got[1:], ref[1:]):
+        close(a_, r_, tol=3e-5, what='unique-row backward, twelve supports')      # (both are bf16x3 sums, split at different points: 1e-5 class)
+    torch.manual_seed(0)
+    m = models.counting_gnnml3().to(dev)
+    y = b.y.float() if b.y.dim() == 1 else b.y[:, 0].float()
+    res = {}
+    for on in (True, False):
+        old = Fn.EDGE_SYM
+        Fn.EDGE_SYM = on
+        try:
+            m.zero_grad()
+            pre = m(b)
+            models.counting_loss(pre, y).backward()
+            res[on] = (pre.detach().clone(), {n: p.grad.clone() for n, p in m.named_parameters()})
+        finally:
+            Fn.EDGE_SYM = old
+    assert torch.equal(res[True][0], res[False][0])
+    for n in res[True][1]:
+        close(res[True][1][n], res[False][1][n], tol=3e-5, what='counting, shared vs plain ' + n)
