@@ -253,7 +253,7 @@ def cpu_oracle_rate(host_batch, nsteps, warm, threads):
     med = float(np.median(t))
     return dict(value=B / med, unit='graphs/s', threads=torch.get_num_threads(), graphs_per_step=B,
                 nodes=int(b.x.size(0)), support_edges=int(b.edge_index2.size(1)), warmup=warm, timed_steps=nsteps,
-                ms_per_step=med * 1e3)
+                ms_per_step=med * 1e3, min_ms=float(np.min(t)) * 1e3, max_ms=float(np.max(t)) * 1e3)
 
 
 def parity_vs_oracle(model, data, base, log):
@@ -361,7 +361,8 @@ def cpu_baseline(cpu_graphs, log):
                 sample='%d ZINC-like graphs/step (N=%d, E=%d), %d timed steps after %d warm-up, median; fwd+bwd+Adam of '
                        'the oracle (op-for-op port of the reference CPU algorithm), torch CPU fp32'
                        % (large['graphs_per_step'], large['nodes'], large['support_edges'], large['timed_steps'], large['warmup']),
-                ms_per_step=large['ms_per_step'], large=large, bs64=bs64, thread_ladder=ladder,
+                ms_per_step=large['ms_per_step'], spread=dict(min_ms=large.get('min_ms'), max_ms=large.get('max_ms'), note='fastest / slowest of the timed steps (median reported): a shared host, the figure is context, not a ratio to quote'),
+                large=large, bs64=bs64, thread_ladder=ladder,
                 host_cores=ncpu, cpu_model=cpu_model_name(), torch_threads_default=default_threads)
 
 

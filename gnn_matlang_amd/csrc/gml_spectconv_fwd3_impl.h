@@ -142,10 +142,15 @@ __global__ __launch_bounds__(GmlFwd3Cfg<S>::NT, 1) void gml_k_spectconv_fwd3(con
     if constexpr (F16) {
         if (tid < 32) cmax[tid] = 0u;
         __syncthreads();
-        for (int e = tid; e < SW * 32 * 32; e += C::NT) {
-            const int f = e & 31, o = (e >> 5) & 31, s = e >> 10;
-            if (f < p.Fin && o < p.Fout)
-                atomicMax(&cmax[o], __float_as_uint(fabsf(p.w[(int64_t)(p.s0 + s) * p.w_ss + (int64_t)f * p.w_si + (int64_t)o * p.w_so])));
+        {   // thread = (column o = tid & 31, slice tid >> 5 of the (s, f) pairs): one atomic per thread, coalesced over o
+            const int o = tid & 31;
+            float m = 0.f;
+            if (o < p.Fout)
+                for (int i = tid >> 5; i < SW * 32; i += C::NT / 32) {
+                    const int s = i >> 5, f = i & 31;
+                    if (f < p.Fin) m = fmaxf(m, fabsf(p.w[(int64_t)(p.s0 + s) * p.w_ss + (int64_t)f * p.w_si + (int64_t)o * p.w_so]));
+                }
+            atomicMax(&cmax[o], __float_as_uint(m));
         }
         __syncthreads();
     }
