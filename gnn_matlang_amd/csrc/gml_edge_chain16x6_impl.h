@@ -72,15 +72,17 @@ __global__ __launch_bounds__(256, 2) void gml_k_edge_chain16x6_fwd(const float* 
     GmlNegI negI;
     gml_chain_make_negI(negI, c16, g);
     const int q0 = 4 * g, c0 = 8 * (g & 1);                    // output rows / in-channels of this lane group
-    const int64_t stride = (int64_t)gridDim.x * 4;
-    int64_t t = (int64_t)blockIdx.x * 4 + wave;
+    // a wave works on PAIRS of tiles (two independent dependency chains per trip: the kernel is latency-bound, not issue-bound, with one)
+    const int64_t stride = (int64_t)gridDim.x * 8;
+    int64_t t = ((int64_t)blockIdx.x * 4 + wave) * 2;
     const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
-    int32_t sid_n = 0;                                          // SYM: the entry's own edge (its store row)
-    auto fetch = [&](int64_t tt, float (&e)[8], int32_t& tp) {  // clamped: always a readable edge
+    struct Tile { float e[8]; int32_t tp, sid; };
+    auto fetch = [&](int64_t tt, Tile& T) {                     // clamped: always a readable edge
         int64_t ed = min(tt * 16 + c16, E - 1);
+        T.sid = 0;
         if constexpr (SYM) {
-            tp = mir[ed];
-            ed = sid_n = uid[ed];
+            T.tp = mir[ed];
+            ed = T.sid = uid[ed];
         }
         const float* p = ea + ed * S;
         if constexpr (S % 4 == 0) {
@@ -88,29 +90,21 @@ __global__ __launch_bounds__(256, 2) void gml_k_edge_chain16x6_fwd(const float* 
             for (int i = 0; i < 2; ++i) {
                 const int c = c0 + 4 * i;
                 const f32x4 v = c < S ? *reinterpret_cast<const f32x4*>(p + c) : zero;
-                e[4 * i] = v.x; e[4 * i + 1] = v.y; e[4 * i + 2] = v.z; e[4 * i + 3] = v.w;
+                T.e[4 * i] = v.x; T.e[4 * i + 1] = v.y; T.e[4 * i + 2] = v.z; T.e[4 * i + 3] = v.w;
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) e[j] = c0 + j < S ? p[c0 + j] : 0.f;
+            for (int j = 0; j < 8; ++j) T.e[j] = c0 + j < S ? p[c0 + j] : 0.f;
         }
-        if constexpr (!SYM) tp = out_t != nullptr ? tpos[ed] : 0;
+        if constexpr (!SYM) T.tp = out_t != nullptr ? tpos[ed] : 0;
     };
-    float en[8];
-    int32_t tpn;
-    fetch(t, en, tpn);
-    for (; t < ntiles; t += stride) {
-        float e[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) e[j] = en[j];
-        const int32_t tp = tpn, sid = sid_n;
-        fetch(t + stride < ntiles ? t + stride : t, en, tpn);   // next tile's rows in flight during this chain
+    auto chain = [&](const Tile& T) -> f32x4 {
         // layer-1 operands: BA = [e_h | e_m], BB = [e_l | e_h] over the lane groups (0, 1 | 2, 3)
         uint32_t a[4], b[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             uint32_t h, m, l;
-            gml_split3_pair(e[2 * j], e[2 * j + 1], h, m, l);
+            gml_split3_pair(T.e[2 * j], T.e[2 * j + 1], h, m, l);
             a[j] = g < 2 ? h : m;
             b[j] = g < 2 ? l : h;
         }
@@ -142,12 +136,14 @@ __global__ __launch_bounds__(256, 2) void gml_k_edge_chain16x6_fwd(const float* 
         o = GML_MFMA(W.a2[0][1], A1[0], o);  o2 = GML_MFMA(W.a2[1][1], A2[0], o2);
         o = GML_MFMA(W.a2[0][0], A1[1], o);  o2 = GML_MFMA(W.a2[1][0], A2[1], o2);
         o = GML_MFMA(W.a2[0][0], A1[0], o);  o2 = GML_MFMA(W.a2[1][0], A2[0], o2);
-        o = o + o2;
-        const int64_t eid = t * 16 + c16;
-        if (eid < E && q0 < S) {
+        return o + o2;
+    };
+    auto store = [&](int64_t tt, const Tile& T, const f32x4 o) {
+        const int64_t eid = tt * 16 + c16;
+        if (tt < ntiles && eid < E && q0 < S) {
             const f32x4 v = f32x4{gml_relu1(o[0]), gml_relu1(o[1]), gml_relu1(o[2]), gml_relu1(o[3])};
-            float* op = out + (SYM ? (int64_t)sid : eid) * S + q0;
-            float* ot = SYM ? (tp >= 0 ? out + (int64_t)tp * S + q0 : nullptr) : (out_t != nullptr ? out_t + (int64_t)tp * S + q0 : nullptr);
+            float* op = out + (SYM ? (int64_t)T.sid : eid) * S + q0;
+            float* ot = SYM ? (T.tp >= 0 ? out + (int64_t)T.tp * S + q0 : nullptr) : (out_t != nullptr ? out_t + (int64_t)T.tp * S + q0 : nullptr);
             if constexpr (S % 4 == 0) {
                 __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(op));
                 if (ot != nullptr) *reinterpret_cast<f32x4*>(ot) = v;
@@ -160,6 +156,18 @@ __global__ __launch_bounds__(256, 2) void gml_k_edge_chain16x6_fwd(const float* 
                     }
             }
         }
+    };
+    Tile N0, N1;
+    fetch(t, N0);
+    fetch(t + 1, N1);
+    for (; t < ntiles; t += stride) {
+        const Tile C0 = N0, C1 = N1;
+        const int64_t tn = t + stride < ntiles ? t + stride : t;
+        fetch(tn, N0);                                          // next pair's rows in flight during these chains
+        fetch(tn + 1, N1);
+        const f32x4 o0 = chain(C0), o1 = chain(C1);
+        store(t, C0, o0);
+        store(t + 1, C1, o1);
     }
 }
 
@@ -167,8 +175,8 @@ template <int S>
 int gml_launch_edge_chain16x6_fwd_sym(const float* ea, const int32_t* uid, const int32_t* mir, int64_t U, const float* w1, const float* w2,
                                       const float* w3, const float* w4, float* out, hipStream_t st) {
     const int64_t ntiles = gml_cdiv(U, 16);
-    int64_t grid = gml_cdiv(ntiles, 4);
-    if (grid > 4 * GML_NUM_CU) grid = 4 * GML_NUM_CU;
+    int64_t grid = gml_cdiv(ntiles, 8);
+    if (grid > 2 * GML_NUM_CU) grid = 2 * GML_NUM_CU;
     if (gml_chain6_accurate_tanh())
         hipLaunchKernelGGL((gml_k_edge_chain16x6_fwd<S, true, true>), dim3((unsigned)grid), dim3(256), 0, st, ea, w1, w2, w3, w4, out, nullptr, nullptr, U, ntiles, uid, mir);
     else
@@ -180,8 +188,8 @@ template <int S>
 int gml_launch_edge_chain16x6_fwd(const float* ea, const float* w1, const float* w2, const float* w3, const float* w4, float* out,
                                   const int32_t* tpos, float* out_t, int64_t E, hipStream_t st) {
     const int64_t ntiles = gml_cdiv(E, 16);
-    int64_t grid = gml_cdiv(ntiles, 4);
-    if (grid > 4 * GML_NUM_CU) grid = 4 * GML_NUM_CU;
+    int64_t grid = gml_cdiv(ntiles, 8);
+    if (grid > 2 * GML_NUM_CU) grid = 2 * GML_NUM_CU;
     if (gml_chain6_accurate_tanh())
         hipLaunchKernelGGL((gml_k_edge_chain16x6_fwd<S, true>), dim3((unsigned)grid), dim3(256), 0, st, ea, w1, w2, w3, w4, out, tpos, out_t, E, ntiles);
     else
