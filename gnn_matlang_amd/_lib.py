@@ -84,6 +84,8 @@ SIGNATURES = {
                                       _p, _i64, _p, _i64, _p, _i64, _p]),
     'gml_edge_mlp_bwd_parts': (_i64, [_i64, _i32, _i32, _i32, _i32]),
     'gml_edge_mlp_wide_fwd': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
+    'gml_edge_mlp_wide_bwd': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
+    'gml_edge_mlp_wide_bwd_h2r': (ctypes.c_int32, [_i32]),
     'gml_edge_mlp_bwd_workspace_bytes': (_sz, [_i64, _i32, _i32]),
     'gml_edge_mlp_bwd': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p, _sz, _p]),
     'gml_node_mix_fwd': (ctypes.c_int, [_p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _i32, _i32, _p]),

@@ -447,10 +447,15 @@ def _edge_branch_torch(ea, w1, w2, w3, w4):
     return torch.relu(torch.addmm(h1 @ w4[:, :h1.size(1)].t(), h23, w4[:, h1.size(1):].t()))
 
 
+EDGE_WIDE_BWD_LIB = _os.environ.get('GML_EDGE_WIDE_BWD_LIB', '0') not in ('0', '')     # A/B: the round-5 library recompute
+
+
 class EdgeBranchWide(torch.autograd.Function):
     """ML3Layer edge branch for 16 < max(S, Sout) <= 48: forward = ONE launch (gml_edge_mlp_wide_fwd: weights in LDS, exact fp32
-    products, no intermediate in HBM -- the library road writes ~30 GB of them at S = 48 on 13 M edges); backward = the library
-    expression recomputed under autograd (no reference script trains more than 12 supports)."""
+    products, no intermediate in HBM -- the library road writes ~30 GB of them at S = 48 on 13 M edges); backward (round 6) = ONE launch
+    for the per-edge part (gml_edge_mlp_wide_bwd: masked output gradient, hidden activations and the three pre-activation gradients,
+    exact fp32) + the four weight gradients as tall contractions on the matrix cores (gml_xty_wide); the supports' own gradient, when
+    asked for, is three library GEMMs.  GML_EDGE_WIDE_BWD_LIB=1: the library expression recomputed under autograd (rounds 1-5)."""
 
     @staticmethod
     def forward(ctx, ea, w1, w2, w3, w4):
@@ -462,18 +467,41 @@ class EdgeBranchWide(torch.autograd.Function):
         with torch.cuda.device(ea.device):
             _lib.call('gml_edge_mlp_wide_fwd', _ptr(ea), _ptr(ws[0]), _ptr(ws[1]), _ptr(ws[2]), _ptr(ws[3]), _ptr(out), int(E), int(S), So,
                       _stream(ea.device))
-        ctx.save_for_backward(ea, w1, w2, w3, w4)
+        ctx.save_for_backward(ea, w1, w2, w3, w4, out)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        ea, w1, w2, w3, w4 = ctx.saved_tensors
+        ea, w1, w2, w3, w4, out = ctx.saved_tensors
         need = ctx.needs_input_grad
+        E, S = ea.shape
+        So = int(w4.size(0))
+        if not EDGE_WIDE_BWD_LIB and not exact_mode('edge') and E > 0:
+            dev = ea.device
+            ws = [_f32c(w.detach(), 'edge weight') for w in (w1, w2, w3, w4)]
+            g = _f32c(g, 'grad_output')
+            H2 = 2 * S
+            H2R = int(_lib.lib().gml_edge_mlp_wide_bwd_h2r(int(S)))
+            with torch.cuda.device(dev):
+                go = torch.empty(E, So, dtype=torch.float32, device=dev)
+                hid = torch.empty(E, 2 * H2R, dtype=torch.float32, device=dev)
+                gz = torch.empty(E, 3 * H2R, dtype=torch.float32, device=dev)
+                _lib.call('gml_edge_mlp_wide_bwd', _ptr(ea), _ptr(ws[0]), _ptr(ws[1]), _ptr(ws[2]), _ptr(ws[3]), _ptr(out), _ptr(g), _ptr(go),
+                          _ptr(hid), _ptr(gz), int(E), int(S), So, _stream(dev))
+                dws = [xty_wide(gz[:, m * H2R:m * H2R + H2], ea) for m in range(3)]           # dW_m = gz_m^T e   [2S, S]
+                d4 = [xty_wide(hid[:, b * H2R:b * H2R + H2], go) for b in range(2)]           # (hid_b^T go)^T    [So, 2S] each
+                if all(t is not None for t in dws + d4):
+                    dw4 = torch.cat([d4[0].t(), d4[1].t()], 1).contiguous()
+                    gin = None
+                    if need[0]:                            # d e = sum_m gz_m W_m (no reference script trains the raw supports)
+                        gin = gz[:, :H2] @ ws[0]
+                        gin.addmm_(gz[:, H2R:H2R + H2], ws[1]).addmm_(gz[:, 2 * H2R:2 * H2R + H2], ws[2])
+                    return gin, dws[0], dws[1], dws[2], dw4
         with torch.enable_grad():
             ins = [t.detach().requires_grad_(n) for t, n in zip((ea, w1, w2, w3, w4), need)]
-            out = _edge_branch_torch(*ins)
+            o2 = _edge_branch_torch(*ins)
             wanted = [t for t, n in zip(ins, need) if n]
-            gs = iter(torch.autograd.grad(out, wanted, g) if wanted else ())
+            gs = iter(torch.autograd.grad(o2, wanted, g) if wanted else ())
         return tuple(next(gs) if n else None for n in need)
 
 

@@ -316,6 +316,15 @@ int gml_edge_mlp_fwd(const float* ea, const void* ea_split, const float* w1, con
  * for the backward (no reference script trains more than 12 supports). */
 int gml_edge_mlp_wide_fwd(const float* ea, const float* w1, const float* w2, const float* w3, const float* w4, float* out,
                           int64_t num_edges, int32_t S, int32_t Sout, gml_stream_t stream);
+/* Its backward, per-edge part (round 6; the autograd of libs/spect_conv.py:205-207): out = the forward's result, gout = dL/dout;
+ * writes go [E, Sout] = gout * (out > 0), hid [E, 2 H2R] = relu(W1 e) | tanh(W2 e) tanh(W3 e) and gz [E, 3 H2R] = the gradients at
+ * the three pre-activations, H2R = gml_edge_mlp_wide_bwd_h2r(S) = 2 S rounded up to a multiple of 4 (rows 16-byte aligned).  The
+ * weight gradients are the tall contractions dW_m = gz[:, m H2R : m H2R + 2 S]^T ea and dW4[:, b 2S : (b+1) 2S] = (hid[:, b H2R : b H2R
+ * + 2 S]^T go)^T (gml_xty_wide); the supports' own gradient sum_m gz_m W_m.  Exact fp32 products; same shape range as the forward. */
+int32_t gml_edge_mlp_wide_bwd_h2r(int32_t S);
+int gml_edge_mlp_wide_bwd(const float* ea, const float* w1, const float* w2, const float* w3, const float* w4, const float* out,
+                          const float* gout, float* go, float* hid, float* gz, int64_t num_edges, int32_t S, int32_t Sout,
+                          gml_stream_t stream);
 
 /* The edge branches of a STACK of ML3Layers in one pass: every layer of Zinc12k.py:338-341 / counting.py:361-366 receives the
  * same raw supports (data.edge_attr2), so L launches of gml_edge_mlp_fwd read them L times.  out[l] [num_edges, Sout] =

@@ -613,7 +613,8 @@ def test_ml3layer_wide_shapes(dev, ne, neo, Fin, n1, n2):
 def test_edge_branch_beyond_16_supports_vs_fp64(dev, S, So, E):
     """gml_edge_mlp_wide_fwd (the edge branch for 16 < S <= 48, libs/spect_conv.py:190-194, 205-207) against the
     oracle's expression in float64 -- exact fp32 products, so far inside 1e-4 -- and the same values as the library road it replaces;
-    gradients (library recompute) against float64 autograd."""
+    gradients THROUGH THE HIP BACKWARD (round 6: gml_edge_mlp_wide_bwd + gml_xty_wide) against float64 autograd,
+    the supports' own gradient included."""
     from gnn_matlang_amd import functional as Fn
     torch.manual_seed(S * 100 + So)
     ea = torch.randn(E, S) * 0.7
