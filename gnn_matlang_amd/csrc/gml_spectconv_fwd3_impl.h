@@ -28,6 +28,10 @@
 #ifndef GML_FWABL
 #define GML_FWABL 0
 #endif
+// cache policy of the wide output stores (0 = default, 2 = nt; A/B: tools/build_variant.py f3nt -DGML_FWD3_ST_AUX=2)
+#ifndef GML_FWD3_ST_AUX
+#define GML_FWD3_ST_AUX 0
+#endif
 #ifdef GML_FWD2_TIMING
 #define GML_TF3(i) do { const unsigned t_ = (unsigned)__builtin_readcyclecounter(); tacc_[i] += t_ - tprev_; tprev_ = t_; } while (0)
 #else
@@ -622,7 +626,7 @@ __global__ __launch_bounds__(GmlFwd3Cfg<S>::NT, 1) void gml_k_spectconv_fwd3(con
                     gml_quad_transpose(ov[ob], lane);
                     const int c = 16 * ob + 4 * (r16 >> 2);
                     const int off = (c < ncols && lr < nr && !(GML_FWABL & 4)) ? (lr * (int)p.ldo + c) * 4 : 0x7fffff00;
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov[ob]), ors, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov[ob]), ors, off, 0, GML_FWD3_ST_AUX);
                 }
                 GML_TF3(7);
             } else {
