@@ -229,6 +229,12 @@ __device__ __forceinline__ void gml_split8_f16(const float (&x)[8], float s, f16
     }
 }
 
+// operand piece type of the projection: bf16 pairs (bf16x3) or f16 pairs under power-of-two scales (f16x3, gml_common.h)
+template <bool F16> struct GmlPiece { using T = bf16x8; };
+template <> struct GmlPiece<true> { using T = f16x8; };
+__device__ __forceinline__ f32x4 gml_mfma_piece(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 gml_mfma_piece(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
 // sum of partial[w * n + j] over w = wl, wl + 16, ... < nparts in ascending order (the fixed order of every
 // partial fold), eight clamped, unconditional loads in flight per step instead of one dependent load per add
 __device__ __forceinline__ float gml_fold_column(const float* __restrict__ partial, int64_t nparts, int64_t n,

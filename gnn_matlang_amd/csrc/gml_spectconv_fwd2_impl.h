@@ -54,10 +54,14 @@ struct GmlFwd2Cfg {
 // ONE edge order (the backward's) and writes its output once -- the second, scattered copy cost the HBM-bound edge forward
 // 37 % of its time (profiles/r02_g_edge_fwd_ablation.txt).  The positions are loaded with the other prefetch loads, the
 // value rows they address after the aggregation loop (the positions have arrived by then: no exposed dependent latency).
-template <int S, int NOB, bool XVEC, bool MIX, bool EP = false, int NW = 8>
+// F16 (round 6, GML_F16X3: see gml_spectconv_fwd3_impl.h): projection and Hadamard branch on f16 (hi, lo) pieces under power-of-two
+// scales -- the conv instantiations of the 8-wave geometry (counting.py's 12 supports, every shape fwd3 does not take)
+template <int S, int NOB, bool XVEC, bool MIX, bool EP = false, int NW = 8, bool F16 = false>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void gml_k_spectconv_fwd2(const GmlFwdParams p) {
     using C = GmlFwd2Cfg<S>;
+    using FT = typename GmlPiece<F16>::T;
     constexpr bool HOUT = (NOB == 0);
+    static_assert(!F16 || (NOB != 0 && NW == 8), "f16 pieces: conv instantiations, 8-wave geometry");
     static_assert(!(EP && NOB == 0), "the stand-alone SpMM instantiations take contiguous value rows");
     static_assert(NW == 8 || (NW == 4 && NOB != 0), "4-wave geometry: conv instantiations only");
     constexpr int NT = 64 * NW, ECAP = C::ecap(NW), XCAP = C::xcap(NW);
@@ -91,21 +95,51 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void gml_k_spectconv_fwd2
     const int g1 = min(g0 + p.groups_per_wg, p.ngroups);
     if (g0 >= g1) return;
 
+    // f16 pieces: the largest magnitude of every output column first (32 words of the column-id area: free until the first commit)
+    uint32_t* cmax = reinterpret_cast<uint32_t*>(col_l);
+    if constexpr (F16) {
+        if (tid < 32) cmax[tid] = 0u;
+        __syncthreads();
+        {
+            const int o = tid & 31;
+            float m = 0.f;
+            if (o < p.Fout)
+                for (int i = tid >> 5; i < S * 32; i += NT / 32) {
+                    const int s = i >> 5, f = i & 31;
+                    if (f < p.Fin) m = fmaxf(m, fabsf(p.w[(int64_t)(p.s0 + s) * p.w_ss + (int64_t)f * p.w_si + (int64_t)o * p.w_so]));
+                }
+            atomicMax(&cmax[o], __float_as_uint(m));
+        }
+        __syncthreads();
+    }
     for (int e = tid; e < S * 32 * 32 && !HOUT; e += NT) {
         const int f = e & 31, o = (e >> 5) & 31, s = e >> 10;
         const float v = (f < p.Fin && o < p.Fout) ? p.w[(int64_t)(p.s0 + s) * p.w_ss + (int64_t)f * p.w_si + (int64_t)o * p.w_so] : 0.f;
-        const __bf16 h = (__bf16)v;
-        const __bf16 l = (__bf16)(v - (float)h);
         const int iof = (s * 32 + o) * 32 + ((((f >> 3) ^ gml_wkey(o)) & 3) << 3) + (f & 7);
-        Wof_h[iof] = h;
-        Wof_l[iof] = l;
+        if constexpr (F16) {
+            float sc, inv;
+            gml_f16_scale_bits(cmax[o], sc, inv);
+            const float vs = v * sc;
+            const _Float16 h = (_Float16)vs;
+            reinterpret_cast<_Float16*>(Wof_h)[iof] = h;
+            reinterpret_cast<_Float16*>(Wof_l)[iof] = (_Float16)(vs - (float)h);
+        } else {
+            const __bf16 h = (__bf16)v;
+            const __bf16 l = (__bf16)(v - (float)h);
+            Wof_h[iof] = h;
+            Wof_l[iof] = l;
+        }
     }
-    float bias_r[NOBA];
+    float bias_r[NOBA], winv_r[NOBA];
 #pragma unroll
-    for (int ob = 0; ob < NOBA; ++ob) bias_r[ob] = (!HOUT && p.bias && ob * 16 + r16 < p.Fout) ? p.bias[ob * 16 + r16] : 0.f;
+    for (int ob = 0; ob < NOBA; ++ob) {
+        bias_r[ob] = (!HOUT && p.bias && ob * 16 + r16 < p.Fout) ? p.bias[ob * 16 + r16] : 0.f;
+        winv_r[ob] = 1.f;
+        if constexpr (F16) { float sc; gml_f16_scale_bits(cmax[ob * 16 + r16], sc, winv_r[ob]); }
+    }
 
-    bf16x8 mwh, mwl;                                           // B[k = f][n = c]: c < F2 -> w11 row c, F2 <= c < 2 F2 -> w12 row c - F2
-    float mbias = 0.f;
+    FT mwh, mwl;                                               // B[k = f][n = c]: c < F2 -> w11 row c, F2 <= c < 2 F2 -> w12 row c - F2
+    float mbias = 0.f, mwinv = 1.f;
     if constexpr (MIXB) {
         float v[8];
 #pragma unroll
@@ -114,7 +148,18 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void gml_k_spectconv_fwd2
             const bool ok = f < p.Fin && r16 < 2 * p.F2;
             v[j] = ok ? (r16 < p.F2 ? p.w11[r16 * p.Fin + f] : p.w12[(r16 - p.F2) * p.Fin + f]) : 0.f;
         }
-        gml_split8(v, mwh, mwl);
+        if constexpr (F16) {
+            float m = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[j]));
+            m = fmaxf(m, __shfl_xor(m, 16));
+            m = fmaxf(m, __shfl_xor(m, 32));
+            float sc;
+            gml_f16_scale_bits(__float_as_uint(m), sc, mwinv);
+            gml_split8_f16(v, sc, mwh, mwl);
+        } else {
+            gml_split8(v, mwh, mwl);
+        }
         if (r16 < p.F2) mbias = p.b11 ? p.b11[r16] : 0.f;
         else if (r16 < 2 * p.F2) mbias = p.b12 ? p.b12[r16 - p.F2] : 0.f;
     }
@@ -377,45 +422,65 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void gml_k_spectconv_fwd2
         }
 
         // ---- projection: out tile = sum_s acc_s W_s (acc split on the fly = A fragments, k = f = 8*kq + j)
-        f32x4 oacc[NOBA];
+        f32x4 oacc[NOBA], oold[F16 ? NOBA : 1];
+        float oscale[NOBA];
 #pragma unroll
-        for (int ob = 0; ob < NOB; ++ob) oacc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ob = 0; ob < NOB; ++ob) { oacc[ob] = f32x4{0.f, 0.f, 0.f, 0.f}; oscale[ob] = 1.f; }
+        if constexpr (F16) {
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob) oold[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         if (p.flags & GML_ACCUM) {                             // the old values travel while the MFMAs run (clamped loads)
 #pragma unroll
             for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const int lr = min((int)((out_rows >> (8 * reg)) & 255u), nr - 1);
-                    oacc[ob][reg] = p.out[(r0 + lr) * p.ldo + min(ob * 16 + r16, p.Fout - 1)];
+                    const float ov = p.out[(r0 + lr) * p.ldo + min(ob * 16 + r16, p.Fout - 1)];
+                    if constexpr (F16) oold[ob][reg] = ov;     // (the accumulators are in scaled units: added in the epilogue)
+                    else oacc[ob][reg] = ov;
                 }
         }
         {
             // W fragments of support s + 1 are requested before the MFMAs of support s (the projection as first written --
             // read, wait, dependent MFMA triple, per block -- exposed one LDS round trip per block)
-            bf16x8 wh[2][NOBA], wl[2][NOBA];
+            FT wh[2][NOBA], wl[2][NOBA];
             auto frag = [&](int s, int st) {
 #pragma unroll
                 for (int ob = 0; ob < NOB; ++ob) {
                     const int o = ob * 16 + r16;               // B[k = f][n = o]: 8 consecutive f of column o
                     const int off = (s * 32 + o) * 32 + (((kq ^ gml_wkey(o)) & 3) << 3);
-                    wh[st][ob] = *reinterpret_cast<const bf16x8*>(Wof_h + off);
-                    wl[st][ob] = *reinterpret_cast<const bf16x8*>(Wof_l + off);
+                    wh[st][ob] = *reinterpret_cast<const FT*>(Wof_h + off);
+                    wl[st][ob] = *reinterpret_cast<const FT*>(Wof_l + off);
                 }
             };
             frag(0, 0);
+            float asc = 1.f;
+            if constexpr (F16) {                               // the tile's scale (gml_spectconv_fwd3_impl.h)
+                float m = 0.f;
+#pragma unroll
+                for (int s = 0; s < S; ++s)
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) m = fmaxf(fmaxf(fabsf(acc[s][h].x), fabsf(acc[s][h].y)), m);
+                float ainv;
+                gml_f16_scale_bits(gml_wave_max_bits(__float_as_uint(m)), asc, ainv);
+#pragma unroll
+                for (int ob = 0; ob < NOB; ++ob) oscale[ob] = ainv * winv_r[ob];
+            }
 #pragma unroll
             for (int s = 0; s < ((GML_FWABL & 2) ? 0 : S); ++s) {
                 const int st = s & 1;
                 if (s + 1 < S) frag(s + 1, st ^ 1);
                 const float av[8] = {acc[s][0].x, acc[s][0].y, acc[s][1].x, acc[s][1].y, acc[s][2].x, acc[s][2].y, acc[s][3].x, acc[s][3].y};
-                bf16x8 ah, al;
-                gml_split8(av, ah, al);
+                FT ah, al;
+                if constexpr (F16) gml_split8_f16(av, asc, ah, al);
+                else gml_split8(av, ah, al);
 #pragma unroll
-                for (int ob = 0; ob < NOB; ++ob) oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wh[st][ob], oacc[ob], 0, 0, 0);
+                for (int ob = 0; ob < NOB; ++ob) oacc[ob] = gml_mfma_piece(al, wh[st][ob], oacc[ob]);
 #pragma unroll
-                for (int ob = 0; ob < NOB; ++ob) oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wl[st][ob], oacc[ob], 0, 0, 0);
+                for (int ob = 0; ob < NOB; ++ob) oacc[ob] = gml_mfma_piece(ah, wl[st][ob], oacc[ob]);
 #pragma unroll
-                for (int ob = 0; ob < NOB; ++ob) oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wh[st][ob], oacc[ob], 0, 0, 0);
+                for (int ob = 0; ob < NOB; ++ob) oacc[ob] = gml_mfma_piece(ah, wh[st][ob], oacc[ob]);
             }
             __builtin_amdgcn_sched_group_barrier(0x100, 2 * NOB, 0);
 #pragma unroll
@@ -436,7 +501,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void gml_k_spectconv_fwd2
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int lr = (int)((out_rows >> (8 * reg)) & 255u);
-                float v = oacc[ob][reg] + bias_r[ob];
+                float v = F16 ? fmaf(oacc[ob][reg], oscale[ob], bias_r[ob]) + oold[F16 ? ob : 0][reg] : oacc[ob][reg] + bias_r[ob];
                 if (relu) v = fmaxf(v, 0.f);
                 const int off = (o < p.Fout && lr < nr && !(GML_FWABL & 4)) ? (lr * (int)p.ldo + o) * 4 : 0x7fffff00;
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ors, off, 0, 0);
@@ -448,15 +513,26 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void gml_k_spectconv_fwd2
 #pragma unroll
             for (int j = 0; j < 8; ++j)
                 if (8 * kq + j >= p.Fin) xrow[j] = 0.f;        // clamped loads fetched a neighbour: outside Fin -> 0
-            bf16x8 xh, xl;
-            gml_split8(xrow, xh, xl);
+            FT xh, xl;
+            float zsc = 1.f;
+            if constexpr (F16) {
+                float m = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(xrow[j]));
+                float xsc, xinv;
+                gml_f16_scale_bits(gml_wave_max_bits(__float_as_uint(m)), xsc, xinv);
+                gml_split8_f16(xrow, xsc, xh, xl);
+                zsc = xinv * mwinv;
+            } else {
+                gml_split8(xrow, xh, xl);
+            }
             f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
-            z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, mwh, z, 0, 0, 0);
-            z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, mwl, z, 0, 0, 0);
-            z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, mwh, z, 0, 0, 0);
+            z = gml_mfma_piece(xl, mwh, z);
+            z = gml_mfma_piece(xh, mwl, z);
+            z = gml_mfma_piece(xh, mwh, z);
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const float t = gml_tanh(z[reg] + mbias);
+                const float t = gml_tanh(fmaf(z[reg], zsc, mbias));
                 const float u = __shfl(t, lane + p.F2);        // partner column c + F2 of the same 16-lane row group
                 const int lr = (int)((out_rows >> (8 * reg)) & 255u);
                 const int off = (r16 < p.F2 && lr < nr) ? (lr * (int)p.ldo + p.mix_col + r16) * 4 : 0x7fffff00;
@@ -490,7 +566,19 @@ int gml_launch_fwd2(const GmlFwdParams& p, dim3 grid, hipStream_t st, bool xvec,
                            GmlFwd2Cfg<SV>::lds_bytes(NWV), st, p);                                           \
         return gml_launch_status();                                                                          \
     }
-#define GML_FWD2_LAUNCH_E(SV, NOBV, XV, MX, EPV) GML_FWD2_LAUNCH_N(SV, NOBV, XV, MX, EPV, 8)
+#define GML_FWD2_LAUNCH_F(SV, NOBV, XV, MX, EPV)                                                             \
+    {                                                                                                        \
+        GML_ALLOW_BIG_LDS(rc_, (&gml_k_spectconv_fwd2<SV, NOBV, XV, MX, EPV, 8, true>), 160 * 1024)          \
+        if (rc_ != hipSuccess) return (int)rc_;                                                              \
+        hipLaunchKernelGGL((gml_k_spectconv_fwd2<SV, NOBV, XV, MX, EPV, 8, true>), grid, dim3(512),          \
+                           GmlFwd2Cfg<SV>::lds_bytes(8), st, p);                                             \
+        return gml_launch_status();                                                                          \
+    }
+#define GML_FWD2_LAUNCH_E(SV, NOBV, XV, MX, EPV)                                                             \
+    {                                                                                                        \
+        if constexpr (NOBV != 0) { if (p.flags & GML_F16X3) GML_FWD2_LAUNCH_F(SV, (NOBV != 0 ? NOBV : 1), XV, MX, EPV) }  \
+        GML_FWD2_LAUNCH_N(SV, NOBV, XV, MX, EPV, 8)                                                          \
+    }
 #define GML_FWD2_LAUNCH(SV, NOBV, XV, MX) GML_FWD2_LAUNCH_E(SV, NOBV, XV, MX, false)
 #define GML_DEFINE_SPMM2(SV)                                                                                 \
     template <>                                                                                              \

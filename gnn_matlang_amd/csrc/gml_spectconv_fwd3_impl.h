@@ -80,12 +80,6 @@ __device__ __forceinline__ void gml_quad_transpose(f32x4& v, int lane) {
     }
 }
 
-// operand piece type of the projection: bf16 pairs (bf16x3) or f16 pairs under power-of-two scales (f16x3, gml_common.h)
-template <bool F16> struct GmlPiece { using T = bf16x8; };
-template <> struct GmlPiece<true> { using T = f16x8; };
-__device__ __forceinline__ f32x4 gml_mfma_piece(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ f32x4 gml_mfma_piece(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
-
 template <int S>
 struct GmlFwd3Cfg {
     static constexpr int ROWS = 128;
