@@ -9,8 +9,13 @@ extern "C" int gml_edge_sym_flags(const int32_t* rowptr_t, const int32_t* col_t,
     if (num_rows < 0 || num_edges < 0 || S <= 0) return GML_E_BADARG;
     if (num_edges == 0) return GML_OK;
     if (!rowptr_t || !col_t || !val_s || !flag || !mirror || num_rows == 0) return GML_E_BADARG;
-    hipLaunchKernelGGL(gml_k_edge_sym_flags, dim3((unsigned)gml_cdiv(num_rows * 16, 256)), dim3(256), 0, (hipStream_t)stream, rowptr_t,
-                       col_t, reinterpret_cast<const uint32_t*>(val_s), num_rows, num_edges, (int)S, flag, mirror);
+    // lanes per source row: the power of two nearest the mean row length (GML_SYM_LPS in the environment overrides: A/B)
+    static const int lps_env = [] { const char* e = getenv("GML_SYM_LPS"); return e ? atoi(e) : -1; }();
+    int lps = 0;
+    while (lps < 4 && (num_rows << (lps + 1)) <= num_edges) ++lps;        // 2^lps <= edges per row
+    if (lps_env >= 0 && lps_env <= 4) lps = lps_env;
+    hipLaunchKernelGGL(gml_k_edge_sym_flags, dim3((unsigned)gml_cdiv(num_rows << lps, 256)), dim3(256), 0, (hipStream_t)stream, rowptr_t,
+                       col_t, reinterpret_cast<const uint32_t*>(val_s), num_rows, num_edges, (int)S, lps, flag, mirror);
     return gml_launch_status();
 }
 

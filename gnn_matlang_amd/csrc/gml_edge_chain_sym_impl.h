@@ -27,15 +27,18 @@
 #define GML_SYM_BWD_WGS 3
 #endif
 
-// flag / mirror of every edge of the SOURCE-keyed view (row r = source, col_t = targets ascending inside a row).  16 lanes share a
-// source row and deal its edges: the row is known without a search, the mirror is found by bisection in the target's row
+// flag / mirror of every edge of the SOURCE-keyed view (row r = source, col_t = targets ascending inside a row).  2^LPS lanes share a
+// source row and deal its edges (the row is known without a search; ZINC-like rows hold ~6 edges: 4 lanes per row), the mirror is
+// found by bisection in the target's row
 __global__ __launch_bounds__(256) void gml_k_edge_sym_flags(const int32_t* __restrict__ rowptr_t, const int32_t* __restrict__ col_t,
-                                                           const uint32_t* __restrict__ val, int64_t N, int64_t E, int S,
+                                                           const uint32_t* __restrict__ val, int64_t N, int64_t E, int S, int LPS,
                                                            int32_t* __restrict__ flag, int32_t* __restrict__ mirror) {
-    const int64_t src = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int64_t gt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t src = gt >> LPS;
     if (src >= N) return;
+    const int lpr = 1 << LPS;
     const int k0 = rowptr_t[src], k1 = rowptr_t[src + 1];
-    for (int k = k0 + (threadIdx.x & 15); k < k1; k += 16) {
+    for (int k = k0 + (int)(gt & (lpr - 1)); k < k1; k += lpr) {
         const int dst = col_t[k];
         int f = 1, m = -1;
         // (a multigraph's repeated edge (i, j) has no unique mirror: such edges -- on either side -- are evaluated alone)
