@@ -27,6 +27,12 @@
 #include "gml_spectconv_fwd3_impl.h"
 
 typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
+// K = 16 piece operands and their MFMA (features 32 .. 47), bf16 pairs or f16 pairs (GML_F16X3)
+template <bool F16> struct GmlPiece4 { using T = bf16x4v; };
+template <> struct GmlPiece4<true> { using T = f16x4v; };
+__device__ __forceinline__ f32x4 gml_mfma_piece4(bf16x4v a, bf16x4v b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 gml_mfma_piece4(f16x4v a, f16x4v b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
 
 // debugging builds (tools/build_variant.py <name> -DGML_F4DBG=<bits>; counters in p.prof, read by gml_debug_f4_counts):
 //   8  after every item's barrier the compute waves compare what landed in LDS with global memory (0 value rows, 1 column ids,
@@ -95,9 +101,12 @@ struct GmlFwd4Cfg {
     static_assert(OFF_EDGE + 2 * EDGE_BYTES <= 160 * 1024, "LDS budget");
 };
 
-template <int S, int FB, int NOB, bool EP, bool X1 = false>
+// F16 (round 6, GML_F16X3: see gml_spectconv_fwd3_impl.h): the projection on f16 (hi, lo) pieces under power-of-two scales
+template <int S, int FB, int NOB, bool EP, bool X1 = false, bool F16 = false>
 __global__ __launch_bounds__(GML_FWD4_NT, 1) void gml_k_spectconv_fwd4(const GmlFwdParams p) {
     using C = GmlFwd4Cfg<S, FB, EP, X1>;
+    using FT = typename GmlPiece<F16>::T;
+    using FT4 = typename GmlPiece4<F16>::T;
     static_assert(S % 2 == 0, "value rows are read as float2 / float4");
     constexpr int ROWS = C::ROWS, ECAP = C::ECAP, XCAP = C::XCAP, VROW = C::VROW, FR = C::FR;
     constexpr int VAL_ALIGN = (S % 4 == 0) ? 4 : 2;
@@ -118,28 +127,70 @@ __global__ __launch_bounds__(GML_FWD4_NT, 1) void gml_k_spectconv_fwd4(const Gml
 
     if (GML_F4_DELAY & 1) GML_F4_IDLE();
     // ---- once per workgroup: W images, zeroed X areas (chunks at or beyond Fin are never written by a DMA and stay zero)
+    // f16 pieces: the largest magnitude of every output column first (32 words at the start of the first X area: zeroed again below)
+    uint32_t* cmax = reinterpret_cast<uint32_t*>(lds_raw + C::x_off(0));
+    float winv_r[NOB];                                         // 1 / (scale of the lane's W columns)
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) winv_r[ob] = 1.f;
+    if constexpr (F16) {
+        if (tid < 32) cmax[tid] = 0u;
+        __syncthreads();
+        {
+            const int o = tid & 31;
+            constexpr int NF = FB ? 48 : 32;
+            float m = 0.f;
+            if (o < p.Fout)
+                for (int i = tid >> 5; i < S * NF; i += C::NT / 32) {
+                    const int s = i / NF, f = i % NF;
+                    if (f < p.Fin) m = fmaxf(m, fabsf(p.w[(int64_t)(p.s0 + s) * p.w_ss + (int64_t)f * p.w_si + (int64_t)o * p.w_so]));
+                }
+            atomicMax(&cmax[o], __float_as_uint(m));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob) { float sc; gml_f16_scale_bits(cmax[ob * 16 + r16], sc, winv_r[ob]); }
+    }
     for (int e = tid; e < S * 32 * 32; e += C::NT) {
         const int f = e & 31, o = (e >> 5) & 31, s = e >> 10;
         const float v = (f < p.Fin && o < p.Fout) ? p.w[(int64_t)(p.s0 + s) * p.w_ss + (int64_t)f * p.w_si + (int64_t)o * p.w_so] : 0.f;
-        const __bf16 h = (__bf16)v;
-        const __bf16 l = (__bf16)(v - (float)h);
         const int iof = (s * 32 + o) * 32 + ((((f >> 3) ^ gml_wkey(o)) & 3) << 3) + (f & 7);
-        Wof_h[iof] = h;
-        Wof_l[iof] = l;
+        if constexpr (F16) {
+            float sc, inv;
+            gml_f16_scale_bits(cmax[o], sc, inv);
+            const float vs = v * sc;
+            const _Float16 h = (_Float16)vs;
+            reinterpret_cast<_Float16*>(Wof_h)[iof] = h;
+            reinterpret_cast<_Float16*>(Wof_l)[iof] = (_Float16)(vs - (float)h);
+        } else {
+            const __bf16 h = (__bf16)v;
+            const __bf16 l = (__bf16)(v - (float)h);
+            Wof_h[iof] = h;
+            Wof_l[iof] = l;
+        }
     }
     if constexpr (FB) {
         for (int e = tid; e < S * 32 * 16; e += C::NT) {
             const int f2 = e & 15, o = (e >> 4) & 31, s = e >> 9;
             const int f = 32 + f2;
             const float v = (f < p.Fin && o < p.Fout) ? p.w[(int64_t)(p.s0 + s) * p.w_ss + (int64_t)f * p.w_si + (int64_t)o * p.w_so] : 0.f;
-            const __bf16 h = (__bf16)v;
-            const __bf16 l = (__bf16)(v - (float)h);
             // [s][o][kq][hi 0..3 | lo 0..3]: the lane's K = 16 fragment pair is ONE 16-byte read
             const int i2 = ((s * 32 + o) * 4 + (f2 >> 2)) * 8 + (f2 & 3);
-            W2_h[i2] = h;
-            W2_h[i2 + 4] = l;
+            if constexpr (F16) {
+                float sc, inv;
+                gml_f16_scale_bits(cmax[o], sc, inv);
+                const float vs = v * sc;
+                const _Float16 h = (_Float16)vs;
+                reinterpret_cast<_Float16*>(W2_h)[i2] = h;
+                reinterpret_cast<_Float16*>(W2_h)[i2 + 4] = (_Float16)(vs - (float)h);
+            } else {
+                const __bf16 h = (__bf16)v;
+                const __bf16 l = (__bf16)(v - (float)h);
+                W2_h[i2] = h;
+                W2_h[i2 + 4] = l;
+            }
         }
     }
+    if constexpr (F16) __syncthreads();                        // (the column maxima sit in the first X area, zeroed next)
 #pragma unroll
     for (int sl = 0; sl < (X1 ? 1 : 2); ++sl)
         for (int i = tid; i < C::X_BYTES / 16; i += C::NT)
@@ -345,13 +396,28 @@ __global__ __launch_bounds__(GML_FWD4_NT, 1) void gml_k_spectconv_fwd4(const Gml
             // the meantime is not interlocked (hipcc assumes operands are read at issue and re-uses them for the next fragment
             // loads at once: wrong tiles on some waves of some launches).  So the loads for support s + 2 are issued only after the
             // VALU split of support s + 1, which cannot overtake the MFMAs of support s: two fragment sets, two split sets.
+            float oscale[NOB];
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob) oscale[ob] = 1.f;
             auto mm = [&](f32x4 (&oacc)[NOB]) {
 #pragma unroll
             for (int ob = 0; ob < NOB; ++ob) oacc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
-            bf16x8 wh[2][NOB], wl[2][NOB];
-            bf16x4v vh[2][NOB], vl[2][NOB];
-            bf16x8 ah[2], al[2];
-            bf16x4v bh[2], bl[2];
+            FT wh[2][NOB], wl[2][NOB];
+            FT4 vh[2][NOB], vl[2][NOB];
+            FT ah[2], al[2];
+            FT4 bh[2], bl[2];
+            float asc = 1.f;
+            if constexpr (F16) {                               // the tile's scale (gml_spectconv_fwd3_impl.h), before the first split
+                float m = 0.f;
+#pragma unroll
+                for (int s = 0; s < S; ++s)
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) m = fmaxf(fmaxf(fabsf(acc[s][h].x), fabsf(acc[s][h].y)), m);
+                float ainv;
+                gml_f16_scale_bits(gml_wave_max_bits(__float_as_uint(m)), asc, ainv);
+#pragma unroll
+                for (int ob = 0; ob < NOB; ++ob) oscale[ob] = ainv * winv_r[ob];
+            }
             // `fa` (zero) is added to every fragment address and passes through a VALU statement behind each support's MFMAs: the
             // next loads then carry an address dependency on an instruction that issues IN ORDER behind those MFMAs
             int fa = 0;
@@ -361,24 +427,36 @@ __global__ __launch_bounds__(GML_FWD4_NT, 1) void gml_k_spectconv_fwd4(const Gml
                 for (int ob = 0; ob < NOB; ++ob) {
                     const int o = ob * 16 + r16;               // B[k = f][n = o]: 8 consecutive f of column o
                     const int off = (s * 32 + o) * 32 + (((kq ^ gml_wkey(o)) & 3) << 3) + fa;
-                    wh[st][ob] = *reinterpret_cast<const bf16x8*>(Wof_h + off);
-                    wl[st][ob] = *reinterpret_cast<const bf16x8*>(Wof_l + off);
+                    wh[st][ob] = *reinterpret_cast<const FT*>(Wof_h + off);
+                    wl[st][ob] = *reinterpret_cast<const FT*>(Wof_l + off);
                     if constexpr (FB) {
-                        const bf16x8 t = *reinterpret_cast<const bf16x8*>(W2_h + ((s * 32 + o) * 4 + kq) * 8 + fa);
-                        vh[st][ob] = bf16x4v{t[0], t[1], t[2], t[3]};
-                        vl[st][ob] = bf16x4v{t[4], t[5], t[6], t[7]};
+                        const FT t = *reinterpret_cast<const FT*>(W2_h + ((s * 32 + o) * 4 + kq) * 8 + fa);
+                        vh[st][ob] = FT4{t[0], t[1], t[2], t[3]};
+                        vl[st][ob] = FT4{t[4], t[5], t[6], t[7]};
                     }
                 }
             };
             auto split = [&](int s, int t) {
                 const float av[8] = {acc[s][0].x, acc[s][0].y, acc[s][1].x, acc[s][1].y, acc[s][2].x, acc[s][2].y, acc[s][3].x, acc[s][3].y};
-                gml_split8(av, ah[t], al[t]);
-                if constexpr (FB) {
-                    bf16x2 h0, l0, h1, l1;
-                    gml_split2(acc[s][4].x, acc[s][4].y, h0, l0);
-                    gml_split2(acc[s][5].x, acc[s][5].y, h1, l1);
-                    bh[t] = bf16x4v{h0[0], h0[1], h1[0], h1[1]};
-                    bl[t] = bf16x4v{l0[0], l0[1], l1[0], l1[1]};
+                if constexpr (F16) {
+                    gml_split8_f16(av, asc, ah[t], al[t]);
+                    if constexpr (FB) {
+                        const f32x2 v0 = acc[s][4] * asc, v1 = acc[s][5] * asc;
+                        const f16x2 h0 = __builtin_convertvector(v0, f16x2), h1 = __builtin_convertvector(v1, f16x2);
+                        const f16x2 l0 = __builtin_convertvector(v0 - __builtin_convertvector(h0, f32x2), f16x2);
+                        const f16x2 l1 = __builtin_convertvector(v1 - __builtin_convertvector(h1, f32x2), f16x2);
+                        bh[t] = FT4{h0[0], h0[1], h1[0], h1[1]};
+                        bl[t] = FT4{l0[0], l0[1], l1[0], l1[1]};
+                    }
+                } else {
+                    gml_split8(av, ah[t], al[t]);
+                    if constexpr (FB) {
+                        bf16x2 h0, l0, h1, l1;
+                        gml_split2(acc[s][4].x, acc[s][4].y, h0, l0);
+                        gml_split2(acc[s][5].x, acc[s][5].y, h1, l1);
+                        bh[t] = FT4{h0[0], h0[1], h1[0], h1[1]};
+                        bl[t] = FT4{l0[0], l0[1], l1[0], l1[1]};
+                    }
                 }
             };
             frag(0, 0);
@@ -410,18 +488,18 @@ __global__ __launch_bounds__(GML_FWD4_NT, 1) void gml_k_spectconv_fwd4(const Gml
                 if (s == S - 1) asm volatile("s_nop 15\n\ts_nop 15");
 #else
 #pragma unroll
-                for (int ob = 0; ob < NOB; ++ob) oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[st], wh[st][ob], oacc[ob], 0, 0, 0);
+                for (int ob = 0; ob < NOB; ++ob) oacc[ob] = gml_mfma_piece(al[st], wh[st][ob], oacc[ob]);
 #pragma unroll
-                for (int ob = 0; ob < NOB; ++ob) oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[st], wl[st][ob], oacc[ob], 0, 0, 0);
+                for (int ob = 0; ob < NOB; ++ob) oacc[ob] = gml_mfma_piece(ah[st], wl[st][ob], oacc[ob]);
 #pragma unroll
-                for (int ob = 0; ob < NOB; ++ob) oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[st], wh[st][ob], oacc[ob], 0, 0, 0);
+                for (int ob = 0; ob < NOB; ++ob) oacc[ob] = gml_mfma_piece(ah[st], wh[st][ob], oacc[ob]);
                 if constexpr (FB) {
 #pragma unroll
-                    for (int ob = 0; ob < NOB; ++ob) oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bl[st], vh[st][ob], oacc[ob], 0, 0, 0);
+                    for (int ob = 0; ob < NOB; ++ob) oacc[ob] = gml_mfma_piece4(bl[st], vh[st][ob], oacc[ob]);
 #pragma unroll
-                    for (int ob = 0; ob < NOB; ++ob) oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bh[st], vl[st][ob], oacc[ob], 0, 0, 0);
+                    for (int ob = 0; ob < NOB; ++ob) oacc[ob] = gml_mfma_piece4(bh[st], vl[st][ob], oacc[ob]);
 #pragma unroll
-                    for (int ob = 0; ob < NOB; ++ob) oacc[ob] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bh[st], vh[st][ob], oacc[ob], 0, 0, 0);
+                    for (int ob = 0; ob < NOB; ++ob) oacc[ob] = gml_mfma_piece4(bh[st], vh[st][ob], oacc[ob]);
                 }
 #endif
                 __builtin_amdgcn_sched_barrier(0);
@@ -446,7 +524,7 @@ __global__ __launch_bounds__(GML_FWD4_NT, 1) void gml_k_spectconv_fwd4(const Gml
                 for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
-                        const float v = oacc[ob][reg] + bias_r[ob];
+                        const float v = F16 ? fmaf(oacc[ob][reg], oscale[ob], bias_r[ob]) : oacc[ob][reg] + bias_r[ob];
                         ov[ob][reg] = relu ? fmaxf(v, 0.f) : v;
                     }
                 const int lr = (int)((out_rows >> (8 * (r16 & 3))) & 255u);        // after the transpose: the row of register r16 & 3
@@ -464,7 +542,7 @@ __global__ __launch_bounds__(GML_FWD4_NT, 1) void gml_k_spectconv_fwd4(const Gml
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
                         const int lr = (int)((out_rows >> (8 * reg)) & 255u);
-                        float v = oacc[ob][reg] + bias_r[ob];
+                        float v = F16 ? fmaf(oacc[ob][reg], oscale[ob], bias_r[ob]) : oacc[ob][reg] + bias_r[ob];
                         if (relu) v = fmaxf(v, 0.f);
                         const int off = (o < p.Fout && lr < nr) ? (lr * (int)p.ldo + o) * 4 : 0x7fffff00;
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ors, off, 0, 0);
@@ -743,13 +821,18 @@ __global__ __launch_bounds__(GML_FWD4_NT, 1) void gml_k_spectconv_fwd4(const Gml
 template <int S, int FB, int NOB>
 int gml_launch_fwd4(const GmlFwdParams& p, dim3 grid, hipStream_t st);
 
-#define GML_FWD4_LAUNCH(SV, FBV, NOBV, EPV, X1V)                                                             \
+#define GML_FWD4_LAUNCH_F(SV, FBV, NOBV, EPV, X1V, F16V)                                                     \
     {                                                                                                        \
-        GML_ALLOW_BIG_LDS(rc_, (&gml_k_spectconv_fwd4<SV, FBV, NOBV, EPV, X1V>), 160 * 1024)                 \
+        GML_ALLOW_BIG_LDS(rc_, (&gml_k_spectconv_fwd4<SV, FBV, NOBV, EPV, X1V, F16V>), 160 * 1024)           \
         if (rc_ != hipSuccess) return (int)rc_;                                                              \
         const size_t lds_ = GmlFwd4Cfg<SV, FBV, EPV, X1V>::lds_bytes();                                      \
-        hipLaunchKernelGGL((gml_k_spectconv_fwd4<SV, FBV, NOBV, EPV, X1V>), grid, dim3(GML_FWD4_NT), lds_, st, p); \
+        hipLaunchKernelGGL((gml_k_spectconv_fwd4<SV, FBV, NOBV, EPV, X1V, F16V>), grid, dim3(GML_FWD4_NT), lds_, st, p); \
         return gml_launch_status();                                                                          \
+    }
+#define GML_FWD4_LAUNCH(SV, FBV, NOBV, EPV, X1V)                                                             \
+    {                                                                                                        \
+        if (p.flags & GML_F16X3) GML_FWD4_LAUNCH_F(SV, FBV, NOBV, EPV, X1V, true)                            \
+        GML_FWD4_LAUNCH_F(SV, FBV, NOBV, EPV, X1V, false)                                                    \
     }
 // GML_FWD_ONEWIN (48-feature shapes only): the single-window form, for batches whose groups need edge chunks
 #define GML_DEFINE_FWD4(SV, FBV, NOBV)                                                                       \

@@ -266,7 +266,8 @@ def rows4(x):
     return v
 
 
-# The FORWARD projection of the 8-wave kernels (fwd3: every ML3Layer of the ZINC config; fwd2: counting.py's 12 supports) on f16 (hi, lo) pieces under power-of-two scales
+# The FORWARD projection of the 8-wave kernels (fwd3: every ML3Layer of the ZINC config; fwd2: counting.py's 12 supports; fwd4: sr25's / mutag's
+# 48-wide layers) on f16 (hi, lo) pieces under power-of-two scales
 # (GML_F16X3, csrc/gml_common.h "f16x3": residual 2^-24 per operand instead of 2^-17, same matrix-pipe instruction count) -- the
 # default since round 6; GML_FWD_F16=0 restores the bf16 pairs.  With the three-piece edge forward (EDGE_FWD6) this makes the whole
 # forward pass fp32-class, which is what trained-state gradients need (profiles/r06_precision_diag.jsonl); the backward kernels

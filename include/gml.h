@@ -63,9 +63,9 @@ enum {
                          edges per work item -- for batches whose groups need edge chunks (the caller knows the batch's largest group) */
     GML_DMA_RING = 32,  /* gml_spectconv_bwd / _bwd_mix: take the LDS-DMA landing-ring kernel (bwd4) where it applies; the
                          forward uses its ring kernel (fwd3) by default (GML_FWD_DMA=0 in the environment turns it off)   */
-    GML_F16X3 = 1024,   /* gml_spectconv_fwd / gml_ml3_fwd on the 8-wave kernels (fwd3 and its register-staged form fwd2): project with f16 (hi, lo) pieces under per-tile /
+    GML_F16X3 = 1024,   /* gml_spectconv_fwd / gml_ml3_fwd on the 8-wave kernels (fwd3, its register-staged form fwd2, the chunked ring kernel fwd4): project with f16 (hi, lo) pieces under per-tile /
                          per-column power-of-two scales instead of bf16 pairs: residual 2^-24 instead of 2^-17 per operand, same
-                         instruction count on the matrix pipe (csrc/gml_common.h "f16x3").  Ignored by the other kernel families (fwd4, the 64-row family). */
+                         instruction count on the matrix pipe (csrc/gml_common.h "f16x3").  Ignored by the 64-row kernel family. */
     GML_NO_FOLD = 512   /* gml_spectconv_bwd / _bwd_mix / _bwd_mix_relu with dw != NULL: dw is NOT written -- the per-workgroup partial
                          sums stay in ws as [parts][S * Fin * Fout], parts = gml_spectconv_bwd_workspace_bytes(...) / (4 S Fin Fout) --
                          for a later gml_fold_many (the reference's batch 64: twelve fold launches of a step become one) */
