@@ -57,6 +57,9 @@ SIGNATURES = {
                                                   _i64, _i32, _i32, _i32, _i32, _i32, _u32, _p, _sz, _p]),
     'gml_spectconv_bwd_mix_relu2': (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _i32, _p, _i32, _i32,
                                                    _i64, _i32, _i32, _i32, _i32, _i32, _u32, _p, _sz, _p]),
+    'gml_spectconv_bwd_had_parts': (ctypes.c_int, [_i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _u32]),
+    'gml_spectconv_bwd_had': (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _i32,
+                                             _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _u32, _p, _sz, _p, _sz, _p]),
     'gml_spectconv_fwd_epi': (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _p, _p, _i64, _i64, _i32, _i32, _i32,
                                              ctypes.c_uint32, _i32, _p, _i32, _p]),
     'gml_spmm_fwd': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _p, _i64, _i32, _i32, _p]),

@@ -375,6 +375,14 @@ __global__ __launch_bounds__(256) void gml_k_split_fold(const float* __restrict_
     if (q < n4 && d4) d4[q] = t;
 }
 
+// the fold alone, for partial rows another kernel produced in this layout (gml_spectconv_bwd_had)
+int gml_split_fold_launch(const float* ws, int64_t nparts, int npart, float* dw11, int n11, float* dw12, int n12, float* db11, int nb11,
+                          float* db12, int nb12, float* dcb, int ncb, hipStream_t st) {
+    hipLaunchKernelGGL(gml_k_split_fold, dim3((unsigned)gml_cdiv(npart, 16)), dim3(256), 0, st, ws, nparts, npart, dw11, n11, dw12, n12,
+                       db11, nb11, db12, nb12, dcb, ncb);
+    return gml_launch_status();
+}
+
 static int sb_finp(int Fin, int F2) {
     if (F2 == 0) return 0;
     return Fin <= 16 ? 16 : (Fin <= 32 ? 32 : (Fin <= 48 ? 48 : (Fin <= 64 ? 64 : -1)));

@@ -173,7 +173,8 @@ static int spectconv_bwd_impl(const int32_t* rowptr, const int32_t* col, const i
                               int64_t num_rows, int32_t S, int32_t Fin, int32_t Fout,
                               int32_t max_group_edges, int32_t max_group_window, uint32_t flags,
                               void* ws, size_t ws_bytes, gml_stream_t stream, const float* dz, const float* wmix, int32_t nmix,
-                              int32_t relu_cols = 0, const float* wmix2 = nullptr, int32_t nmix1 = -1) {
+                              int32_t relu_cols = 0, const float* wmix2 = nullptr, int32_t nmix1 = -1,
+                              const float* hb11 = nullptr, const float* hb12 = nullptr, float* hpart = nullptr) {
     if (num_rows < 0 || S <= 0 || Fin <= 0 || Fout <= 0 || ldx < Fin || ldg < Fout) return GML_E_BADARG;
     if (dx && lddx < Fin) return GML_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
@@ -194,6 +195,10 @@ static int spectconv_bwd_impl(const int32_t* rowptr, const int32_t* col, const i
     p.nrows = num_rows; p.S = S; p.Fin = Fin; p.Fout = Fout; p.flags = flags;
     p.dz = dz; p.wmix = wmix; p.nmix = nmix; p.relu_cols = relu_cols;
     p.wmix2 = wmix2; p.nmix1 = (wmix2 && nmix1 >= 0 && nmix1 <= nmix) ? nmix1 : nmix;
+    p.hb11 = hb11; p.hb12 = hb12; p.hpart = hpart;
+    if (hpart != nullptr && (pl.layout != 3 || pl.nw != 8 || (flags & (GML_ACCUM | GML_DVAL_ACCUM)) || !dw ||
+                             pl.lds + GML_BWD3_HAD_LDS(128, 8) > 160 * 1024))
+        return GML_E_UNSUPPORTED;
     if (dz != nullptr && (pl.layout != 3 || (flags & GML_ACCUM) || (((uintptr_t)dz) & 15) != 0))
         return GML_E_UNSUPPORTED;
 #ifdef GML_BWD2_TIMING
@@ -229,7 +234,10 @@ static int spectconv_bwd_impl(const int32_t* rowptr, const int32_t* col, const i
                       !(flags & GML_DVAL_ACCUM) && GmlBwd5Cfg<2>::lds_bytes(pl.ecap, pl.xcap) <= 160 * 1024 &&
                       (dz == nullptr || (xvec_strict && p.dxvec));
     if (five && !xvec_strict) p.xvec = 0;
-    if (five) {
+    if (hpart != nullptr) {                                  /* the output stage inside the 8-wave kernel (gml_spectconv_bwd_had) */
+        if (five || dma) return GML_E_UNSUPPORTED;
+        rc = gml_launch_bwd3_had(p, dim3(pl.grid), pl.lds + GML_BWD3_HAD_LDS(128, 8), st);
+    } else if (five) {
         rc = gml_launch_bwd5<2>(p, dim3(pl.grid), GmlBwd5Cfg<2>::lds_bytes(pl.ecap, pl.xcap), st);
     } else if (dma) {
 #define GML_BWD4_GO(SV, A) if (S == SV && nfb == A) rc = gml_launch_bwd4<SV, A>(p, dim3(pl.grid), st);
@@ -341,4 +349,49 @@ extern "C" int gml_spectconv_bwd_mix_relu2(const int32_t* rowptr, const int32_t*
     if (relu_cols > 0 && (bwd4_env() || (flags & GML_DMA_RING))) return GML_E_UNSUPPORTED;
     return spectconv_bwd_impl(rowptr, col, ginfo, val, x, ldx, g, ldg, w, dx, lddx, dval, dw, num_rows, S, Fin, Fout,
                               max_group_edges, max_group_window, flags, ws, ws_bytes, stream, dz, wmix_a, nmix, relu_cols, wmix_b, nmix_a);
+}
+
+// ---------------------------------------------------------------------------------------------
+// gml_spectconv_bwd_mix_relu2 with the WHOLE output stage of the ML3Layer inside (libs/spect_conv.py:209-212, backward): instead of
+// gml_ml3_split_bwd_ex (pre-masked form) + this kernel, ONE launch.  g [num_rows, ldg >= 32] is the pre-masked gradient at the layer
+// output: columns [0, 30) at the conv output, columns 30, 31 at the two Hadamard units.  Shape class: S = 8, 17 .. 32 input
+// features (multiple of 4), Fout = 30, F2 = 2 (Zinc12k.py:338-341).  Per workgroup one partial [dw11 | dw12 | db11 | db12 | dcb]
+// lands in hws (gml_spectconv_bwd_had_parts rows of 4 Fin + 4 + Fout floats); with every one of dcb .. db12 NULL they stay there
+// (gml_fold_many), otherwise they are folded in fixed order into the given ones.
+// ---------------------------------------------------------------------------------------------
+int gml_split_fold_launch(const float* ws, int64_t nparts, int npart, float* dw11, int n11, float* dw12, int n12, float* db11, int nb11,
+                          float* db12, int nb12, float* dcb, int ncb, hipStream_t st);
+
+static bool had_env() { static const bool v = [] { const char* e = getenv("GML_BWD_HAD"); return !(e && e[0] == '0'); }(); return v; }
+
+extern "C" int gml_spectconv_bwd_had_parts(int64_t num_rows, int32_t S, int32_t Fin, int32_t Fout, int32_t F2, int32_t want_dx,
+                                           int32_t max_group_edges, int32_t max_group_window, uint32_t flags) {
+    /* (without dx -- the model's first layer -- the input width need not be a multiple of 4: only the x rows must be float4-readable) */
+    if (!had_env() || num_rows <= 0 || F2 != 2 || Fout != 30 || !gml_spectconv_bwd_mix_supported(S, want_dx ? Fin : (Fin + 3) / 4 * 4, Fout, 4, flags)) return 0;
+    if (bwd4_env() || bwd5_env() || (flags & (GML_DMA_RING | GML_ACCUM | GML_DVAL_ACCUM))) return 0;
+    const BwdPlan pl = plan_bwd(num_rows, S, Fin, Fout, max_group_edges, max_group_window, flags);
+    if (!pl.ok || pl.layout != 3 || pl.nw != 8 || pl.lds + GML_BWD3_HAD_LDS(128, 8) > 160 * 1024) return 0;
+    return pl.grid;
+}
+
+extern "C" int gml_spectconv_bwd_had(const int32_t* rowptr, const int32_t* col, const int32_t* ginfo, const float* val,
+                                     const float* x, int64_t ldx, const float* g, int64_t ldg, const float* w,
+                                     float* dx, int64_t lddx, float* dval, float* dw, const float* w11, const float* b11,
+                                     const float* w12, const float* b12, int32_t relu_cols, float* dcb, float* dw11, float* db11,
+                                     float* dw12, float* db12, int64_t num_rows, int32_t S, int32_t Fin, int32_t Fout, int32_t F2,
+                                     int32_t max_group_edges, int32_t max_group_window, uint32_t flags, void* ws, size_t ws_bytes,
+                                     void* hws, size_t hws_bytes, gml_stream_t stream) {
+    if (relu_cols < 0 || relu_cols > Fin || ldg < Fout + F2 || (!dx && relu_cols != 0)) return GML_E_BADARG;
+    const int parts = gml_spectconv_bwd_had_parts(num_rows, S, Fin, Fout, F2, dx != nullptr, max_group_edges, max_group_window, flags);
+    if (parts == 0 || !w11 || !w12 || !dw) return GML_E_UNSUPPORTED;
+    if (!dx && !((ldx % 4 == 0) && (((uintptr_t)x & 15) == 0) && (Fin + 3) / 4 * 4 <= ldx)) return GML_E_UNSUPPORTED;   /* float4-readable x rows */
+    const int npart = 4 * Fin + 4 + Fout;
+    if (!hws || hws_bytes < sizeof(float) * (size_t)parts * npart) return GML_E_WORKSPACE;
+    /* (dz = the kernel's own: any non-NULL, 16-byte aligned pointer selects the DZ road of the dispatch; it is never read) */
+    const int rc = spectconv_bwd_impl(rowptr, col, ginfo, val, x, ldx, g, ldg, w, dx, lddx, dval, dw, num_rows, S, Fin, Fout,
+                                      max_group_edges, max_group_window, flags, ws, ws_bytes, stream, (const float*)hws, w11, 4, relu_cols, w12, 2,
+                                      b11, b12, (float*)hws);
+    if (rc != GML_OK) return rc;
+    if (!dcb && !dw11 && !db11 && !dw12 && !db12) return GML_OK;
+    return gml_split_fold_launch((const float*)hws, parts, npart, dw11, 2 * Fin, dw12, 2 * Fin, db11, 2, db12, 2, dcb, Fout, (hipStream_t)stream);
 }

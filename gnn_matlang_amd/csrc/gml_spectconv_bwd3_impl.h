@@ -110,9 +110,44 @@ struct GmlBwd3Cfg {
 #define GML_T3(i)
 #endif
 
+// sums over the 16 lanes of a DPP row of nine values at once (butterfly: every lane ends with the totals; fixed order per lane).
+// One v_add_f32_dpp per value and step, written out: the builtin form compiles to a DPP move + an add for most of them.  The nine
+// chains are interleaved, so a value is read eight instructions after it was written (a DPP operand needs two wait states behind
+// the VALU write, which the compiler does not insert around inline assembly: the s_nop covers the first read of a block).
+#define GML_DPP9_(ctrl)                                                                                                          \
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf\n\t" \
+        "v_add_f32_dpp %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %3, %3, %3 " ctrl " row_mask:0xf bank_mask:0xf\n\t"           \
+        "v_add_f32_dpp %4, %4, %4 " ctrl " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %5, %5, %5 " ctrl " row_mask:0xf bank_mask:0xf\n\t"           \
+        "v_add_f32_dpp %6, %6, %6 " ctrl " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %7, %7, %7 " ctrl " row_mask:0xf bank_mask:0xf\n\t"           \
+        "v_add_f32_dpp %8, %8, %8 " ctrl " row_mask:0xf bank_mask:0xf"                                                         \
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]))
+__device__ __forceinline__ void gml_row16_sum9(float (&v)[9]) {
+    GML_DPP9_("quad_perm:[1,0,3,2]");
+    GML_DPP9_("quad_perm:[2,3,0,1]");
+    GML_DPP9_("row_half_mirror");
+    GML_DPP9_("row_mirror");
+}
+
+// ablation builds of the HAD form (results WRONG, timing only): 1 = no bias sums, 2 = no own-row g loads, 4 = no Hadamard recompute
+#ifndef GML_HADV
+#define GML_HADV 0
+#endif
+// LDS the HAD form adds behind the wmix rows: biases [4], dz rows [ROWS][4], per-wave bias sums [NW][36]
+#define GML_BWD3_HAD_LDS(ROWS_, NW_) (16 + (ROWS_) * 16 + (NW_) * 36 * 4)
+
 // DZ: dx starts from dz[row] . wmix (see GmlBwdParams) instead of zero / the old dx values
-template <int S, int NFB, int NW, bool XV, bool DZ = false, int NOB = 2>
+// HAD (with DZ; Fout = 30, two Hadamard units): the ML3Layer's output stage (libs/spect_conv.py:209-212 backward) inside this kernel --
+//   dz of the group's own rows is RECOMPUTED at the top of the group from the x row the lanes hold (4 dot products over the 4 lanes
+//   of a row, tanh and its derivative in the lane that ends with the sum, the partner's tanh by one permlane swap) and the row's two
+//   Hadamard gradients g[row][30, 31]: neither a dz array nor a separate pass over g and x exists;
+//   dw11 / dw12 = dz^T X ride in the existing row contraction: P channels 30, 31 (outputs the layer does not have) of supports 0 and
+//   1 carry the four dz values, so dW_0[:, 30], dW_0[:, 31], dW_1[:, 30], dW_1[:, 31] ARE dw11[0], dw11[1], dw12[0], dw12[1];
+//   the bias gradients (column sums of g over own rows, row sums of dz) are folded over the 16 rows of a wave with DPP adds and kept
+//   per wave in LDS (fixed order; no registers live across the edge loop).
+template <int S, int NFB, int NW, bool XV, bool DZ = false, int NOB = 2, bool HAD = false>
 __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdParams p) {
+    // (HAD without DZ: a layer whose input needs no gradient -- the model's first: no dX projection, p.dx = NULL)
+    static_assert(!HAD || (XV && NOB == 2 && NFB == 2 && S >= 2), "the fused output stage is compiled for the ZINC shape class");
     using C = GmlBwd3Cfg<S, NFB, NW, NOB>;
     constexpr int NH = 2 * NOB, GC = 4 * NOB;                // f32x2 accumulators per support and lane; float4 chunks of a G row
     static_assert(!DZ || NOB == 2, "the dz hand-over is compiled for the ZINC shape class");
@@ -142,6 +177,9 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
     unsigned char* xT = VALG ? rreg + (size_t)p.xcap * LDG * 4 : rreg + C::r_bytes(p.ecap, p.xcap);
     unsigned char* pT = VALG ? xT + C::XT_BYTES : rreg;
     float* wm_l = reinterpret_cast<float*>(VALG ? pT + C::PT_BYTES : xT + C::XT_BYTES);  // DZ: [4][32] rows of wmix, zero padded (the plan's lds includes these 512 bytes)
+    float* hb_l = wm_l + 128;                                // HAD: b11[0], b11[1], b12[0], b12[1]
+    float* dzf = hb_l + 4;                                   // HAD: [position][4] dz of the group's rows
+    float* bsum = dzf + ROWS * 4;                            // HAD: [wave][36]: column sums of g (0 .. 31), row sums of dz (32 .. 35)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -167,8 +205,12 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
             for (int i = 0; i < GML_B3DELAY; ++i) __builtin_amdgcn_s_sleep(127);
     }
 #endif
-    if constexpr (DZ) {
+    if constexpr (DZ || HAD) {
         if (tid < 128) wm_l[tid] = ((tid >> 5) < p.nmix && (tid & 31) < p.Fin) ? ((tid >> 5) < p.nmix1 ? p.wmix[(tid >> 5) * p.Fin + (tid & 31)] : p.wmix2[((tid >> 5) - p.nmix1) * p.Fin + (tid & 31)]) : 0.f;
+    }
+    if constexpr (HAD) {
+        if (tid < 4) hb_l[tid] = tid < 2 ? (p.hb11 ? p.hb11[tid] : 0.f) : (p.hb12 ? p.hb12[tid - 2] : 0.f);
+        if (tid < NW * 36) bsum[tid] = 0.f;
     }
     // W -> bf16 (hi, lo) image, zero padded to 32 x 32
     constexpr int WO = 16 * NOB;                             // output rows of one support's image
@@ -213,6 +255,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
     f32x4 gv4[NG4];
     float xb[8];
     float xb2[NIMG == 2 ? 8 : 1];                            // NFB = 3: features 32 + 8 kq .. + 7 of the own row (kq >= 2: beyond 48, zero)
+    float gown[HAD ? 8 : 1];                                 // HAD: columns 8 kq .. + 7 of the own row of g
     auto vec_group = [&](const int4 gi) {
         return (VW > 1) && p.gvec && gi.y <= C::ECAP_MAX && gi.w <= C::XCAP_MAX;
     };
@@ -246,6 +289,15 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
                 xb[4 * q4] = __uint_as_float(t.x); xb[4 * q4 + 1] = __uint_as_float(t.y);
                 xb[4 * q4 + 2] = __uint_as_float(t.z); xb[4 * q4 + 3] = __uint_as_float(t.w);
             }
+            if constexpr (HAD && !(GML_HADV & 2)) {
+                const auto rs_go = rsrc(p.g + r0 * p.ldg, (p.nrows - r0) * p.ldg * 4);
+#pragma unroll
+                for (int q4 = 0; q4 < 2; ++q4) {
+                    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_go, row_n * ldgb + 32 * kq + 16 * q4, 0, 0);
+                    gown[4 * q4] = __uint_as_float(t.x); gown[4 * q4 + 1] = __uint_as_float(t.y);
+                    gown[4 * q4 + 2] = __uint_as_float(t.z); gown[4 * q4 + 3] = __uint_as_float(t.w);
+                }
+            }
             rpv = (int)__builtin_amdgcn_raw_buffer_load_b32(rs_rp, tid * 4, 0, 0);
 #pragma unroll
             for (int t = 0; t < NC; ++t) cv[t] = (int)__builtin_amdgcn_raw_buffer_load_b32(rs_col, tid * 4, NT * 4 * t, 0);
@@ -266,6 +318,14 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
                     const f32x4 u = *reinterpret_cast<const f32x4*>(xr + min(32 + 8 * kq + 4 * q4, f4max));
                     xb2[4 * q4] = u.x; xb2[4 * q4 + 1] = u.y; xb2[4 * q4 + 2] = u.z; xb2[4 * q4 + 3] = u.w;
                 }
+            }
+        }
+        if constexpr (HAD && !(GML_HADV & 2)) {
+            const float* gr = p.g + min(r0 + row_n, p.nrows - 1) * p.ldg + 8 * kq;
+#pragma unroll
+            for (int q4 = 0; q4 < 2; ++q4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(gr + 4 * q4);
+                gown[4 * q4] = t.x; gown[4 * q4 + 1] = t.y; gown[4 * q4 + 2] = t.z; gown[4 * q4 + 3] = t.w;
             }
         }
         rpv = p.rowptr[min(r0 + tid, p.nrows)];
@@ -318,6 +378,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
         if (g0 < g1) commit(gi_c, (int)min((int64_t)ROWS, p.nrows - (int64_t)g0 * ROWS));
         __syncthreads();
     }
+    if constexpr (HAD && !LATEC) __syncthreads();           // wm_l / hb_l / bsum are read at the top of the first group
     for (int g = g0; g < g1; ++g) {
         const int64_t r0 = (int64_t)g * ROWS;
         const int nr = (int)min((int64_t)ROWS, p.nrows - r0);
@@ -346,12 +407,72 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
                 for (int t = 0; t < 8; ++t) xb2[t] = (rvalid && 32 + 8 * kq + t < p.Fin) ? xr[32 + t] : 0.f;
             }
         }
+        f32x4 dzv = f32x4{0.f, 0.f, 0.f, 0.f};
+        // ---- HAD: output stage of the group's own rows, in three pieces placed around / inside the Z projection (its matrix-pipe
+        //      chain leaves most VALU issue slots free): (a) LDS reads + the four partial dot products, (b) pure VALU: fold over the
+        //      row's lanes, tanh, dz, the DPP sums of the bias gradients, (c) the per-wave records + dz back as one float4
+        float had_a[4], had_g6 = 0.f, had_g7 = 0.f, had_bs[9];   // (had_bs: column sums of g, 0 .. 7; the row sum of dz, 8)
+        const int pos_h = wave * 16 + r16;
+        auto had_pre = [&]() {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (!(rvalid && 8 * kq + j < p.Fin)) xb[j] = 0.f;
+                if ((!BUFLD && !rvalid) || (GML_HADV & 2)) gown[j] = 0.f;       // (buffer loads: rows beyond the array read zeros)
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(wm_l + q * 32 + 8 * kq);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(wm_l + q * 32 + 8 * kq + 4);
+                f32x2 a2 = f32x2{xb[0], xb[1]} * f32x2{w0.x, w0.y};
+                a2 = f32x2{xb[2], xb[3]} * f32x2{w0.z, w0.w} + a2;
+                a2 = f32x2{xb[4], xb[5]} * f32x2{w1.x, w1.y} + a2;
+                a2 = f32x2{xb[6], xb[7]} * f32x2{w1.z, w1.w} + a2;
+                had_a[q] = a2.x + a2.y;
+            }
+            had_g6 = __shfl(gown[6], r16 + 48); had_g7 = __shfl(gown[7], r16 + 48);   // g[row][30], g[row][31] sit in lane kq = 3
+        };
+        auto had_valu = [&]() {
+            // the four lanes of a row fold their partial sums: lane kq ends with pre-activation kq (fc11 units 0, 1, fc12 units 0, 1)
+            const auto a01 = __builtin_amdgcn_permlane16_swap(__float_as_uint(had_a[0]), __float_as_uint(had_a[1]), false, false);
+            const auto a23 = __builtin_amdgcn_permlane16_swap(__float_as_uint(had_a[2]), __float_as_uint(had_a[3]), false, false);
+            const float c01 = __uint_as_float(a01[0]) + __uint_as_float(a01[1]);
+            const float c23 = __uint_as_float(a23[0]) + __uint_as_float(a23[1]);
+            const auto bq = __builtin_amdgcn_permlane32_swap(__float_as_uint(c01), __float_as_uint(c23), false, false);
+            const float pre = __uint_as_float(bq[0]) + __uint_as_float(bq[1]) + hb_l[kq];
+            float th, dh;
+            gml_tanh_d(pre, th, dh);
+            const auto tsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(th), __float_as_uint(th), false, false);
+            const float tpart = __uint_as_float(kq < 2 ? tsw[1] : tsw[0]);       // tanh of the partner unit (lane kq ^ 2)
+            const float dzo = (GML_HADV & 4) ? 0.f : ((kq & 1) ? had_g7 : had_g6) * tpart * dh;   // dz[row][kq]
+            dzf[pos_h * 4 + kq] = dzo;
+            if constexpr (!(GML_HADV & 1)) {                 // bias gradients: sums over the wave's 16 rows (every lane ends with them)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) had_bs[j] = gown[j];
+                had_bs[8] = dzo;
+                gml_row16_sum9(had_bs);
+            }
+        };
+        auto had_post = [&]() {
+            if constexpr (!(GML_HADV & 1)) {
+                if (r16 == 0) {                              // one lane per kq adds them to the wave's record
+                    float* bw = bsum + wave * 36;
+                    f32x4 o0 = *reinterpret_cast<const f32x4*>(bw + 8 * kq), o1 = *reinterpret_cast<const f32x4*>(bw + 8 * kq + 4);
+                    o0 += f32x4{had_bs[0], had_bs[1], had_bs[2], had_bs[3]};
+                    o1 += f32x4{had_bs[4], had_bs[5], had_bs[6], had_bs[7]};
+                    *reinterpret_cast<f32x4*>(bw + 8 * kq) = o0;
+                    *reinterpret_cast<f32x4*>(bw + 8 * kq + 4) = o1;
+                    bw[32 + kq] += had_bs[8];
+                }
+            }
+            dzv = *reinterpret_cast<const f32x4*>(dzf + pos_h * 4);              // (the wave's own writes: no barrier)
+        };
         if constexpr (!LATEC) commit(gi, nr);
         bf16x8 xh, xl;                                       // own X row, features 8*kq .. 8*kq+7: B fragment of Z^T, row of the X image
         bf16x8 xh2, xl2;                                     // NFB = 3: features 32 + 8*kq .. + 7 (the second K block / image)
         unsigned xpos = 0;                                   // DZ, relu_cols > 0: bit j = (x[row][8 kq + j] > 0), the relu mask of the layer below
         f32x2 Z[S][NH], P[S][NH];
         auto zproj = [&]() {
+        if constexpr (HAD) { had_pre(); __builtin_amdgcn_sched_barrier(0); }
         if constexpr (XV) {
 #pragma unroll
             for (int j = 0; j < 8; ++j)
@@ -389,6 +510,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
                 }
             };
             if (!(GML_ABL & 16)) frag(0, 0);
+            if constexpr (HAD) had_valu();                   // (no LDS reads inside: the pipeline below counts them)
 #pragma unroll
             for (int s = 0; s < S; ++s) {
                 const int st = s & 1;
@@ -428,8 +550,10 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
             for (int s = 0; s < S; ++s) {
                 if (s + 1 < S) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NOB * NIMG, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 3 * NOB * NIMG, 0);
+                if constexpr (HAD) __builtin_amdgcn_sched_group_barrier(0x002, 24, 0);   // the output stage's VALU work rides between the MFMA groups
             }
         }
+        if constexpr (HAD) { __builtin_amdgcn_sched_barrier(0); had_post(); }
         };
         if constexpr (ZEARLY) zproj();                       // (needs the W image and the lane's own x row only: neither is part of the commit)
         if constexpr (!LATEC) __syncthreads();
@@ -437,11 +561,10 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
         // old dx values (accumulate mode): the lane's own row, features 16 fb + 4 kq .. + 3 (D rows of dX^T);
         // DZ: the row's 4 Hadamard-branch gradients instead (one 16-byte load; dx then starts from dz . wmix)
         f32x4 dxa[NFB];
-        f32x4 dzv = f32x4{0.f, 0.f, 0.f, 0.f};
         const bool dxv = p.dx && p.dxvec;                    // dx rows float4-addressable (Fin % 4 == 0, aligned rows)
         if constexpr (DZ) {
-            dzv = *reinterpret_cast<const f32x4*>(p.dz + min(r0 + row, p.nrows - 1) * 4);
-        } else {
+            if constexpr (!HAD) dzv = *reinterpret_cast<const f32x4*>(p.dz + min(r0 + row, p.nrows - 1) * 4);
+        } else if constexpr (!HAD) {
             const float* dxb = p.dx ? p.dx : p.x;            // (no dx wanted: any readable rows, the values are dropped)
             const int64_t ldb = p.dx ? p.lddx : p.ldx;
             const float* dr = dxb + min(r0 + row, p.nrows - 1) * ldb;
@@ -659,6 +782,12 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
         // P -> bf16 (hi, lo) once: B fragments of dX^T (k = o = 8*kq + j) and the rows of the P image.  Before the next
         // group's loads are issued: P and its split are both live here, the prefetch registers are not yet.
         typedef typename std::conditional<NOB == 2, bf16x8, bf16x4>::type PFrag;   // (NOB = 1: the 4 live k slots; the rest is zero)
+        if constexpr (HAD) {                                 // channels 30, 31 of supports 0, 1 carry dz (their W rows are zero: dX is not touched)
+            if (kqo == 3) {
+                P[0][3] = f32x2{dzv[0], dzv[1]};
+                P[1][3] = f32x2{dzv[2], dzv[3]};
+            }
+        }
         PFrag PH[S], PL[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) {
@@ -728,7 +857,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
         GML_T3(9);
         // ---- dX^T = W P^T: A[i = f][k = o] = W_s[f][o] comes transposed out of the [s][o][f] image: lane (t, kq) passes the
         //      address of row o = 8 kq + 4 h + (t >> 2), 8-byte chunk 4 fb + (t & 3), and receives W[8 kq + 4 h + j][16 fb + t]
-        if (p.dx && !(GML_ABL & 32)) {
+        if ((DZ || !HAD) && p.dx && !(GML_ABL & 32)) {
             if constexpr (DZ) {
 #pragma unroll
                 for (int fb = 0; fb < NFB; ++fb) {
@@ -931,9 +1060,24 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
                     for (int reg = 0; reg < 4; ++reg) {
                         const int f = fb * 16 + 4 * kq + reg;
                         if (f < p.Fin && o < p.Fout) out[((int64_t)s * p.Fin + f) * p.Fout + o] = dwacc[sl][i][reg];
+                        if constexpr (HAD) {                 // dW_s[f][30 + u], s < 2: row 2 s + u of [dw11; dw12]
+                            if (f < p.Fin && o >= 30 && s < 2)
+                                p.hpart[(int64_t)wg * (4 * p.Fin + 4 + p.Fout) + (2 * s + (o - 30)) * p.Fin + f] = dwacc[sl][i][reg];
+                        }
                     }
                 }
             }
+    }
+    if constexpr (HAD) {
+        __syncthreads();                                     // every wave's record is complete
+        if (g0 < g1 && tid < 36) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) v += bsum[w * 36 + tid];
+            float* hp = p.hpart + (int64_t)wg * (4 * p.Fin + 4 + p.Fout) + 4 * p.Fin;
+            if (tid >= 32) hp[tid - 32] = v;                 // db11 | db12
+            else if (tid < p.Fout) hp[4 + tid] = v;          // dcb
+        }
     }
 }
 
@@ -957,6 +1101,9 @@ struct GmlBwd3Dz<S, NFB, NW, true> {
     }
 };
 #define GML_BWD3_HAS_DZ(SV, NFBV, NWV) ((SV) == 8 && (NFBV) == 2 && (NWV) == 8)
+
+// the HAD form (gml_bwd3_fam_h.hip): lds = the plan's bytes + GML_BWD3_HAD_LDS
+int gml_launch_bwd3_had(const GmlBwdParams& p, dim3 grid, size_t lds, hipStream_t st);
 
 #define GML_DEFINE_BWD3(SV, NFBV, NWV)                                                                       \
     template <>                                                                                              \

@@ -55,6 +55,13 @@ struct GmlBwdParams {
     // ML3Layer feeding an ML3Layer): dx[:, f < relu_cols] is written already multiplied by (x[:, f] > 0) -- it IS the gradient at
     // that layer's conv output, so its output-stage backward needs neither its saved output nor a second [N, C] array
     int32_t relu_cols;
+    // bwd3 HAD form (gml_spectconv_bwd_had; ZINC's 30 + 2 layers): the whole output stage of the layer runs inside the conv backward.
+    // g = the pre-masked gradient at the layer output [N, Fout + 2] (columns Fout, Fout + 1: the Hadamard branch's), wmix / wmix2 =
+    // fc11.weight / fc12.weight, hb11 / hb12 their biases (or NULL); dz is formed per group from the rows the kernel holds and never
+    // stored; hpart [grid][4 Fin + 4 + Fout] receives one partial [dw11 | dw12 | db11 | db12 | dcb] per workgroup (gml_ml3_split_bwd's order)
+    const float* hb11;
+    const float* hb12;
+    float* hpart;
 #ifdef GML_BWD2_TIMING
     unsigned long long* prof;    // debug build: per-phase cycle sums
 #endif

@@ -1021,12 +1021,27 @@ def conv_bwd_takes_dz(csr, S, Fin, Fout, nmix):
 
 
 BWD_DMA = _os.environ.get('GML_BWD_DMA') == '1'     # fused backward on the LDS-DMA ring kernel (bwd4) where it applies; A/B switch
+BWD_HAD = _os.environ.get('GML_BWD_HAD', '1') != '0'  # ML3Layer output stage inside the conv backward (gml_spectconv_bwd_had); A/B switch
 
 
-def fused_conv_bwd(csr, val_t, x, G, weight, need_x, need_val, need_w, dx_accum_into=None, mix=None, relu_cols=0):
+def conv_bwd_had_parts(csr, S, Fin, Fout, F2, want_dx=True):
+    """Partial rows of gml_spectconv_bwd_had for this shape (0: the shape / the build has no fused output stage)."""
+    if not BWD_HAD or BWD_DMA or exact_mode():
+        return 0
+    plan = _bwd_plan(csr, S, Fin, Fout)
+    if plan is None or plan[4] != 128:
+        return 0
+    return int(_lib.lib().gml_spectconv_bwd_had_parts(csr.N, int(S), int(Fin), int(Fout), int(F2), 1 if want_dx else 0, plan[2][0], plan[2][1],
+                                                      plan[0]))
+
+
+def fused_conv_bwd(csr, val_t, x, G, weight, need_x, need_val, need_w, dx_accum_into=None, mix=None, relu_cols=0, had=None):
     """one launch: dX, dval (source order), dW.  val_t: supports in source order.  mix = (dz [N, 4], wmix [nmix, Fin]):
     dX = conv part + dz wmix (instead of accumulating into a dx another kernel wrote).  relu_cols (with mix): dX[:, f] for
-    f < relu_cols is written multiplied by (x[:, f] > 0) (gml_spectconv_bwd_mix_relu: the relu of the ML3Layer below)."""
+    f < relu_cols is written multiplied by (x[:, f] > 0) (gml_spectconv_bwd_mix_relu: the relu of the ML3Layer below).
+    had = {'w': (w11, b11, w12, b12), 'parts': rows}: the ML3Layer output stage inside the launch (gml_spectconv_bwd_had; G is then a
+    view of the pre-masked [N, >= Fout + 2] gradient whose columns Fout, Fout + 1 are the Hadamard units'); had['out'] receives
+    (dcb, dw11, db11, dw12, db12)."""
     S, Fin, Fout = weight.shape
     dev = x.device
     flags, ginfo, gmax, nbytes, _ = _bwd_plan(csr, S, Fin, Fout)
@@ -1051,6 +1066,35 @@ def fused_conv_bwd(csr, val_t, x, G, weight, need_x, need_val, need_w, dx_accum_
         flags |= _lib.GML_NO_FOLD
         flat = torch.empty(S * Fin * Fout, dtype=torch.float32, device=dev)       # (a view of it goes to autograd: see edge_mlp_bwd)
         fq.append((ws, nbytes // (4 * S * Fin * Fout), S * Fin * Fout, [(flat, flat.numel())]))
+    if had is not None:
+        w11, b11, w12, b12 = had['w']
+        npart, parts = 4 * Fin + 4 + Fout, int(had['parts'])
+        hws = torch.empty(parts * npart, dtype=torch.float32, device=dev)
+        hfq = _fold_queue()
+        if hfq is not None:                                  # (same layout as gml_ml3_split_bwd's partial rows: same fold job)
+            hflat = torch.empty(npart, dtype=torch.float32, device=dev)
+            hfq.append((hws, parts, npart, [(hflat, npart)]))
+            dw11, dw12 = hflat[:2 * Fin].view_as(w11), hflat[2 * Fin:4 * Fin].view_as(w12)
+            db11 = hflat[4 * Fin:4 * Fin + 2] if b11 is not None else None
+            db12 = hflat[4 * Fin + 2:4 * Fin + 4] if b12 is not None else None
+            dcb = hflat[4 * Fin + 4:]
+            kd = (None,) * 5
+        else:
+            dw11, dw12 = torch.empty_like(w11), torch.empty_like(w12)
+            db11 = torch.empty_like(b11) if b11 is not None else None
+            db12 = torch.empty_like(b12) if b12 is not None else None
+            dcb = torch.empty(Fout, dtype=torch.float32, device=dev)
+            kd = (dcb, dw11, db11, dw12, db12)
+        had['out'] = (dcb, dw11, db11, dw12, db12)
+        with _Timed('spectconv_bwd', q + 8 * csr.N, f):        # (+ the own rows' two Hadamard columns; the rest it reads anyway)
+            _lib.call('gml_spectconv_bwd_had', _ptr(csr.rowptr_t), _ptr(csr.col_t), _ptr(ginfo), _ptr(val_t),
+                      _ptr(x), int(x.stride(0)), _ptr(G), int(G.stride(0)), _ptr(weight), _ptr(dx), Fin, _ptr(dval_t),
+                      _ptr(dw), _ptr(w11), _ptr(b11), _ptr(w12), _ptr(b12), int(relu_cols), _ptr(kd[0]), _ptr(kd[1]), _ptr(kd[2]),
+                      _ptr(kd[3]), _ptr(kd[4]), csr.N, S, Fin, Fout, 2, gmax[0], gmax[1], flags, _ptr(ws),
+                      ws.numel() if ws is not None else 0, _ptr(hws), hws.numel() * 4, _stream(dev))
+        if fq is not None:
+            dw = flat.view(S, Fin, Fout)
+        return dx, dval_t, dw
     with _Timed('spectconv_bwd', q, f):
         if mix is not None:
             dz, wmix = mix
@@ -1122,7 +1166,7 @@ def fused_conv_bwd_split48(csr, val_t, x, G, weight, need_x, need_val, need_w, d
 
 # ---------------------------------------------------------------------------- shared backward pieces
 def _conv_backward(csr, x, val, weight, G, need_x, need_val, need_w, val_t=None, want_source_order=False,
-                   dx_accum_into=None, mix=None, relu_cols=0):
+                   dx_accum_into=None, mix=None, relu_cols=0, had=None):
     """G [N,Fout] contiguous = gradient at the (pre-activation) conv output.
     Returns dx, dval, dw; dval is in source order when want_source_order (and the fused kernel ran).
     dx_accum_into: [N,Fin] buffer that already holds a partial dx; the conv contribution is added to it."""
@@ -1148,7 +1192,7 @@ def _conv_backward(csr, x, val, weight, G, need_x, need_val, need_w, val_t=None,
             dx, dval_t, dw = fused_conv_bwd_split48(csr, val_t, x, G, weight, need_x, need_val, need_w, dx_accum_into, sp48)
         else:
             _path('conv_bwd', 'fused (group kind %d)' % _bwd_plan(csr, S, Fin, Fout)[4], S, Fin, Fout)
-            dx, dval_t, dw = fused_conv_bwd(csr, val_t, x, G, weight, need_x, need_val, need_w, dx_accum_into, mix, relu_cols)
+            dx, dval_t, dw = fused_conv_bwd(csr, val_t, x, G, weight, need_x, need_val, need_w, dx_accum_into, mix, relu_cols, had)
         if need_val and not want_source_order:
             with _Timed('dval_from_source_order'):
                 dval_t = csr.from_source_order(dval_t)
@@ -1396,10 +1440,31 @@ class ML3LayerFunction(torch.autograd.Function):
             pre = ctx.chain_out is not None and ctx.chain_out.premasked and gy_seg is None
             if ctx.chain_out is not None:
                 ctx.chain_out.premasked = False
-            r = ml3_split_bwd(gy, out, nout1, x, w11, b11, w12, b12, need_dx=need[0], need_dcb=want_cb, dz_out=use_dz, gy_seg=gy_seg,
-                              premasked=pre) \
-                if mixk else ml3_split_bwd(gy, out, nout1, need_dcb=want_cb, gy_seg=gy_seg, premasked=pre)
-            if r is not None:
+            # ZINC's 30 + 2 layers with a pre-masked gradient: the output stage runs INSIDE the conv backward (one launch, no dz array,
+            # no second pass over gy and x)
+            hparts = 0
+            x4 = x.stride(0) % 4 == 0 and x.stride(0) >= (Fin + 3) // 4 * 4 and x.data_ptr() % 16 == 0     # float4-readable x rows
+            if ((use_dz or (mixk and not need[0] and x4)) and pre and nout2 == 2 and need[6] and need[8] and need[10] and gy.stride(1) == 1
+                    and gy.stride(0) % 4 == 0 and gy.stride(0) >= C and gy.data_ptr() % 16 == 0):
+                hparts = conv_bwd_had_parts(csr, S, Fin, nout1, nout2, want_dx=need[0])
+            if hparts > 0:
+                had = {'w': (w11, b11, w12, b12), 'parts': hparts}
+                rc = ctx.chain_in.cols if (need[0] and ctx.chain_in is not None and not BWD_DMA) else 0
+                dx, dea, dcw, dea_src = _conv_backward(csr, x, ea, cw, gy[:, :nout1], need[0], need_val, True, val_t=ea_t,
+                                                       want_source_order=learnedge, relu_cols=rc, had=had)
+                if rc:
+                    ctx.chain_in.premasked = True
+                g[6] = dcw
+                dcb_, g[8], g[9], g[10], g[11] = had['out']
+                g[7] = dcb_ if want_cb else None
+                r = False                                    # (done: neither branch below)
+            else:
+                r = ml3_split_bwd(gy, out, nout1, x, w11, b11, w12, b12, need_dx=need[0], need_dcb=want_cb, dz_out=use_dz, gy_seg=gy_seg,
+                                  premasked=pre) \
+                    if mixk else ml3_split_bwd(gy, out, nout1, need_dcb=want_cb, gy_seg=gy_seg, premasked=pre)
+            if r is False:
+                pass
+            elif r is not None:
                 # one pass: relu mask, conv1.bias gradient, Hadamard branch (its dx written, conv adds to it)
                 G, dx0, g[7], g[8], g[9], g[10], g[11] = r
                 mix = (dx0, (w11.detach().contiguous(), w12.detach().contiguous())) if use_dz else None    # (rows of wmix from both arrays)

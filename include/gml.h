@@ -80,6 +80,29 @@ int gml_spectconv_bwd_mix_relu2(const int32_t* rowptr, const int32_t* col, const
                                 int32_t S, int32_t Fin, int32_t Fout, int32_t max_group_edges, int32_t max_group_window,
                                 uint32_t flags, void* ws, size_t ws_bytes, gml_stream_t stream);
 
+/* gml_spectconv_bwd_mix_relu2 with the whole output stage of the ML3Layer inside -- the backward of
+ *   out = cat[ relu(conv(x)) , tanh(fc11 x) * tanh(fc12 x) ]          (libs/spect_conv.py:209-212)
+ * for a layer whose output gradient arrives pre-masked (the consumer layer's conv backward applied this layer's relu mask,
+ * relu_cols above): ONE launch instead of gml_ml3_split_bwd_ex + gml_spectconv_bwd_mix_relu2.  g [num_rows, ldg >= Fout + F2] is
+ * that gradient (columns [0, Fout) at the conv output, columns Fout, Fout + 1 at the Hadamard units); neither a dz array nor a second
+ * pass over g and x exists -- dz is recomputed per 128-row group from the x rows the kernel holds, dw11 / dw12 ride in the kernel's own
+ * row contraction (bf16x3 products like dw), the bias gradients are folded per wave in fixed order.  Shape class: S = 8,
+ * 17 .. 32 input features (multiple of 4), Fout = 30, F2 = 2 (Zinc12k.py:338-341); gml_spectconv_bwd_had_parts returns 0 outside it
+ * (and with GML_BWD_HAD=0 in the environment), otherwise the number of partial rows [dw11 | dw12 | db11 | db12 | dcb]
+ * (4 Fin + 4 + Fout floats each) hws must hold.  dcb = dw11 = db11 = dw12 = db12 = NULL: the partials stay in hws for gml_fold_many;
+ * otherwise they are folded into the given ones (dw11, dw12 required then; b11 / db11, b12 / db12 may be NULL).  dw required.
+ * dx = NULL (want_dx = 0; the model's first layer, whose input is data): no dX is formed; then 17 .. 32 input features of any count,
+ * x rows float4-readable up to roundup4(Fin) (ldx % 4 == 0, 16-byte aligned base), relu_cols = 0. */
+int gml_spectconv_bwd_had_parts(int64_t num_rows, int32_t S, int32_t Fin, int32_t Fout, int32_t F2, int32_t want_dx,
+                                int32_t max_group_edges, int32_t max_group_window, uint32_t flags);
+int gml_spectconv_bwd_had(const int32_t* rowptr, const int32_t* col, const int32_t* ginfo, const float* val,
+                          const float* x, int64_t ldx, const float* g, int64_t ldg, const float* w,
+                          float* dx, int64_t lddx, float* dval, float* dw, const float* w11, const float* b11,
+                          const float* w12, const float* b12, int32_t relu_cols, float* dcb, float* dw11, float* db11,
+                          float* dw12, float* db12, int64_t num_rows, int32_t S, int32_t Fin, int32_t Fout, int32_t F2,
+                          int32_t max_group_edges, int32_t max_group_window, uint32_t flags, void* ws, size_t ws_bytes,
+                          void* hws, size_t hws_bytes, gml_stream_t stream);
+
 /* Deferred folds.  Every weight-gradient kernel of the library leaves one partial sum per workgroup in its workspace and folds
  * them in a second launch.  At the reference's batch size those folds are launches of a few microseconds of work each; a caller
  * may skip them -- GML_NO_FOLD above; gml_ml3_split_bwd(_ex) with dcb = dw11 = db11 = dw12 = db12 = NULL (partials [parts][2 F2 Fin +

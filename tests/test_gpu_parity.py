@@ -1270,6 +1270,7 @@ def test_stacked_ml3_relu_handover_matches_unchained(dev, monkeypatch):
     calls = []
     real = Fn.ml3_split_bwd
     monkeypatch.setattr(Fn, 'ml3_split_bwd', lambda *a, **k: (calls.append(bool(k.get('premasked'))), real(*a, **k))[1])
+    monkeypatch.setattr(Fn, 'BWD_HAD', False)                # the two-launch form first: output stage, then conv backward
     ref = run(False)
     assert calls == [False, False, False]
     del calls[:]
@@ -1282,6 +1283,20 @@ def test_stacked_ml3_relu_handover_matches_unchained(dev, monkeypatch):
     assert calls == [False, True, False], calls
     for a, b in zip(got, ref):
         close(a, b, tol=1e-6, what='relu hand-over with a foreign tensor in between')
+    # the pre-masked layers' output stage inside their conv backward (gml_spectconv_bwd_had; the default): they make no output-stage
+    # launch at all; fc11 / fc12 weight gradients move to bf16x3 products, so the comparison is at 2e-5 of each tensor's scale
+    monkeypatch.setattr(Fn, 'BWD_HAD', True)
+    del calls[:]
+    got = run(True)
+    assert calls == [False, True], calls                     # (top layer; the first layer's [N, 25] input rows are not float4-readable
+                                                             #  here -- models.zinc_gnnml3 pads them --: it keeps the one-pass kernel)
+    for a, b in zip(got, ref):
+        close(a, b, tol=2e-5, what='relu hand-over, output stage inside the conv backward, vs unchained')
+    del calls[:]
+    got = run(True, clone_between=True)
+    assert calls == [False, False], calls                    # (top layer, and the first layer whose hand-over was dropped)
+    for a, b in zip(got, ref):
+        close(a, b, tol=2e-5, what='output stage inside the conv backward with a foreign tensor in between')
 
 
 def test_relu_handover_below_a_layer_without_hadamard_branch(dev, monkeypatch):
@@ -2245,6 +2260,49 @@ def test_model_step_with_and_without_unique_row_sharing(dev):
     sb = dsd.batch_assembled(torch.arange(16, device=dev), dsd.bounds(16))
     c = sb.csr('edge_index2')
     assert c.sym_index(c.to_source_order(c.sort_values(sb.edge_attr2))) is None
+
+
+def test_model_step_with_the_output_stage_inside_the_conv_backward(dev):
+    """the ZINC GNNML3 step with GML_BWD_HAD on / off (gml_spectconv_bwd_had: relu mask hand-over, Hadamard branch, bias sums and the
+    dz . w start of dx inside the conv backward of the layers whose gradient arrives pre-masked) -- the forward is the same code, every
+    parameter gradient within 2e-5 of its scale (dw11 / dw12 move from exact fp32 products to bf16x3 ones, the pre-activations are
+    summed in another order); the fused road is really taken (launch count of the split kernel) and repeats itself bit for bit;
+    a tail group (N not a multiple of 128) and the deferred-fold scope are covered by the two batch sizes / the second loop."""
+    from gnn_matlang_amd import functional as Fn, models
+    for ngraphs, defer in ((128, False), (37, True)):
+        b = _sym_batch(dev, ngraphs=ngraphs)
+        torch.manual_seed(1)
+        m = models.zinc_gnnml3().to(dev)
+        res = {}
+        for on in (True, False, True):
+            old = Fn.BWD_HAD
+            Fn.BWD_HAD = on
+            Fn.PROFILE = {}
+            try:
+                m.zero_grad()
+                pre = m(b)
+                loss = models.zinc_loss(pre, b.y)
+                if defer:
+                    with Fn.deferred_folds(list(m.parameters())):
+                        loss.backward()
+                else:
+                    loss.backward()
+                torch.cuda.synchronize()
+                cur = (pre.detach().clone(), {n: p.grad.clone() for n, p in m.named_parameters()}, Fn.profile_summary(Fn.PROFILE))
+                if on and True in res:
+                    for n in cur[1]:
+                        assert torch.equal(cur[1][n], res[True][1][n]), 'fused output stage does not repeat itself: ' + n
+                res[on] = cur
+            finally:
+                Fn.BWD_HAD = old
+                Fn.PROFILE = None
+        assert torch.equal(res[True][0], res[False][0])
+        ns_on = res[True][2].get('ml3_split_bwd', {}).get('launches', 0)
+        ns_off = res[False][2].get('ml3_split_bwd', {}).get('launches', 0)
+        assert ns_off == 4 and ns_on == 1, (ns_on, ns_off)           # layers 1 .. 3 of the four lose their output-stage launch (the last one's
+                                                                     # gradient arrives per graph and unmasked: it keeps the one-pass kernel)
+        for n in res[True][1]:
+            close(res[True][1][n], res[False][1][n], tol=2e-5, what='fused vs split output stage ' + n)
 
 
 def test_edge_sym_pairing_with_repeated_and_one_sided_edges(dev):
