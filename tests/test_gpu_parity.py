@@ -1288,8 +1288,8 @@ def test_stacked_ml3_relu_handover_matches_unchained(dev, monkeypatch):
     monkeypatch.setattr(Fn, 'BWD_HAD', True)
     del calls[:]
     got = run(True)
-    assert calls == [False, True], calls                     # (top layer; the first layer's [N, 25] input rows are not float4-readable
-                                                             #  here -- models.zinc_gnnml3 pads them --: it keeps the one-pass kernel)
+    assert calls == [False, True], calls                     # (top layer; the first layer's input WANTS a gradient in this test and its 25
+                                                             #  features are not a multiple of 4 -- no dz form: it keeps the one-pass kernel)
     for a, b in zip(got, ref):
         close(a, b, tol=2e-5, what='relu hand-over, output stage inside the conv backward, vs unchained')
     del calls[:]
