@@ -98,6 +98,8 @@ SIGNATURES = {
     'gml_relu_bwd': (ctypes.c_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i32, _p]),
     'gml_segment_sum': (ctypes.c_int, [_p, _i64, _p, _p, _i64, _i64, _i32, _i32, _p]),
     'gml_segment_bcast': (ctypes.c_int, [_p, _i64, _p, _p, _i64, _i64, _i32, _i32, _p]),
+    'gml_segment_sum_mask': (ctypes.c_int, [_p, _i64, _p, _p, _i64, _p, _i64, _i32, _i32, _p]),
+    'gml_segment_bcast_mask': (ctypes.c_int, [_p, _i64, _p, _p, _p, _i64, _i64, _i32, _i32, _p]),
     'gml_segment_max': (ctypes.c_int, [_p, _i64, _p, _p, _i64, _p, _i64, _i32, _p]),
     'gml_segment_max_bwd': (ctypes.c_int, [_p, _i64, _p, _p, _p, _i64, _i64, _i32, _p]),
     'gml_dense_pack': (ctypes.c_int, [_p, _p, _i64, _i32, _i32, _i32, _p]),

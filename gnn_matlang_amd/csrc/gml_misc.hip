@@ -343,6 +343,77 @@ extern "C" int gml_segment_sum(const float* x, int64_t ldx, const int32_t* ptr, 
     return gml_launch_status();
 }
 
+// gml_k_segment_sum for 32-column rows that also leaves bit c = (x[row][c] > 0) of every row in mask[row]: the 32 lanes that sum a
+// segment hold a whole row per step, one ballot is the row's relu pattern.  The layer in front of the pool is an ML3Layer whose
+// output is [relu(conv) | Hadamard columns] (Zinc12k.py:338-343): its backward then needs 4 bytes per row instead of the saved
+// output (gml_segment_bcast_mask).  Same sums, in the same order, as gml_k_segment_sum.
+__global__ __launch_bounds__(256) void gml_k_segment_sum_mask32(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ ptr,
+                                                                float* __restrict__ out, int64_t ldo, uint32_t* __restrict__ mask,
+                                                                int64_t nseg, int mean) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t g = i >> 5;
+    const int c = (int)(i & 31);
+    const bool live = g < nseg;
+    const bool pad = live && (mean & GML_POOL_SKIP_LAST) && g == nseg - 1;     // the padding graph of a static batch: zeros, rows not read
+    const int r0 = (live && !pad) ? ptr[g] : 0, r1 = (live && !pad) ? ptr[g + 1] : 0;
+    const bool upper = (threadIdx.x & 32) != 0;              // which half of the wave's ballot is this segment's
+    float a = 0.f;
+    constexpr int U = 32;
+    for (int r = r0; r < r1; r += U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = x[(int64_t)min(r + u, r1 - 1) * ldx + c];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (r + u < r1) {
+                a += v[u];
+                const unsigned long long b = __ballot(v[u] > 0.f);           // (only the lanes inside the branch vote)
+                const uint32_t m = upper ? (uint32_t)(b >> 32) : (uint32_t)b;
+                if (c == 0) mask[r + u] = m;
+            }
+    }
+    if (!live) return;
+    if (mean & 1) a = a / (float)max(r1 - r0, 1);
+    out[g * ldo + c] = a;
+}
+
+extern "C" int gml_segment_sum_mask(const float* x, int64_t ldx, const int32_t* ptr, float* out, int64_t ldo, uint32_t* mask,
+                                    int64_t num_segments, int32_t F, int32_t mean, gml_stream_t stream) {
+    if (num_segments < 0 || F != 32 || ldx < F || ldo < F) return F != 32 && F > 0 ? GML_E_UNSUPPORTED : GML_E_BADARG;
+    if (num_segments == 0) return GML_OK;
+    if (!x || !ptr || !out || !mask) return GML_E_BADARG;
+    hipLaunchKernelGGL(gml_k_segment_sum_mask32, dim3((unsigned)gml_cdiv(num_segments * 32, 256)), dim3(256), 0,
+                       (hipStream_t)stream, x, ldx, ptr, out, ldo, mask, num_segments, mean);
+    return gml_launch_status();
+}
+
+// gradient of the pool for that layer, relu mask applied on the way: out[row][c] = g[seg[row]][c] * (c >= nrelu || bit c of mask[row]).
+// One lane per (row, 4 columns): 4 + 4 bytes read (the gradient rows are cache hits), 128 written per row.
+__global__ __launch_bounds__(256) void gml_k_segment_bcast_mask32(const float* __restrict__ g, int64_t ldg, const int32_t* __restrict__ seg,
+                                                                  const uint32_t* __restrict__ mask, float* __restrict__ out, int64_t ldo,
+                                                                  int64_t nrows, int nrelu) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t row = i >> 3;
+    const int ch = (int)(i & 7);
+    if (row >= nrows) return;
+    const uint32_t m = mask[row] | (nrelu < 32 ? (~0u << nrelu) : 0u);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(g + (int64_t)seg[row] * ldg + 4 * ch);
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = ((m >> (4 * ch + k)) & 1u) ? v[k] : 0.f;
+    *reinterpret_cast<f32x4*>(out + row * ldo + 4 * ch) = o;
+}
+
+extern "C" int gml_segment_bcast_mask(const float* g, int64_t ldg, const int32_t* seg, const uint32_t* mask, float* out, int64_t ldo,
+                                      int64_t num_rows, int32_t F, int32_t nrelu, gml_stream_t stream) {
+    if (num_rows < 0 || F != 32 || nrelu < 0 || nrelu > 32 || ldg < 32 || ldo < 32) return F != 32 && F > 0 ? GML_E_UNSUPPORTED : GML_E_BADARG;
+    if (num_rows == 0) return GML_OK;
+    if (!g || !seg || !mask || !out || ((ldg | ldo) & 3) || (((uintptr_t)g | (uintptr_t)out) & 15)) return GML_E_BADARG;
+    hipLaunchKernelGGL(gml_k_segment_bcast_mask32, dim3((unsigned)gml_cdiv(num_rows * 8, 256)), dim3(256), 0, (hipStream_t)stream,
+                       g, ldg, seg, mask, out, ldo, num_rows, nrelu);
+    return gml_launch_status();
+}
+
 // gradient of the pooling: every row of a segment receives the segment's gradient row.  One wave per
 // segment sweep: lanes <-> (row offset, column), coalesced stores.
 __global__ void gml_k_segment_bcast(const float* __restrict__ g, int64_t ldg, const int32_t* __restrict__ ptr,

@@ -969,6 +969,26 @@ def segment_sum(x, ptr, mean=False):
     return out
 
 
+def segment_sum_mask(x, ptr, mean=False):
+    """segment_sum for 32-column rows + the relu pattern of every row (uint32 per row as int32 [N]: bit c = x[row][c] > 0)."""
+    ptr = _ptr32(ptr)
+    B, F = int(ptr.numel() - 1), int(x.size(1))
+    out = torch.empty(B, F, dtype=torch.float32, device=x.device)
+    mask = torch.empty(int(x.size(0)), dtype=torch.int32, device=x.device)
+    with _Timed('pool'):
+        _lib.call('gml_segment_sum_mask', _ptr(x), int(x.stride(0)), _ptr(ptr), _ptr(out), F, _ptr(mask), B, F, int(mean), _stream(x.device))
+    return out, mask
+
+
+def segment_bcast_mask(g, seg, mask, nrelu):
+    """the pool's gradient per row with the relu pattern applied: out[row, c] = g[seg[row], c] * (c >= nrelu or bit c of mask[row])."""
+    N = int(seg.numel())
+    out = torch.empty(N, 32, dtype=torch.float32, device=g.device)
+    with _Timed('pool'):
+        _lib.call('gml_segment_bcast_mask', _ptr(g), int(g.stride(0)), _ptr(seg), _ptr(mask), _ptr(out), 32, N, 32, int(nrelu), _stream(g.device))
+    return out
+
+
 def segment_max(x, ptr):
     """global_max_pool over a batch whose nodes are grouped per graph: (max [B, F], argmax rows [B, F] int32)."""
     ptr = _ptr32(ptr)
@@ -1386,8 +1406,14 @@ class ML3LayerFunction(torch.autograd.Function):
         ctx.chain_in = chain_in if (CHAIN and chain_in is not None and chain_in.cols <= Fin) else None
         ctx.chain_out = chain_out if (CHAIN and ctx.pool is None) else None
         ctx.save_for_backward(x, val, (ea if learnedge and epos is None else None), w1, w2, w3, w4, cw, w11, b11, w12, b12, out, ea_t)
+        ctx.pool_mask = None
         if ctx.pool is not None:
-            pooled = segment_sum(out, pool_ptr, int(pool_mean) & 3)
+            # ZINC's 30 + 2 top layer: the pool also leaves the relu pattern of every row (4 bytes) -- the backward then takes the
+            # pre-masked road with the output stage inside the conv backward instead of reading the saved output
+            if BWD_HAD and mixk and nout1 == 30 and nout2 == 2 and out.stride(0) == 32 and not exact_mode():
+                pooled, ctx.pool_mask = segment_sum_mask(out, pool_ptr, int(pool_mean) & 3)
+            else:
+                pooled = segment_sum(out, pool_ptr, int(pool_mean) & 3)
             if int(pool_mean) & 2:
                 skip_last_mask(pooled)                         # (created outside any later graph capture of the backward)
             return pooled
@@ -1410,6 +1436,7 @@ class ML3LayerFunction(torch.autograd.Function):
             ea = val
         g = [None] * 23
         gy_seg = None
+        pre_top = False
         if ctx.pool is not None:                               # gy is the POOLED gradient [B, C]
             pptr, pseg, pmean = ctx.pool
             # GML_POOL_SKIP_LAST: the padding graph's pooled row was written, not computed -- its gradient must not reach the nodes.
@@ -1425,6 +1452,13 @@ class ML3LayerFunction(torch.autograd.Function):
                     cnt = (pptr[1:] - pptr[:-1]).clamp(min=1).to(gy.dtype).unsqueeze(1)
                     gy = gy / cnt
                 gy_seg = pseg
+                if (ctx.pool_mask is not None and BWD_HAD and mixk_ and nout2 == 2 and need[0] and need[6] and need[8] and need[10]
+                        and gy.stride(1) == 1 and gy.stride(0) % 4 == 0 and gy.data_ptr() % 16 == 0
+                        and conv_bwd_takes_dz(csr, S, Fin, nout1, 4) and conv_bwd_had_parts(csr, S, Fin, nout1, nout2) > 0):
+                    # the pool's gradient per row with the relu pattern applied (4 + 4 bytes read, 128 written per row): the layer
+                    # then runs like the ones below it -- pre-masked, output stage inside the conv backward
+                    gy = segment_bcast_mask(gy, pseg, ctx.pool_mask, nout1)
+                    gy_seg, pre_top = None, True
             else:
                 gy = segment_bcast(gy, pptr, N, pmean)
         with torch.cuda.device(x.device):
@@ -1437,7 +1471,7 @@ class ML3LayerFunction(torch.autograd.Function):
             # per row (dz) instead of writing a [N, Fin] array the conv kernel reads back
             use_dz = bool(mixk and need[0] and conv_bwd_takes_dz(csr, S, Fin, nout1, 2 * nout2))
             # the consumer of this layer's output already applied the relu mask to gy (ChainToken); read once, then cleared
-            pre = ctx.chain_out is not None and ctx.chain_out.premasked and gy_seg is None
+            pre = (ctx.chain_out is not None and ctx.chain_out.premasked and gy_seg is None) or pre_top
             if ctx.chain_out is not None:
                 ctx.chain_out.premasked = False
             # ZINC's 30 + 2 layers with a pre-masked gradient: the output stage runs INSIDE the conv backward (one launch, no dz array,

@@ -474,6 +474,17 @@ int gml_segment_sum(const float* x, int64_t ldx, const int32_t* ptr, float* out,
 /* its gradient: out[r, :] = g[seg(r), :] (/ segment length when mean != 0) for r in [ptr[seg], ptr[seg+1]) */
 int gml_segment_bcast(const float* g, int64_t ldg, const int32_t* ptr, float* out, int64_t ldo,
                       int64_t num_segments, int32_t F, int32_t mean, gml_stream_t stream);
+
+/* gml_segment_sum for 32-column rows that also leaves the relu pattern of every row -- bit c of mask[row] = (x[row][c] > 0) -- and
+ * the pool gradient broadcast that applies it: out[row][c] = g[seg[row]][c] * (c >= nrelu || bit c of mask[row]).  For the ML3Layer
+ * directly in front of global_add_pool / global_mean_pool (Zinc12k.py:338-343, out = [relu(conv) | Hadamard columns]): its backward
+ * reads 4 bytes per row instead of the saved output, and the pre-masked [num_rows, 32] gradient is what gml_spectconv_bwd_had takes.
+ * F must be 32 (GML_E_UNSUPPORTED otherwise); mean: the flag word of gml_segment_sum; for a mean pool the caller divides g by the
+ * segment sizes first.  Same sums, in the same order, as gml_segment_sum. */
+int gml_segment_sum_mask(const float* x, int64_t ldx, const int32_t* ptr, float* out, int64_t ldo, uint32_t* mask,
+                         int64_t num_segments, int32_t F, int32_t mean, gml_stream_t stream);
+int gml_segment_bcast_mask(const float* g, int64_t ldg, const int32_t* seg, const uint32_t* mask, float* out, int64_t ldo,
+                           int64_t num_rows, int32_t F, int32_t nrelu, gml_stream_t stream);
 /* out[g, c] = max_{r in [ptr[g], ptr[g+1])} x[r, c]  (global_max_pool, /root/reference/enzymes.py:384); argmax[g, c]
  * (int32 [num_segments, F], may be NULL) = the first row that attains it; an empty segment gives 0 / -1 */
 int gml_segment_max(const float* x, int64_t ldx, const int32_t* ptr, float* out, int64_t ldo, int32_t* argmax,

@@ -2262,6 +2262,33 @@ def test_model_step_with_and_without_unique_row_sharing(dev):
     assert c.sym_index(c.to_source_order(c.sort_values(sb.edge_attr2))) is None
 
 
+def test_pool_with_relu_pattern_and_its_masked_gradient(dev):
+    """gml_segment_sum_mask = gml_segment_sum bit for bit + bit c of mask[row] = (x[row][c] > 0); gml_segment_bcast_mask = the pool's
+    gradient per row times that pattern below nrelu; add and mean flag, ragged segments incl. empty ones and one beyond 32 rows, the
+    padding-graph flag of a static batch."""
+    from gnn_matlang_amd import functional as Fn, _lib
+    g = torch.Generator().manual_seed(3)
+    sizes = torch.tensor([5, 0, 23, 1, 40, 0, 17, 33, 2, 64, 9], dtype=torch.int64)
+    ptr = torch.cat([torch.zeros(1, dtype=torch.int64), sizes.cumsum(0)]).to(torch.int32).to(dev)
+    N = int(sizes.sum())
+    x = torch.randn(N, 32, generator=g).to(dev)
+    x[torch.rand(N, 32, generator=g).to(dev) < 0.3] = 0.0                         # exact zeros: not positive
+    seg = torch.repeat_interleave(torch.arange(len(sizes)), sizes).to(torch.int32).to(dev)
+    bits = ((x > 0).to(torch.int64) << torch.arange(32, device=dev)).sum(1)
+    for flag in (0, 1, _lib.GML_POOL_SKIP_LAST):
+        ref = Fn.segment_sum(x, ptr, flag)
+        got, mask = Fn.segment_sum_mask(x, ptr, flag)
+        assert torch.equal(ref, got)
+        live = N - (int(sizes[-1]) if flag & _lib.GML_POOL_SKIP_LAST else 0)      # (the padding graph's rows are not read)
+        assert torch.equal(mask[:live].to(torch.int64) & 0xffffffff, bits[:live])
+    _, mask = Fn.segment_sum_mask(x, ptr, 0)
+    gp = torch.randn(len(sizes), 32, generator=g).to(dev)
+    for nrelu in (30, 32, 0):
+        out = Fn.segment_bcast_mask(gp, seg, mask, nrelu)
+        keep = (x > 0) | (torch.arange(32, device=dev) >= nrelu)
+        assert torch.equal(out, gp[seg.long()] * keep)
+
+
 def test_model_step_with_the_output_stage_inside_the_conv_backward(dev):
     """the ZINC GNNML3 step with GML_BWD_HAD on / off (gml_spectconv_bwd_had: relu mask hand-over, Hadamard branch, bias sums and the
     dz . w start of dx inside the conv backward of the layers whose gradient arrives pre-masked) -- the forward is the same code, every
@@ -2299,8 +2326,8 @@ def test_model_step_with_the_output_stage_inside_the_conv_backward(dev):
         assert torch.equal(res[True][0], res[False][0])
         ns_on = res[True][2].get('ml3_split_bwd', {}).get('launches', 0)
         ns_off = res[False][2].get('ml3_split_bwd', {}).get('launches', 0)
-        assert ns_off == 4 and ns_on == 1, (ns_on, ns_off)           # layers 1 .. 3 of the four lose their output-stage launch (the last one's
-                                                                     # gradient arrives per graph and unmasked: it keeps the one-pass kernel)
+        assert ns_off == 4 and ns_on == 0, (ns_on, ns_off)           # no output-stage launch is left (the top layer's gradient is expanded
+                                                                     # from the pool with the relu pattern the pool kernel recorded)
         for n in res[True][1]:
             close(res[True][1][n], res[False][1][n], tol=2e-5, what='fused vs split output stage ' + n)
 
