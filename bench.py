@@ -446,7 +446,8 @@ def main():
     # the framework's own training step (dist.TrainStep): zero -> forward + L1-sum loss -> backward with the weight-gradient folds deferred
     # into ONE launch (functional.deferred_folds: bit-identical sums) -> flat all-reduce (nothing with one rank) -> fused Adam
     from gnn_matlang_amd.dist import TrainStep
-    trainer = TrainStep(model, lambda mod, d_: models.zinc_loss(mod(d_), d_.y), opt, sync=sync)
+    # (zinc_step_loss = zinc_loss(model(data), data.y) with the readout head + loss as one pass each way: functional.HeadL1BigFunction)
+    trainer = TrainStep(model, lambda mod, d_: models.zinc_step_loss(mod, d_), opt, sync=sync)
 
     def step(d=None):
         return trainer.step(data if d is None else d)

@@ -72,6 +72,10 @@ SIGNATURES = {
     'gml_head_l1_fwd': (ctypes.c_int, [_p, _i64, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p]),
     'gml_head_l1_fwd_acc': (ctypes.c_int, [_p, _i64, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p]),
     'gml_head_l1_bwd': (ctypes.c_int, [_p, _i64, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _i64, _p, _p, _p, _p, _p]),
+    'gml_head_l1_big_workspace_floats': (_sz, [_i64, _i32, _i32]),
+    'gml_head_l1_big_fwd': (ctypes.c_int, [_p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _sz, _p]),
+    'gml_head_l1_big_bwd': (ctypes.c_int, [_p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _i32, _p, _p, _i64, _p, _p, _p, _p,
+                                           _p, _sz, _p]),
     'gml_dense_dw_slices': (_i32, [_i32]),
     'gml_dense_dw_workspace_bytes': (_sz, [_i32, _i32, _i32, _i32]),
     'gml_dense_conv_bwd_w': (ctypes.c_int, [_p, _p, _i64, _p, _i64, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _sz, _p]),

@@ -910,6 +910,61 @@ class HeadL1Function(torch.autograd.Function):
         return gp, None, None, dw1, db1, dw2, db2, None
 
 
+class HeadL1BigFunction(torch.autograd.Function):
+    """HeadL1Function for any number of rows (nin = nh = 32; csrc/gml_head_big.hip): one pass + a fold each way instead of the ~16
+    launches of the general road (two library GEMMs, relu, the loss's elementwise chain and their backward) at the bench's batch size."""
+
+    @staticmethod
+    def forward(ctx, p, y, valid, w1, b1, w2, b2, loss_sum=None):
+        p = _f32c(p, 'pooled')
+        R, nin = p.shape
+        nws = int(_lib.lib().gml_head_l1_big_workspace_floats(int(R), int(nin), int(w1.size(0))))
+        ws = torch.empty(nws, dtype=torch.float32, device=p.device)
+        loss = torch.empty((), dtype=torch.float32, device=p.device)
+        with torch.cuda.device(p.device):
+            with _Timed('head'):
+                _lib.call('gml_head_l1_big_fwd', _ptr(p), int(p.stride(0)), _ptr(y), _ptr(valid), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2),
+                          int(R), int(y.numel()), int(nin), int(w1.size(0)), _ptr(loss), _ptr(loss_sum), _ptr(ws), nws, _stream(p.device))
+        ctx.save_for_backward(p, y, valid, w1, b1, w2, b2)
+        ctx.nws = nws
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        p, y, valid, w1, b1, w2, b2 = ctx.saved_tensors
+        R, nin = p.shape
+        nh = int(w1.size(0))
+        dev = p.device
+        gp = torch.empty(R, nin, dtype=torch.float32, device=dev)
+        ws = torch.empty(ctx.nws, dtype=torch.float32, device=dev)
+        g = g.contiguous()
+        npart = nh * nin + 2 * nh + 1
+        fq = _fold_queue()
+        if fq is not None:                                   # the partials stay in ws; the gradients are views of the flat buffer the fold fills
+            flat = torch.empty(npart, dtype=torch.float32, device=dev)
+            fq.append((ws, ctx.nws // npart, npart, [(flat, npart)]))
+            dw1, db1 = flat[:nh * nin].view_as(w1), (flat[nh * nin:nh * nin + nh] if b1 is not None else None)
+            dw2 = flat[nh * nin + nh:nh * nin + 2 * nh].view_as(w2)
+            db2 = flat[nh * nin + 2 * nh:] if b2 is not None else None
+            kd = (None,) * 4
+        else:
+            dw1, dw2 = torch.empty_like(w1), torch.empty_like(w2)
+            db1 = torch.empty_like(b1) if b1 is not None else None
+            db2 = torch.empty_like(b2) if b2 is not None else None
+            kd = (dw1, db1, dw2, db2)
+        with torch.cuda.device(dev):
+            with _Timed('head'):
+                _lib.call('gml_head_l1_big_bwd', _ptr(p), int(p.stride(0)), _ptr(y), _ptr(valid), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2),
+                          int(R), int(y.numel()), int(nin), nh, _ptr(g), _ptr(gp), nin, _ptr(kd[0]), _ptr(kd[1]), _ptr(kd[2]), _ptr(kd[3]),
+                          _ptr(ws), ctx.nws, _stream(dev))
+        return gp, None, None, dw1, db1, dw2, db2, None
+
+
+def head_l1_big_supported(p, w1, w2):
+    return (p.is_cuda and p.dtype == torch.float32 and p.dim() == 2 and int(p.size(1)) == 32 and tuple(w1.shape) == (32, 32)
+            and tuple(w2.shape) == (1, 32) and p.size(0) > 0 and not _os.environ.get('GML_NO_HEAD_BIG'))
+
+
 def head_l1_supported(p, w1, w2):
     R, nin, nh = int(p.size(0)), int(p.size(1)), int(w1.size(0))
     return (p.is_cuda and p.dtype == torch.float32 and R <= 256 and nin <= 64 and nh <= 64 and int(w2.size(0)) == 1

@@ -323,6 +323,10 @@ def zinc_step_loss(model, data, valid=None, loss_sum=None):
             return Fn.HeadL1Function.apply(x, y, valid, model.fc1.weight, model.fc1.bias, model.fc2.weight, model.fc2.bias, loss_sum)
         if small and nl <= ng:                              # (not the fused head after all: the promise above does not hold -- redo)
             x = model.features(data)
+        if Fn.head_l1_big_supported(x, model.fc1.weight, model.fc2.weight) and nl <= x.size(0):
+            # any batch size: one pass + a fold each way (rows beyond nl -- a static batch's padding graph -- get a zero gradient)
+            y = data.y[:nl].float().contiguous()
+            return Fn.HeadL1BigFunction.apply(x, y, valid, model.fc1.weight, model.fc1.bias, model.fc2.weight, model.fc2.bias, loss_sum)
         pre = tall_linear(F.relu(tall_linear(x, model.fc1)), model.fc2)
     else:
         pre = model(data)

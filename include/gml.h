@@ -599,6 +599,21 @@ int gml_head_l1_bwd(const float* p, int64_t ldp, const float* y, const float* va
                     const float* gscale, float* gp, int64_t ldgp, float* dw1, float* db1, float* dw2, float* db2,
                     gml_stream_t stream);
 
+/* The same head + loss for ANY number of rows (nin = nh = 32: GNNML3's 30 + 2 features, fc1 32 -> 32; GML_E_UNSUPPORTED otherwise --
+ * the caller keeps its general road): one pass forward + the fold of the per-workgroup loss partials, one pass backward (forward
+ * recomputed; gp written; dw1 / db1 / dw2 / db2 contracted over the rows with exact f32 matrix-core products, one partial per
+ * workgroup) + the fixed-order fold.  ws: gml_head_l1_big_workspace_floats(rows, nin, nh) floats (0: shape not served).  _bwd with
+ * dw1 = dw2 = NULL: the partials [parts][1089] (dw1 | db1 | dw2 | db2) stay in ws for gml_fold_many, parts = workspace_floats / 1089.
+ * Replaces ~16 launches of the general road (Zinc12k.py:343-345, :365 at the bench's batch size). */
+size_t gml_head_l1_big_workspace_floats(int64_t rows, int32_t nin, int32_t nh);
+int gml_head_l1_big_fwd(const float* p, int64_t ldp, const float* y, const float* valid, const float* w1, const float* b1,
+                        const float* w2, const float* b2, int64_t rows, int64_t rows_loss, int32_t nin, int32_t nh,
+                        float* loss, float* loss_sum, void* ws, size_t ws_floats, gml_stream_t stream);
+int gml_head_l1_big_bwd(const float* p, int64_t ldp, const float* y, const float* valid, const float* w1, const float* b1,
+                        const float* w2, const float* b2, int64_t rows, int64_t rows_loss, int32_t nin, int32_t nh,
+                        const float* gscale, float* gp, int64_t ldgp, float* dw1, float* db1, float* dw2, float* db2,
+                        void* ws, size_t ws_floats, gml_stream_t stream);
+
 /* GNNML1 block in one launch each way (csrc/gml_gnnml1.hip) -- /root/reference/sr25.py:231-240 (graph8c.py: the same class),
  * mnist75.py:296-318, mutag.py:253-262.  a = fc_i1(x), c = conv_i1(x) = (A^T x) Wc + bc (SpectConv, K = 1, selfconn = False,
  * libs/spect_conv.py:64-96 with one support), f2 = fc_i2(x), f3 = fc_i3(x):

@@ -1046,6 +1046,57 @@ def test_fused_head_and_l1_loss_equals_the_plain_path(dev, padded):
         close(p.grad, 0.25 * gp[n], tol=2e-5, what='scaled ' + n)
 
 
+@pytest.mark.parametrize('rows', [1, 255, 257, 1000, 70001])
+def test_head_and_l1_loss_for_any_batch_size_vs_fp64(dev, rows):
+    """functional.HeadL1BigFunction (csrc/gml_head_big.hip; Zinc12k.py:343-345, :365): loss and every gradient against the same
+    head evaluated in fp64 by torch -- row counts around the 256-row tiles and beyond one tile per workgroup, rows that do not enter
+    the loss (zero gradient), a validity mask, an upstream scale, the running loss sum, the deferred-fold road (bit-identical), and a
+    bitwise repeat."""
+    from gnn_matlang_amd import functional as Fn
+    g = torch.Generator().manual_seed(rows)
+    R, Rl = rows, max(rows - 3, 1) if rows > 1 else 1
+    p = torch.randn(R, 32, generator=g).to(dev).requires_grad_(True)
+    y = torch.randn(Rl, generator=g).to(dev)
+    valid = (torch.rand(Rl, generator=g) > 0.2).float().to(dev)
+    w1 = (torch.randn(32, 32, generator=g) * 0.3).to(dev).requires_grad_(True)
+    b1 = (torch.randn(32, generator=g) * 0.3).to(dev).requires_grad_(True)
+    w2 = (torch.randn(1, 32, generator=g) * 0.3).to(dev).requires_grad_(True)
+    b2 = (torch.randn(1, generator=g) * 0.3).to(dev).requires_grad_(True)
+    prm = [p, w1, b1, w2, b2]
+    assert Fn.head_l1_big_supported(p, w1, w2)
+
+    def ref():
+        pd, w1d, b1d, w2d, b2d = [t.detach().double().requires_grad_(True) for t in prm]
+        pre = torch.relu(pd @ w1d.t() + b1d) @ w2d.t() + b2d
+        l = ((pre[:Rl, 0] - y.double()).abs() * valid.double()).sum()
+        (0.5 * l).backward()
+        return l, [pd.grad, w1d.grad, b1d.grad, w2d.grad, b2d.grad]
+
+    def run(defer):
+        for t in prm:
+            t.grad = None
+        acc = torch.full((1,), 2.0, device=dev)
+        l = Fn.HeadL1BigFunction.apply(p, y, valid, w1, b1, w2, b2, acc)
+        if defer:
+            with Fn.deferred_folds(prm):
+                (0.5 * l).backward()
+        else:
+            (0.5 * l).backward()
+        assert abs(float(acc) - 2.0 - float(l.detach())) <= 1e-5 * max(abs(float(l.detach())), 1.0)
+        return l.detach().clone(), [t.grad.clone() for t in prm]
+
+    lr, gr = ref()
+    l0, g0 = run(False)
+    assert abs(float(l0) - float(lr)) <= 2e-6 * max(abs(float(lr)), 1.0), (float(l0), float(lr))
+    for a, b, n in zip(g0, gr, ['p', 'w1', 'b1', 'w2', 'b2']):
+        close(a, b, tol=2e-6, what='big head grad ' + n)
+    assert not g0[0][Rl:].any()                                                   # rows outside the loss: zero gradient
+    l1, g1 = run(True)
+    assert torch.equal(l0, l1)
+    for a, b in zip(g0, g1):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('model', ['zinc', 'counting'])
 def test_deferred_folds_are_bit_identical(dev, model):
     """functional.deferred_folds (include/gml.h "Deferred folds": the partial-sum folds of a backward pass as ONE gml_fold_many launch)
