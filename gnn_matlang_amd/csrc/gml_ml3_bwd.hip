@@ -48,21 +48,32 @@ struct GmlSplitBwdParams {
 // VEC / VX = 4: the leading dimensions of gy, y, G / of x, dx are multiples of 4 floats and the bases 16-byte
 // aligned (float4 accesses); 1 otherwise
 // DZO: the dz hand-over form (dz out, no dx; 2 F2 <= 4: one block of Hadamard columns) -- the ZINC path; only this form is pipelined
-template <int FINP, int VEC, int VX, bool DZO = false>
-__global__ __launch_bounds__(SB_ROWS, (FINP <= 32 ? 2 : 1)) void gml_k_ml3_split_bwd(const GmlSplitBwdParams p) {
-    constexpr int MAXCB = DZO ? 1 : SB_MAXCB;
+// MM (round 6; wide Hadamard branches: counting.py's 16, sr25.py's 16, mutag.py's 24 units): the two projections of the stage --
+//   z = X Wc^T (pre-activations) and dx = dz Wc -- run on the f32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 products -- a
+//   bf16x3 z is not good enough) like the weight-gradient contraction, each wave on its own 64 rows.  The row-per-lane
+//   form reads every weight through a wave-wide LDS broadcast (2 x 2 x F2 x FINP / 4 16-byte reads per row: 1,152 at mutag's 24 + 24 /
+//   48 inputs) and was bound by exactly that: 0.33 ms per launch at 0.19 of the HBM roof.  Layout changes for it: the w12 units start
+//   at a 16-aligned column F2P (a unit and its partner land in the same lane of the D tiles), the Hadamard gradients g sit in the
+//   dz tile until dz replaces them (no gi tile: two workgroups per CU still fit), leading dimensions = 4 or 20 mod 32 (conflict-free
+//   or 2-way for both operand patterns).
+template <int FINP, int VEC, int VX, bool DZO = false, bool MM = false>
+__global__ __launch_bounds__(SB_ROWS, (FINP <= 32 || MM ? 2 : 1)) void gml_k_ml3_split_bwd(const GmlSplitBwdParams p) {
+    static_assert(!MM || (!DZO && FINP >= 16 && VEC == 4 && VX == 4), "the matrix-core form is compiled for float4-addressable rows");
+    constexpr int MAXCB = DZO ? 1 : (MM ? 4 : SB_MAXCB);
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int LDX = FINP + 1;                              // odd: row-per-lane accesses are conflict free
+    constexpr int LDX = MM ? FINP + (FINP % 32 == 16 ? 4 : 20) : FINP + 1;   // odd: row-per-lane accesses are conflict free
+    constexpr int LDW = MM ? LDX : FINP;                       // rows of the weight image
     constexpr int NFB = FINP / 16;
     const int F2 = p.F2, Fin = p.Fin, nout1 = p.nout1;
     const bool premasked = p.y == nullptr;                     // (uniform) gy's conv columns are G already
-    const int C2 = 2 * F2, C2P = (C2 + 15) / 16 * 16, LDZ = C2P + 1, ncb = C2P / 16, LDI = F2 | 1;
+    const int F2P = MM ? (F2 + 15) / 16 * 16 : F2;             // first w12 unit's column
+    const int C2 = 2 * F2, C2L = MM ? 2 * F2P : C2, C2P = (C2L + 15) / 16 * 16, LDZ = C2P + (MM ? 4 : 1), ncb = C2P / 16, LDI = F2 | 1;
     float* xs = lds;                                           // [SB_ROWS][LDX]   x tile, later the dx tile
-    float* wc = xs + SB_ROWS * LDX;                            // [C2][FINP]   w11 rows then w12 rows, zero padded
-    float* bc = wc + C2 * FINP;                                // [C2]
-    float* gz = bc + ((C2 + 3) / 4 * 4);                       // [SB_ROWS][LDZ]   dz1 | dz2
-    float* gi = gz + (FINP ? SB_ROWS * LDZ : 0);               // [SB_ROWS][LDI]   gy[:, nout1:]
-    float* red = FINP ? gi + SB_ROWS * LDI : lds;              // [SB_ROWS]    bias partial fold
+    float* wc = xs + SB_ROWS * LDX;                            // [C2L][LDW]   w11 rows then w12 rows, zero padded
+    float* bc = wc + C2L * LDW;                                // [C2L]
+    float* gz = bc + ((C2L + 3) / 4 * 4);                      // [SB_ROWS][LDZ]   dz1 | dz2
+    float* gi = gz + (FINP ? SB_ROWS * LDZ : 0);               // [SB_ROWS][LDI]   gy[:, nout1:]   (MM: inside gz)
+    float* red = FINP ? gi + (MM ? 0 : SB_ROWS * LDI) : lds;   // [SB_ROWS]    bias partial fold
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
     // pass A: lane <-> VEC consecutive columns, RPS rows per sweep
@@ -72,11 +83,16 @@ __global__ __launch_bounds__(SB_ROWS, (FINP <= 32 ? 2 : 1)) void gml_k_ml3_split
     const int fa_y = min(fa, (Cy - 1) / VEC * VEC), fa_o = min(fa, (nout1 - 1) / VEC * VEC);   // clamped: loads stay inside
     const int ldgy = (int)p.ldgy, ldy = (int)p.ldy, ldg = (int)p.ldg, ldx = (int)p.ldx, lddx = (int)p.lddx;
     if constexpr (FINP > 0) {
-        for (int i = tid; i < C2 * FINP; i += SB_ROWS) {
+        for (int i = tid; i < C2L * FINP; i += SB_ROWS) {
             const int c = i / FINP, f = i % FINP;
-            wc[i] = (f < Fin) ? ((c < F2) ? p.w11[c * Fin + f] : p.w12[(c - F2) * Fin + f]) : 0.f;
+            const int u = c < F2P ? c : c - F2P;               // unit inside its half (MM: u >= F2 is padding)
+            const float v = (f < Fin && u < F2) ? ((c < F2P) ? p.w11[u * Fin + f] : p.w12[u * Fin + f]) : 0.f;
+            wc[c * LDW + f] = v;
         }
-        for (int i = tid; i < C2; i += SB_ROWS) bc[i] = (i < F2) ? (p.b11 ? p.b11[i] : 0.f) : (p.b12 ? p.b12[i - F2] : 0.f);
+        for (int i = tid; i < C2L; i += SB_ROWS) {
+            const int u = i < F2P ? i : i - F2P;
+            bc[i] = u < F2 ? ((i < F2P) ? (p.b11 ? p.b11[u] : 0.f) : (p.b12 ? p.b12[u] : 0.f)) : 0.f;
+        }
     }
     float bacc[VEC];
 #pragma unroll
@@ -211,7 +227,7 @@ __global__ __launch_bounds__(SB_ROWS, (FINP <= 32 ? 2 : 1)) void gml_k_ml3_split
                         gm[k] = (rv && fa + k < nout1 && vo[j][k] > 0.f) ? vg[j][k] : 0.f;
                         bacc[k] += gm[k];
                         if constexpr (FINP > 0)
-                            if (fa + k >= nout1 && fa + k < Cy) gi[rr * LDI + (fa + k - nout1)] = rv ? vg[j][k] : 0.f;
+                            if (fa + k >= nout1 && fa + k < Cy) (MM ? gz[rr * LDZ + (fa + k - nout1)] : gi[rr * LDI + (fa + k - nout1)]) = rv ? vg[j][k] : 0.f;
                     }
                     if (rv && fa < ldg && !premasked) {
                         const int off = __umul24(rr, ldg) + fa;
@@ -226,7 +242,46 @@ __global__ __launch_bounds__(SB_ROWS, (FINP <= 32 ? 2 : 1)) void gml_k_ml3_split
             __syncthreads();
             if constexpr (pipe) { if (t + (int)gridDim.x < p.ntiles) issue(t + gridDim.x); }   // the next tile's rows travel during pass B
             // ---- pass B: one row per lane
-            float xr[FINP], dxr[DZO ? 1 : FINP];
+            float xr[MM ? 1 : FINP], dxr[(DZO || MM) ? 1 : FINP];
+            if constexpr (MM) {
+                // ---- pass B on the matrix cores: Z^T = Wc X^T for the wave's own 64 rows, 16 at a time.  D[i = unit][j = row]: lane
+                //      (r16, kq) ends with units 16 ub + 4 kq + reg of row 16 rb + r16 -- and, from the second product, with their
+                //      partners F2P + (the same): tanh, its derivative and dz in place, g read from / dz written to the lane's own 16
+                //      bytes of the dz tile
+                for (int c = F2; c < F2P; ++c) gz[tid * LDZ + c] = 0.f;          // (padding units: g = 0, so that 0 * garbage cannot appear)
+                const int rbase = wave * 64, nub = F2P / 16;
+#pragma unroll 1
+                for (int rbk = 0; rbk < 4; ++rbk) {
+                    const int row = rbase + rbk * 16 + r16;
+                    for (int ub = 0; ub < nub; ++ub) {
+                        f32x4 z1 = f32x4{0.f, 0.f, 0.f, 0.f}, z2 = f32x4{0.f, 0.f, 0.f, 0.f};
+                        const float* a1p = wc + (ub * 16 + r16) * LDW + kq;
+                        const float* a2p = wc + (F2P + ub * 16 + r16) * LDW + kq;
+                        const float* bp = xs + row * LDX + kq;
+#pragma unroll
+                        for (int ks = 0; ks < FINP / 4; ++ks) {
+                            const float b = bp[4 * ks];
+                            z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1p[4 * ks], b, z1, 0, 0, 0);
+                            z2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2p[4 * ks], b, z2, 0, 0, 0);
+                        }
+                        float* gq = gz + row * LDZ + ub * 16 + 4 * kq;
+                        const f32x4 g4 = *reinterpret_cast<const f32x4*>(gq);
+                        const f32x4 ba = *reinterpret_cast<const f32x4*>(bc + ub * 16 + 4 * kq);
+                        const f32x4 bb = *reinterpret_cast<const f32x4*>(bc + F2P + ub * 16 + 4 * kq);
+                        f32x4 d1, d2;
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) {
+                            float ta, tb, da, db;
+                            gml_tanh_d(z1[reg] + ba[reg], ta, da);
+                            gml_tanh_d(z2[reg] + bb[reg], tb, db);
+                            d1[reg] = g4[reg] * tb * da;
+                            d2[reg] = g4[reg] * ta * db;
+                        }
+                        *reinterpret_cast<f32x4*>(gq) = d1;
+                        *reinterpret_cast<f32x4*>(gq + F2P) = d2;
+                    }
+                }
+            } else {
 #pragma unroll
             for (int f = 0; f < FINP; ++f) { xr[f] = xs[tid * LDX + f]; if constexpr (!DZO) dxr[f] = 0.f; }
             for (int c = C2; c < C2P; ++c) gz[tid * LDZ + c] = 0.f;
@@ -261,6 +316,7 @@ __global__ __launch_bounds__(SB_ROWS, (FINP <= 32 ? 2 : 1)) void gml_k_ml3_split
                     }
                 }
             }
+            }   // (!MM)
             // weight / bias gradients of this wave's 64 rows: D[c][f] += sum_rows dz[row][c] * [x | 1][row][f]
             // (the wave reads only its own rows of gz and xs, written by its own lanes above)
             const int rb = wave * 64;
@@ -285,8 +341,31 @@ __global__ __launch_bounds__(SB_ROWS, (FINP <= 32 ? 2 : 1)) void gml_k_ml3_split
                 if (tid < nr) *reinterpret_cast<f32x4*>(p.dz + (r0 + tid) * 4) = v;
             }
             if (!DZO && p.dx != nullptr) {                     // dx tile through LDS: row-per-lane in, coalesced out
+                if constexpr (MM) {
+                    // dX^T = Wc^T dZ^T for the wave's own rows (x of those rows is no longer needed: the contraction above was its
+                    // last reader): D[i = f][j = row], A[i = f][k = unit] = wc[unit][f], B[k = unit][j = row] = dz[row][unit]
+                    const int rbase = wave * 64;
+#pragma unroll 1
+                    for (int rbk = 0; rbk < 4; ++rbk) {
+                        const int row = rbase + rbk * 16 + r16;
+                        f32x4 dxa[NFB];
 #pragma unroll
-                for (int f = 0; f < FINP; ++f) xs[tid * LDX + f] = dxr[DZO ? 0 : f];
+                        for (int fb = 0; fb < NFB; ++fb) dxa[fb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        const float* bp = gz + row * LDZ + kq;
+                        const float* ap = wc + kq * LDW + r16;
+                        for (int ks = 0; ks < C2P / 4; ++ks) {
+                            const float b = bp[4 * ks];
+#pragma unroll
+                            for (int fb = 0; fb < NFB; ++fb)
+                                dxa[fb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * ks * LDW + fb * 16], b, dxa[fb], 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int fb = 0; fb < NFB; ++fb) *reinterpret_cast<f32x4*>(xs + row * LDX + fb * 16 + 4 * kq) = dxa[fb];
+                    }
+                } else {
+#pragma unroll
+                for (int f = 0; f < FINP; ++f) xs[tid * LDX + f] = dxr[(DZO || MM) ? 0 : f];
+                }
                 __syncthreads();
                 constexpr int FV = FINP / VX, RPX = SB_ROWS / FV, NIX = (SB_ROWS + RPX - 1) / RPX;
                 float* dxb = p.dx + r0 * p.lddx;
@@ -325,7 +404,13 @@ __global__ __launch_bounds__(SB_ROWS, (FINP <= 32 ? 2 : 1)) void gml_k_ml3_split
 #pragma unroll
             for (int w = 1; w < SB_WAVES; ++w) v += wred[(w * NA + a) * 64 + ln];
             const int reg = a & 3, fb = (a >> 2) % (NFB + 1), cb = (a >> 2) / (NFB + 1);
-            const int c = cb * 16 + 4 * (ln >> 4) + reg, j = ln & 15;
+            int c = cb * 16 + 4 * (ln >> 4) + reg;
+            const int j = ln & 15;
+            if constexpr (MM) {                                // padded unit columns -> rows of [dw11; dw12]
+                const int u = c < F2P ? c : c - F2P;
+                if (c >= C2L || u >= F2) continue;
+                c = c < F2P ? u : F2 + u;
+            }
             if (c >= C2) continue;
             if (fb < NFB) {
                 const int f = fb * 16 + j;
@@ -394,9 +479,15 @@ static int sb_grid(int64_t num_rows) {
     return (int)(nt < GML_NUM_CU * wgs ? nt : GML_NUM_CU * wgs);
 }
 static int sb_npart(int Fin, int nout1, int F2) { return 2 * F2 * Fin + 2 * F2 + nout1; }
-static size_t sb_lds(int FINP, int F2) {
+static size_t sb_lds(int FINP, int F2, bool mm = false) {
     const int C2 = 2 * F2, C2P = (C2 + 15) / 16 * 16;
     size_t fl = SB_ROWS * 4;                                                // red (VEC <= 4 columns per thread)
+    if (mm) {                                                               // (the layout of the MM instantiation: see the kernel)
+        const int F2P = (F2 + 15) / 16 * 16, C2L = 2 * F2P, LDX = FINP + (FINP % 32 == 16 ? 4 : 20);
+        fl += (size_t)SB_ROWS * LDX + (size_t)C2L * LDX + C2L + (size_t)SB_ROWS * (C2L + 4);
+        const size_t fold = (size_t)SB_WAVES * 4 * (FINP / 16 + 1) * 4 * 64;
+        return sizeof(float) * (fl > fold ? fl : fold);
+    }
     if (FINP > 0) fl += (size_t)SB_ROWS * (FINP + 1) + (size_t)C2 * FINP + (C2 + 3) / 4 * 4 + (size_t)SB_ROWS * (C2P + 1) +
                         (size_t)SB_ROWS * (F2 | 1);
     const size_t fold = FINP > 0 ? (size_t)SB_WAVES * SB_MAXCB * (FINP / 16 + 1) * 4 * 64 : 0;   // wred aliases xs.. : must fit
@@ -445,7 +536,12 @@ static int split_bwd_impl(const float* gy, int64_t ldgy, const int32_t* gy_seg, 
     p.npart = sb_npart(Fin, nout1, F2);
     { static const int np = [] { const char* e = getenv("GML_SPLIT_PIPE"); return (e && e[0] == '0') ? 1 : 0; }(); p.nopipe = np; }
     const int grid = sb_grid(num_rows);
-    const size_t lds = sb_lds(FINP, F2);
+    /* wide Hadamard branches on float4-addressable rows: the projections on the matrix cores (GML_SPLIT_MM=0: the row-per-lane form) */
+    static const bool mm_env = [] { const char* e = getenv("GML_SPLIT_MM"); return !(e && e[0] == '0'); }();
+    const bool vec44 = (((ldgy | ldy | ldg) & 3) == 0 && (((uintptr_t)gy | (uintptr_t)y | (uintptr_t)G) & 15) == 0) &&
+                       (F2 == 0 || (((ldx | (dx ? lddx : 0)) & 3) == 0 && (((uintptr_t)x | (uintptr_t)dx) & 15) == 0));
+    const bool mm = mm_env && F2 >= 8 && F2 <= 32 && FINP >= 16 && vec44 && dz == nullptr && sb_lds(FINP, F2, true) <= 160 * 1024;
+    const size_t lds = sb_lds(FINP, F2, mm);
     const int va = (((ldgy | ldy | ldg) & 3) == 0 && (((uintptr_t)gy | (uintptr_t)y | (uintptr_t)G) & 15) == 0) ? 4 : 1;
     const int vx = (F2 == 0 || (((ldx | (dx ? lddx : 0)) & 3) == 0 && (((uintptr_t)x | (uintptr_t)dx) & 15) == 0)) ? 4 : 1;
 #define SB_GO(FP, VA, VXX)                                                                                       \
@@ -464,7 +560,14 @@ static int split_bwd_impl(const float* gy, int64_t ldgy, const int32_t* gy_seg, 
         hipLaunchKernelGGL((gml_k_ml3_split_bwd<FP, 4, 4, true>), dim3(grid), dim3(SB_ROWS), lds, st, p);        \
     }
     SB_GO_DZ(16) SB_GO_DZ(32)
-    if (!dzo) {
+#define SB_GO_MM(FP)                                                                                             \
+    if (mm && FINP == FP) {                                                                                      \
+        GML_ALLOW_BIG_LDS(arc, (&gml_k_ml3_split_bwd<FP, 4, 4, false, true>), 160 * 1024)                        \
+        if (arc != hipSuccess) return (int)arc;                                                                  \
+        hipLaunchKernelGGL((gml_k_ml3_split_bwd<FP, 4, 4, false, true>), dim3(grid), dim3(SB_ROWS), lds, st, p); \
+    }
+    SB_GO_MM(16) SB_GO_MM(32) SB_GO_MM(48) SB_GO_MM(64)
+    if (!dzo && !mm) {
     SB_GO(0, 1, 4) SB_GO(0, 4, 4) SB_GO4(16) SB_GO4(32) SB_GO4(48) SB_GO4(64)
     }
     int rc = gml_launch_status();
