@@ -1465,7 +1465,8 @@ class ML3LayerFunction(torch.autograd.Function):
         if ctx.pool is not None:
             # ZINC's 30 + 2 top layer: the pool also leaves the relu pattern of every row (4 bytes) -- the backward then takes the
             # pre-masked road with the output stage inside the conv backward instead of reading the saved output
-            if BWD_HAD and mixk and nout1 == 30 and nout2 == 2 and out.stride(0) == 32 and not exact_mode():
+            if (BWD_HAD and mixk and nout1 == 30 and nout2 == 2 and out.stride(0) == 32 and not exact_mode()
+                    and any(ctx.needs_input_grad)):              # (inference: the plain pool)
                 pooled, ctx.pool_mask = segment_sum_mask(out, pool_ptr, int(pool_mean) & 3)
             else:
                 pooled = segment_sum(out, pool_ptr, int(pool_mean) & 3)
