@@ -625,8 +625,9 @@ def main():
                     r = dict(bound='hbm', achieved=gbs, peak=HBM_PEAK_GBS, unit='GB/s', frac=gbs / HBM_PEAK_GBS)
                 r.update(traffic=None, kernel=kernel, launches=nl, avg_launch_ms=k['ms'],
                          ms_per_step=k['ms'] * nl / args.steps,
-                         projection_arith='bf16x3 split on the bf16 matrix cores, fp32 accumulate' if bf16x3
-                         else 'f32-input MFMA',
+                         projection_arith=(('f16 (hi, lo) split under power-of-two scales, 3 products on the f16 matrix cores, fp32 accumulate'
+                                            if (tag == 'spectconv_fwd' and Fn.FWD_F16) else
+                                            'bf16x3 split on the bf16 matrix cores, fp32 accumulate') if bf16x3 else 'f32-input MFMA'),
                          algorithmic_bytes_per_launch=k['bytes'], algorithmic_flops_per_launch=k['flops'],
                          t_hbm_ms=t_hbm * 1e3, t_matrix_ms=t_mat * 1e3, t_valu_edge_ms=ef / (MFMA_F32_PEAK_TFLOPS * 1e12) * 1e3,
                          hbm_GBps=gbs, hbm_frac=gbs / HBM_PEAK_GBS,
@@ -641,7 +642,9 @@ def main():
             ed_b = sum(4 * E_ * 8 * 30 for f in fins) * args.steps              # P update + Z.g dot
             cands = []
             if 'spectconv_bwd' in summ:
-                cands.append(roof('spectconv_bwd', '%s (fused SpectConv backward: dX, dval, dW)' % ('gml_k_spectconv_bwd (f32-input MFMA)' if Fn.F32_MFMA else ('gml_k_spectconv_bwd4' if Fn.BWD_DMA else 'gml_k_spectconv_bwd3')), pj_b, ed_b))
+                cands.append(roof('spectconv_bwd', '%s (fused SpectConv backward: dX, dval, dW%s)' % (
+                    'gml_k_spectconv_bwd (f32-input MFMA)' if Fn.F32_MFMA else ('gml_k_spectconv_bwd4' if Fn.BWD_DMA else 'gml_k_spectconv_bwd3'),
+                    '; carries the ML3Layer output stage' if (Fn.BWD_HAD and not Fn.F32_MFMA and not Fn.BWD_DMA) else ''), pj_b, ed_b))
             if 'spectconv_fwd' in summ:
                 cands.append(roof('spectconv_fwd', '%s (fused SpectConv forward; also carries the Hadamard branch)' % ('gml_k_spectconv_fwd (f32-input MFMA)' if Fn.F32_MFMA else 'gml_k_spectconv_fwd3 (LDS-DMA ring)'), pj_f, ed_f))
             # HBM bytes per launch from the PMC counters: collected OFFLINE with the same command under rocprofv3
