@@ -540,7 +540,7 @@ static int split_bwd_impl(const float* gy, int64_t ldgy, const int32_t* gy_seg, 
     static const bool mm_env = [] { const char* e = getenv("GML_SPLIT_MM"); return !(e && e[0] == '0'); }();
     const bool vec44 = (((ldgy | ldy | ldg) & 3) == 0 && (((uintptr_t)gy | (uintptr_t)y | (uintptr_t)G) & 15) == 0) &&
                        (F2 == 0 || (((ldx | (dx ? lddx : 0)) & 3) == 0 && (((uintptr_t)x | (uintptr_t)dx) & 15) == 0));
-    const bool mm = mm_env && F2 >= 8 && F2 <= 32 && FINP >= 16 && vec44 && dz == nullptr && sb_lds(FINP, F2, true) <= 160 * 1024;
+    const bool mm = mm_env && F2 >= 16 && F2 <= 32 && FINP >= 32 && vec44 && dz == nullptr && sb_lds(FINP, F2, true) <= 160 * 1024;
     const size_t lds = sb_lds(FINP, F2, mm);
     const int va = (((ldgy | ldy | ldg) & 3) == 0 && (((uintptr_t)gy | (uintptr_t)y | (uintptr_t)G) & 15) == 0) ? 4 : 1;
     const int vx = (F2 == 0 || (((ldx | (dx ? lddx : 0)) & 3) == 0 && (((uintptr_t)x | (uintptr_t)dx) & 15) == 0)) ? 4 : 1;
