@@ -57,7 +57,10 @@ struct GmlSplitBwdParams {
 //   dz tile until dz replaces them (no gi tile: two workgroups per CU still fit), leading dimensions = 4 or 20 mod 32 (conflict-free
 //   or 2-way for both operand patterns).
 template <int FINP, int VEC, int VX, bool DZO = false, bool MM = false>
-__global__ __launch_bounds__(SB_ROWS, (FINP <= 32 || MM ? 2 : 1)) void gml_k_ml3_split_bwd(const GmlSplitBwdParams p) {
+__global__ __launch_bounds__((MM ? 2 : 1) * SB_ROWS, (FINP <= 32 || MM ? 2 : 1)) void gml_k_ml3_split_bwd(const GmlSplitBwdParams p) {
+    // MM: 256 threads share a 128-row tile -- every per-wave phase works on 32 rows instead of 64, so two workgroups per CU are two
+    // waves per SIMD on the same LDS (one wave per SIMD left every load and LDS latency of the phases exposed)
+    constexpr int NT = (MM ? 2 : 1) * SB_ROWS, NWV = NT / 64, RPW = SB_ROWS / NWV;
     static_assert(!MM || (!DZO && FINP >= 16 && VEC == 4 && VX == 4), "the matrix-core form is compiled for float4-addressable rows");
     constexpr int MAXCB = DZO ? 1 : (MM ? 4 : SB_MAXCB);
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -77,19 +80,19 @@ __global__ __launch_bounds__(SB_ROWS, (FINP <= 32 || MM ? 2 : 1)) void gml_k_ml3
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
     // pass A: lane <-> VEC consecutive columns, RPS rows per sweep
-    const int CPV = p.CP / VEC, RPS = SB_ROWS / CPV, NIT = SB_ROWS / RPS;
+    const int CPV = p.CP / VEC, RPS = NT / CPV, NIT = SB_ROWS / RPS;
     const int fa = (tid & (CPV - 1)) * VEC, ra = tid / CPV;
     const int Cy = nout1 + F2;                                 // live columns of gy
     const int fa_y = min(fa, (Cy - 1) / VEC * VEC), fa_o = min(fa, (nout1 - 1) / VEC * VEC);   // clamped: loads stay inside
     const int ldgy = (int)p.ldgy, ldy = (int)p.ldy, ldg = (int)p.ldg, ldx = (int)p.ldx, lddx = (int)p.lddx;
     if constexpr (FINP > 0) {
-        for (int i = tid; i < C2L * FINP; i += SB_ROWS) {
+        for (int i = tid; i < C2L * FINP; i += NT) {
             const int c = i / FINP, f = i % FINP;
             const int u = c < F2P ? c : c - F2P;               // unit inside its half (MM: u >= F2 is padding)
             const float v = (f < Fin && u < F2) ? ((c < F2P) ? p.w11[u * Fin + f] : p.w12[u * Fin + f]) : 0.f;
             wc[c * LDW + f] = v;
         }
-        for (int i = tid; i < C2L; i += SB_ROWS) {
+        for (int i = tid; i < C2L; i += NT) {
             const int u = i < F2P ? i : i - F2P;
             bc[i] = u < F2 ? ((i < F2P) ? (p.b11 ? p.b11[u] : 0.f) : (p.b12 ? p.b12[u] : 0.f)) : 0.f;
         }
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(SB_ROWS, (FINP <= 32 || MM ? 2 : 1)) void gml_k_ml3
             }
         } else {
         if constexpr (FINP > 0) {                              // x tile: lane <-> VX features, 8 / 16 loads in flight
-            constexpr int FV = FINP / VX, RPX = SB_ROWS / FV, NIX = (SB_ROWS + RPX - 1) / RPX;
+            constexpr int FV = FINP / VX, RPX = NT / FV, NIX = (SB_ROWS + RPX - 1) / RPX;
             constexpr int XCH = 8;
             const float* xb = p.x + r0 * p.ldx;
             const int f = (tid % FV) * VX, rb = tid / FV, fc = min(f, (Fin - 1) / VX * VX);
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(SB_ROWS, (FINP <= 32 || MM ? 2 : 1)) void gml_k_ml3
             }
 #pragma unroll
             for (int j = 0; j < SB_CHUNK; ++j) {
-                {
+                if (j0 + j < NIT) {                             // (MM at narrow rows: fewer sweeps than a chunk)
                     const int rr = ra + (j0 + j) * RPS;
                     const bool rv = rr < nr;
                     float gm[VEC];
@@ -238,6 +241,10 @@ __global__ __launch_bounds__(SB_ROWS, (FINP <= 32 || MM ? 2 : 1)) void gml_k_ml3
             }
         }
         }   // (!pipe)
+        if constexpr (MM) {                                    // padding units: g = 0, so that 0 * garbage cannot appear (read by the row's wave below)
+            if (tid < SB_ROWS)
+                for (int c = F2; c < F2P; ++c) gz[tid * LDZ + c] = 0.f;
+        }
         if constexpr (FINP > 0) {
             __syncthreads();
             if constexpr (pipe) { if (t + (int)gridDim.x < p.ntiles) issue(t + gridDim.x); }   // the next tile's rows travel during pass B
@@ -248,10 +255,9 @@ __global__ __launch_bounds__(SB_ROWS, (FINP <= 32 || MM ? 2 : 1)) void gml_k_ml3
                 //      (r16, kq) ends with units 16 ub + 4 kq + reg of row 16 rb + r16 -- and, from the second product, with their
                 //      partners F2P + (the same): tanh, its derivative and dz in place, g read from / dz written to the lane's own 16
                 //      bytes of the dz tile
-                for (int c = F2; c < F2P; ++c) gz[tid * LDZ + c] = 0.f;          // (padding units: g = 0, so that 0 * garbage cannot appear)
-                const int rbase = wave * 64, nub = F2P / 16;
+                const int rbase = wave * RPW, nub = F2P / 16;
 #pragma unroll 1
-                for (int rbk = 0; rbk < 4; ++rbk) {
+                for (int rbk = 0; rbk < RPW / 16; ++rbk) {
                     const int row = rbase + rbk * 16 + r16;
                     for (int ub = 0; ub < nub; ++ub) {
                         f32x4 z1 = f32x4{0.f, 0.f, 0.f, 0.f}, z2 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -319,9 +325,9 @@ __global__ __launch_bounds__(SB_ROWS, (FINP <= 32 || MM ? 2 : 1)) void gml_k_ml3
             }   // (!MM)
             // weight / bias gradients of this wave's 64 rows: D[c][f] += sum_rows dz[row][c] * [x | 1][row][f]
             // (the wave reads only its own rows of gz and xs, written by its own lanes above)
-            const int rb = wave * 64;
+            const int rb = wave * RPW;
 #pragma unroll
-            for (int t16 = 0; t16 < 16; ++t16) {
+            for (int t16 = 0; t16 < RPW / 4; ++t16) {
                 const int rr = rb + 4 * t16 + kq;
 #pragma unroll
                 for (int cb = 0; cb < MAXCB; ++cb) {
@@ -344,9 +350,9 @@ __global__ __launch_bounds__(SB_ROWS, (FINP <= 32 || MM ? 2 : 1)) void gml_k_ml3
                 if constexpr (MM) {
                     // dX^T = Wc^T dZ^T for the wave's own rows (x of those rows is no longer needed: the contraction above was its
                     // last reader): D[i = f][j = row], A[i = f][k = unit] = wc[unit][f], B[k = unit][j = row] = dz[row][unit]
-                    const int rbase = wave * 64;
+                    const int rbase = wave * RPW;
 #pragma unroll 1
-                    for (int rbk = 0; rbk < 4; ++rbk) {
+                    for (int rbk = 0; rbk < RPW / 16; ++rbk) {
                         const int row = rbase + rbk * 16 + r16;
                         f32x4 dxa[NFB];
 #pragma unroll
@@ -367,7 +373,7 @@ __global__ __launch_bounds__(SB_ROWS, (FINP <= 32 || MM ? 2 : 1)) void gml_k_ml3
                 for (int f = 0; f < FINP; ++f) xs[tid * LDX + f] = dxr[(DZO || MM) ? 0 : f];
                 }
                 __syncthreads();
-                constexpr int FV = FINP / VX, RPX = SB_ROWS / FV, NIX = (SB_ROWS + RPX - 1) / RPX;
+                constexpr int FV = FINP / VX, RPX = NT / FV, NIX = (SB_ROWS + RPX - 1) / RPX;
                 float* dxb = p.dx + r0 * p.lddx;
                 const int f = (tid % FV) * VX, rbx = tid / FV;
 #pragma unroll 8
@@ -398,11 +404,11 @@ __global__ __launch_bounds__(SB_ROWS, (FINP <= 32 || MM ? 2 : 1)) void gml_k_ml3
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) wred[(wave * NA + (cb * (NFB + 1) + fb) * 4 + reg) * 64 + lane] = acc[cb][fb][reg];
         __syncthreads();
-        for (int it = tid; it < NA * 64; it += SB_ROWS) {
+        for (int it = tid; it < NA * 64; it += NT) {
             const int a = it >> 6, ln = it & 63;
             float v = wred[a * 64 + ln];
 #pragma unroll
-            for (int w = 1; w < SB_WAVES; ++w) v += wred[(w * NA + a) * 64 + ln];
+            for (int w = 1; w < NWV; ++w) v += wred[(w * NA + a) * 64 + ln];
             const int reg = a & 3, fb = (a >> 2) % (NFB + 1), cb = (a >> 2) / (NFB + 1);
             int c = cb * 16 + 4 * (ln >> 4) + reg;
             const int j = ln & 15;
@@ -481,11 +487,11 @@ static int sb_grid(int64_t num_rows) {
 static int sb_npart(int Fin, int nout1, int F2) { return 2 * F2 * Fin + 2 * F2 + nout1; }
 static size_t sb_lds(int FINP, int F2, bool mm = false) {
     const int C2 = 2 * F2, C2P = (C2 + 15) / 16 * 16;
-    size_t fl = SB_ROWS * 4;                                                // red (VEC <= 4 columns per thread)
+    size_t fl = (mm ? 2 : 1) * SB_ROWS * 4;                                 // red (VEC <= 4 columns per thread)
     if (mm) {                                                               // (the layout of the MM instantiation: see the kernel)
         const int F2P = (F2 + 15) / 16 * 16, C2L = 2 * F2P, LDX = FINP + (FINP % 32 == 16 ? 4 : 20);
         fl += (size_t)SB_ROWS * LDX + (size_t)C2L * LDX + C2L + (size_t)SB_ROWS * (C2L + 4);
-        const size_t fold = (size_t)SB_WAVES * 4 * (FINP / 16 + 1) * 4 * 64;
+        const size_t fold = (size_t)2 * SB_WAVES * 4 * (FINP / 16 + 1) * 4 * 64;
         return sizeof(float) * (fl > fold ? fl : fold);
     }
     if (FINP > 0) fl += (size_t)SB_ROWS * (FINP + 1) + (size_t)C2 * FINP + (C2 + 3) / 4 * 4 + (size_t)SB_ROWS * (C2P + 1) +
@@ -564,7 +570,7 @@ static int split_bwd_impl(const float* gy, int64_t ldgy, const int32_t* gy_seg, 
     if (mm && FINP == FP) {                                                                                      \
         GML_ALLOW_BIG_LDS(arc, (&gml_k_ml3_split_bwd<FP, 4, 4, false, true>), 160 * 1024)                        \
         if (arc != hipSuccess) return (int)arc;                                                                  \
-        hipLaunchKernelGGL((gml_k_ml3_split_bwd<FP, 4, 4, false, true>), dim3(grid), dim3(SB_ROWS), lds, st, p); \
+        hipLaunchKernelGGL((gml_k_ml3_split_bwd<FP, 4, 4, false, true>), dim3(grid), dim3(2 * SB_ROWS), lds, st, p); \
     }
     SB_GO_MM(16) SB_GO_MM(32) SB_GO_MM(48) SB_GO_MM(64)
     if (!dzo && !mm) {
