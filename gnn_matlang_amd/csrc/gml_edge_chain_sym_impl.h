@@ -51,13 +51,30 @@ __global__ __launch_bounds__(256) void gml_k_edge_sym_flags(const int32_t* __res
                 if (col_t[mid] < (int)src) a = mid + 1; else b = mid;
             }
             if (a < e1 && col_t[a] == (int)src && !(a + 1 < e1 && col_t[a + 1] == (int)src)) {
-                bool same = true;
-                for (int s = 0; s < S; ++s) same = same && (val[(int64_t)k * S + s] == val[(int64_t)a * S + s]);
-                if (same) { f = src < dst ? 2 : 0; m = a; }
+                // a unique pair: the copy with src < dst compares the two rows ONCE and writes both records (the other copy reaches this
+                // point under exactly the mirrored conditions and leaves its record to it): half the row reads of the pass
+                if ((int)src < dst) {
+                    bool same = true;
+                    const uint32_t* pk = val + (int64_t)k * S;
+                    const uint32_t* pa = val + (int64_t)a * S;
+                    if ((S & 3) == 0 && (reinterpret_cast<uintptr_t>(val) & 15) == 0) {   // rows of aligned 16-byte groups
+                        for (int s4 = 0; s4 < S; s4 += 4) {
+                            const u32x4 x = *reinterpret_cast<const u32x4*>(pk + s4), y = *reinterpret_cast<const u32x4*>(pa + s4);
+                            same = same && x.x == y.x && x.y == y.y && x.z == y.z && x.w == y.w;
+                        }
+                    } else {
+                        for (int s = 0; s < S; ++s) same = same && (pk[s] == pa[s]);
+                    }
+                    flag[k] = same ? 2 : 1;
+                    mirror[k] = same ? a : -1;
+                    flag[a] = same ? 0 : 1;
+                    mirror[a] = -1;
+                }
+                continue;
             }
         }
         flag[k] = f;
-        mirror[k] = f == 2 ? m : -1;
+        mirror[k] = m;
     }
 }
 
