@@ -132,6 +132,8 @@ __device__ __forceinline__ void gml_row16_sum9(float (&v)[9]) {
 #ifndef GML_HADV
 #define GML_HADV 0
 #endif
+// (scheduling: the stage's pieces sit around / inside the Z projection and the compiler places them -- fences around the stage and
+//  explicit VALU groups between the projection's MFMA groups both measured SLOWER, profiles/r06_d_ab_notes.txt)
 // LDS the HAD form adds behind the wmix rows: biases [4], dz rows [ROWS][4], per-wave bias sums [NW][36]
 #define GML_BWD3_HAD_LDS(ROWS_, NW_) (16 + (ROWS_) * 16 + (NW_) * 36 * 4)
 
@@ -408,9 +410,9 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
             }
         }
         f32x4 dzv = f32x4{0.f, 0.f, 0.f, 0.f};
-        // ---- HAD: output stage of the group's own rows, in three pieces placed around / inside the Z projection (its matrix-pipe
-        //      chain leaves most VALU issue slots free): (a) LDS reads + the four partial dot products, (b) pure VALU: fold over the
-        //      row's lanes, tanh, dz, the DPP sums of the bias gradients, (c) the per-wave records + dz back as one float4
+        // ---- HAD: output stage of the group's own rows, in three pieces inside the Z projection's code (its matrix-pipe chain leaves
+        //      most VALU issue slots free; the compiler interleaves): (a) LDS reads + the four partial dot products, (b) pure VALU:
+        //      fold over the row's lanes, tanh, dz, the DPP sums of the bias gradients, (c) the per-wave records + dz back as one float4
         float had_a[4], had_g6 = 0.f, had_g7 = 0.f, had_bs[9];   // (had_bs: column sums of g, 0 .. 7; the row sum of dz, 8)
         const int pos_h = wave * 16 + r16;
         auto had_pre = [&]() {
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
         unsigned xpos = 0;                                   // DZ, relu_cols > 0: bit j = (x[row][8 kq + j] > 0), the relu mask of the layer below
         f32x2 Z[S][NH], P[S][NH];
         auto zproj = [&]() {
-        if constexpr (HAD) { had_pre(); __builtin_amdgcn_sched_barrier(0); }
+        if constexpr (HAD) had_pre();
         if constexpr (XV) {
 #pragma unroll
             for (int j = 0; j < 8; ++j)
@@ -550,10 +552,9 @@ __global__ __launch_bounds__(64 * NW, 2) void gml_k_spectconv_bwd3(const GmlBwdP
             for (int s = 0; s < S; ++s) {
                 if (s + 1 < S) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NOB * NIMG, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 3 * NOB * NIMG, 0);
-                if constexpr (HAD) __builtin_amdgcn_sched_group_barrier(0x002, 24, 0);   // the output stage's VALU work rides between the MFMA groups
             }
         }
-        if constexpr (HAD) { __builtin_amdgcn_sched_barrier(0); had_post(); }
+        if constexpr (HAD) had_post();
         };
         if constexpr (ZEARLY) zproj();                       // (needs the W image and the lane's own x row only: neither is part of the commit)
         if constexpr (!LATEC) __syncthreads();
